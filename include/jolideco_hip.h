@@ -1,0 +1,165 @@
+/*
+ * jolideco_hip.h -- C-ABI of libjolideco_hip.so: the MI355X (gfx950) implementation of the
+ * Jolideco MAP-deconvolution inner loop.
+ *
+ * The reference (pure Python/PyTorch, /root/reference) has no FFI for this path; its seam is the
+ * Python object protocol.  Each entry point below names the reference code it replaces
+ * (file:line relative to the reference root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative jd_status otherwise; the message of the
+ *     last failure on the calling thread is available from jd_last_error()
+ *   - all `float*` image arguments are DEVICE pointers to contiguous row-major fp32 (H, W)
+ *     images borrowed from the caller (PyTorch owns them); handles own their workspaces
+ *   - all work is enqueued asynchronously on the `stream` argument (a hipStream_t passed as
+ *     void*); no call synchronises except *_create and *_destroy
+ *   - scalar outputs (`*_out`) are DEVICE pointers to one float
+ *   - no C++ exceptions cross this boundary; handles are not thread-safe
+ */
+#ifndef JOLIDECO_HIP_H
+#define JOLIDECO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  JD_OK = 0,
+  JD_ERR_INVALID = -1, /* bad argument / unsupported shape */
+  JD_ERR_HIP = -2,     /* a HIP runtime call failed */
+  JD_ERR_FFT = -3,     /* a rocFFT call failed */
+  JD_ERR_ALLOC = -4
+} jd_status;
+
+#define JD_MAX_COMPONENTS 8
+
+typedef struct jd_conv_plan jd_conv_plan; /* FFT-convolution geometry + rocFFT plans + workspaces */
+typedef struct jd_gmm jd_gmm;             /* GMM constants in MFMA fragment order + workspaces */
+
+/* library ------------------------------------------------------------------------------- */
+int jd_version(void);
+const char* jd_last_error(void);
+/* number of HIP devices visible / name of the compiled target ("gfx950") */
+const char* jd_target_arch(void);
+
+/* FFT convolution plan --------------------------------------------------------------------
+ * Replaces the per-call shape logic of jolideco/utils/torch.py:363-370 (`convolve_fft_torch`):
+ * linear "same" convolution of an (H, W) image with a (kh, kw) kernel on a zero padded
+ * (Hp, Wp) grid, Hp >= H+kh-1, Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5,7-smooth, Wp % 4
+ * == 0) sizes; the crop offset is the reference's `_centered` offset ((kh-1)/2, (kw-1)/2)
+ * (utils/torch.py:337-344).  `exact_shape` != 0 forces (Hp, Wp) = (H+kh-1, W+kw-1), i.e. the
+ * reference's grid.  */
+int jd_conv_plan_create(int H, int W, int kh, int kw, int exact_shape, jd_conv_plan** plan_out);
+int jd_conv_plan_destroy(jd_conv_plan* plan);
+/* shape[0..5] = {H, W, Hp, Wp, oy, ox} */
+int jd_conv_plan_shape(const jd_conv_plan* plan, int* shape6);
+/* number of complex64 elements of one kernel spectrum: Hp * (Wp/2 + 1) */
+size_t jd_conv_plan_spectrum_size(const jd_conv_plan* plan);
+
+/* K-hat = rfft2(psf, s=(Hp, Wp)) / (Hp*Wp), computed ONCE per (dataset, component) and cached by
+ * the caller in `khat` (device, 2*spectrum_size floats).  Replaces the per-call
+ * `torch.fft.rfft2(kernel, s=shape)` of utils/torch.py:368 (and the unused cache of
+ * models/npred.py:117-127).  The 1/(Hp*Wp) of the unnormalised inverse transform is folded in. */
+int jd_conv_psf_spectrum(jd_conv_plan* plan, const float* psf, float* khat, void* stream);
+
+/* out[H,W] = crop( irfft2( rfft2(pad(image * scale_image)) * khat ) ); scale_image may be NULL.
+ * Stand-alone `convolve_fft_torch` (utils/torch.py:347-370); used at setup for the exposure edge
+ * correction of models/npred.py:108-113 and by NPredModel.forward (npred.py:175-179). */
+int jd_conv_same(jd_conv_plan* plan, const float* image, const float* scale_image, const float* khat,
+                 float* out, void* stream);
+
+/* Fused forward model + Poisson NLL + gradient for ONE dataset and n_comp flux components.
+ * Replaces, per optimizer step (jolideco/core.py:217-221,228):
+ *   NPredModels.evaluate            models/npred.py:210-261  (sum_c clip(conv(flux_c*E_c, psf_c),0) + bkg)
+ *   NPredModel.forward              models/npred.py:160-191  (upsampling_factor 1, no rmf)
+ *   convolve_fft_torch              utils/torch.py:347-370
+ *   nn.PoissonNLLLoss(log_input=False, reduction="mean", eps, full=True)   loss.py:35-37
+ *   and the autograd backward of all of the above down to d loss / d flux_c.
+ * loss_out      <- mean(n - c*log(n+eps)) + stirling_mean        (device scalar)
+ * grad_flux[c]  <- (accumulate ? += : =) grad_scale * E_c * corr(psf_c, g * [conv_c >= 0]),
+ *                  g = (1 - c/(n+eps)) / (H*W);  pass grad_flux == NULL for a forward-only
+ *                  evaluation (PoissonLoss.evaluate, loss.py:56-71).
+ * npred_out     optional (H, W) output of the total predicted counts.
+ * `stirling_mean` = mean([c>1] * (c*log c - c + 0.5*log(2*pi*c))) is flux independent and is
+ * supplied by the caller (computed once per dataset). */
+int jd_npred_poisson_fwd_bwd(jd_conv_plan* plan, int n_comp, const float* const* flux,
+                             const float* const* exposure, const float* const* khat,
+                             const float* background, const float* counts, float stirling_mean,
+                             float eps, float* loss_out, float* const* grad_flux, int accumulate,
+                             float grad_scale, float* npred_out, void* stream);
+
+/* Same chain split at the reference's object seams, for callers that keep the reference's own
+ * loop structure (autograd.Function wrappers in jolideco_amd/ops.py):
+ * conv_padded[c] are plan-owned buffers exposed through jd_conv_plan_conv_buffer. */
+int jd_poisson_nll(const float* npred, const float* counts, size_t n, float stirling_mean, float eps,
+                   float* loss_out, float* grad_npred /* nullable; (1 - c/(n+eps))/n_total */,
+                   void* stream);
+/* grad_image (+)= scale_image * crop_adjoint( irfft2( rfft2(pad(grad_out)) * conj(khat) ) ):
+ * the adjoint of jd_conv_same (autograd of utils/torch.py:367-370). */
+int jd_conv_same_adjoint(jd_conv_plan* plan, const float* grad_out, const float* scale_image,
+                         const float* khat, float* grad_image, int accumulate, void* stream);
+
+/* GMM patch prior ------------------------------------------------------------------------
+ * jd_gmm_create takes HOST pointers to the fp32 constants of
+ * jolideco/priors/patches/gmm.py: precisions_cholesky (K, D, D) (:139-149, utils/numpy.py:16-34),
+ * means_precisions_cholesky (K, D) (:217-228), const_k[k] = -0.5*D*log(2*pi) + log_det_cholesky[k]
+ * + log_weights[k] (:235-240,114-117,276-281) and pixel_weights (D,) (:283-299).  D must be 64
+ * (8x8 patches).  The library re-lays them out in MFMA fragment order with sqrt(pixel_weight)
+ * folded into the columns. */
+int jd_gmm_create(int K, int D, const float* prec_chol, const float* mu_prec, const float* const_k,
+                  const float* pixel_w, jd_gmm** gmm_out);
+int jd_gmm_destroy(jd_gmm* gmm);
+
+/* log-prior value and gradient of GMMPatchPrior.__call__ (priors/patches/core.py:189-246) with
+ * IdentityImageNorm, SubtractMeanPatchNorm (utils/norms.py:97-103), cycle-spin roll by
+ * (shift_y, shift_x) (utils/torch.py:108-119), patch size 8, stride `stride`
+ * (utils/torch.py:226-275), GaussianMixtureModel.estimate_log_prob (patches/gmm.py:262-281),
+ * max over components (marginalize = 0) or logsumexp (marginalize = 1).
+ *   value_out       <- (accumulate_value ? += : =) value_scale * sum_{patches in shard} v_patch
+ *   grad_flux_accum += grad_coef * d(sum_{patches in shard} v_patch)/d flux   (NULL: forward only)
+ *   argmax_out      optional int32 per patch (global patch index order), max mode only
+ * Only patch rows [patch_row_begin, patch_row_end) are evaluated (multi-GPU shard of the prior;
+ * pass 0 and -1 for all rows). */
+int jd_gmm_prior_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int stride, int shift_y,
+                         int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
+                         float value_scale, float* value_out, int accumulate_value, float grad_coef,
+                         float* grad_flux_accum, int32_t* argmax_out, void* stream);
+
+/* (Np, K) log-probabilities of explicit patches: GaussianMixtureModel.estimate_log_prob
+ * (patches/gmm.py:262-281).  x: (n, 64) device, out: (n, K) device. */
+int jd_gmm_estimate_log_prob(jd_gmm* gmm, const float* x, int n, float* out, void* stream);
+
+/* Element-wise priors: InverseGammaPrior (priors/core.py:207-226; kind 1: alpha, beta) and
+ * ExponentialPrior (priors/core.py:308-326; kind 2: alpha).  value_out <- sum(v)/n + log_const;
+ * grad_flux_accum += grad_coef * d value / d flux. */
+int jd_elementwise_prior_fwd_bwd(int kind, const float* flux, size_t n, float alpha, float beta,
+                                 float log_const, float* value_out, float grad_coef,
+                                 float* grad_flux_accum, void* stream);
+
+/* Parameter update -------------------------------------------------------------------------
+ * flux = exp(theta) [* mask]   (SpatialFluxComponent.flux_upsampled, models/core.py:583-594) */
+int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, void* stream);
+
+/* One torch.optim.Adam step (jolideco/core.py:39-42,229) on theta with the chain rule of
+ * models/core.py:588-592 fused in: g_theta = grad_flux * flux_in.  Writes theta, exp_avg,
+ * exp_avg_sq in place, writes flux_out = exp(theta_new) [* mask] (may alias flux_in or be a second
+ * buffer so the caller can keep the pre-step flux for the loss trace, core.py:247) and zeroes
+ * grad_flux when zero_grad != 0.  step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t),
+ * one_minus_beta1 = 1 - beta1 and one_minus_beta2 = 1 - beta2 are computed by the caller in double
+ * precision and rounded once, as torch does (fp32(1 - 0.999) != 1 - fp32(0.999)). */
+int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux, float* exp_avg,
+                 float* exp_avg_sq, const float* mask, size_t n, float step_size, float beta1,
+                 float beta2, float one_minus_beta1, float one_minus_beta2, float bias2_sqrt, float eps,
+                 int zero_grad, void* stream);
+/* plain SGD (core.py:41): theta -= lr * grad_flux * flux_in */
+int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
+                const float* mask, size_t n, float lr, int zero_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JOLIDECO_HIP_H */

@@ -1,0 +1,118 @@
+"""ctypes binding of libjolideco_hip.so (the C-ABI declared in include/jolideco_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+PyTorch is imported first so that the HIP runtime / rocFFT already loaded by torch are the ones
+this library binds to (same sonames) and device pointers/streams are interchangeable.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from pathlib import Path
+
+import torch  # noqa: F401  (must precede the CDLL so one HIP runtime is shared)
+
+__all__ = ["lib", "library_path", "check", "ptr", "stream_ptr", "EXPORTS"]
+
+LIB_NAME = "libjolideco_hip.so"
+
+
+def library_path():
+    """Path of the in-tree shared library (built by `make -C jolideco_amd/csrc`)."""
+    override = os.environ.get("JOLIDECO_HIP_LIBRARY")
+    return Path(override) if override else Path(__file__).resolve().parent / LIB_NAME
+
+
+fp = POINTER(c_float)
+fpp = POINTER(c_void_p)
+
+# name -> (restype, argtypes); one entry per symbol declared in include/jolideco_hip.h
+EXPORTS = {
+    "jd_version": (c_int, []),
+    "jd_last_error": (c_char_p, []),
+    "jd_target_arch": (c_char_p, []),
+    "jd_conv_plan_create": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "jd_conv_plan_destroy": (c_int, [c_void_p]),
+    "jd_conv_plan_shape": (c_int, [c_void_p, POINTER(c_int)]),
+    "jd_conv_plan_spectrum_size": (c_size_t, [c_void_p]),
+    "jd_conv_psf_spectrum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jd_conv_same": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jd_conv_same_adjoint": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "jd_npred_poisson_fwd_bwd": (
+        c_int,
+        [c_void_p, c_int, fpp, fpp, fpp, c_void_p, c_void_p, c_float, c_float, c_void_p, fpp, c_int, c_float,
+         c_void_p, c_void_p],
+    ),
+    "jd_poisson_nll": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "jd_gmm_create": (c_int, [c_int, c_int, fp, fp, fp, fp, POINTER(c_void_p)]),
+    "jd_gmm_destroy": (c_int, [c_void_p]),
+    "jd_gmm_prior_fwd_bwd": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
+         c_float, c_void_p, c_void_p, c_void_p],
+    ),
+    "jd_gmm_estimate_log_prob": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "jd_elementwise_prior_fwd_bwd": (
+        c_int,
+        [c_int, c_void_p, c_size_t, c_float, c_float, c_float, c_void_p, c_float, c_void_p, c_void_p],
+    ),
+    "jd_flux_from_theta": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "jd_adam_step": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
+         c_float, c_float, c_float, c_float, c_int, c_void_p],
+    ),
+    "jd_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not path.exists():
+            raise RuntimeError(
+                f"{path} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `make -C jolideco_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`."
+            )
+        handle = ctypes.CDLL(str(path))
+        for name, (restype, argtypes) in EXPORTS.items():
+            fn = getattr(handle, name)  # AttributeError -> missing export
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(status):
+    """Raise RuntimeError with the library's message for a non-zero status."""
+    if status != 0:
+        msg = lib().jd_last_error()
+        raise RuntimeError(f"libjolideco_hip error {status}: {msg.decode() if msg else '?'}")
+
+
+def ptr(tensor):
+    """Device pointer of a contiguous fp32/int32 CUDA(HIP) tensor, or None."""
+    if tensor is None:
+        return None
+    if not tensor.is_cuda:
+        raise RuntimeError("libjolideco_hip needs tensors on a HIP device (no CPU fallback)")
+    if not tensor.is_contiguous():
+        raise RuntimeError("libjolideco_hip needs contiguous tensors")
+    return c_void_p(tensor.data_ptr())
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (for the `const float* const*` arguments)."""
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        p = ptr(t)
+        arr[i] = p.value if p is not None else None
+    return arr
+
+
+def stream_ptr(device=None):
+    """Current torch HIP stream as a void*."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

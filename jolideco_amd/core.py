@@ -1,0 +1,437 @@
+"""MAP deconvolver driver (reference: jolideco/core.py:46-282).
+
+`MAPDeconvolver.run()` keeps the reference's constructor, call signature, result object and loss
+trace.  Two fit modes:
+
+* ``fit_mode="sequential"`` (default) -- the reference's semantics, exactly: one optimizer step per
+  dataset on ``L_d - beta * logprior / n_datasets`` (core.py:214-229), a fresh cycle-spin draw per
+  prior evaluation, and one no-grad trace row per epoch evaluated on the STALE fluxes of the last
+  step (core.py:247, loss.py:212-250).  Steps depend on each other through the optimizer, so with
+  several GPUs every rank runs the same replica (no collective).
+* ``fit_mode="joint"`` -- one optimizer step per epoch on ``sum_d L_d - beta * logprior``.  With
+  `torch.distributed` initialised, datasets are sharded round-robin over the ranks, the GMM prior
+  is sharded by patch rows, and ONE all-reduce (RCCL over xGMI) sums the flux gradients and the
+  loss scalars per step; every rank then applies the identical parameter update.
+
+All arithmetic of the step runs in libjolideco_hip.so; there is no CPU fallback.
+"""
+import copy
+import logging
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import check, ptr, stream_ptr
+from .distributed import DistContext
+from .loss import TotalLoss
+from .models import FluxComponents, SpatialFluxComponent
+from .ops import adam_bias_terms
+from .utils.torch import TORCH_DEFAULT_DEVICE
+
+log = logging.getLogger(__name__)
+
+__all__ = ["MAPDeconvolver", "MAPDeconvolverResult"]
+
+OPTIMIZER = ("adam", "sgd")
+FIT_MODES = ("sequential", "joint")
+
+
+class _ComponentState:
+    """Device buffers of one flux component during a fit: theta (the nn.Parameter's storage),
+    two flux buffers (current / previous, so the trace can see the pre-step flux), the flux
+    gradient accumulator and the Adam moments."""
+
+    def __init__(self, name, component, grad):
+        self.name = name
+        self.component = component
+        theta = component._flux_upsampled.data
+        if not theta.is_cuda:
+            raise RuntimeError("components must be on a HIP device: jolideco_amd has no CPU path")
+        self.theta = theta.reshape(theta.shape[-2:])
+        self.shape = tuple(self.theta.shape)
+        self.mask = None
+        if component.mask is not None:
+            self.mask = component.mask.to(theta.device, torch.float32).reshape(self.shape).contiguous()
+        self.flux = [torch.empty_like(self.theta), torch.empty_like(self.theta)]
+        self.cur = 0
+        self.grad = grad.reshape(self.shape)  # view into the flat communication buffer
+        self.exp_avg = torch.zeros_like(self.theta)
+        self.exp_avg_sq = torch.zeros_like(self.theta)
+        self.frozen = component.frozen
+        check(
+            _hip.lib().jd_flux_from_theta(
+                ptr(self.theta), ptr(self.mask), ptr(self.flux[0]), self.theta.numel(), stream_ptr(theta.device)
+            )
+        )
+
+    @property
+    def flux_cur(self):
+        return self.flux[self.cur]
+
+    @property
+    def flux_prev(self):
+        return self.flux[1 - self.cur]
+
+
+class MAPDeconvolver:
+    """Maximum A-Posteriori deconvolver
+
+    Attributes
+    ----------
+    n_epochs : int
+        Number of epochs to train
+    beta : float
+        Scale factor for the prior.
+    learning_rate : float
+        Learning rate
+    compute_error : bool
+        Whether to compute flux error (not implemented)
+    stop_early : bool
+        Stop once the validation loss stops improving (average over the last n epochs).
+    stop_early_n_average : int
+        Number of epochs to average over.
+    device : str
+        HIP device, "cuda" or "cuda:<i>".
+    display_progress : bool
+        Show a tqdm progress bar (forces one device->host sync per epoch).
+    optimizer_type : {"adam", "sgd"}
+    optimizer_kwargs : dict
+        ``lr``, and for Adam ``betas`` and ``eps``.
+    checkpoint_path : str
+        Not implemented (the reference writes ASDF files).
+    fit_mode : {"sequential", "joint"}
+        See the module docstring.
+    """
+
+    _default_flux_component = "flux"
+
+    def __init__(
+        self,
+        n_epochs=1_000,
+        beta=1,
+        learning_rate=0.1,
+        compute_error=False,
+        stop_early=False,
+        stop_early_n_average=10,
+        device=TORCH_DEFAULT_DEVICE,
+        display_progress=True,
+        optimizer_type="adam",
+        optimizer_kwargs=None,
+        checkpoint_path=None,
+        fit_mode="sequential",
+    ):
+        self.n_epochs = n_epochs
+        self.beta = beta
+        self.learning_rate = learning_rate
+        if compute_error:
+            raise NotImplementedError("compute_error (Hessian diagonal) is not implemented in jolideco_amd")
+        self.compute_error = False
+        self.stop_early = stop_early
+        self.stop_early_n_average = stop_early_n_average
+        self.display_progress = display_progress
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                f"jolideco_amd runs on an AMD GPU through libjolideco_hip.so only; got device {device}. "
+                "There is no CPU fallback."
+            )
+        self.device = device
+        if optimizer_type not in OPTIMIZER:
+            raise ValueError(f"Unknown optimizer: {optimizer_type}, must be one of {OPTIMIZER}")
+        self.optimizer_type = optimizer_type
+        self.optimizer_kwargs = dict(optimizer_kwargs or {})
+        self.optimizer_kwargs.setdefault("lr", self.learning_rate)
+        unknown = set(self.optimizer_kwargs) - {"lr", "betas", "eps"}
+        if unknown:
+            raise NotImplementedError(f"optimizer_kwargs {sorted(unknown)} are not implemented in jolideco_amd")
+        if checkpoint_path is not None:
+            raise NotImplementedError("checkpoints (ASDF) are not implemented in jolideco_amd")
+        self.checkpoint_path = None
+        if fit_mode not in FIT_MODES:
+            raise ValueError(f"Unknown fit_mode: {fit_mode}, must be one of {FIT_MODES}")
+        self.fit_mode = fit_mode
+
+    def to_dict(self):
+        data = {k: v for k, v in self.__dict__.items() if k not in ("optimizer_kwargs",)}
+        data["device"] = str(self.device)
+        data["checkpoint_path"] = str(self.checkpoint_path)
+        return data
+
+    def __str__(self):
+        lines = [self.__class__.__name__, "-" * len(self.__class__.__name__), ""]
+        lines += [f"  {k:22s}: {v}" for k, v in self.to_dict().items()]
+        return "\n".join(lines)
+
+    # ------------------------------------------------------------------------------------------
+    def _optimizer_step(self, states, step):
+        """Fused chain rule + optimizer update of every non-frozen component; swaps the flux
+        buffers so `flux_prev` is the flux the step was computed with."""
+        lib = _hip.lib()
+        lr = self.optimizer_kwargs["lr"]
+        for st in states:
+            n = st.theta.numel()
+            stream = stream_ptr(st.theta.device)
+            if st.frozen:
+                st.flux[1 - st.cur].copy_(st.flux_cur)
+                st.grad.zero_()
+            elif self.optimizer_type == "adam":
+                beta1, beta2 = self.optimizer_kwargs.get("betas", (0.9, 0.999))
+                eps = self.optimizer_kwargs.get("eps", 1e-8)
+                step_size, bias2_sqrt = adam_bias_terms(step, lr, beta1, beta2)
+                check(
+                    lib.jd_adam_step(
+                        ptr(st.theta), ptr(st.flux_cur), ptr(st.flux[1 - st.cur]), ptr(st.grad), ptr(st.exp_avg),
+                        ptr(st.exp_avg_sq), ptr(st.mask), n, step_size, beta1, beta2, 1 - beta1, 1 - beta2, bias2_sqrt, eps, 1,
+                        stream,
+                    )
+                )
+            else:
+                check(
+                    lib.jd_sgd_step(
+                        ptr(st.theta), ptr(st.flux_cur), ptr(st.flux[1 - st.cur]), ptr(st.grad), ptr(st.mask), n, lr,
+                        1, stream,
+                    )
+                )
+            st.cur = 1 - st.cur
+
+    def run(self, datasets, datasets_validation=None, components=None, calibrations=None):
+        """Run the MAP deconvolver
+
+        Parameters
+        ----------
+        datasets : dict of [str, dict]
+            name -> dict with "counts", "psf" (array or {component: array}), "exposure", "background".
+        datasets_validation : dict of [str, dict]
+            Validation datasets (trace column and early stopping only).
+        components : `FluxComponents` or `SpatialFluxComponent`
+        calibrations : None
+            `NPredCalibrations` are not implemented.
+
+        Returns
+        -------
+        result : `MAPDeconvolverResult`
+        """
+        if self.stop_early and datasets_validation is None:
+            raise ValueError("Early stopping requires providing test datasets")
+        if calibrations is not None:
+            raise NotImplementedError("NPredCalibrations are not implemented in jolideco_amd yet")
+        if isinstance(components, SpatialFluxComponent):
+            components = {self._default_flux_component: components}
+        components = FluxComponents(components)
+        components_init = copy.deepcopy(components)
+
+        _hip.lib()  # fail loudly before touching anything if the extension is missing
+        dist = DistContext.current()
+        with torch.cuda.device(self.device):
+            return self._run(datasets, datasets_validation, components, components_init, dist)
+
+    def _run(self, datasets, datasets_validation, components, components_init, dist):
+        from tqdm.auto import tqdm
+
+        components = components.to(self.device)
+        joint = self.fit_mode == "joint"
+        names_all = list(datasets)
+        # joint mode shards the datasets over the ranks; sequential mode runs full replicas
+        if joint and dist.world_size > 1:
+            local_names = dist.shard_items(names_all)
+        else:
+            local_names = names_all
+        local_datasets = {n: datasets[n] for n in local_names}
+        if not local_datasets and not joint:
+            raise ValueError("no datasets given")
+
+        total_loss = TotalLoss.from_datasets_and_components(
+            datasets=local_datasets if local_datasets else {},
+            datasets_validation=datasets_validation,
+            components=components,
+            beta=self.beta,
+            device=self.device,
+        )
+        # the trace always has one column per GLOBAL dataset
+        total_loss.poisson_loss.names_all_global = names_all
+        priors = list(total_loss.prior_loss.priors.values())
+        n_d, n_c = len(names_all), len(components)
+        n_val = total_loss.poisson_loss_validation.n_datasets if total_loss.poisson_loss_validation else 0
+        # ONE flat buffer = [flux gradients of all components | scalars of one epoch] so that the
+        # joint step needs a single all-reduce.  scalars: [dataset losses (global order) |
+        # log-priors | validation losses]
+        numels = [c._flux_upsampled.numel() for c in components.values()]
+        n_scalars = n_d + n_c + n_val
+        comm = torch.zeros(sum(numels) + n_scalars, dtype=torch.float32, device=self.device)
+        offsets = np.concatenate([[0], np.cumsum(numels)])
+        states = [
+            _ComponentState(name, comp, comm[offsets[i] : offsets[i + 1]])
+            for i, (name, comp) in enumerate(components.items())
+        ]
+        scalars = comm[offsets[-1] :]
+        trace_dev = torch.zeros((self.n_epochs, scalars.numel()), dtype=torch.float32, device=self.device)
+        slot_d = {name: i for i, name in enumerate(names_all)}
+        local_idx = [(slot_d[name], i) for i, name in enumerate(local_names)]  # (global slot, local index)
+
+        def slot(i):
+            return scalars[i : i + 1]
+
+        def prior_rows(prior, state):
+            if joint and dist.world_size > 1 and prior.shardable:
+                return dist.shard_range(prior.n_patch_rows(state.shape))
+            return None
+
+        n_epochs_run = 0
+        step = 0
+        trace = total_loss.trace
+        host_rows = []
+        disable = not self.display_progress
+        with tqdm(total=self.n_epochs * len(datasets), disable=disable) as pbar:
+            for epoch in range(self.n_epochs):
+                pbar.set_description(f"Epoch {epoch + 1}")
+                if joint:
+                    # ---- one step on sum_d L_d - beta * logprior ------------------------------
+                    fluxes = [st.flux_cur for st in states]
+                    grads = [st.grad for st in states]
+                    if dist.world_size > 1:
+                        scalars.zero_()
+                    first = True
+                    for gslot, li in local_idx:
+                        total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
+                        first = False
+                    if first:
+                        for g in grads:
+                            g.zero_()
+                    for ci, (st, prior) in enumerate(zip(states, priors)):
+                        if dist.world_size > 1 and not prior.shardable and dist.rank != 0:
+                            continue  # cheap element-wise priors: rank 0 only, summed by the all-reduce
+                        prior.device_fwd_bwd(
+                            st.flux_cur, slot(n_d + ci), grad=st.grad, coef=-float(self.beta),
+                            patch_rows=prior_rows(prior, st),
+                        )
+                    if dist.world_size > 1:
+                        dist.all_reduce_sum(comm)
+                    step += 1
+                    self._optimizer_step(states, step)
+                    pbar.update(len(datasets))
+                else:
+                    # ---- the reference loop: one step per dataset (core.py:214-229) -------------
+                    for gslot, li in local_idx:
+                        fluxes = [st.flux_cur for st in states]
+                        grads = [st.grad for st in states]
+                        total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
+                        coef = -float(self.beta) / total_loss.prior_weight
+                        for ci, (st, prior) in enumerate(zip(states, priors)):
+                            prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef)
+                        step += 1
+                        self._optimizer_step(states, step)
+                        pbar.update(1)
+                    # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------
+                    stale = [st.flux_prev for st in states]
+                    for gslot, li in local_idx:
+                        total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
+                    for ci, (st, prior) in enumerate(zip(states, priors)):
+                        prior.device_fwd_bwd(st.flux_prev, slot(n_d + ci))
+                if n_val:
+                    # validation losses on the same fluxes the trace row refers to
+                    vfl = [st.flux_prev for st in states]
+                    for vi in range(n_val):
+                        total_loss.poisson_loss_validation.fwd_bwd(vi, vfl, slot(n_d + n_c + vi))
+                trace_dev[epoch].copy_(scalars)
+                n_epochs_run = epoch + 1
+
+                if self.stop_early or self.display_progress:
+                    # the only per-epoch device->host sync, and only when the caller asked for it
+                    while len(host_rows) < n_epochs_run:
+                        host_rows.append(self._row(total_loss, trace_dev[len(host_rows)].cpu().numpy(), n_d, n_c, n_val))
+                    row = host_rows[-1]
+                    if self.stop_early and n_epochs_run > self.stop_early_n_average:
+                        recent = [r["datasets-validation-total"] for r in host_rows[-self.stop_early_n_average :]]
+                        if row["datasets-validation-total"] > np.mean(recent):
+                            break
+                    pbar.set_postfix(
+                        total=row["total"], datasets_total=row["datasets-total"], priors_total=row["priors-total"]
+                    )
+
+        values = trace_dev[:n_epochs_run].cpu().numpy()
+        for epoch in range(n_epochs_run):
+            trace.add_row(self._row(total_loss, values[epoch], n_d, n_c, n_val))
+
+        return MAPDeconvolverResult(
+            config=self.to_dict(),
+            components=components,
+            components_init=components_init,
+            trace_loss=trace,
+            calibrations=None,
+            calibrations_init=None,
+            wcs=None,
+        )
+
+    @staticmethod
+    def _row(total_loss, values, n_d, n_c, n_val):
+        names_d = getattr(total_loss.poisson_loss, "names_all_global", total_loss.poisson_loss.names_all)
+        loss_datasets = [float(v) for v in values[:n_d]]
+        loss_priors = [float(v) for v in values[n_d : n_d + n_c]]
+        loss_val = [float(v) for v in values[n_d + n_c :]] if n_val else None
+        # make_row iterates poisson_loss.names_all: give it the global names
+        local = total_loss.poisson_loss.names_all
+        total_loss.poisson_loss.names_all = names_d
+        try:
+            return total_loss.make_row(loss_datasets, loss_priors, "", loss_val)
+        finally:
+            total_loss.poisson_loss.names_all = local
+
+
+class MAPDeconvolverResult:
+    """MAP deconvolver result (reference: jolideco/core.py:285-378)."""
+
+    def __init__(
+        self, config, components, trace_loss, components_init=None, calibrations=None, calibrations_init=None,
+        wcs=None,
+    ):
+        self._components = components
+        self._components_init = components_init
+        self.trace_loss = trace_loss
+        self._calibrations = calibrations
+        self._calibrations_init = calibrations_init
+        self._config = config
+        self._wcs = wcs
+
+    @property
+    def components(self):
+        return self._components
+
+    @property
+    def components_init(self):
+        return self._components_init
+
+    @property
+    def calibrations(self):
+        return self._calibrations
+
+    @property
+    def calibrations_init(self):
+        return self._calibrations_init
+
+    @property
+    def flux_total(self):
+        return self.components.flux_total_numpy
+
+    @property
+    def flux_upsampled_total(self):
+        return self.components.flux_upsampled_total_numpy
+
+    @property
+    def config(self):
+        return self._config
+
+    def write(self, filename, overwrite=False, format=None):
+        """Write fluxes and the loss trace to a numpy ``.npz`` archive.  The reference's FITS / ASDF
+        writers (jolideco/utils/io) need astropy / asdf and are out of scope."""
+        filename = Path(filename)
+        if format not in (None, "npz"):
+            raise NotImplementedError(f"format {format!r} is not implemented in jolideco_amd (use 'npz')")
+        if filename.exists() and not overwrite:
+            raise OSError(f"{filename} exists")
+        arrays = {f"flux/{name}": flux for name, flux in self.components.to_numpy().items()}
+        for name in self.trace_loss.colnames:
+            if name != "filename":
+                arrays[f"trace/{name}"] = self.trace_loss[name]
+        np.savez_compressed(filename, **arrays)

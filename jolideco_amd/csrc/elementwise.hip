@@ -1,0 +1,500 @@
+// HBM-bound element-wise kernels of the MAP step (gfx950): pad*exposure (K1), k-space complex
+// multiply (K2), fused clip + background + Poisson NLL + gradient (K3), adjoint epilogue (K5),
+// exp/chain-rule + Adam/SGD (K6) and the element-wise priors.  All are streaming kernels:
+// one pass over each operand, 16 B per lane where the row alignment allows it, fp64 block
+// partials + a single fixed-order finalize for every scalar so results are run-to-run identical.
+#include "jd_common.h"
+#include "kernels.h"
+
+namespace jd {
+
+constexpr int BLOCK = 256;
+
+// ------------------------------------------------------------------------------------------
+// finalize: out = [out +] scale * sum(partials) + offset   (one block, fixed order)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void finalize_sum_kernel(const double* __restrict__ partials, int n,
+                                                            double scale, double offset,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ double smem[BLOCK / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += BLOCK) acc += partials[i];
+  double total = block_sum<BLOCK>(acc, smem);
+  if (threadIdx.x == 0) {
+    double v = scale * total + offset;
+    if (accumulate) v += (double)out[0];
+    out[0] = (float)v;
+  }
+}
+
+int launch_finalize_sum(const double* partials, int n, double scale, double offset, float* out,
+                        int accumulate, hipStream_t stream) {
+  finalize_sum_kernel<<<1, BLOCK, 0, stream>>>(partials, n, scale, offset, out, accumulate);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: padded[y][x] = image[y][x] * scale[y][x] inside (H, W), 0 in the padding
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(BLOCK) void pad_mul_kernel(const float* __restrict__ image,
+                                                       const float* __restrict__ scale,
+                                                       float* __restrict__ padded, int H, int W, int Wp) {
+  const int y = blockIdx.y;
+  const int x0 = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
+  if (x0 >= Wp) return;
+  float v[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+  if (y < H && x0 < W) {
+    const size_t off = (size_t)y * W + x0;
+    if constexpr (VEC == 4) {
+      // W % 4 == 0 on this path, so x0 < W implies x0 + 3 < W
+      const float4 a = *reinterpret_cast<const float4*>(image + off);
+      float4 s = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (scale) s = *reinterpret_cast<const float4*>(scale + off);
+      v[0] = a.x * s.x, v[1] = a.y * s.y, v[2] = a.z * s.z, v[3] = a.w * s.w;
+    } else {
+      v[0] = image[off] * (scale ? scale[off] : 1.f);
+    }
+  }
+  float* dst = padded + (size_t)y * Wp + x0;
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    dst[0] = v[0];
+  }
+}
+
+int launch_pad_mul(const float* image, const float* scale, float* padded, int H, int W, int Hp, int Wp,
+                   hipStream_t stream) {
+  const bool vec = (W % 4 == 0) && (Wp % 4 == 0);
+  const int per_block = BLOCK * (vec ? 4 : 1);
+  dim3 grid((Wp + per_block - 1) / per_block, Hp);
+  if (vec)
+    pad_mul_kernel<4><<<grid, BLOCK, 0, stream>>>(image, scale, padded, H, W, Wp);
+  else
+    pad_mul_kernel<1><<<grid, BLOCK, 0, stream>>>(image, scale, padded, H, W, Wp);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: spec *= khat   or   spec *= conj(khat)     (interleaved complex64)
+// ------------------------------------------------------------------------------------------
+template <bool CONJ>
+__global__ __launch_bounds__(BLOCK) void cmul_kernel(float2* __restrict__ spec,
+                                                    const float2* __restrict__ khat, size_t n) {
+  const size_t stride = (size_t)gridDim.x * BLOCK * 2;
+  for (size_t i = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * 2; i < n; i += stride) {
+    if (i + 1 < n) {
+      float4 a = *reinterpret_cast<float4*>(spec + i);
+      const float4 k = *reinterpret_cast<const float4*>(khat + i);
+      const float k1 = CONJ ? -k.y : k.y, k3 = CONJ ? -k.w : k.w;
+      float4 r;
+      r.x = a.x * k.x - a.y * k1;
+      r.y = a.x * k1 + a.y * k.x;
+      r.z = a.z * k.z - a.w * k3;
+      r.w = a.z * k3 + a.w * k.z;
+      *reinterpret_cast<float4*>(spec + i) = r;
+    } else {
+      const float2 a = spec[i];
+      const float2 k = khat[i];
+      const float ky = CONJ ? -k.y : k.y;
+      spec[i] = make_float2(a.x * k.x - a.y * ky, a.x * ky + a.y * k.x);
+    }
+  }
+}
+
+int launch_cmul(float2* spec, const float2* khat, size_t n, bool conj, hipStream_t stream) {
+  size_t blocks = (n / 2 + BLOCK - 1) / BLOCK;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks == 0) blocks = 1;
+  if (conj)
+    cmul_kernel<true><<<(unsigned)blocks, BLOCK, 0, stream>>>(spec, khat, n);
+  else
+    cmul_kernel<false><<<(unsigned)blocks, BLOCK, 0, stream>>>(spec, khat, n);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: fused clip + sum over components + background + Poisson NLL partial sums + gradient.
+// Reads conv_c at the crop offset of the padded grid, writes g_c over the WHOLE padded grid
+// (zeros outside (H, W)) so the buffer is directly the input of the adjoint R2C.
+// Algorithmic bytes: 16 B/pixel for one component (conv, background, counts in; g out).
+// ------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
+  __shared__ double smem[BLOCK / 64];
+  const int y = blockIdx.y;
+  const int x0 = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
+  double local = 0.0;
+  const bool in_image = (y < a.H) && (x0 < a.W);
+  float g[VEC];
+  float conv[JD_MAX_COMPONENTS][VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) g[i] = 0.f;
+
+  if (in_image) {
+    float n[VEC], b[VEC], c[VEC];
+    const size_t off = (size_t)y * a.W + x0;
+    const size_t poff = (size_t)(y + a.oy) * a.Wp + (x0 + a.ox);
+    if constexpr (VEC == 4) {
+      const float4 bb = *reinterpret_cast<const float4*>(a.background + off);
+      const float4 cc = *reinterpret_cast<const float4*>(a.counts + off);
+      b[0] = bb.x, b[1] = bb.y, b[2] = bb.z, b[3] = bb.w;
+      c[0] = cc.x, c[1] = cc.y, c[2] = cc.z, c[3] = cc.w;
+    } else {
+      b[0] = a.background[off];
+      c[0] = a.counts[off];
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) n[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < JD_MAX_COMPONENTS; ++k) {
+      if (k >= a.n_comp) break;
+      if constexpr (VEC == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(a.conv[k] + poff);
+        conv[k][0] = v.x, conv[k][1] = v.y, conv[k][2] = v.z, conv[k][3] = v.w;
+      } else {
+        conv[k][0] = a.conv[k][poff];
+      }
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) n[i] += fmaxf(conv[k][i], 0.f);  // clip per component, npred.py:191
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      n[i] += b[i];  // background added last, un-convolved (npred.py:234-261)
+      const float ne = n[i] + a.eps;
+      local += (double)(n[i] - c[i] * logf(ne));
+      g[i] = (1.f - c[i] / ne) * a.inv_n;
+    }
+    if (a.npred_out) {
+      if constexpr (VEC == 4)
+        *reinterpret_cast<float4*>(a.npred_out + off) = make_float4(n[0], n[1], n[2], n[3]);
+      else
+        a.npred_out[off] = n[0];
+    }
+  }
+
+  if (a.write_grad && x0 < a.Wp) {
+    const size_t goff = (size_t)y * a.Wp + x0;
+#pragma unroll
+    for (int k = 0; k < JD_MAX_COMPONENTS; ++k) {
+      if (k >= a.n_comp) break;
+      float gk[VEC];
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        gk[i] = (in_image && conv[k][i] >= 0.f) ? g[i] : 0.f;  // clamp backward: passes where conv >= 0
+      if constexpr (VEC == 4)
+        *reinterpret_cast<float4*>(a.g[k] + goff) = make_float4(gk[0], gk[1], gk[2], gk[3]);
+      else
+        a.g[k][goff] = gk[0];
+    }
+  }
+
+  const double total = block_sum<BLOCK>(local, smem);
+  if (threadIdx.x == 0) a.partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
+}
+
+int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stream) {
+  const bool vec = (a.W % 4 == 0) && (a.Wp % 4 == 0) && (a.ox % 4 == 0);
+  const int per_block = BLOCK * (vec ? 4 : 1);
+  const int span = a.write_grad ? a.Wp : a.W;
+  const int rows = a.write_grad ? a.Hp : a.H;
+  dim3 grid((span + per_block - 1) / per_block, rows);
+  *n_partials = grid.x * grid.y;
+  if (vec)
+    poisson_fused_kernel<4><<<grid, BLOCK, 0, stream>>>(a);
+  else
+    poisson_fused_kernel<1><<<grid, BLOCK, 0, stream>>>(a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+int poisson_fused_max_partials(int Hp, int Wp) { return ((Wp + BLOCK - 1) / BLOCK) * Hp; }
+
+// ------------------------------------------------------------------------------------------
+// K5: adjoint epilogue. grad[p][q] (+)= coef * scale[p][q] * corr[(p-oy) mod Hp][(q-ox) mod Wp]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void adjoint_epilogue_kernel(const float* __restrict__ corr,
+                                                                const float* __restrict__ scale,
+                                                                float* __restrict__ grad, int H, int W,
+                                                                int Hp, int Wp, int oy, int ox,
+                                                                float coef, int accumulate) {
+  const int p = blockIdx.y;
+  const int q = blockIdx.x * BLOCK + threadIdx.x;
+  if (q >= W) return;
+  int sy = p - oy;
+  if (sy < 0) sy += Hp;
+  int sx = q - ox;
+  if (sx < 0) sx += Wp;
+  const size_t off = (size_t)p * W + q;
+  float v = corr[(size_t)sy * Wp + sx] * coef;
+  if (scale) v *= scale[off];
+  if (accumulate) v += grad[off];
+  grad[off] = v;
+}
+
+int launch_adjoint_epilogue(const float* corr, const float* scale, float* grad, int H, int W, int Hp,
+                            int Wp, int oy, int ox, float coef, int accumulate, hipStream_t stream) {
+  dim3 grid((W + BLOCK - 1) / BLOCK, H);
+  adjoint_epilogue_kernel<<<grid, BLOCK, 0, stream>>>(corr, scale, grad, H, W, Hp, Wp, oy, ox, coef,
+                                                      accumulate);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+// crop: out[y][x] = padded[y+oy][x+ox]
+__global__ __launch_bounds__(BLOCK) void crop_kernel(const float* __restrict__ padded,
+                                                    float* __restrict__ out, int H, int W, int Wp, int oy,
+                                                    int ox) {
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * BLOCK + threadIdx.x;
+  if (x >= W) return;
+  out[(size_t)y * W + x] = padded[(size_t)(y + oy) * Wp + (x + ox)];
+}
+
+int launch_crop(const float* padded, float* out, int H, int W, int Wp, int oy, int ox, hipStream_t stream) {
+  dim3 grid((W + BLOCK - 1) / BLOCK, H);
+  crop_kernel<<<grid, BLOCK, 0, stream>>>(padded, out, H, W, Wp, oy, ox);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone Poisson NLL on a flat npred (autograd.Function seam of loss.py:35-37)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void poisson_nll_kernel(const float* __restrict__ npred,
+                                                           const float* __restrict__ counts, size_t n,
+                                                           float eps, float inv_n,
+                                                           float* __restrict__ grad,
+                                                           double* __restrict__ partials) {
+  __shared__ double smem[BLOCK / 64];
+  double local = 0.0;
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const float v = npred[i], c = counts[i];
+    const float ve = v + eps;
+    local += (double)(v - c * logf(ve));
+    if (grad) grad[i] = (1.f - c / ve) * inv_n;
+  }
+  const double total = block_sum<BLOCK>(local, smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: chain rule + Adam (torch.optim.Adam single-tensor formula) + exp of the new theta
+// ------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float* theta;
+  const float* flux_in;
+  float* flux_out;
+  float* grad_flux;
+  float* m;
+  float* v;
+  const float* mask;
+  size_t n;
+  float step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, lr;
+  int zero_grad, sgd;
+};
+
+__device__ inline void adam_update(float& th, float& m, float& v, float g, const AdamArgs& a) {
+  if (a.sgd) {
+    th = th - a.lr * g;
+    return;
+  }
+  // exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  m = m + a.one_minus_beta1 * (g - m);
+  v = v * a.beta2 + a.one_minus_beta2 * (g * g);
+  const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
+  th = th - a.step_size * (m / denom);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(BLOCK) void adam_kernel(AdamArgs a) {
+  const size_t stride = (size_t)gridDim.x * BLOCK * VEC;
+  for (size_t i = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * VEC; i < a.n; i += stride) {
+    float th[VEC], f[VEC], gf[VEC], m[VEC], v[VEC], mk[VEC];
+    if constexpr (VEC == 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(a.theta + i);
+      const float4 f4 = *reinterpret_cast<const float4*>(a.flux_in + i);
+      const float4 g4 = *reinterpret_cast<const float4*>(a.grad_flux + i);
+      th[0] = t4.x, th[1] = t4.y, th[2] = t4.z, th[3] = t4.w;
+      f[0] = f4.x, f[1] = f4.y, f[2] = f4.z, f[3] = f4.w;
+      gf[0] = g4.x, gf[1] = g4.y, gf[2] = g4.z, gf[3] = g4.w;
+      if (!a.sgd) {
+        const float4 m4 = *reinterpret_cast<const float4*>(a.m + i);
+        const float4 v4 = *reinterpret_cast<const float4*>(a.v + i);
+        m[0] = m4.x, m[1] = m4.y, m[2] = m4.z, m[3] = m4.w;
+        v[0] = v4.x, v[1] = v4.y, v[2] = v4.z, v[3] = v4.w;
+      }
+      if (a.mask) {
+        const float4 k4 = *reinterpret_cast<const float4*>(a.mask + i);
+        mk[0] = k4.x, mk[1] = k4.y, mk[2] = k4.z, mk[3] = k4.w;
+      }
+    } else {
+      th[0] = a.theta[i], f[0] = a.flux_in[i], gf[0] = a.grad_flux[i];
+      if (!a.sgd) m[0] = a.m[i], v[0] = a.v[i];
+      if (a.mask) mk[0] = a.mask[i];
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      // d flux / d theta = exp(theta) * mask = flux  (models/core.py:588-592)
+      adam_update(th[k], m[k], v[k], gf[k] * f[k], a);
+      f[k] = expf(th[k]);
+      if (a.mask) f[k] *= mk[k];
+    }
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(a.theta + i) = make_float4(th[0], th[1], th[2], th[3]);
+      *reinterpret_cast<float4*>(a.flux_out + i) = make_float4(f[0], f[1], f[2], f[3]);
+      if (!a.sgd) {
+        *reinterpret_cast<float4*>(a.m + i) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<float4*>(a.v + i) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (a.zero_grad) *reinterpret_cast<float4*>(a.grad_flux + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      a.theta[i] = th[0], a.flux_out[i] = f[0];
+      if (!a.sgd) a.m[i] = m[0], a.v[i] = v[0];
+      if (a.zero_grad) a.grad_flux[i] = 0.f;
+    }
+  }
+}
+
+static int launch_adam(const AdamArgs& a, hipStream_t stream) {
+  const bool vec = (a.n % 4 == 0);
+  const size_t per_block = (size_t)BLOCK * (vec ? 4 : 1);
+  size_t blocks = (a.n + per_block - 1) / per_block;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks == 0) blocks = 1;
+  if (vec)
+    adam_kernel<4><<<(unsigned)blocks, BLOCK, 0, stream>>>(a);
+  else
+    adam_kernel<1><<<(unsigned)blocks, BLOCK, 0, stream>>>(a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+__global__ __launch_bounds__(BLOCK) void flux_from_theta_kernel(const float* __restrict__ theta,
+                                                               const float* __restrict__ mask,
+                                                               float* __restrict__ flux, size_t n) {
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    float f = expf(theta[i]);
+    if (mask) f *= mask[i];
+    flux[i] = f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// element-wise priors
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void elementwise_prior_kernel(int kind, const float* __restrict__ flux,
+                                                                 size_t n, float alpha, float beta,
+                                                                 float coef, float* __restrict__ grad,
+                                                                 double* __restrict__ partials) {
+  __shared__ double smem[BLOCK / 64];
+  double local = 0.0;
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    const float f = flux[i];
+    float value, dv;
+    if (kind == 1) {  // inverse gamma: -beta/f + (-alpha-1)*log f      (priors/core.py:223-224)
+      value = -beta / f + (-alpha - 1.f) * logf(f);
+      dv = beta / (f * f) + (-alpha - 1.f) / f;
+    } else {  // exponential: -alpha * f                                (priors/core.py:324)
+      value = -alpha * f;
+      dv = -alpha;
+    }
+    local += (double)value;
+    if (grad) grad[i] += coef * dv;
+  }
+  const double total = block_sum<BLOCK>(local, smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// small per-process scratch for the stand-alone reductions (grown on demand, never freed while
+// the library is loaded; one per device would be needed for multi-device processes -- the
+// framework runs one process per GPU)
+static double* g_partials = nullptr;
+static size_t g_partials_cap = 0;
+static int ensure_partials(size_t n) {
+  if (n <= g_partials_cap) return JD_OK;
+  if (g_partials) (void)hipFree(g_partials);
+  g_partials = nullptr;
+  g_partials_cap = 0;
+  JD_HIP(hipMalloc(&g_partials, n * sizeof(double)));
+  g_partials_cap = n;
+  return JD_OK;
+}
+
+}  // namespace jd
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace jd;
+
+extern "C" int jd_poisson_nll(const float* npred, const float* counts, size_t n, float stirling_mean,
+                              float eps, float* loss_out, float* grad_npred, void* stream) {
+  JD_REQUIRE(npred && counts && loss_out && n > 0, "jd_poisson_nll: null argument or n == 0");
+  size_t blocks = (n + BLOCK - 1) / BLOCK;
+  if (blocks > 2048) blocks = 2048;
+  int rc = ensure_partials(8192);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  poisson_nll_kernel<<<(unsigned)blocks, BLOCK, 0, s>>>(npred, counts, n, eps, 1.f / (float)n, grad_npred,
+                                                       g_partials);
+  JD_LAUNCH_CHECK();
+  return launch_finalize_sum(g_partials, (int)blocks, 1.0 / (double)n, (double)stirling_mean, loss_out, 0, s);
+}
+
+extern "C" int jd_elementwise_prior_fwd_bwd(int kind, const float* flux, size_t n, float alpha, float beta,
+                                            float log_const, float* value_out, float grad_coef,
+                                            float* grad_flux_accum, void* stream) {
+  JD_REQUIRE(kind == 1 || kind == 2, "jd_elementwise_prior_fwd_bwd: kind must be 1 (inverse-gamma) or 2 (exponential)");
+  JD_REQUIRE(flux && value_out && n > 0, "jd_elementwise_prior_fwd_bwd: null argument or n == 0");
+  size_t blocks = (n + BLOCK - 1) / BLOCK;
+  if (blocks > 2048) blocks = 2048;
+  int rc = ensure_partials(8192);
+  if (rc) return rc;
+  hipStream_t s = as_stream(stream);
+  elementwise_prior_kernel<<<(unsigned)blocks, BLOCK, 0, s>>>(kind, flux, n, alpha, beta, grad_coef,
+                                                             grad_flux_accum, g_partials);
+  JD_LAUNCH_CHECK();
+  return launch_finalize_sum(g_partials, (int)blocks, 1.0 / (double)n, (double)log_const, value_out, 0, s);
+}
+
+extern "C" int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, void* stream) {
+  JD_REQUIRE(theta && flux && n > 0, "jd_flux_from_theta: null argument or n == 0");
+  size_t blocks = (n + BLOCK - 1) / BLOCK;
+  if (blocks > 8192) blocks = 8192;
+  flux_from_theta_kernel<<<(unsigned)blocks, BLOCK, 0, as_stream(stream)>>>(theta, mask, flux, n);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+extern "C" int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
+                            float* exp_avg, float* exp_avg_sq, const float* mask, size_t n, float step_size,
+                            float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
+                            float bias2_sqrt, float eps, int zero_grad, void* stream) {
+  JD_REQUIRE(theta && flux_in && flux_out && grad_flux && exp_avg && exp_avg_sq && n > 0,
+             "jd_adam_step: null argument or n == 0");
+  AdamArgs a{theta, flux_in, flux_out, grad_flux, exp_avg, exp_avg_sq, mask, n,
+             step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, 0.f, zero_grad, 0};
+  return launch_adam(a, as_stream(stream));
+}
+
+extern "C" int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
+                           const float* mask, size_t n, float lr, int zero_grad, void* stream) {
+  JD_REQUIRE(theta && flux_in && flux_out && grad_flux && n > 0, "jd_sgd_step: null argument or n == 0");
+  AdamArgs a{theta, flux_in, flux_out, grad_flux, nullptr, nullptr, mask, n,
+             0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, lr, zero_grad, 1};
+  return launch_adam(a, as_stream(stream));
+}
+
+extern "C" int jd_version(void) { return 100; }
+extern "C" const char* jd_last_error(void) { return jd::error_buffer(); }
+extern "C" const char* jd_target_arch(void) { return "gfx950"; }

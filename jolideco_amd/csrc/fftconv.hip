@@ -1,0 +1,255 @@
+// FFT "same" convolution on rocFFT (R2C / C2R, single precision, out-of-place) and the fused
+// forward-model + Poisson step built on it.  One plan per image/PSF geometry; kernel spectra are
+// computed once per (dataset, component) and cached by the caller.
+#include <rocfft/rocfft.h>
+
+#include <mutex>
+
+#include "jd_common.h"
+#include "kernels.h"
+
+#define JD_FFT(call)                                                                               \
+  do {                                                                                             \
+    rocfft_status s_ = (call);                                                                     \
+    if (s_ != rocfft_status_success)                                                               \
+      return jd::fail(JD_ERR_FFT, "%s failed with rocfft_status %d (%s:%d)", #call, (int)s_,       \
+                      __FILE__, __LINE__);                                                         \
+  } while (0)
+
+struct jd_conv_plan {
+  int H = 0, W = 0, kh = 0, kw = 0, Hp = 0, Wp = 0, oy = 0, ox = 0;
+  size_t nspec = 0;  // complex elements of one spectrum
+  rocfft_plan fwd = nullptr, inv = nullptr;
+  rocfft_execution_info info = nullptr;
+  void* work = nullptr;
+  size_t work_bytes = 0;
+  float* pad[JD_MAX_COMPONENTS] = {nullptr};   // R2C inputs (padded u = flux*E, later padded g)
+  float* conv[JD_MAX_COMPONENTS] = {nullptr};  // C2R outputs (padded convolution / correlation)
+  float2* spec = nullptr;
+  double* partials = nullptr;
+  int partials_cap = 0;
+};
+
+namespace jd {
+
+static bool is_smooth(int n) {
+  for (int p : {2, 3, 5, 7})
+    while (n % p == 0) n /= p;
+  return n == 1;
+}
+
+// smallest 2,3,5,7-smooth integer >= n that is a multiple of `mult`
+static int next_fast_len(int n, int mult) {
+  int m = ((n + mult - 1) / mult) * mult;
+  while (!is_smooth(m)) m += mult;
+  return m;
+}
+
+static int ensure_component_buffers(jd_conv_plan* p, int n_comp) {
+  const size_t bytes = (size_t)p->Hp * p->Wp * sizeof(float);
+  for (int c = 0; c < n_comp; ++c) {
+    if (!p->pad[c]) JD_HIP(hipMalloc(&p->pad[c], bytes));
+    if (!p->conv[c]) JD_HIP(hipMalloc(&p->conv[c], bytes));
+  }
+  return JD_OK;
+}
+
+static int exec_fft(jd_conv_plan* p, rocfft_plan plan, void* in, void* out, hipStream_t stream) {
+  JD_FFT(rocfft_execution_info_set_stream(p->info, stream));
+  void* in_buf[1] = {in};
+  void* out_buf[1] = {out};
+  JD_FFT(rocfft_execute(plan, in_buf, out_buf, p->info));
+  return JD_OK;
+}
+
+// conv[c] <- irfft2( rfft2(pad(image*scale)) * khat )   (padded layout, crop on read)
+static int conv_forward(jd_conv_plan* p, int c, const float* image, const float* scale, const float* khat,
+                        hipStream_t stream) {
+  int rc = launch_pad_mul(image, scale, p->pad[c], p->H, p->W, p->Hp, p->Wp, stream);
+  if (rc) return rc;
+  if ((rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream))) return rc;
+  if ((rc = launch_cmul(p->spec, reinterpret_cast<const float2*>(khat), p->nspec, false, stream))) return rc;
+  return exec_fft(p, p->inv, p->spec, p->conv[c], stream);
+}
+
+// conv[c] <- irfft2( rfft2(pad[c]) * conj(khat) )   (pad[c] already holds the padded gradient)
+static int corr_backward(jd_conv_plan* p, int c, const float* khat, hipStream_t stream) {
+  int rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream);
+  if (rc) return rc;
+  if ((rc = launch_cmul(p->spec, reinterpret_cast<const float2*>(khat), p->nspec, true, stream))) return rc;
+  return exec_fft(p, p->inv, p->spec, p->conv[c], stream);
+}
+
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        size_t n, float s) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * s;
+}
+
+}  // namespace jd
+
+using namespace jd;
+
+extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int exact_shape, jd_conv_plan** plan_out) {
+  JD_REQUIRE(plan_out, "jd_conv_plan_create: plan_out is null");
+  JD_REQUIRE(H > 0 && W > 0 && kh > 0 && kw > 0, "jd_conv_plan_create: non-positive shape (%d,%d,%d,%d)", H,
+             W, kh, kw);
+  JD_REQUIRE((long)H * W < (1L << 31), "jd_conv_plan_create: image too large");
+  static std::once_flag once;
+  static rocfft_status setup_status = rocfft_status_success;
+  std::call_once(once, [] { setup_status = rocfft_setup(); });
+  if (setup_status != rocfft_status_success) return fail(JD_ERR_FFT, "rocfft_setup failed (%d)", (int)setup_status);
+
+  jd_conv_plan* p = new (std::nothrow) jd_conv_plan();
+  if (!p) return fail(JD_ERR_ALLOC, "jd_conv_plan_create: out of host memory");
+  p->H = H, p->W = W, p->kh = kh, p->kw = kw;
+  const int fh = H + kh - 1, fw = W + kw - 1;
+  p->Hp = exact_shape ? fh : next_fast_len(fh, 2);
+  p->Wp = exact_shape ? fw : next_fast_len(fw, 4);
+  p->oy = (kh - 1) / 2;  // `_centered`: (full - new) // 2   (utils/torch.py:337-344)
+  p->ox = (kw - 1) / 2;
+  p->nspec = (size_t)p->Hp * (p->Wp / 2 + 1);
+
+  auto cleanup = [&](int rc) {
+    jd_conv_plan_destroy(p);
+    return rc;
+  };
+  const size_t lengths[2] = {(size_t)p->Wp, (size_t)p->Hp};  // rocFFT: fastest dimension first
+  rocfft_status s;
+  s = rocfft_plan_create(&p->fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                         rocfft_precision_single, 2, lengths, 1, nullptr);
+  if (s != rocfft_status_success) return cleanup(fail(JD_ERR_FFT, "rocfft_plan_create(R2C %dx%d) failed (%d)", p->Hp, p->Wp, (int)s));
+  s = rocfft_plan_create(&p->inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                         rocfft_precision_single, 2, lengths, 1, nullptr);
+  if (s != rocfft_status_success) return cleanup(fail(JD_ERR_FFT, "rocfft_plan_create(C2R %dx%d) failed (%d)", p->Hp, p->Wp, (int)s));
+  s = rocfft_execution_info_create(&p->info);
+  if (s != rocfft_status_success) return cleanup(fail(JD_ERR_FFT, "rocfft_execution_info_create failed (%d)", (int)s));
+  size_t wf = 0, wi = 0;
+  rocfft_plan_get_work_buffer_size(p->fwd, &wf);
+  rocfft_plan_get_work_buffer_size(p->inv, &wi);
+  p->work_bytes = wf > wi ? wf : wi;
+  if (p->work_bytes) {
+    if (hipMalloc(&p->work, p->work_bytes) != hipSuccess)
+      return cleanup(fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc(%zu) for the rocFFT work buffer failed", p->work_bytes));
+    s = rocfft_execution_info_set_work_buffer(p->info, p->work, p->work_bytes);
+    if (s != rocfft_status_success) return cleanup(fail(JD_ERR_FFT, "rocfft_execution_info_set_work_buffer failed (%d)", (int)s));
+  }
+  if (hipMalloc(&p->spec, p->nspec * sizeof(float2)) != hipSuccess)
+    return cleanup(fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc of the spectrum buffer failed"));
+  p->partials_cap = poisson_fused_max_partials(p->Hp, p->Wp);
+  if (hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
+    return cleanup(fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc of the partial sums failed"));
+  int rc = ensure_component_buffers(p, 1);
+  if (rc) return cleanup(rc);
+  *plan_out = p;
+  return JD_OK;
+}
+
+extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
+  if (!p) return JD_OK;
+  (void)hipDeviceSynchronize();
+  if (p->fwd) rocfft_plan_destroy(p->fwd);
+  if (p->inv) rocfft_plan_destroy(p->inv);
+  if (p->info) rocfft_execution_info_destroy(p->info);
+  if (p->work) (void)hipFree(p->work);
+  if (p->spec) (void)hipFree(p->spec);
+  if (p->partials) (void)hipFree(p->partials);
+  for (int c = 0; c < JD_MAX_COMPONENTS; ++c) {
+    if (p->pad[c]) (void)hipFree(p->pad[c]);
+    if (p->conv[c]) (void)hipFree(p->conv[c]);
+  }
+  delete p;
+  return JD_OK;
+}
+
+extern "C" int jd_conv_plan_shape(const jd_conv_plan* p, int* shape6) {
+  JD_REQUIRE(p && shape6, "jd_conv_plan_shape: null argument");
+  shape6[0] = p->H, shape6[1] = p->W, shape6[2] = p->Hp, shape6[3] = p->Wp, shape6[4] = p->oy, shape6[5] = p->ox;
+  return JD_OK;
+}
+
+extern "C" size_t jd_conv_plan_spectrum_size(const jd_conv_plan* p) { return p ? p->nspec : 0; }
+
+extern "C" int jd_conv_psf_spectrum(jd_conv_plan* p, const float* psf, float* khat, void* stream) {
+  JD_REQUIRE(p && psf && khat, "jd_conv_psf_spectrum: null argument");
+  hipStream_t s = as_stream(stream);
+  int rc = launch_pad_mul(psf, nullptr, p->pad[0], p->kh, p->kw, p->Hp, p->Wp, s);
+  if (rc) return rc;
+  if ((rc = exec_fft(p, p->fwd, p->pad[0], p->spec, s))) return rc;
+  const size_t n = p->nspec * 2;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  const float scale = (float)(1.0 / ((double)p->Hp * (double)p->Wp));
+  scale_copy_kernel<<<(unsigned)blocks, 256, 0, s>>>(reinterpret_cast<const float*>(p->spec), khat, n, scale);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+extern "C" int jd_conv_same(jd_conv_plan* p, const float* image, const float* scale_image, const float* khat,
+                            float* out, void* stream) {
+  JD_REQUIRE(p && image && khat && out, "jd_conv_same: null argument");
+  hipStream_t s = as_stream(stream);
+  int rc = conv_forward(p, 0, image, scale_image, khat, s);
+  if (rc) return rc;
+  return launch_crop(p->conv[0], out, p->H, p->W, p->Wp, p->oy, p->ox, s);
+}
+
+extern "C" int jd_conv_same_adjoint(jd_conv_plan* p, const float* grad_out, const float* scale_image,
+                                    const float* khat, float* grad_image, int accumulate, void* stream) {
+  JD_REQUIRE(p && grad_out && khat && grad_image, "jd_conv_same_adjoint: null argument");
+  hipStream_t s = as_stream(stream);
+  int rc = launch_pad_mul(grad_out, nullptr, p->pad[0], p->H, p->W, p->Hp, p->Wp, s);
+  if (rc) return rc;
+  if ((rc = corr_backward(p, 0, khat, s))) return rc;
+  return launch_adjoint_epilogue(p->conv[0], scale_image, grad_image, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox,
+                                 1.f, accumulate, s);
+}
+
+extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,
+                                        const float* const* exposure, const float* const* khat,
+                                        const float* background, const float* counts, float stirling_mean,
+                                        float eps, float* loss_out, float* const* grad_flux, int accumulate,
+                                        float grad_scale, float* npred_out, void* stream) {
+  JD_REQUIRE(p && flux && exposure && khat && background && counts && loss_out,
+             "jd_npred_poisson_fwd_bwd: null argument");
+  JD_REQUIRE(n_comp >= 1 && n_comp <= JD_MAX_COMPONENTS, "jd_npred_poisson_fwd_bwd: n_comp = %d not in [1, %d]",
+             n_comp, JD_MAX_COMPONENTS);
+  for (int c = 0; c < n_comp; ++c) {
+    JD_REQUIRE(flux[c] && khat[c], "jd_npred_poisson_fwd_bwd: flux[%d] or khat[%d] is null", c, c);
+    if (grad_flux) JD_REQUIRE(grad_flux[c], "jd_npred_poisson_fwd_bwd: grad_flux[%d] is null", c);
+  }
+  hipStream_t s = as_stream(stream);
+  int rc = ensure_component_buffers(p, n_comp);
+  if (rc) return rc;
+
+  // forward model per component (models/npred.py:175-179)
+  for (int c = 0; c < n_comp; ++c)
+    if ((rc = conv_forward(p, c, flux[c], exposure[c], khat[c], s))) return rc;
+
+  // fused clip + background + NLL + gradient (models/npred.py:191,254-261; loss.py:35-37)
+  PoissonArgs a{};
+  for (int c = 0; c < n_comp; ++c) {
+    a.conv[c] = p->conv[c];
+    a.g[c] = p->pad[c];
+  }
+  a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = p->partials;
+  a.n_comp = n_comp, a.H = p->H, a.W = p->W, a.Hp = p->Hp, a.Wp = p->Wp, a.oy = p->oy, a.ox = p->ox;
+  a.eps = eps;
+  const double n_pix = (double)p->H * (double)p->W;
+  a.inv_n = (float)(1.0 / n_pix);
+  a.write_grad = grad_flux ? 1 : 0;
+  int n_partials = 0;
+  if ((rc = launch_poisson_fused(a, &n_partials, s))) return rc;
+  if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
+    return rc;
+  if (!grad_flux) return JD_OK;
+
+  // adjoint: d loss / d flux_c = E_c * corr(psf_c, g_c)
+  for (int c = 0; c < n_comp; ++c) {
+    if ((rc = corr_backward(p, c, khat[c], s))) return rc;
+    if ((rc = launch_adjoint_epilogue(p->conv[c], exposure[c], grad_flux[c], p->H, p->W, p->Hp, p->Wp, p->oy,
+                                      p->ox, grad_scale, accumulate, s)))
+      return rc;
+  }
+  return JD_OK;
+}

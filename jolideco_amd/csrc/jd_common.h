@@ -1,0 +1,81 @@
+// Shared host-side helpers for libjolideco_hip.so (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/jolideco_hip.h"
+
+namespace jd {
+
+inline char* error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+inline int fail(int status, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+#define JD_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return jd::fail(JD_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                      __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define JD_LAUNCH_CHECK()                                                                     \
+  do {                                                                                        \
+    hipError_t e_ = hipGetLastError();                                                        \
+    if (e_ != hipSuccess)                                                                     \
+      return jd::fail(JD_ERR_HIP, "kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),  \
+                      __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define JD_REQUIRE(cond, ...)                                                                 \
+  do {                                                                                        \
+    if (!(cond)) return jd::fail(JD_ERR_INVALID, __VA_ARGS__);                                \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// wave64 reductions ------------------------------------------------------------------------
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Deterministic block reduction of a double: every thread passes its value, thread 0 gets the
+// block total (fixed order: lanes within a wave by xor-butterfly, waves in index order).
+template <int BLOCK>
+__device__ inline double block_sum(double v, double* smem /* BLOCK/64 doubles */) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) smem[wave] = v;
+  __syncthreads();
+  double total = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < BLOCK / 64; ++i) total += smem[i];
+  }
+  return total;
+}
+
+// out = (accumulate ? out : 0) + scale * sum(partials[0..n)) + offset, summed in index order in fp64.
+int launch_finalize_sum(const double* partials, int n, double scale, double offset, float* out,
+                        int accumulate, hipStream_t stream);
+
+}  // namespace jd

@@ -1,0 +1,28 @@
+// Internal launch prototypes shared between the translation units of libjolideco_hip.so.
+#pragma once
+#include "jd_common.h"
+
+namespace jd {
+
+struct PoissonArgs {
+  const float* conv[JD_MAX_COMPONENTS];  // padded (Hp, Wp) convolution results, read at the crop offset
+  float* g[JD_MAX_COMPONENTS];           // padded (Hp, Wp) outputs: masked d loss / d conv_c
+  const float* background;
+  const float* counts;
+  float* npred_out;  // nullable
+  double* partials;
+  int n_comp, H, W, Hp, Wp, oy, ox;
+  float eps, inv_n;
+  int write_grad;
+};
+
+int launch_pad_mul(const float* image, const float* scale, float* padded, int H, int W, int Hp, int Wp,
+                   hipStream_t stream);
+int launch_cmul(float2* spec, const float2* khat, size_t n, bool conj, hipStream_t stream);
+int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stream);
+int poisson_fused_max_partials(int Hp, int Wp);
+int launch_adjoint_epilogue(const float* corr, const float* scale, float* grad, int H, int W, int Hp,
+                            int Wp, int oy, int ox, float coef, int accumulate, hipStream_t stream);
+int launch_crop(const float* padded, float* out, int H, int W, int Wp, int oy, int ox, hipStream_t stream);
+
+}  // namespace jd

@@ -1,0 +1,192 @@
+"""Loss assembly (reference: jolideco/loss.py).
+
+`PoissonLoss`, `PriorLoss` and `TotalLoss` keep the reference's attributes and call signatures.
+Each has the autograd-visible methods of the reference (`evaluate`, `__call__`, `loss_function`)
+and a fused device path (`*_fwd_bwd`) that the fit loop uses: values land in device scalars, the
+gradients are accumulated by the HIP kernels without autograd.
+"""
+import numpy as np
+import torch
+
+from .models import NPredModels
+from .ops import PoissonNLLFunction, stirling_mean
+from .utils.table import TraceTable
+from .utils.torch import TORCH_DEFAULT_DEVICE
+
+__all__ = ["PoissonLoss", "PriorLoss", "TotalLoss"]
+
+
+class _PoissonNLLLoss:
+    """Callable equivalent of nn.PoissonNLLLoss(log_input=False, reduction="mean", eps=1e-25,
+    full=True) (jolideco/loss.py:35-37) running on the HIP kernel; the flux independent Stirling
+    mean is cached per counts tensor."""
+
+    def __init__(self):
+        self._stirling = {}
+
+    def stirling(self, counts):
+        key = (counts.data_ptr(), counts.numel())
+        if key not in self._stirling:
+            self._stirling[key] = stirling_mean(counts.detach().cpu().numpy())
+        return self._stirling[key]
+
+    def __call__(self, npred, counts):
+        return PoissonNLLFunction.apply(npred, counts, self.stirling(counts))
+
+
+class PoissonLoss:
+    """Poisson loss of all datasets.
+
+    Attributes
+    ----------
+    counts_all : list of `~torch.Tensor`  (1, 1, H, W) on the device
+    npred_models_all : list of `NPredModels`
+    names_all : list of str
+    """
+
+    def __init__(self, counts_all, npred_models_all, names_all):
+        if len(counts_all) != len(npred_models_all):
+            raise ValueError("counts_all and npred_models_all must have the same length")
+        self.counts_all = counts_all
+        self.npred_models_all = npred_models_all
+        self.names_all = names_all
+        self.loss_function = _PoissonNLLLoss()
+        self.stirling_all = [self.loss_function.stirling(c) for c in counts_all]
+
+    @property
+    def n_datasets(self):
+        return len(self.counts_all)
+
+    @property
+    def iter_by_dataset(self):
+        for data in zip(self.counts_all, self.npred_models_all):
+            yield data
+
+    def evaluate(self, fluxes):
+        """Per-dataset losses as a detached tensor (jolideco/loss.py:56-71)."""
+        out = torch.empty(self.n_datasets, dtype=torch.float32, device=self.counts_all[0].device)
+        with torch.no_grad():
+            for idx in range(self.n_datasets):
+                self.fwd_bwd(idx, [f.detach().reshape(f.shape[-2:]) for f in fluxes], out[idx : idx + 1])
+        return out
+
+    def __call__(self, fluxes):
+        return torch.sum(self.evaluate(fluxes=fluxes))
+
+    def fwd_bwd(self, idx, fluxes, loss_out, grads=None, accumulate=False, grad_scale=1.0, npred_out=None):
+        """Fused forward model + Poisson NLL (+ gradient) of dataset ``idx``."""
+        self.npred_models_all[idx].fwd_bwd(
+            fluxes, self.counts_all[idx], self.stirling_all[idx], loss_out, grads=grads, accumulate=accumulate,
+            grad_scale=grad_scale, npred_out=npred_out,
+        )
+
+    @classmethod
+    def from_datasets(cls, datasets, components, calibrations=None, device=TORCH_DEFAULT_DEVICE):
+        if calibrations:
+            raise NotImplementedError("NPredCalibrations are not implemented in jolideco_amd yet")
+        npred_models_all, counts_all = [], []
+        for name, dataset in datasets.items():
+            models = NPredModels.from_dataset_numpy(dataset=dataset, components=components, device=device)
+            npred_models_all.append(models)
+            counts = torch.from_numpy(np.ascontiguousarray(dataset["counts"], dtype=np.float32)[None, None])
+            counts_all.append(counts.to(device))
+        return cls(counts_all=counts_all, npred_models_all=npred_models_all, names_all=list(datasets))
+
+
+class PriorLoss:
+    """Prior loss: one prior per flux component (jolideco/loss.py:136-168)."""
+
+    def __init__(self, priors):
+        self.priors = priors
+
+    def evaluate(self, fluxes):
+        return [prior(flux=flux) for flux, prior in zip(fluxes, self.priors.values())]
+
+    def __call__(self, fluxes):
+        return sum(self.evaluate(fluxes=fluxes))
+
+
+class TotalLoss:
+    """Total loss = sum of dataset losses - beta * sum of log-priors."""
+
+    def __init__(self, poisson_loss, prior_loss, poisson_loss_validation=None, beta=1):
+        self.poisson_loss = poisson_loss
+        self.poisson_loss_validation = poisson_loss_validation
+        self.prior_loss = prior_loss
+        self.beta = beta
+        self._trace = None
+
+    @property
+    def trace_names(self):
+        """Column layout of the reference's trace table (jolideco/loss.py:192-210)."""
+        names = ["total", "datasets-total", "priors-total"]
+        names += [f"prior-{name}" for name in self.prior_loss.priors]
+        names += [f"dataset-{name}" for name in self.poisson_loss.names_all]
+        if self.poisson_loss_validation:
+            names += ["datasets-validation-total"]
+        names += ["filename"]
+        return names
+
+    @property
+    def trace(self):
+        if self._trace is None:
+            self._trace = TraceTable(names=self.trace_names)
+        return self._trace
+
+    @property
+    def prior_weight(self):
+        """Number of datasets (jolideco/loss.py:252-255)."""
+        return len(self.poisson_loss.counts_all)
+
+    def make_row(self, loss_datasets, loss_priors, filename="", loss_validation=None):
+        """Trace row with the reference's names and signs (jolideco/loss.py:226-250)."""
+        loss_datasets_total = sum(loss_datasets)
+        loss_priors_total = self.beta * sum(loss_priors)
+        row = {
+            "total": loss_datasets_total - loss_priors_total,
+            "datasets-total": loss_datasets_total,
+            "priors-total": -loss_priors_total,
+            "filename": filename,
+        }
+        for name, value in zip(self.prior_loss.priors, loss_priors):
+            row[f"prior-{name}"] = -self.beta * value
+        for name, value in zip(self.poisson_loss.names_all, loss_datasets):
+            row[f"dataset-{name}"] = value
+        if loss_validation is not None:
+            row["datasets-validation-total"] = sum(loss_validation)
+        return row
+
+    @torch.no_grad()
+    def append_trace(self, fluxes, filename=""):
+        """Re-evaluate every dataset loss and every prior on ``fluxes`` and append one row
+        (jolideco/loss.py:212-250).  Consumes one cycle-spin draw per GMM prior, like the reference."""
+        loss_datasets = [float(v) for v in self.poisson_loss.evaluate(fluxes=fluxes).cpu()]
+        loss_priors = [float(torch.as_tensor(v)) for v in self.prior_loss.evaluate(fluxes=fluxes)]
+        loss_validation = None
+        if self.poisson_loss_validation:
+            loss_validation = [float(v) for v in self.poisson_loss_validation.evaluate(fluxes=fluxes).cpu()]
+        self.trace.add_row(self.make_row(loss_datasets, loss_priors, filename, loss_validation))
+
+    def __call__(self, fluxes):
+        loss_datasets = self.poisson_loss.evaluate(fluxes=fluxes)
+        loss_priors = self.prior_loss.evaluate(fluxes=fluxes)
+        return sum(loss_datasets) - self.beta * sum(loss_priors)
+
+    @classmethod
+    def from_datasets_and_components(
+        cls, datasets, components, datasets_validation=None, beta=1, calibrations=None, device=TORCH_DEFAULT_DEVICE
+    ):
+        poisson_loss = PoissonLoss.from_datasets(
+            datasets=datasets, components=components, device=device, calibrations=calibrations
+        )
+        poisson_loss_validation = None
+        if datasets_validation:
+            poisson_loss_validation = PoissonLoss.from_datasets(
+                datasets=datasets_validation, components=components, calibrations=calibrations, device=device
+            )
+        return cls(
+            poisson_loss=poisson_loss,
+            poisson_loss_validation=poisson_loss_validation,
+            prior_loss=PriorLoss(priors=components.priors),
+            beta=beta,
+        )

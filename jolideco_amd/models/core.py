@@ -1,0 +1,185 @@
+"""Flux components (reference: jolideco/models/core.py:354-607,720-842).
+
+A `SpatialFluxComponent` owns the log-flux parameter theta as an `nn.Parameter` so that user code
+that inspects `.parameters()` keeps working.  During a fit the parameter, its flux image, the
+gradient accumulator and the optimizer moments live on the HIP device and are updated by the fused
+kernels (csrc/elementwise.hip); `flux_upsampled` is the autograd-visible `exp(theta) [* mask]`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..priors import Prior, Priors, UniformPrior
+
+__all__ = ["SpatialFluxComponent", "FluxComponents"]
+
+
+class SpatialFluxComponent(nn.Module):
+    """Dense spatial flux component.
+
+    Parameters
+    ----------
+    flux_upsampled : `~torch.Tensor`
+        Initial flux, shape (1, 1, H, W).
+    mask : `~torch.Tensor`
+        Optional boolean mask multiplied onto the flux.
+    use_log_flux : bool
+        Optimise log(flux) (only True is implemented).
+    upsampling_factor : int
+        Only 1 is implemented.
+    prior : `Prior`
+        Prior of this component (default uniform).
+    frozen : bool
+        Exclude the component from the optimisation.
+    """
+
+    is_sparse = False
+
+    def __init__(
+        self,
+        flux_upsampled,
+        flux_upsampled_error=None,
+        mask=None,
+        use_log_flux=True,
+        upsampling_factor=1,
+        prior=None,
+        frozen=False,
+        wcs=None,
+    ):
+        super().__init__()
+        if not flux_upsampled.ndim == 4:
+            raise ValueError(f"Flux tensor must be four dimensional. Got {flux_upsampled.ndim}")
+        if not use_log_flux:
+            raise NotImplementedError("use_log_flux=False is not implemented in jolideco_amd")
+        if upsampling_factor not in (None, 1):
+            raise NotImplementedError("upsampling_factor != 1 is not implemented in jolideco_amd yet")
+        flux_upsampled = torch.log(flux_upsampled.to(torch.float32))
+        self._flux_upsampled = nn.Parameter(flux_upsampled)
+        self._flux_upsampled_error = flux_upsampled_error
+        if mask is not None and not mask.shape == flux_upsampled.shape:
+            raise ValueError(
+                f"Flux and mask need to have the same shape, got {flux_upsampled.shape} and {mask.shape}"
+            )
+        self.mask = mask
+        self._use_log_flux = True
+        self.upsampling_factor = 1
+        self.prior = prior if prior is not None else UniformPrior()
+        self.frozen = frozen
+        self._wcs = wcs
+
+    @classmethod
+    def from_numpy(cls, flux, mask=None, **kwargs):
+        """Create from a 2-D numpy flux image (reference: models/core.py:505-540)."""
+        flux = torch.from_numpy(np.asarray(flux)[np.newaxis, np.newaxis].astype(np.float32))
+        if mask is not None:
+            mask = torch.from_numpy(np.asarray(mask)[np.newaxis, np.newaxis].astype(bool))
+        return cls(flux_upsampled=flux, mask=mask, **kwargs)
+
+    @classmethod
+    def from_flux_init_datasets(cls, datasets, **kwargs):
+        """Average of counts / exposure - background over datasets (models/core.py:542-566)."""
+        fluxes = [d["counts"] / d["exposure"] - d["background"] for d in datasets]
+        return cls.from_numpy(flux=np.nanmean(fluxes, axis=0), **kwargs)
+
+    def parameters(self, recurse=True):
+        return [] if self.frozen else super().parameters(recurse)
+
+    @property
+    def wcs(self):
+        return self._wcs
+
+    @property
+    def shape(self):
+        return self._flux_upsampled.shape
+
+    @property
+    def shape_image(self):
+        return tuple(self.shape[-2:])
+
+    @property
+    def use_log_flux(self):
+        return self._use_log_flux
+
+    @property
+    def flux_upsampled(self):
+        """exp(theta) [* mask] as an autograd-visible tensor (models/core.py:583-594)."""
+        flux = torch.exp(self._flux_upsampled)
+        if self.mask is not None:
+            flux = flux * self.mask.to(flux.device)
+        return flux
+
+    @property
+    def flux(self):
+        return self.flux_upsampled
+
+    @property
+    def flux_upsampled_error(self):
+        return self._flux_upsampled_error
+
+    @property
+    def flux_numpy(self):
+        return self.flux.detach().cpu().numpy()[0, 0]
+
+    @property
+    def flux_upsampled_numpy(self):
+        return self.flux_upsampled.detach().cpu().numpy()[0, 0]
+
+    def to_dict(self, include_data=None):
+        data = {
+            "use_log_flux": True,
+            "upsampling_factor": 1,
+            "frozen": self.frozen,
+            "prior": self.prior.to_dict(),
+        }
+        if include_data == "numpy":
+            data["flux_upsampled"] = self.flux_upsampled_numpy
+            if self.mask is not None:
+                data["mask"] = self.mask.cpu().numpy()
+        return data
+
+
+class FluxComponents(nn.ModuleDict):
+    """Dict of flux components (reference: models/core.py:720-842)."""
+
+    def parameters(self):
+        parameters = []
+        for component in self.values():
+            if not component.frozen:
+                parameters.extend(component.parameters())
+        return parameters
+
+    @property
+    def priors(self):
+        priors = Priors()
+        for name, component in self.items():
+            priors[name] = component.prior
+        return priors
+
+    def to_numpy(self):
+        return {name: np.squeeze(c.flux_upsampled.detach().cpu().numpy()) for name, c in self.items()}
+
+    @property
+    def fluxes_numpy(self):
+        return {name: c.flux_numpy for name, c in self.items()}
+
+    @property
+    def fluxes_upsampled_numpy(self):
+        return self.to_numpy()
+
+    @property
+    def flux_upsampled_total_numpy(self):
+        return np.sum([flux for flux in self.fluxes_upsampled_numpy.values()], axis=0)
+
+    @property
+    def flux_total_numpy(self):
+        return np.sum([flux for flux in self.fluxes_numpy.values()], axis=0)
+
+    def to_flux_tuple(self):
+        return tuple(c.flux_upsampled for c in self.values())
+
+    def set_flux_errors(self, flux_errors):
+        for name, flux_error in flux_errors.items():
+            self[name]._flux_upsampled_error = flux_error
+
+    def to_dict(self, include_data=None):
+        return {name: c.to_dict(include_data=include_data) for name, c in self.items()}

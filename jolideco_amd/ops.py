@@ -1,0 +1,302 @@
+"""Python handles over the C-ABI of libjolideco_hip.so and the autograd seams built on them.
+
+`ConvPlan` / `GmmHandle` own the native handles; the `*Function` classes are the
+`torch.autograd.Function` wrappers that sit where the reference calls ATen ops
+(SURVEY.md section 8(b)).  Nothing in this module computes on the CPU: every method requires HIP
+tensors and raises RuntimeError otherwise.
+"""
+import ctypes
+import math
+from ctypes import c_float, c_int, c_void_p
+
+import numpy as np
+import torch
+
+from . import _hip
+from ._hip import check, ptr, ptr_array, stream_ptr
+
+__all__ = [
+    "ConvPlan",
+    "GmmHandle",
+    "ConvSameFunction",
+    "PoissonNLLFunction",
+    "GMMPatchPriorFunction",
+    "ElementwisePriorFunction",
+    "stirling_mean",
+    "require_hip_tensor",
+]
+
+POISSON_EPS = 1e-25  # jolideco/loss.py:36
+
+
+def require_hip_tensor(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(f"{name} must live on a HIP device: jolideco_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def stirling_mean(counts):
+    """mean([c>1] * (c log c - c + 0.5 log(2 pi c))): the flux-independent Stirling term of
+    nn.PoissonNLLLoss(full=True) (jolideco/loss.py:35-37), computed once per dataset in float64."""
+    c = np.asarray(counts, dtype=np.float64)
+    term = np.zeros_like(c)
+    m = c > 1
+    term[m] = c[m] * np.log(c[m]) - c[m] + 0.5 * np.log(2 * np.pi * c[m])
+    return float(term.mean())
+
+
+class ConvPlan:
+    """FFT 'same'-convolution plan for one (H, W, kh, kw) geometry (jd_conv_plan)."""
+
+    _cache = {}
+
+    def __init__(self, H, W, kh, kw, device, exact_shape=False):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ConvPlan needs a HIP device (no CPU fallback)")
+        handle = c_void_p()
+        with torch.cuda.device(self.device):
+            check(_hip.lib().jd_conv_plan_create(H, W, kh, kw, int(exact_shape), ctypes.byref(handle)))
+        self._handle = handle
+        shape = (c_int * 6)()
+        check(_hip.lib().jd_conv_plan_shape(self._handle, shape))
+        self.H, self.W, self.Hp, self.Wp, self.oy, self.ox = (int(v) for v in shape)
+        self.kh, self.kw = kh, kw
+        self.spectrum_size = int(_hip.lib().jd_conv_plan_spectrum_size(self._handle))
+
+    @classmethod
+    def get(cls, H, W, kh, kw, device, exact_shape=False):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = (str(device), H, W, kh, kw, bool(exact_shape))
+        if key not in cls._cache:
+            cls._cache[key] = cls(H, W, kh, kw, device, exact_shape)
+        return cls._cache[key]
+
+    @classmethod
+    def clear_cache(cls):
+        for plan in cls._cache.values():
+            plan.close()
+        cls._cache.clear()
+
+    def close(self):
+        if self._handle is not None:
+            _hip.lib().jd_conv_plan_destroy(self._handle)
+            self._handle = None
+
+    # --- kernel spectrum (once per dataset and component) -----------------------------------
+    def psf_spectrum(self, psf):
+        psf = require_hip_tensor(psf, "psf")
+        if tuple(psf.shape[-2:]) != (self.kh, self.kw):
+            raise ValueError(f"psf shape {tuple(psf.shape)} does not match the plan ({self.kh}, {self.kw})")
+        khat = torch.empty(2 * self.spectrum_size, dtype=torch.float32, device=psf.device)
+        check(_hip.lib().jd_conv_psf_spectrum(self._handle, ptr(psf), ptr(khat), stream_ptr(psf.device)))
+        return khat
+
+    def _check_image(self, image, name):
+        image = require_hip_tensor(image, name)
+        if tuple(image.shape[-2:]) != (self.H, self.W) or image.numel() != self.H * self.W:
+            raise ValueError(f"{name} shape {tuple(image.shape)} does not match the plan ({self.H}, {self.W})")
+        return image
+
+    def conv_same(self, image, scale, khat):
+        image = self._check_image(image, "image")
+        if scale is not None:
+            scale = self._check_image(scale, "scale")
+        out = torch.empty_like(image)
+        check(_hip.lib().jd_conv_same(self._handle, ptr(image), ptr(scale), ptr(khat), ptr(out), stream_ptr(image.device)))
+        return out
+
+    def conv_same_adjoint(self, grad_out, scale, khat, grad_image=None, accumulate=False):
+        grad_out = self._check_image(grad_out, "grad_out")
+        if grad_image is None:
+            grad_image = torch.empty_like(grad_out)
+            accumulate = False
+        check(
+            _hip.lib().jd_conv_same_adjoint(
+                self._handle, ptr(grad_out), ptr(scale), ptr(khat), ptr(grad_image), int(accumulate),
+                stream_ptr(grad_out.device),
+            )
+        )
+        return grad_image
+
+    def npred_poisson_fwd_bwd(
+        self, fluxes, exposures, khats, background, counts, stirling, loss_out, grads=None, accumulate=False,
+        grad_scale=1.0, npred_out=None, eps=POISSON_EPS,
+    ):
+        """Fused forward model + Poisson NLL (+ gradient) of one dataset; see include/jolideco_hip.h."""
+        n = len(fluxes)
+        if not (len(exposures) == len(khats) == n):
+            raise ValueError("fluxes, exposures and khats must have the same length")
+        for f in fluxes:
+            self._check_image(f, "flux")
+        check(
+            _hip.lib().jd_npred_poisson_fwd_bwd(
+                self._handle, n, ptr_array(fluxes), ptr_array(exposures), ptr_array(khats), ptr(background),
+                ptr(counts), c_float(stirling), c_float(eps), ptr(loss_out),
+                ptr_array(grads) if grads is not None else None, int(accumulate), c_float(grad_scale),
+                ptr(npred_out), stream_ptr(background.device),
+            )
+        )
+
+
+class GmmHandle:
+    """GMM constants in MFMA fragment order on the device (jd_gmm)."""
+
+    def __init__(self, precisions_cholesky, means_precisions_cholesky, log_det_cholesky, log_weights,
+                 pixel_weights, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("GmmHandle needs a HIP device (no CPU fallback)")
+        pc = np.ascontiguousarray(precisions_cholesky, dtype=np.float32)
+        mp = np.ascontiguousarray(means_precisions_cholesky, dtype=np.float32)
+        K, D, _ = pc.shape
+        # const_k = -0.5 * D * log(2 pi) + log|P_k| + log pi_k   (patches/gmm.py:276-281)
+        two_pi_log = np.float32(np.log(np.float32(2 * np.pi)))
+        const_k = (
+            np.float32(-0.5) * (np.float32(D) * two_pi_log)
+            + np.asarray(log_det_cholesky, dtype=np.float32)
+            + np.asarray(log_weights, dtype=np.float32)
+        ).astype(np.float32)
+        pw = np.ascontiguousarray(np.asarray(pixel_weights, dtype=np.float32).reshape(-1))
+        self.K, self.D = K, D
+        handle = c_void_p()
+        as_fp = lambda a: a.ctypes.data_as(ctypes.POINTER(c_float))  # noqa: E731
+        with torch.cuda.device(self.device):
+            check(_hip.lib().jd_gmm_create(K, D, as_fp(pc), as_fp(mp), as_fp(const_k), as_fp(pw), ctypes.byref(handle)))
+        self._handle = handle
+
+    def close(self):
+        if self._handle is not None:
+            _hip.lib().jd_gmm_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prior_fwd_bwd(self, flux, stride, shifts, value_out, value_scale, grad=None, grad_coef=0.0,
+                      marginalize=False, patch_rows=(0, -1), accumulate_value=False, argmax_out=None):
+        flux = require_hip_tensor(flux, "flux")
+        H, W = flux.shape[-2:]
+        if flux.numel() != H * W:
+            raise ValueError("flux must be a single (H, W) image")
+        sy, sx = (0, 0) if shifts is None else shifts
+        check(
+            _hip.lib().jd_gmm_prior_fwd_bwd(
+                self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(patch_rows[0]), int(patch_rows[1]),
+                int(bool(marginalize)), c_float(value_scale), ptr(value_out), int(accumulate_value),
+                c_float(grad_coef), ptr(grad), ptr(argmax_out), stream_ptr(flux.device),
+            )
+        )
+
+    def estimate_log_prob(self, x):
+        x = require_hip_tensor(x, "x")
+        if x.ndim != 2 or x.shape[1] != self.D:
+            raise ValueError(f"x must have shape (n, {self.D}), got {tuple(x.shape)}")
+        out = torch.empty((x.shape[0], self.K), dtype=torch.float32, device=x.device)
+        if x.shape[0]:
+            check(_hip.lib().jd_gmm_estimate_log_prob(self._handle, ptr(x), x.shape[0], ptr(out), stream_ptr(x.device)))
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+# autograd seams
+# ------------------------------------------------------------------------------------------
+class ConvSameFunction(torch.autograd.Function):
+    """out = conv_same(image * scale, psf) through rocFFT; backward = correlation with the PSF.
+    Stands where the reference calls `convolve_fft_torch` (jolideco/utils/torch.py:347-370)."""
+
+    @staticmethod
+    def forward(ctx, image, scale, khat, plan):
+        ctx.plan, ctx.scale, ctx.khat = plan, scale, khat
+        ctx.shape = image.shape
+        return plan.conv_same(image, scale, khat).reshape(image.shape)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad = ctx.plan.conv_same_adjoint(grad_out.contiguous(), ctx.scale, ctx.khat)
+        return grad.reshape(ctx.shape), None, None, None
+
+
+class PoissonNLLFunction(torch.autograd.Function):
+    """nn.PoissonNLLLoss(log_input=False, reduction='mean', eps=1e-25, full=True) (loss.py:35-37)."""
+
+    @staticmethod
+    def forward(ctx, npred, counts, stirling):
+        npred = require_hip_tensor(npred, "npred")
+        counts = require_hip_tensor(counts, "counts")
+        loss = torch.empty(1, dtype=torch.float32, device=npred.device)
+        grad = torch.empty_like(npred)
+        check(
+            _hip.lib().jd_poisson_nll(
+                ptr(npred), ptr(counts), npred.numel(), c_float(stirling), c_float(POISSON_EPS), ptr(loss), ptr(grad),
+                stream_ptr(npred.device),
+            )
+        )
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_loss, None, None
+
+
+class GMMPatchPriorFunction(torch.autograd.Function):
+    """Scalar GMM patch log-prior with its HIP gradient (priors/patches/core.py:227-246)."""
+
+    @staticmethod
+    def forward(ctx, flux, handle, stride, shifts, marginalize, value_scale):
+        image = require_hip_tensor(flux, "flux")
+        value = torch.empty(1, dtype=torch.float32, device=image.device)
+        grad = None
+        if flux.requires_grad:
+            if marginalize:
+                raise NotImplementedError("gradient of the marginalized GMM prior is not implemented yet")
+            grad = torch.zeros(image.shape[-2:], dtype=torch.float32, device=image.device)
+        handle.prior_fwd_bwd(
+            image.reshape(image.shape[-2:]), stride, shifts, value, value_scale, grad=grad, grad_coef=value_scale,
+            marginalize=marginalize,
+        )
+        ctx.grad, ctx.shape = grad, flux.shape
+        return value.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_value):
+        return (ctx.grad * grad_value).reshape(ctx.shape), None, None, None, None, None
+
+
+class ElementwisePriorFunction(torch.autograd.Function):
+    """InverseGammaPrior / ExponentialPrior value and gradient (priors/core.py:207-226,308-326)."""
+
+    @staticmethod
+    def forward(ctx, flux, kind, alpha, beta, log_const):
+        image = require_hip_tensor(flux, "flux")
+        value = torch.empty(1, dtype=torch.float32, device=image.device)
+        grad = torch.zeros_like(image) if flux.requires_grad else None
+        check(
+            _hip.lib().jd_elementwise_prior_fwd_bwd(
+                int(kind), ptr(image), image.numel(), c_float(alpha), c_float(beta), c_float(log_const), ptr(value),
+                c_float(1.0 / image.numel()), ptr(grad), stream_ptr(image.device),
+            )
+        )
+        ctx.grad, ctx.shape = grad, flux.shape
+        return value.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_value):
+        return (ctx.grad * grad_value).reshape(ctx.shape), None, None, None, None
+
+
+def adam_bias_terms(step, lr, beta1, beta2):
+    """step_size and sqrt(bias_correction2) exactly as torch.optim.Adam computes them
+    (python floats = float64), torch/optim/adam.py `_single_tensor_adam`."""
+    bias1 = 1 - beta1**step
+    bias2 = 1 - beta2**step
+    return lr / bias1, math.sqrt(bias2)

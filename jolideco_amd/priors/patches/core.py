@@ -1,0 +1,114 @@
+"""GMM patch prior (reference: jolideco/priors/patches/core.py:30-246)."""
+import torch
+
+from ...utils.norms import IdentityImageNorm, SubtractMeanPatchNorm
+from ...utils.torch import TORCH_DEFAULT_DEVICE, cycle_spin_shifts, get_default_generator
+from ..core import Prior
+from .gmm import GaussianMixtureModel
+
+__all__ = ["GMMPatchPrior"]
+
+
+class GMMPatchPrior(Prior):
+    """Patch prior: expected (max or marginal) GMM log-likelihood of all overlapping patches.
+
+    Same constructor as the reference.  Options that are not on the accelerated path
+    (``cycle_spin_subpix``, ``jitter``, non-identity ``norm``, other patch norms) raise
+    NotImplementedError instead of silently running something else.
+    """
+
+    shardable = True
+
+    def __init__(
+        self,
+        gmm=None,
+        stride=None,
+        cycle_spin=True,
+        cycle_spin_subpix=False,
+        generator=None,
+        norm=None,
+        patch_norm=None,
+        jitter=False,
+        marginalize=False,
+        device=TORCH_DEFAULT_DEVICE,
+    ):
+        super().__init__()
+        if gmm is None:
+            gmm = GaussianMixtureModel.from_registry(name="zoran-weiss")
+        self.gmm = gmm
+        self.stride = gmm.meta.stride if stride is None else stride
+        if self.stride is None:
+            raise ValueError("stride must be given either explicitly or through gmm.meta.stride")
+        self.cycle_spin = cycle_spin
+        if cycle_spin_subpix:
+            raise NotImplementedError("cycle_spin_subpix is not implemented in jolideco_amd")
+        if jitter:
+            raise NotImplementedError("jitter is not implemented in jolideco_amd")
+        self.cycle_spin_subpix = False
+        self.jitter = False
+        # shifts are ALWAYS drawn from a host generator (torch default seed), see utils/torch.py
+        self.generator = generator if generator is not None else get_default_generator("cpu")
+        if self.generator.device.type != "cpu":
+            raise ValueError("the cycle-spin generator must be a CPU generator")
+        norm = norm if norm is not None else IdentityImageNorm()
+        if not isinstance(norm, IdentityImageNorm):
+            raise NotImplementedError("only IdentityImageNorm is implemented in jolideco_amd")
+        self.norm = norm
+        patch_norm = patch_norm if patch_norm is not None else gmm.meta.patch_norm
+        if not isinstance(patch_norm, SubtractMeanPatchNorm):
+            raise NotImplementedError("only SubtractMeanPatchNorm is implemented in jolideco_amd")
+        self.patch_norm = patch_norm
+        self.marginalize = marginalize
+        self.device = torch.device(device)
+        self.last_shifts = None
+
+    @property
+    def patch_shape(self):
+        return self.gmm.patch_shape
+
+    @property
+    def overlap(self):
+        return max(self.patch_shape) - self.stride
+
+    @property
+    def log_like_weight(self):
+        """stride^2 / patch area (priors/patches/core.py:222-225)."""
+        return self.stride**2 / (self.patch_shape[0] * self.patch_shape[1])
+
+    def draw_shifts(self):
+        """One pair of cycle-spin draws (None when cycle_spin is off)."""
+        shifts = cycle_spin_shifts(self.patch_shape, self.generator) if self.cycle_spin else None
+        self.last_shifts = shifts
+        return shifts
+
+    def __call__(self, flux, mask=None):
+        """Differentiable log-prior of a (1, 1, H, W) HIP tensor; draws one pair of shifts."""
+        from ...ops import GMMPatchPriorFunction
+
+        shifts = self.draw_shifts()
+        scale = self.log_like_weight / flux.numel()
+        return GMMPatchPriorFunction.apply(
+            flux, self.gmm.handle(flux.device), self.stride, shifts, self.marginalize, scale
+        )
+
+    def device_fwd_bwd(self, flux, value_out, grad=None, coef=0.0, patch_rows=None, shifts="draw"):
+        """Fused path: value -> device scalar, ``grad += coef * d logprior / d flux``."""
+        if isinstance(shifts, str):
+            shifts = self.draw_shifts()
+        scale = self.log_like_weight / flux.numel()
+        self.gmm.handle(flux.device).prior_fwd_bwd(
+            flux.reshape(flux.shape[-2:]), self.stride, shifts, value_out, scale, grad=grad, grad_coef=coef * scale,
+            marginalize=self.marginalize, patch_rows=patch_rows or (0, -1),
+        )
+
+    def n_patch_rows(self, shape):
+        return (shape[-2] - self.patch_shape[0]) // self.stride + 1
+
+    def to_dict(self):
+        data = super().to_dict()
+        data.update(
+            stride=int(self.stride), cycle_spin=bool(self.cycle_spin), cycle_spin_subpix=False, jitter=False,
+            gmm=self.gmm.to_dict(), norm=self.norm.to_dict(), patch_norm=self.patch_norm.to_dict(),
+            device=str(self.device),
+        )
+        return data
