@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the MAP deconvolution inner loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`, configs[2]): 2048x2048 image, 8 synthetic observations with
+varying PSF / exposure / background, one flux component with a GMM patch prior (8x8 patches, stride
+4, K = 128 components), fp32, JOINT fit: one "step" = one optimizer iteration on
+sum_d L_d - beta * logprior = for every observation the forward model (rocFFT R2C / k-space
+multiply / C2R), the fused Poisson NLL + gradient pass and the adjoint FFTs; the GMM prior value +
+gradient; (N > 1) ONE RCCL all-reduce of the flux gradient; the fused chain rule + Adam update.
+Total work is fixed as N grows (observations round-robin over the ranks, the prior split by patch
+rows): strong scaling.  All inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step (the GMM
+forward kernel: fp32 matrix-core roof), `roofline_poisson` the fused Poisson pass (HBM roof), both
+from hipEvent pairs recorded by the library around every launch inside the timed region.
+`cpu_baseline` times oracle/cpu_ref.py (the PyTorch-CPU restatement of the reference) on a bounded
+sample on rank 0 at N = 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (H, W, n_obs, K)
+    "c2": (1024, 1024, 1, 128),
+    "c3": (2048, 2048, 8, 128),
+    "c4": (4096, 4096, 1, 128),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+PATCH, D, STRIDE = 8, 64, 4
+
+
+def build_session(cfg_name, device, seed=0):
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+    from jolideco_amd.data import synthetic_gmm, synthetic_observations
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    H, W, n_obs, K = CONFIGS[cfg_name]
+    datasets, _, flux_init = synthetic_observations(shape=(H, W), n_obs=n_obs, seed=seed)
+    means, covs, weights = synthetic_gmm(K, D, seed=0)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=STRIDE))
+    comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+    deconvolver = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="joint")
+    return deconvolver.session(datasets, components=comp)
+
+
+def cpu_baseline(cfg_name, sample_edge=1024, steps=10):
+    """Time the CPU oracle (the PyTorch-CPU restatement of the reference's joint step) on a
+    `sample_edge`^2 crop of the same workload (same number of observations, same PSFs, same GMM)
+    and scale to the full image by the pixel ratio (the cost is linear in the patch count)."""
+    from jolideco_amd.data import synthetic_gmm, synthetic_observations
+    from oracle import cpu_ref
+
+    H, W, n_obs, K = CONFIGS[cfg_name]
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    edge = min(sample_edge, H)
+    datasets, _, flux_init = synthetic_observations(shape=(edge, edge), n_obs=n_obs, seed=0)
+    means, covs, weights = synthetic_gmm(K, D, seed=0)
+    gmm = cpu_ref.GMM.from_numpy(means, covs, weights, stride=STRIDE)
+    prior = cpu_ref.GMMPatchPriorRef(gmm)
+    theta = cpu_ref.log_flux_parameter(flux_init)
+    data = [cpu_ref.DatasetRef.from_numpy(d, ["flux"]) for d in datasets.values()]
+    optimizer = torch.optim.Adam([theta], lr=0.1)
+
+    def step():
+        optimizer.zero_grad()
+        fluxes = (cpu_ref.to_flux(theta),)
+        total, _, _ = cpu_ref.joint_loss(data, fluxes, [prior], 1.0)
+        total.backward()
+        optimizer.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    scale = (H * W) / float(edge * edge)
+    return {
+        "value": 1.0 / (dt * scale),
+        "unit": "iters/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (
+            f"oracle/cpu_ref.py joint step (autograd, torch {torch.__version__} CPU, {cores} threads) on a "
+            f"{edge}x{edge} crop, {n_obs} obs, GMM K={K}: {dt:.3f} s/step over {steps} steps after 1 warm-up; "
+            f"scaled by the pixel ratio {scale:.0f} to {H}x{W}"
+        ),
+        "sample_seconds_per_step": dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (libjolideco_hip.so has no CPU fallback)")
+    from jolideco_amd import _hip
+    from jolideco_amd.distributed import init_from_env
+
+    dist_ctx = init_from_env()
+    world = dist_ctx.world_size
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    H, W, n_obs, K = CONFIGS[args.config]
+    session = build_session(args.config, device)
+    torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        session.epoch()
+    torch.cuda.synchronize(device)
+    dist_ctx.barrier()
+    torch.cuda.synchronize(device)
+
+    _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        session.epoch()
+    torch.cuda.synchronize(device)
+    dist_ctx.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    prof = _hip.profile_read()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the fit must have produced finite numbers
+    scal = session.scalars.detach().cpu().numpy()
+    if not np.all(np.isfinite(scal)):
+        raise SystemExit(f"non-finite losses after the timed region: {scal}")
+
+    if dist_ctx.rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    n_py, n_px = (H - PATCH) // STRIDE + 1, (W - PATCH) // STRIDE + 1
+    rows = dist_ctx.shard_range(n_py) if world > 1 else (0, n_py)
+    np_local = (rows[1] - rows[0]) * n_px
+
+    def avg_ms(name):
+        total, count = prof[name]
+        return (total / count if count else None), count
+
+    # dominant kernel: GMM forward, fp32 matrix cores.  Algorithmic flop per launch =
+    # Np * K * (2 D^2 + 4 D)  (SURVEY.md section 8(d)).
+    gmm_ms, gmm_n = avg_ms("gmm_fwd")
+    gmm_flop = np_local * K * (2 * D * D + 4 * D)
+    roof_gmm = None
+    if gmm_ms:
+        achieved = gmm_flop / (gmm_ms * 1e-3) / 1e12
+        roof_gmm = {
+            "kernel": "gmm_fwd_kernel", "bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "avg_launch_ms": gmm_ms, "launches": gmm_n, "flop_per_launch": gmm_flop,
+        }
+    # fused Poisson pass: 16 B/pixel (conv, background, counts in; g out)
+    poi_ms, poi_n = avg_ms("poisson_fused")
+    poi_bytes = 16 * H * W
+    roof_poi = None
+    if poi_ms:
+        achieved = poi_bytes / (poi_ms * 1e-3) / 1e9
+        roof_poi = {
+            "kernel": "poisson_fused_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes,
+        }
+    kernel_ms_per_step = {k: (v[0] / args.steps) for k, v in prof.items() if v[1]}
+    dominant = max(kernel_ms_per_step, key=kernel_ms_per_step.get) if kernel_ms_per_step else None
+    roofline = roof_poi if dominant == "poisson_fused" else roof_gmm
+
+    out = {
+        "metric": "MAP iters/sec at 2048x2048, 8-obs joint fit" if args.config == "c3" else f"MAP iters/sec ({args.config})",
+        "value": args.steps / elapsed,
+        "unit": "iters/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: {H}x{W}, {n_obs} observations (17x17 Gaussian PSFs, varying exposure/"
+                        f"background), GMM patch prior 8x8 stride 4 K={K}, joint fit, Adam lr 0.1",
+            "global_observations": n_obs,
+            "sharding": f"observations round-robin over {world} rank(s), prior by patch rows, 1 all-reduce/step"
+            if world > 1 else "single GPU",
+        },
+        "roofline": roofline,
+        "roofline_poisson": roof_poi,
+        "kernel_ms_per_step": kernel_ms_per_step,
+        "dominant_kernel": dominant,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.config)
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

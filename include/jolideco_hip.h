@@ -159,6 +159,30 @@ int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* gra
 int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
                 const float* mask, size_t n, float lr, int zero_grad, void* stream);
 
+/* Kernel timers -----------------------------------------------------------------------------
+ * New (the reference has no profiler hooks).  After jd_profile_enable(n) the
+ * library brackets every launch of the kernels below with a hipEvent pair on the launch stream
+ * (at most n pairs; further launches are not timed); jd_profile_read synchronises on the recorded
+ * events and returns the summed duration and the number of timed launches of one kernel.
+ * Calling jd_profile_enable again resets the counters. */
+enum {
+  JD_KERNEL_POISSON_FUSED = 0,   /* K3: clip + background + Poisson NLL + gradient */
+  JD_KERNEL_GMM_FWD = 1,         /* K4: GMM patch log-likelihood, max / logsumexp over components */
+  JD_KERNEL_GMM_BWD = 2,         /* K4b: per-patch gradient for the selected component(s) */
+  JD_KERNEL_GMM_GATHER = 3,      /* K4c: deterministic overlap-add of the patch gradients */
+  JD_KERNEL_PAD_MUL = 4,         /* K1 */
+  JD_KERNEL_CMUL = 5,            /* K2 */
+  JD_KERNEL_ADJOINT_EPILOGUE = 6,/* K5 */
+  JD_KERNEL_ADAM = 7,            /* K6 */
+  JD_KERNEL_FFT_R2C = 8,         /* rocFFT real forward transform (all its kernels) */
+  JD_KERNEL_FFT_C2R = 9,         /* rocFFT real inverse transform (all its kernels) */
+  JD_KERNEL_COUNT = 10
+};
+int jd_profile_enable(int capacity);
+int jd_profile_disable(void);
+int jd_profile_read(int kernel, double* total_ms, long long* launches);
+const char* jd_kernel_name(int kernel);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ this library binds to (same sonames) and device pointers/streams are interchange
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
 from pathlib import Path
 
 import torch  # noqa: F401  (must precede the CDLL so one HIP runtime is shared)
@@ -62,6 +62,15 @@ EXPORTS = {
          c_float, c_float, c_float, c_float, c_int, c_void_p],
     ),
     "jd_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
+    "jd_profile_enable": (c_int, [c_int]),
+    "jd_profile_disable": (c_int, []),
+    "jd_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_longlong)]),
+    "jd_kernel_name": (c_char_p, [c_int]),
+}
+
+KERNEL_IDS = {
+    "poisson_fused": 0, "gmm_fwd": 1, "gmm_bwd": 2, "gmm_gather": 3, "pad_mul": 4, "cmul": 5,
+    "adjoint_epilogue": 6, "adam": 7, "fft_r2c": 8, "fft_c2r": 9,
 }
 
 _lib = None
@@ -84,6 +93,22 @@ def lib():
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+def profile_enable(capacity=8192):
+    """Start timing the library's kernels with hipEvent pairs on their launch stream."""
+    check(lib().jd_profile_enable(int(capacity)))
+
+
+def profile_read():
+    """{kernel: (total_ms, launches)} of the launches timed since `profile_enable`; synchronises."""
+    out = {}
+    for name, kid in KERNEL_IDS.items():
+        total, count = c_double(0.0), c_longlong(0)
+        check(lib().jd_profile_read(kid, ctypes.byref(total), ctypes.byref(count)))
+        out[name] = (total.value, count.value)
+    lib().jd_profile_disable()
+    return out
 
 
 def check(status):

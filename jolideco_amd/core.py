@@ -32,7 +32,7 @@ from .utils.torch import TORCH_DEFAULT_DEVICE
 
 log = logging.getLogger(__name__)
 
-__all__ = ["MAPDeconvolver", "MAPDeconvolverResult"]
+__all__ = ["MAPDeconvolver", "MAPDeconvolverResult", "FitSession"]
 
 OPTIMIZER = ("adam", "sgd")
 FIT_MODES = ("sequential", "joint")
@@ -227,114 +227,33 @@ class MAPDeconvolver:
         with torch.cuda.device(self.device):
             return self._run(datasets, datasets_validation, components, components_init, dist)
 
+    def session(self, datasets, datasets_validation=None, components=None):
+        """Set up a fit without running it: uploads the datasets, builds the FFT plans / kernel
+        spectra / GMM handles and returns a `FitSession` whose ``epoch()`` enqueues one epoch of
+        the fit on the current HIP stream (used by `run` and by bench.py)."""
+        if isinstance(components, SpatialFluxComponent):
+            components = {self._default_flux_component: components}
+        components = FluxComponents(components)
+        _hip.lib()
+        with torch.cuda.device(self.device):
+            return FitSession(self, datasets, datasets_validation, components, DistContext.current())
+
     def _run(self, datasets, datasets_validation, components, components_init, dist):
         from tqdm.auto import tqdm
 
-        components = components.to(self.device)
-        joint = self.fit_mode == "joint"
-        names_all = list(datasets)
-        # joint mode shards the datasets over the ranks; sequential mode runs full replicas
-        if joint and dist.world_size > 1:
-            local_names = dist.shard_items(names_all)
-        else:
-            local_names = names_all
-        local_datasets = {n: datasets[n] for n in local_names}
-        if not local_datasets and not joint:
-            raise ValueError("no datasets given")
-
-        total_loss = TotalLoss.from_datasets_and_components(
-            datasets=local_datasets if local_datasets else {},
-            datasets_validation=datasets_validation,
-            components=components,
-            beta=self.beta,
-            device=self.device,
-        )
-        # the trace always has one column per GLOBAL dataset
-        total_loss.poisson_loss.names_all_global = names_all
-        priors = list(total_loss.prior_loss.priors.values())
-        n_d, n_c = len(names_all), len(components)
-        n_val = total_loss.poisson_loss_validation.n_datasets if total_loss.poisson_loss_validation else 0
-        # ONE flat buffer = [flux gradients of all components | scalars of one epoch] so that the
-        # joint step needs a single all-reduce.  scalars: [dataset losses (global order) |
-        # log-priors | validation losses]
-        numels = [c._flux_upsampled.numel() for c in components.values()]
-        n_scalars = n_d + n_c + n_val
-        comm = torch.zeros(sum(numels) + n_scalars, dtype=torch.float32, device=self.device)
-        offsets = np.concatenate([[0], np.cumsum(numels)])
-        states = [
-            _ComponentState(name, comp, comm[offsets[i] : offsets[i + 1]])
-            for i, (name, comp) in enumerate(components.items())
-        ]
-        scalars = comm[offsets[-1] :]
-        trace_dev = torch.zeros((self.n_epochs, scalars.numel()), dtype=torch.float32, device=self.device)
-        slot_d = {name: i for i, name in enumerate(names_all)}
-        local_idx = [(slot_d[name], i) for i, name in enumerate(local_names)]  # (global slot, local index)
-
-        def slot(i):
-            return scalars[i : i + 1]
-
-        def prior_rows(prior, state):
-            if joint and dist.world_size > 1 and prior.shardable:
-                return dist.shard_range(prior.n_patch_rows(state.shape))
-            return None
-
+        session = FitSession(self, datasets, datasets_validation, components, dist)
+        total_loss = session.total_loss
+        n_d, n_c, n_val = session.n_d, session.n_c, session.n_val
+        trace_dev = torch.zeros((self.n_epochs, session.scalars.numel()), dtype=torch.float32, device=self.device)
         n_epochs_run = 0
-        step = 0
-        trace = total_loss.trace
         host_rows = []
         disable = not self.display_progress
         with tqdm(total=self.n_epochs * len(datasets), disable=disable) as pbar:
             for epoch in range(self.n_epochs):
                 pbar.set_description(f"Epoch {epoch + 1}")
-                if joint:
-                    # ---- one step on sum_d L_d - beta * logprior ------------------------------
-                    fluxes = [st.flux_cur for st in states]
-                    grads = [st.grad for st in states]
-                    if dist.world_size > 1:
-                        scalars.zero_()
-                    first = True
-                    for gslot, li in local_idx:
-                        total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
-                        first = False
-                    if first:
-                        for g in grads:
-                            g.zero_()
-                    for ci, (st, prior) in enumerate(zip(states, priors)):
-                        if dist.world_size > 1 and not prior.shardable and dist.rank != 0:
-                            continue  # cheap element-wise priors: rank 0 only, summed by the all-reduce
-                        prior.device_fwd_bwd(
-                            st.flux_cur, slot(n_d + ci), grad=st.grad, coef=-float(self.beta),
-                            patch_rows=prior_rows(prior, st),
-                        )
-                    if dist.world_size > 1:
-                        dist.all_reduce_sum(comm)
-                    step += 1
-                    self._optimizer_step(states, step)
-                    pbar.update(len(datasets))
-                else:
-                    # ---- the reference loop: one step per dataset (core.py:214-229) -------------
-                    for gslot, li in local_idx:
-                        fluxes = [st.flux_cur for st in states]
-                        grads = [st.grad for st in states]
-                        total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
-                        coef = -float(self.beta) / total_loss.prior_weight
-                        for ci, (st, prior) in enumerate(zip(states, priors)):
-                            prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef)
-                        step += 1
-                        self._optimizer_step(states, step)
-                        pbar.update(1)
-                    # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------
-                    stale = [st.flux_prev for st in states]
-                    for gslot, li in local_idx:
-                        total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
-                    for ci, (st, prior) in enumerate(zip(states, priors)):
-                        prior.device_fwd_bwd(st.flux_prev, slot(n_d + ci))
-                if n_val:
-                    # validation losses on the same fluxes the trace row refers to
-                    vfl = [st.flux_prev for st in states]
-                    for vi in range(n_val):
-                        total_loss.poisson_loss_validation.fwd_bwd(vi, vfl, slot(n_d + n_c + vi))
-                trace_dev[epoch].copy_(scalars)
+                session.epoch()
+                pbar.update(len(datasets))
+                trace_dev[epoch].copy_(session.scalars)
                 n_epochs_run = epoch + 1
 
                 if self.stop_early or self.display_progress:
@@ -350,13 +269,14 @@ class MAPDeconvolver:
                         total=row["total"], datasets_total=row["datasets-total"], priors_total=row["priors-total"]
                     )
 
+        trace = total_loss.trace
         values = trace_dev[:n_epochs_run].cpu().numpy()
         for epoch in range(n_epochs_run):
             trace.add_row(self._row(total_loss, values[epoch], n_d, n_c, n_val))
 
         return MAPDeconvolverResult(
             config=self.to_dict(),
-            components=components,
+            components=session.components,
             components_init=components_init,
             trace_loss=trace,
             calibrations=None,
@@ -377,6 +297,124 @@ class MAPDeconvolver:
             return total_loss.make_row(loss_datasets, loss_priors, "", loss_val)
         finally:
             total_loss.poisson_loss.names_all = local
+
+
+class FitSession:
+    """Device state of one fit and the per-epoch step sequence (jolideco/core.py:209-247).
+
+    ``epoch()`` enqueues, without any host synchronisation:
+
+    * sequential mode -- for every dataset: fused forward model + Poisson NLL + gradient, prior
+      value + gradient scaled by ``-beta / n_datasets``, fused chain rule + optimizer step; then
+      the trace evaluation of every dataset loss and every prior on the STALE fluxes (core.py:247);
+    * joint mode -- the gradients of this rank's datasets and of its share of the prior
+      accumulated into one flat buffer, ONE all-reduce (world size > 1), one optimizer step.
+
+    ``scalars`` holds the epoch's [dataset losses (global order) | log-priors | validation losses].
+    """
+
+    def __init__(self, deconvolver, datasets, datasets_validation, components, dist):
+        self.cfg = deconvolver
+        self.dist = dist
+        device = deconvolver.device
+        self.components = components = components.to(device)
+        self.joint = deconvolver.fit_mode == "joint"
+        names_all = list(datasets)
+        # joint mode shards the datasets over the ranks; sequential mode runs full replicas
+        if self.joint and dist.world_size > 1:
+            local_names = dist.shard_items(names_all)
+        else:
+            local_names = names_all
+        local_datasets = {n: datasets[n] for n in local_names}
+        if not local_datasets and not self.joint:
+            raise ValueError("no datasets given")
+
+        self.total_loss = TotalLoss.from_datasets_and_components(
+            datasets=local_datasets if local_datasets else {},
+            datasets_validation=datasets_validation,
+            components=components,
+            beta=deconvolver.beta,
+            device=device,
+        )
+        # the trace always has one column per GLOBAL dataset
+        self.total_loss.poisson_loss.names_all_global = names_all
+        self.priors = list(self.total_loss.prior_loss.priors.values())
+        self.n_d, self.n_c = len(names_all), len(components)
+        val = self.total_loss.poisson_loss_validation
+        self.n_val = val.n_datasets if val else 0
+        # ONE flat buffer = [flux gradients of all components | scalars of one epoch] so that the
+        # joint step needs a single all-reduce.
+        numels = [c._flux_upsampled.numel() for c in components.values()]
+        n_scalars = self.n_d + self.n_c + self.n_val
+        self.comm = torch.zeros(sum(numels) + n_scalars, dtype=torch.float32, device=device)
+        offsets = np.concatenate([[0], np.cumsum(numels)])
+        self.states = [
+            _ComponentState(name, comp, self.comm[offsets[i] : offsets[i + 1]])
+            for i, (name, comp) in enumerate(components.items())
+        ]
+        self.scalars = self.comm[offsets[-1] :]
+        slot_d = {name: i for i, name in enumerate(names_all)}
+        self.local_idx = [(slot_d[name], i) for i, name in enumerate(local_names)]  # (global slot, local index)
+        self.step = 0
+
+    def _slot(self, i):
+        return self.scalars[i : i + 1]
+
+    def _prior_rows(self, prior, state):
+        if self.joint and self.dist.world_size > 1 and prior.shardable:
+            return self.dist.shard_range(prior.n_patch_rows(state.shape))
+        return None
+
+    def epoch(self):
+        cfg, dist, states, priors, total_loss = self.cfg, self.dist, self.states, self.priors, self.total_loss
+        n_d, n_c = self.n_d, self.n_c
+        slot = self._slot
+        if self.joint:
+            # ---- one step on sum_d L_d - beta * logprior ------------------------------------
+            fluxes = [st.flux_cur for st in states]
+            grads = [st.grad for st in states]
+            if dist.world_size > 1:
+                self.scalars.zero_()
+            first = True
+            for gslot, li in self.local_idx:
+                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
+                first = False
+            if first:
+                for g in grads:
+                    g.zero_()
+            for ci, (st, prior) in enumerate(zip(states, priors)):
+                if dist.world_size > 1 and not prior.shardable and dist.rank != 0:
+                    continue  # cheap element-wise priors: rank 0 only, summed by the all-reduce
+                prior.device_fwd_bwd(
+                    st.flux_cur, slot(n_d + ci), grad=st.grad, coef=-float(cfg.beta),
+                    patch_rows=self._prior_rows(prior, st),
+                )
+            if dist.world_size > 1:
+                dist.all_reduce_sum(self.comm)
+            self.step += 1
+            cfg._optimizer_step(states, self.step)
+        else:
+            # ---- the reference loop: one step per dataset (core.py:214-229) -------------------
+            for gslot, li in self.local_idx:
+                fluxes = [st.flux_cur for st in states]
+                grads = [st.grad for st in states]
+                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
+                coef = -float(cfg.beta) / total_loss.prior_weight
+                for ci, (st, prior) in enumerate(zip(states, priors)):
+                    prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef)
+                self.step += 1
+                cfg._optimizer_step(states, self.step)
+            # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------------
+            stale = [st.flux_prev for st in states]
+            for gslot, li in self.local_idx:
+                total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
+            for ci, (st, prior) in enumerate(zip(states, priors)):
+                prior.device_fwd_bwd(st.flux_prev, slot(n_d + ci))
+        if self.n_val:
+            # validation losses on the same fluxes the trace row refers to
+            vfl = [st.flux_prev for st in states]
+            for vi in range(self.n_val):
+                total_loss.poisson_loss_validation.fwd_bwd(vi, vfl, slot(n_d + n_c + vi))
 
 
 class MAPDeconvolverResult:

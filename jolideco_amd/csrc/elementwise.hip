@@ -72,6 +72,7 @@ int launch_pad_mul(const float* image, const float* scale, float* padded, int H,
   const bool vec = (W % 4 == 0) && (Wp % 4 == 0);
   const int per_block = BLOCK * (vec ? 4 : 1);
   dim3 grid((Wp + per_block - 1) / per_block, Hp);
+  ProfScope prof(JD_KERNEL_PAD_MUL, stream);
   if (vec)
     pad_mul_kernel<4><<<grid, BLOCK, 0, stream>>>(image, scale, padded, H, W, Wp);
   else
@@ -111,6 +112,7 @@ int launch_cmul(float2* spec, const float2* khat, size_t n, bool conj, hipStream
   size_t blocks = (n / 2 + BLOCK - 1) / BLOCK;
   if (blocks > 8192) blocks = 8192;
   if (blocks == 0) blocks = 1;
+  ProfScope prof(JD_KERNEL_CMUL, stream);
   if (conj)
     cmul_kernel<true><<<(unsigned)blocks, BLOCK, 0, stream>>>(spec, khat, n);
   else
@@ -206,6 +208,7 @@ int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stre
   const int rows = a.write_grad ? a.Hp : a.H;
   dim3 grid((span + per_block - 1) / per_block, rows);
   *n_partials = grid.x * grid.y;
+  ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
   if (vec)
     poisson_fused_kernel<4><<<grid, BLOCK, 0, stream>>>(a);
   else
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(BLOCK) void adjoint_epilogue_kernel(const float* __
 int launch_adjoint_epilogue(const float* corr, const float* scale, float* grad, int H, int W, int Hp,
                             int Wp, int oy, int ox, float coef, int accumulate, hipStream_t stream) {
   dim3 grid((W + BLOCK - 1) / BLOCK, H);
+  ProfScope prof(JD_KERNEL_ADJOINT_EPILOGUE, stream);
   adjoint_epilogue_kernel<<<grid, BLOCK, 0, stream>>>(corr, scale, grad, H, W, Hp, Wp, oy, ox, coef,
                                                       accumulate);
   JD_LAUNCH_CHECK();
@@ -369,6 +373,7 @@ static int launch_adam(const AdamArgs& a, hipStream_t stream) {
   size_t blocks = (a.n + per_block - 1) / per_block;
   if (blocks > 4096) blocks = 4096;
   if (blocks == 0) blocks = 1;
+  ProfScope prof(JD_KERNEL_ADAM, stream);
   if (vec)
     adam_kernel<4><<<(unsigned)blocks, BLOCK, 0, stream>>>(a);
   else

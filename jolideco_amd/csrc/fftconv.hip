@@ -58,6 +58,7 @@ static int exec_fft(jd_conv_plan* p, rocfft_plan plan, void* in, void* out, hipS
   JD_FFT(rocfft_execution_info_set_stream(p->info, stream));
   void* in_buf[1] = {in};
   void* out_buf[1] = {out};
+  ProfScope prof(plan == p->fwd ? JD_KERNEL_FFT_R2C : JD_KERNEL_FFT_C2R, stream);
   JD_FFT(rocfft_execute(plan, in_buf, out_buf, p->info));
   return JD_OK;
 }

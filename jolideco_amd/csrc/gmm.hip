@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "jd_common.h"
+#include "kernels.h"
 
 namespace jd {
 
@@ -416,6 +417,7 @@ static int launch_fwd(const GmmFwdArgs& a, int tiles, hipStream_t s, int* n_wave
   const long waves = (n + per_wave - 1) / per_wave;
   const unsigned blocks = (unsigned)((waves + 3) / 4);
   *n_waves_out = (int)waves;
+  ProfScope prof(JD_KERNEL_GMM_FWD, s);
   switch (tiles) {
     case 4: gmm_fwd_kernel<4, MODE><<<blocks, 256, 0, s>>>(a); break;
     case 2: gmm_fwd_kernel<2, MODE><<<blocks, 256, 0, s>>>(a); break;
@@ -476,7 +478,10 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   long bwd_blocks = (n + 3) / 4;
   const long cap = (long)g->n_cu * 8;
   if (bwd_blocks > cap) bwd_blocks = cap;
-  gmm_bwd_max_kernel<<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
+  {
+    ProfScope prof(JD_KERNEL_GMM_BWD, s);
+    gmm_bwd_max_kernel<<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
+  }
   JD_LAUNCH_CHECK();
 
   GmmGatherArgs ga{};
@@ -486,7 +491,10 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   ga.y_end = (patch_row_end - 1) * stride + P;
   ga.coef = grad_coef;
   dim3 grid((W + 255) / 256, ga.y_end - ga.y_begin);
-  gmm_gather_kernel<<<grid, 256, 0, s>>>(ga);
+  {
+    ProfScope prof(JD_KERNEL_GMM_GATHER, s);
+    gmm_gather_kernel<<<grid, 256, 0, s>>>(ga);
+  }
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

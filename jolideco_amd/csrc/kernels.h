@@ -25,4 +25,14 @@ int launch_adjoint_epilogue(const float* corr, const float* scale, float* grad, 
                             int Wp, int oy, int ox, float coef, int accumulate, hipStream_t stream);
 int launch_crop(const float* padded, float* out, int H, int W, int Wp, int oy, int ox, hipStream_t stream);
 
+// kernel timers (profile.hip): RAII bracket around one launch
+int prof_begin(int kernel, hipStream_t s);
+void prof_end(int slot, hipStream_t s);
+struct ProfScope {
+  int slot;
+  hipStream_t s;
+  ProfScope(int kernel, hipStream_t stream) : slot(prof_begin(kernel, stream)), s(stream) {}
+  ~ProfScope() { prof_end(slot, s); }
+};
+
 }  // namespace jd

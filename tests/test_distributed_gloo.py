@@ -1,0 +1,162 @@
+"""CPU, world_size 2 over gloo: the multi-GPU partitioning of the joint step (jolideco_amd/distributed.py).
+
+The HIP kernels cannot run here, so each rank evaluates ITS shard with the CPU oracle (datasets
+round-robin, the GMM prior by contiguous patch rows of the same rolled image), packs
+[flux gradient | dataset losses | log-prior] into the flat communication buffer exactly like
+`FitSession`, and ONE `DistContext.all_reduce_sum` must reproduce the single-process joint
+gradient and loss scalars of the golden harness (tests/golden/joint_multi.npz).  Every rank then
+applies the same Adam update and must end with bit-identical parameters (no broadcast needed).
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REPO = Path(__file__).resolve().parent.parent
+for p in (str(REPO), str(REPO / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _prior_rows_value_and_grad(flux_t, gmm, stride, shifts, rows, cpu_ref):
+    """Oracle evaluation of the patch rows [rows[0], rows[1]) of the rolled image: the shard a rank
+    owns.  Returns sum of max-log-likelihoods (unscaled) with autograd attached."""
+    rolled = torch.roll(flux_t, shifts=shifts, dims=(2, 3))
+    lo, hi = rows
+    if hi <= lo:
+        return flux_t.sum() * 0.0
+    band = rolled[:, :, lo * stride : (hi - 1) * stride + 8, :]
+    loglike = cpu_ref.gmm_patch_log_like(band, gmm, stride, None)
+    return torch.sum(torch.max(loglike, dim=1).values)
+
+
+def _worker(rank, world_size, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from conftest import unpack_datasets
+    from jolideco_amd.distributed import DistContext, init_from_env
+    from oracle import cpu_ref
+
+    ctx = init_from_env(backend="gloo")
+    assert isinstance(ctx, DistContext) and ctx.world_size == world_size and ctx.rank == rank
+
+    j = dict(np.load(REPO / "tests" / "golden" / "joint_multi.npz"))
+    datasets = unpack_datasets(j, "joint/data/")
+    names = list(datasets)
+    gmm = cpu_ref.GMM.from_numpy(j["gmm/means"], j["gmm/covariances"], j["gmm/weights"], stride=4)
+    theta = cpu_ref.log_flux_parameter(j["joint/flux_init"])
+    H, W = theta.shape[-2:]
+    n_d = len(names)
+    beta = 1.0
+
+    # same shifts on every rank: identically seeded host generators
+    generator = torch.Generator(device="cpu")
+    shifts = cpu_ref.draw_cycle_spin_shifts(generator, (8, 8))
+
+    flux = cpu_ref.to_flux(theta)
+    local_names = ctx.shard_items(names)
+    assert local_names == [n for i, n in enumerate(names) if i % world_size == rank]
+    n_rows = (H - 8) // 4 + 1
+    rows = ctx.shard_range(n_rows)
+
+    comm = torch.zeros(H * W + n_d + 1)
+    objective = flux.sum() * 0.0
+    for name in local_names:
+        d = cpu_ref.DatasetRef.from_numpy(datasets[name], ["flux"])
+        loss = d.loss((flux,))
+        comm[H * W + names.index(name)] = loss.detach()
+        objective = objective + loss
+    scale = (4 * 4 / 64) / (H * W)
+    prior_part = _prior_rows_value_and_grad(flux, gmm, 4, shifts, rows, cpu_ref) * scale
+    comm[H * W + n_d] = prior_part.detach()
+    objective = objective - beta * prior_part
+    (grad_flux,) = torch.autograd.grad(objective, flux)
+    comm[: H * W] = grad_flux.reshape(-1)
+
+    ctx.all_reduce_sum(comm)  # the ONE collective of the step
+    ctx.barrier()
+
+    # identical Adam update on every rank (chain rule d flux / d theta = flux)
+    opt = torch.optim.Adam([theta], lr=0.1)
+    theta.grad = (comm[: H * W].reshape(theta.shape) * flux.detach())
+    opt.step()
+
+    gathered = [torch.zeros_like(theta) for _ in range(world_size)]
+    dist.all_gather(gathered, theta.detach())
+    if rank == 0:
+        np.savez(Path(out_dir) / "result.npz", comm=comm.numpy(), theta=theta.detach().numpy(),
+                 theta_other=gathered[1].numpy(), rows=np.array(rows), shifts=np.array(shifts))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sharded_joint_step_matches_single_process(tmp_path, golden):
+    from conftest import unpack_datasets
+    from oracle import cpu_ref
+
+    world_size = 2
+    mp.spawn(_worker, args=(world_size, _free_port(), str(tmp_path)), nprocs=world_size, join=True)
+    res = dict(np.load(tmp_path / "result.npz"))
+
+    # single-process reference of the same joint step
+    j = golden("joint_multi")
+    datasets = unpack_datasets(j, "joint/data/")
+    gmm = cpu_ref.GMM.from_numpy(j["gmm/means"], j["gmm/covariances"], j["gmm/weights"], stride=4)
+    theta = cpu_ref.log_flux_parameter(j["joint/flux_init"])
+    H, W = theta.shape[-2:]
+    data = [cpu_ref.DatasetRef.from_numpy(d, ["flux"]) for d in datasets.values()]
+    flux = cpu_ref.to_flux(theta)
+    prior = cpu_ref.GMMPatchPriorRef(gmm)
+    total, losses, priors = cpu_ref.joint_loss(data, (flux,), [prior], 1.0)
+    (grad_flux,) = torch.autograd.grad(total, flux, retain_graph=True)
+    assert tuple(res["shifts"]) == prior.last_shifts
+
+    comm = res["comm"]
+    got_grad = comm[: H * W].reshape(H, W)
+    ref_grad = grad_flux.numpy()[0, 0]
+    assert np.abs(got_grad - ref_grad).max() < 2e-6 * np.abs(ref_grad).max()
+    np.testing.assert_allclose(comm[H * W : H * W + len(data)], [float(v.detach()) for v in losses], rtol=1e-6)
+    np.testing.assert_allclose(comm[H * W + len(data)], float(priors[0].detach()), rtol=2e-6)
+    # first trace row of the golden joint fit = these values
+    np.testing.assert_allclose(comm[H * W : H * W + len(data)].sum(), j["joint/trace/datasets-total"][0], rtol=1e-6)
+    np.testing.assert_allclose(-comm[H * W + len(data)], j["joint/trace/priors-total"][0], rtol=1e-5)
+    # replicas stay bit-identical without a broadcast
+    assert np.array_equal(res["theta"], res["theta_other"])
+    # and the update equals the single-process Adam step
+    opt = torch.optim.Adam([theta], lr=0.1)
+    total.backward()
+    opt.step()
+    assert np.abs(res["theta"] - theta.detach().numpy()).max() < 1e-6
+
+
+def test_shard_rules():
+    from jolideco_amd.distributed import DistContext
+
+    for world in (1, 2, 3, 8):
+        ranges = [DistContext(rank=r, world_size=world).shard_range(509) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == 509
+        assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+        sizes = [b - a for a, b in ranges]
+        assert max(sizes) - min(sizes) <= 1
+        items = list(range(11))
+        owned = [DistContext(rank=r, world_size=world).shard_items(items) for r in range(world)]
+        assert sorted(sum(owned, [])) == items
+    # more ranks than rows: empty shards are legal
+    ranges = [DistContext(rank=r, world_size=8).shard_range(3) for r in range(8)]
+    assert sum(b - a for a, b in ranges) == 3
+    # single process: the collective is a no-op
+    buf = torch.arange(4.0)
+    assert DistContext().all_reduce_sum(buf) is buf
