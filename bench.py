@@ -59,7 +59,24 @@ def build_session(cfg_name, device, seed=0):
     return deconvolver.session(datasets, components=comp)
 
 
-def cpu_baseline(cfg_name, sample_edge=1024, steps=10):
+def host_cores(cap=16):
+    """Cores this process may really use: affinity mask, cgroup CPU quota and the GPU box's share
+    (16 cores per GPU) -- over-subscribing a quota-limited container makes the CPU leg crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg_name, sample_edge=1024, max_steps=10, budget_s=15.0):
     """Time the CPU oracle (the PyTorch-CPU restatement of the reference's joint step) on a
     `sample_edge`^2 crop of the same workload (same number of observations, same PSFs, same GMM)
     and scale to the full image by the pixel ratio (the cost is linear in the patch count)."""
@@ -67,7 +84,7 @@ def cpu_baseline(cfg_name, sample_edge=1024, steps=10):
     from oracle import cpu_ref
 
     H, W, n_obs, K = CONFIGS[cfg_name]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     edge = min(sample_edge, H)
     datasets, _, flux_init = synthetic_observations(shape=(edge, edge), n_obs=n_obs, seed=0)
@@ -86,9 +103,12 @@ def cpu_baseline(cfg_name, sample_edge=1024, steps=10):
         optimizer.step()
 
     step()  # warm-up
+    log("cpu_baseline: warm-up step done")
     t0 = time.perf_counter()
-    for _ in range(steps):
+    steps = 0
+    while steps < max_steps and (steps == 0 or time.perf_counter() - t0 < budget_s):
         step()
+        steps += 1
     dt = (time.perf_counter() - t0) / steps
     scale = (H * W) / float(edge * edge)
     return {
@@ -128,8 +148,10 @@ def main():
     torch.cuda.set_device(device)
 
     H, W, n_obs, K = CONFIGS[args.config]
+    log(f"building {args.config}: {H}x{W}, {n_obs} obs, K={K} on {device}")
     session = build_session(args.config, device)
     torch.cuda.synchronize(device)
+    log("session ready; warm-up")
 
     for _ in range(args.warmup):
         session.epoch()
@@ -137,6 +159,7 @@ def main():
     dist_ctx.barrier()
     torch.cuda.synchronize(device)
 
+    log("timed region")
     _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -145,6 +168,7 @@ def main():
     dist_ctx.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
     prof = _hip.profile_read()
 
     if world > 1:
@@ -223,6 +247,7 @@ def main():
         "kernel_ms_per_step": kernel_ms_per_step,
         "dominant_kernel": dominant,
     }
+    log("gpu result: " + json.dumps(out))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)
     print(json.dumps(out))
