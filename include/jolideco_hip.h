@@ -46,22 +46,37 @@ const char* jd_last_error(void);
 /* number of HIP devices visible / name of the compiled target ("gfx950") */
 const char* jd_target_arch(void);
 
-/* FFT convolution plan --------------------------------------------------------------------
+/* Convolution plan --------------------------------------------------------------------------
  * Replaces the per-call shape logic of jolideco/utils/torch.py:363-370 (`convolve_fft_torch`):
- * linear "same" convolution of an (H, W) image with a (kh, kw) kernel on a zero padded
- * (Hp, Wp) grid, Hp >= H+kh-1, Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5,7-smooth, Wp % 4
- * == 0) sizes; the crop offset is the reference's `_centered` offset ((kh-1)/2, (kw-1)/2)
- * (utils/torch.py:337-344).  `exact_shape` != 0 forces (Hp, Wp) = (H+kh-1, W+kw-1), i.e. the
- * reference's grid.  */
-int jd_conv_plan_create(int H, int W, int kh, int kw, int exact_shape, jd_conv_plan** plan_out);
+ * linear "same" convolution of an (H, W) image with a (kh, kw) kernel, zero outside the image; the
+ * crop offset is the reference's `_centered` offset ((kh-1)/2, (kw-1)/2) (utils/torch.py:337-344).
+ * Two methods compute the same function:
+ *   FFT    rocFFT R2C / k-space multiply / C2R on a zero padded (Hp, Wp) grid, Hp >= H+kh-1,
+ *          Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5,7-smooth, Wp % 4 == 0) sizes
+ *          (JD_CONV_MODE_FFT_EXACT forces the reference's own grid (H+kh-1, W+kw-1));
+ *   DIRECT the sum over PSF taps on the fp32 matrix cores (exact fmaf chain), PSFs up to 33x33;
+ *          padding, exposure scaling and crop are folded into the kernel (csrc/directconv.hip).
+ * JD_CONV_MODE_AUTO picks DIRECT when the PSF is small enough for it to be faster. */
+enum {
+  JD_CONV_MODE_AUTO = 0,
+  JD_CONV_MODE_FFT_EXACT = 1,
+  JD_CONV_MODE_FFT = 2,
+  JD_CONV_MODE_DIRECT = 3
+};
+int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_conv_plan** plan_out);
 int jd_conv_plan_destroy(jd_conv_plan* plan);
-/* shape[0..5] = {H, W, Hp, Wp, oy, ox} */
+/* shape[0..5] = {H, W, Hp, Wp, oy, ox}; (Hp, Wp) = (H, W) for the direct method */
 int jd_conv_plan_shape(const jd_conv_plan* plan, int* shape6);
-/* number of complex64 elements of one kernel spectrum: Hp * (Wp/2 + 1) */
+/* 0 = FFT, 1 = DIRECT */
+int jd_conv_plan_method(const jd_conv_plan* plan);
+/* HALF the number of floats of one per-(dataset, component) kernel operator buffer `khat`:
+ * FFT: complex64 elements of the kernel spectrum, Hp * (Wp/2 + 1); DIRECT: floats of one Toeplitz
+ * fragment table (the buffer holds the forward and the adjoint table). */
 size_t jd_conv_plan_spectrum_size(const jd_conv_plan* plan);
 
-/* K-hat = rfft2(psf, s=(Hp, Wp)) / (Hp*Wp), computed ONCE per (dataset, component) and cached by
- * the caller in `khat` (device, 2*spectrum_size floats).  Replaces the per-call
+/* Kernel operator of one PSF, computed ONCE per (dataset, component) and cached by the caller in
+ * `khat` (device, 2*spectrum_size floats).  FFT: K-hat = rfft2(psf, s=(Hp, Wp)) / (Hp*Wp); DIRECT: the
+ * PSF in MFMA fragment order (forward and flipped).  Replaces the per-call
  * `torch.fft.rfft2(kernel, s=shape)` of utils/torch.py:368 (and the unused cache of
  * models/npred.py:117-127).  The 1/(Hp*Wp) of the unnormalised inverse transform is folded in. */
 int jd_conv_psf_spectrum(jd_conv_plan* plan, const float* psf, float* khat, void* stream);
@@ -176,7 +191,8 @@ enum {
   JD_KERNEL_ADAM = 7,            /* K6 */
   JD_KERNEL_FFT_R2C = 8,         /* rocFFT real forward transform (all its kernels) */
   JD_KERNEL_FFT_C2R = 9,         /* rocFFT real inverse transform (all its kernels) */
-  JD_KERNEL_COUNT = 10
+  JD_KERNEL_DIRECT_CONV = 10,    /* MFMA Toeplitz convolution / correlation (small PSFs) */
+  JD_KERNEL_COUNT = 11
 };
 int jd_profile_enable(int capacity);
 int jd_profile_disable(void);

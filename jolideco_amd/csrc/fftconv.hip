@@ -18,7 +18,9 @@
 
 struct jd_conv_plan {
   int H = 0, W = 0, kh = 0, kw = 0, Hp = 0, Wp = 0, oy = 0, ox = 0;
-  size_t nspec = 0;  // complex elements of one spectrum
+  int method = jd::JD_CONV_FFT;  // JD_CONV_FFT: rocFFT on the padded (Hp, Wp) grid | JD_CONV_DIRECT: MFMA Toeplitz
+  int py = 0, px = 0;        // offset of the (H, W) image inside the conv / pad buffers (FFT: oy, ox; direct: 0)
+  size_t nspec = 0;  // complex elements of one spectrum (direct: floats of one Toeplitz fragment table)
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   void* work = nullptr;
@@ -66,6 +68,9 @@ static int exec_fft(jd_conv_plan* p, rocfft_plan plan, void* in, void* out, hipS
 // conv[c] <- irfft2( rfft2(pad(image*scale)) * khat )   (padded layout, crop on read)
 static int conv_forward(jd_conv_plan* p, int c, const float* image, const float* scale, const float* khat,
                         hipStream_t stream) {
+  if (p->method == JD_CONV_DIRECT)
+    return launch_direct_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0,
+                              1.f, 0, stream);
   int rc = launch_pad_mul(image, scale, p->pad[c], p->H, p->W, p->Hp, p->Wp, stream);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream))) return rc;
@@ -73,12 +78,27 @@ static int conv_forward(jd_conv_plan* p, int c, const float* image, const float*
   return exec_fft(p, p->inv, p->spec, p->conv[c], stream);
 }
 
-// conv[c] <- irfft2( rfft2(pad[c]) * conj(khat) )   (pad[c] already holds the padded gradient)
+// grad (+)= coef * scale * crop_adjoint( corr(pad[c], psf) ); pad[c] already holds the (padded) gradient g_c.
+// FFT: conv[c] <- irfft2( rfft2(pad[c]) * conj(khat) ), then the K5 epilogue; direct: one fused kernel.
+static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const float* scale, float* grad, float coef,
+                              int accumulate, hipStream_t stream);
+
 static int corr_backward(jd_conv_plan* p, int c, const float* khat, hipStream_t stream) {
   int rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream);
   if (rc) return rc;
   if ((rc = launch_cmul(p->spec, reinterpret_cast<const float2*>(khat), p->nspec, true, stream))) return rc;
   return exec_fft(p, p->inv, p->spec, p->conv[c], stream);
+}
+
+static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const float* scale, float* grad, float coef,
+                              int accumulate, hipStream_t stream) {
+  if (p->method == JD_CONV_DIRECT)
+    return launch_direct_conv(p->pad[c], nullptr, khat + p->nspec, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                              1, coef, accumulate, stream);
+  int rc = corr_backward(p, c, khat, stream);
+  if (rc) return rc;
+  return launch_adjoint_epilogue(p->conv[c], scale, grad, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox, coef, accumulate,
+                                 stream);
 }
 
 __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ in, float* __restrict__ out,
@@ -91,11 +111,34 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict
 
 using namespace jd;
 
-extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int exact_shape, jd_conv_plan** plan_out) {
+extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_conv_plan** plan_out) {
   JD_REQUIRE(plan_out, "jd_conv_plan_create: plan_out is null");
   JD_REQUIRE(H > 0 && W > 0 && kh > 0 && kw > 0, "jd_conv_plan_create: non-positive shape (%d,%d,%d,%d)", H,
              W, kh, kw);
   JD_REQUIRE((long)H * W < (1L << 31), "jd_conv_plan_create: image too large");
+  JD_REQUIRE(mode >= JD_CONV_MODE_AUTO && mode <= JD_CONV_MODE_DIRECT, "jd_conv_plan_create: unknown mode %d", mode);
+  JD_REQUIRE(mode != JD_CONV_MODE_DIRECT || direct_conv_supported(kh, kw),
+             "jd_conv_plan_create: the direct method supports PSFs up to 33x33, got %dx%d", kh, kw);
+  const bool exact_shape = mode == JD_CONV_MODE_FFT_EXACT;
+  if (mode == JD_CONV_MODE_DIRECT || (mode == JD_CONV_MODE_AUTO && direct_conv_supported(kh, kw))) {
+    jd_conv_plan* p = new (std::nothrow) jd_conv_plan();
+    if (!p) return fail(JD_ERR_ALLOC, "jd_conv_plan_create: out of host memory");
+    p->method = JD_CONV_DIRECT;
+    p->H = H, p->W = W, p->kh = kh, p->kw = kw, p->Hp = H, p->Wp = W;
+    p->oy = (kh - 1) / 2, p->ox = (kw - 1) / 2, p->py = 0, p->px = 0;
+    p->nspec = direct_conv_fragment_floats(kh, kw);
+    p->partials_cap = poisson_fused_max_partials(H, W);
+    int rc = JD_OK;
+    if (hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
+      rc = fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc of the partial sums failed");
+    if (!rc) rc = ensure_component_buffers(p, 1);
+    if (rc) {
+      jd_conv_plan_destroy(p);
+      return rc;
+    }
+    *plan_out = p;
+    return JD_OK;
+  }
   static std::once_flag once;
   static rocfft_status setup_status = rocfft_status_success;
   std::call_once(once, [] { setup_status = rocfft_setup(); });
@@ -109,6 +152,7 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int exact_shape
   p->Wp = exact_shape ? fw : next_fast_len(fw, 4);
   p->oy = (kh - 1) / 2;  // `_centered`: (full - new) // 2   (utils/torch.py:337-344)
   p->ox = (kw - 1) / 2;
+  p->py = p->oy, p->px = p->ox;
   p->nspec = (size_t)p->Hp * (p->Wp / 2 + 1);
 
   auto cleanup = [&](int rc) {
@@ -171,9 +215,12 @@ extern "C" int jd_conv_plan_shape(const jd_conv_plan* p, int* shape6) {
 
 extern "C" size_t jd_conv_plan_spectrum_size(const jd_conv_plan* p) { return p ? p->nspec : 0; }
 
+extern "C" int jd_conv_plan_method(const jd_conv_plan* p) { return p ? p->method : -1; }
+
 extern "C" int jd_conv_psf_spectrum(jd_conv_plan* p, const float* psf, float* khat, void* stream) {
   JD_REQUIRE(p && psf && khat, "jd_conv_psf_spectrum: null argument");
   hipStream_t s = as_stream(stream);
+  if (p->method == JD_CONV_DIRECT) return launch_toeplitz_fragments(psf, khat, khat + p->nspec, p->kh, p->kw, s);
   int rc = launch_pad_mul(psf, nullptr, p->pad[0], p->kh, p->kw, p->Hp, p->Wp, s);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[0], p->spec, s))) return rc;
@@ -190,6 +237,8 @@ extern "C" int jd_conv_same(jd_conv_plan* p, const float* image, const float* sc
                             float* out, void* stream) {
   JD_REQUIRE(p && image && khat && out, "jd_conv_same: null argument");
   hipStream_t s = as_stream(stream);
+  if (p->method == JD_CONV_DIRECT)
+    return launch_direct_conv(image, scale_image, khat, out, nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0, s);
   int rc = conv_forward(p, 0, image, scale_image, khat, s);
   if (rc) return rc;
   return launch_crop(p->conv[0], out, p->H, p->W, p->Wp, p->oy, p->ox, s);
@@ -199,11 +248,12 @@ extern "C" int jd_conv_same_adjoint(jd_conv_plan* p, const float* grad_out, cons
                                     const float* khat, float* grad_image, int accumulate, void* stream) {
   JD_REQUIRE(p && grad_out && khat && grad_image, "jd_conv_same_adjoint: null argument");
   hipStream_t s = as_stream(stream);
+  if (p->method == JD_CONV_DIRECT)
+    return launch_direct_conv(grad_out, nullptr, khat + p->nspec, grad_image, scale_image, p->H, p->W, p->kh, p->kw,
+                              p->oy, p->ox, 1, 1.f, accumulate, s);
   int rc = launch_pad_mul(grad_out, nullptr, p->pad[0], p->H, p->W, p->Hp, p->Wp, s);
   if (rc) return rc;
-  if ((rc = corr_backward(p, 0, khat, s))) return rc;
-  return launch_adjoint_epilogue(p->conv[0], scale_image, grad_image, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox,
-                                 1.f, accumulate, s);
+  return corr_backward_into(p, 0, khat, scale_image, grad_image, 1.f, accumulate, s);
 }
 
 extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,
@@ -234,7 +284,7 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
     a.g[c] = p->pad[c];
   }
   a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = p->partials;
-  a.n_comp = n_comp, a.H = p->H, a.W = p->W, a.Hp = p->Hp, a.Wp = p->Wp, a.oy = p->oy, a.ox = p->ox;
+  a.n_comp = n_comp, a.H = p->H, a.W = p->W, a.Hp = p->Hp, a.Wp = p->Wp, a.oy = p->py, a.ox = p->px;
   a.eps = eps;
   const double n_pix = (double)p->H * (double)p->W;
   a.inv_n = (float)(1.0 / n_pix);
@@ -246,11 +296,7 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
   if (!grad_flux) return JD_OK;
 
   // adjoint: d loss / d flux_c = E_c * corr(psf_c, g_c)
-  for (int c = 0; c < n_comp; ++c) {
-    if ((rc = corr_backward(p, c, khat[c], s))) return rc;
-    if ((rc = launch_adjoint_epilogue(p->conv[c], exposure[c], grad_flux[c], p->H, p->W, p->Hp, p->Wp, p->oy,
-                                      p->ox, grad_scale, accumulate, s)))
-      return rc;
-  }
+  for (int c = 0; c < n_comp; ++c)
+    if ((rc = corr_backward_into(p, c, khat[c], exposure[c], grad_flux[c], grad_scale, accumulate, s))) return rc;
   return JD_OK;
 }

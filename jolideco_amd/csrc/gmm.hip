@@ -17,6 +17,7 @@
 // y for that component and applies P' once more, the overlap-add is done race-free and in a fixed
 // order by a gather pass (every pixel sums its <= 4 patch contributions).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "jd_common.h"
@@ -194,63 +195,212 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(GmmFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Backward, max mode: per patch  gamma = -P'_k* (x^T P'_k* - m'_k*),  gbar = gamma - mean(gamma)
-// One wave per patch; lane = pixel (row-major 8x8).  P' rows and columns are read coalesced from
-// the row-major copy and its transpose (both L2 resident).
+// Backward, max mode: per patch  gamma = -P'_k* (xbar^T P'_k* - m'_k*),  gbar = gamma - mean(gamma).
+// Every patch uses the matrix of ITS arg-max component, so the patches are first bucketed by
+// component (counting sort: LDS histograms + one global atomic per bin and block; the order inside a
+// bucket does not influence any result); buckets are padded to 32 slots.  One wave then takes a
+// 32-slot group, i.e. 32 patches that share P'_k, and runs both products on the matrix cores:
+//   Y^T = P'^T Xbar^T - m'      (as in the forward kernel)
+//   G^T = P' Y^T                (the Y accumulators ARE the B operand: lane (h, c) holds Y[j][c] for 32
+//                                values of j, and the A fragments of this product are laid out on the
+//                                host in exactly that j order, so no lane movement / LDS is needed)
+// 128 MFMAs per 32 patches instead of 2 x 16 KB of matrix reads per patch.
 // ------------------------------------------------------------------------------------------
-struct GmmBwdArgs {
-  const float* flux;
-  const float* prow;  // K * 64 * 64, P'[k][i][j]
-  const float* pcol;  // K * 64 * 64, P'[k][j][i] (transpose)
-  const float* mrow;  // K * 64, m'
-  const int32_t* argmax;
-  float* gpatch;  // (n_end - n_begin) * 64
-  int H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+struct GmmBucketArgs {
+  const int32_t* argmax;  // global patch index -> component or -1
+  int n_begin, n_end, K;
+  int* counts;    // K      (zeroed by the caller)
+  int* cursor;    // K      (zeroed by the caller)
+  int* offsets;   // K + 1  exclusive scan of the padded counts; offsets[K] = total slots
+  int32_t* order; // slot -> global patch index, -1 for padding (pre-filled with -1 by the caller)
+  float* gpatch;  // rows of filtered patches (argmax < 0) are zeroed here
 };
 
-__device__ __forceinline__ float readlane_f(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+constexpr int BUCKET_CHUNK = 1024;  // patches per block (4 per thread)
+constexpr int BUCKET_MAX_K = 4096;  // LDS histogram capacity
+
+__global__ __launch_bounds__(256) void gmm_bucket_count_kernel(GmmBucketArgs a) {
+  extern __shared__ int hist[];
+  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
+  __syncthreads();
+  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
+#pragma unroll
+  for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
+    const int n = base + i * 256 + threadIdx.x;
+    if (n < a.n_end) {
+      const int k = a.argmax[n];
+      if (k >= 0) atomicAdd(&hist[k], 1);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < a.K; k += 256)
+    if (hist[k]) atomicAdd(&a.counts[k], hist[k]);
 }
+
+__global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
+  // exclusive scan of the padded bucket sizes: thread t owns a contiguous segment of bins,
+  // the 256 segment sums are scanned in LDS (Hillis-Steele)
+  __shared__ int part[2][256];
+  const int seg = (a.K + 255) / 256;
+  const int k0 = threadIdx.x * seg;
+  int local = 0;
+  for (int k = k0; k < k0 + seg && k < a.K; ++k) local += (a.counts[k] + 31) & ~31;
+  int cur = 0;
+  part[0][threadIdx.x] = local;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int v = part[cur][threadIdx.x];
+    if ((int)threadIdx.x >= off) v += part[cur][threadIdx.x - off];
+    part[cur ^ 1][threadIdx.x] = v;
+    cur ^= 1;
+    __syncthreads();
+  }
+  int total = part[cur][threadIdx.x] - local;  // exclusive prefix of this thread's segment
+  for (int k = k0; k < k0 + seg && k < a.K; ++k) {
+    a.offsets[k] = total;
+    total += (a.counts[k] + 31) & ~31;
+  }
+  if (threadIdx.x == 255) a.offsets[a.K] = part[cur][255];
+}
+
+__global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a) {
+  extern __shared__ int hist[];  // [0, K): block-local counts, then the block's base inside each bucket
+  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
+  __syncthreads();
+  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
+  int kk[BUCKET_CHUNK / 256], rank[BUCKET_CHUNK / 256];
+#pragma unroll
+  for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
+    const int n = base + i * 256 + threadIdx.x;
+    kk[i] = -2;
+    if (n < a.n_end) {
+      kk[i] = a.argmax[n];
+      if (kk[i] >= 0) {
+        rank[i] = atomicAdd(&hist[kk[i]], 1);
+      } else {  // filtered patch (patches/core.py:215-216): no gradient
+        float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
+        for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < a.K; k += 256) {
+    const int c = hist[k];
+    hist[k] = c ? a.offsets[k] + atomicAdd(&a.cursor[k], c) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < BUCKET_CHUNK / 256; ++i)
+    if (kk[i] >= 0) a.order[hist[kk[i]] + rank[i]] = base + i * 256 + threadIdx.x;
+}
+
+struct GmmBwdArgs {
+  const float* flux;
+  const float* pfrag;  // as in the forward kernel
+  const float* mfrag;
+  const float* gfrag;  // K * 2 * FRAG_FLOATS: A fragments of the second product
+  const int32_t* argmax;
+  const int32_t* order;
+  const int* offsets;  // offsets[K] = total slots
+  float* gpatch;       // (n_end - n_begin) * 64
+  int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+};
 
 __global__ __launch_bounds__(256) void gmm_bwd_max_kernel(GmmBwdArgs a) {
   const int lane = threadIdx.x & 63;
+  const int h = lane >> 5, c = lane & 31;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * 4;
-  const int r = lane >> 3, cc = lane & 7;
-  for (int n = a.n_begin + wave_global; n < a.n_end; n += n_waves) {
-    const int k = __builtin_amdgcn_readfirstlane(a.argmax[n]);
-    float* out = a.gpatch + (size_t)(n - a.n_begin) * D;
-    if (k < 0) {  // patch filtered out (patches/core.py:215-216): no gradient
-      out[lane] = 0.f;
-      continue;
-    }
-    const int py = n / a.nPx, px = n % a.nPx;
-    const int yy = wrap(py * a.stride + r - a.shift_y, a.H);
-    const int xx = wrap(px * a.stride + cc - a.shift_x, a.W);
-    const float xv = a.flux[(size_t)yy * a.W + xx];
-    const float xb = xv - wave_sum(xv) * (1.f / 64.f);
+  const int n_groups = a.offsets[a.K] >> 5;
+  for (int g = wave_global; g < n_groups; g += n_waves) {
+    const int n = a.order[32 * g + c];
+    const bool valid = n >= 0;
+    // slot 0 of a group is always occupied (padding sits at the end of a bucket)
+    const int k = __builtin_amdgcn_readfirstlane(a.argmax[__builtin_amdgcn_readfirstlane(n)]);
 
-    const float* prow = a.prow + (size_t)k * D * D + lane;
-    const float* pcol = a.pcol + (size_t)k * D * D + lane;
-    float y0 = -a.mrow[k * D + lane], y1 = 0.f, y2 = 0.f, y3 = 0.f;
+    // ---- B operand: pixels 32h .. 32h+31 of patch c, mean subtracted --------------------------
+    float x[32];
+    {
+      const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
+      float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < D; i += 4) {
-      y0 = fmaf(readlane_f(xb, i), prow[(i + 0) * D], y0);
-      y1 = fmaf(readlane_f(xb, i + 1), prow[(i + 1) * D], y1);
-      y2 = fmaf(readlane_f(xb, i + 2), prow[(i + 2) * D], y2);
-      y3 = fmaf(readlane_f(xb, i + 3), prow[(i + 3) * D], y3);
-    }
-    const float y = (y0 + y1) + (y2 + y3);  // lane j holds y'_j
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const int yy = wrap(py * a.stride + 4 * h + r - a.shift_y, a.H);
+        const float* row = a.flux + (size_t)yy * a.W;
 #pragma unroll
-    for (int j = 0; j < D; j += 4) {
-      g0 = fmaf(readlane_f(y, j), pcol[(j + 0) * D], g0);
-      g1 = fmaf(readlane_f(y, j + 1), pcol[(j + 1) * D], g1);
-      g2 = fmaf(readlane_f(y, j + 2), pcol[(j + 2) * D], g2);
-      g3 = fmaf(readlane_f(y, j + 3), pcol[(j + 3) * D], g3);
+        for (int cc = 0; cc < 8; ++cc) {
+          const int xx = wrap(px * a.stride + cc - a.shift_x, a.W);
+          const float v = valid ? row[xx] : 0.f;
+          x[8 * r + cc] = v;
+          sum += v;
+        }
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.f / 64.f);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) x[s] -= mean;
     }
-    const float gamma = -((g0 + g1) + (g2 + g3));  // lane i holds d l / d xbar_i
-    out[lane] = gamma - wave_sum(gamma) * (1.f / 64.f);  // adjoint of the mean subtraction
+
+    // ---- Y^T = P'^T Xbar^T - m' ------------------------------------------------------------------
+    f32x16 y[2];
+    {
+      const float4* pk = reinterpret_cast<const float4*>(a.pfrag) + (size_t)k * (2 * FRAG_FLOATS / 4) + lane;
+      const float4* mk = reinterpret_cast<const float4*>(a.mfrag) + (size_t)k * 16 + h * 4;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float4 A[8];
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) A[qd] = pk[rb * (FRAG_FLOATS / 4) + qd * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 m = mk[rb * 8 + i];
+          y[rb][4 * i] = m.x, y[rb][4 * i + 1] = m.y, y[rb][4 * i + 2] = m.z, y[rb][4 * i + 3] = m.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          const float av = (s & 3) == 0 ? A[s >> 2].x : (s & 3) == 1 ? A[s >> 2].y : (s & 3) == 2 ? A[s >> 2].z : A[s >> 2].w;
+          y[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[s], y[rb], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- G^T = P' Y^T : k-step s feeds lane (h, c) value y[s >> 4][s & 15] ------------------------
+    f32x16 gacc[2];
+    {
+      const float4* gk = reinterpret_cast<const float4*>(a.gfrag) + (size_t)k * (2 * FRAG_FLOATS / 4) + lane;
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb) {
+        float4 A[8];
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) A[qd] = gk[pb * (FRAG_FLOATS / 4) + qd * 64];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gacc[pb][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          const float av = (s & 3) == 0 ? A[s >> 2].x : (s & 3) == 1 ? A[s >> 2].y : (s & 3) == 2 ? A[s >> 2].z : A[s >> 2].w;
+          gacc[pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, y[s >> 4][s & 15], gacc[pb], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- gamma = -G, subtract its mean over the 64 pixels (adjoint of the mean subtraction) -------
+    float sum = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += gacc[pb][i];
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.f / 64.f);
+    if (valid) {
+      // lane (h, c) holds pixels 32 pb + 8 q + 4 h + (0..3) of its patch in gacc[pb][4 q .. 4 q + 3]
+      float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          out[8 * pb + 2 * q + h] = make_float4(mean - gacc[pb][4 * q], mean - gacc[pb][4 * q + 1],
+                                                mean - gacc[pb][4 * q + 2], mean - gacc[pb][4 * q + 3]);
+    }
   }
 }
 
@@ -304,12 +454,13 @@ struct jd_gmm {
   float* pfrag = nullptr;
   float* mfrag = nullptr;
   float* const_k = nullptr;
-  float* prow = nullptr;
-  float* pcol = nullptr;
-  float* mrow = nullptr;
+  float* gfrag = nullptr;
+  int* bucket = nullptr;  // counts (K) | cursor (K) | offsets (K + 1)
   // workspaces (grown on demand)
   int32_t* argmax = nullptr;
   size_t argmax_cap = 0;
+  int32_t* order = nullptr;
+  size_t order_cap = 0;
   float* gpatch = nullptr;
   size_t gpatch_cap = 0;
   double* partials = nullptr;
@@ -333,25 +484,23 @@ static int grow(Tp** ptr, size_t* cap, size_t need) {
 extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float* mu_prec, const float* const_k,
                              const float* pixel_w, jd_gmm** gmm_out) {
   JD_REQUIRE(gmm_out && prec_chol && mu_prec && const_k && pixel_w, "jd_gmm_create: null argument");
-  JD_REQUIRE(K >= 1 && K <= 65536, "jd_gmm_create: K = %d out of range", K);
+  JD_REQUIRE(K >= 1 && K <= BUCKET_MAX_K, "jd_gmm_create: K = %d out of range [1, %d]", K, BUCKET_MAX_K);
   JD_REQUIRE(Dn == D, "jd_gmm_create: only 8x8 patches (D = 64) are supported, got D = %d", Dn);
   jd_gmm* g = new (std::nothrow) jd_gmm();
   if (!g) return fail(JD_ERR_ALLOC, "jd_gmm_create: out of host memory");
   g->K = K;
 
-  std::vector<float> pfrag((size_t)K * 2 * FRAG_FLOATS), mfrag((size_t)K * 64), prow((size_t)K * D * D),
-      pcol((size_t)K * D * D), mrow((size_t)K * D);
+  std::vector<float> pfrag((size_t)K * 2 * FRAG_FLOATS), gfrag((size_t)K * 2 * FRAG_FLOATS), mfrag((size_t)K * 64),
+      prow((size_t)D * D), mrow(D);
   double sw[D];
   for (int j = 0; j < D; ++j) sw[j] = std::sqrt((double)pixel_w[j]);
   for (int k = 0; k < K; ++k) {
     const float* Pk = prec_chol + (size_t)k * D * D;
     for (int i = 0; i < D; ++i)
       for (int j = 0; j < D; ++j) {
-        const float v = (float)((double)Pk[i * D + j] * sw[j]);  // P'[i][j] = P[i][j] * sqrt(w_j)
-        prow[((size_t)k * D + i) * D + j] = v;
-        pcol[((size_t)k * D + j) * D + i] = v;
+        prow[(size_t)i * D + j] = (float)((double)Pk[i * D + j] * sw[j]);  // P'[i][j] = P[i][j] * sqrt(w_j)
       }
-    for (int j = 0; j < D; ++j) mrow[(size_t)k * D + j] = (float)((double)mu_prec[(size_t)k * D + j] * sw[j]);
+    for (int j = 0; j < D; ++j) mrow[j] = (float)((double)mu_prec[(size_t)k * D + j] * sw[j]);
     // MFMA A fragments: [k][rb][qd][lane][e] = P'[pixel 32h + 4qd + e][j = 32rb + c]
     for (int rb = 0; rb < 2; ++rb)
       for (int qd = 0; qd < 8; ++qd)
@@ -359,14 +508,26 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
           for (int e = 0; e < 4; ++e) {
             const int hh = lane >> 5, cc = lane & 31;
             const int pix = 32 * hh + 4 * qd + e, j = 32 * rb + cc;
-            pfrag[(((size_t)(k * 2 + rb) * 8 + qd) * 64 + lane) * 4 + e] = prow[((size_t)k * D + pix) * D + j];
+            pfrag[(((size_t)(k * 2 + rb) * 8 + qd) * 64 + lane) * 4 + e] = prow[(size_t)pix * D + j];
+          }
+    // A fragments of the backward product G^T = P' Y^T: [k][pb][qd][lane][e], k-step s = 4 qd + e
+    // pairs with the Y accumulator register (rb = s >> 4, i = s & 15) of lane half hh, which holds
+    // j = 32 rb + (i & 3) + 8 (i >> 2) + 4 hh
+    for (int pb = 0; pb < 2; ++pb)
+      for (int qd = 0; qd < 8; ++qd)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 4; ++e) {
+            const int hh = lane >> 5, cc = lane & 31, st = 4 * qd + e;
+            const int rb = st >> 4, i = st & 15;
+            const int j = 32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hh, pix = 32 * pb + cc;
+            gfrag[(((size_t)(k * 2 + pb) * 8 + qd) * 64 + lane) * 4 + e] = prow[(size_t)pix * D + j];
           }
     // accumulator init: [k][rb][h][i] = -m'[j = 32rb + (i&3) + 8(i>>2) + 4h]
     for (int rb = 0; rb < 2; ++rb)
       for (int hh = 0; hh < 2; ++hh)
         for (int i = 0; i < 16; ++i) {
           const int j = 32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          mfrag[(((size_t)k * 2 + rb) * 2 + hh) * 16 + i] = -mrow[(size_t)k * D + j];
+          mfrag[(((size_t)k * 2 + rb) * 2 + hh) * 16 + i] = -mrow[j];
         }
   }
   auto upload = [&](float** dst, const float* src, size_t n) -> int {
@@ -376,10 +537,13 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
   };
   int rc;
   if ((rc = upload(&g->pfrag, pfrag.data(), pfrag.size())) || (rc = upload(&g->mfrag, mfrag.data(), mfrag.size())) ||
-      (rc = upload(&g->const_k, const_k, K)) || (rc = upload(&g->prow, prow.data(), prow.size())) ||
-      (rc = upload(&g->pcol, pcol.data(), pcol.size())) || (rc = upload(&g->mrow, mrow.data(), mrow.size()))) {
+      (rc = upload(&g->const_k, const_k, K)) || (rc = upload(&g->gfrag, gfrag.data(), gfrag.size()))) {
     jd_gmm_destroy(g);
     return rc;
+  }
+  if (hipMalloc(&g->bucket, (size_t)(3 * K + 1) * sizeof(int)) != hipSuccess) {
+    jd_gmm_destroy(g);
+    return fail(JD_ERR_ALLOC, "jd_gmm_create: hipMalloc of the bucket counters failed");
   }
   int dev = 0;
   hipDeviceProp_t prop;
@@ -392,9 +556,11 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
 extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (!g) return JD_OK;
   (void)hipDeviceSynchronize();
-  for (float* p : {g->pfrag, g->mfrag, g->const_k, g->prow, g->pcol, g->mrow, g->gpatch})
+  for (float* p : {g->pfrag, g->mfrag, g->const_k, g->gfrag, g->gpatch})
     if (p) (void)hipFree(p);
   if (g->argmax) (void)hipFree(g->argmax);
+  if (g->order) (void)hipFree(g->order);
+  if (g->bucket) (void)hipFree(g->bucket);
   if (g->partials) (void)hipFree(g->partials);
   delete g;
   return JD_OK;
@@ -402,6 +568,10 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
 
 // Pick the number of 32-patch tiles per wave so that the grid fills the 4 SIMDs of every CU.
 static int pick_tiles(long n_patches, int n_cu) {
+  if (const char* env = getenv("JD_GMM_TILES")) {  // tuning override: 1, 2 or 4
+    const int t = atoi(env);
+    if (t == 1 || t == 2 || t == 4) return t;
+  }
   const long simds = (long)n_cu * 4;
   for (int t : {4, 2}) {
     const long waves = (n_patches + 32L * t - 1) / (32L * t);
@@ -471,15 +641,30 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   if (!grad_flux_accum) return JD_OK;
 
   if ((rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;
-  GmmBwdArgs b{};
-  b.flux = flux, b.prow = g->prow, b.pcol = g->pcol, b.mrow = g->mrow, b.argmax = arg, b.gpatch = g->gpatch;
-  b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
-  b.n_begin = n_begin, b.n_end = n_end;
-  long bwd_blocks = (n + 3) / 4;
-  const long cap = (long)g->n_cu * 8;
-  if (bwd_blocks > cap) bwd_blocks = cap;
+  const size_t slots_cap = (size_t)n + 32 * (size_t)g->K;
+  if ((rc = grow(&g->order, &g->order_cap, slots_cap))) return rc;
+  // ---- bucket the patches by arg-max component -------------------------------------------------
+  GmmBucketArgs bk{};
+  bk.argmax = arg, bk.n_begin = n_begin, bk.n_end = n_end, bk.K = g->K;
+  bk.counts = g->bucket, bk.cursor = g->bucket + g->K, bk.offsets = g->bucket + 2 * g->K;
+  bk.order = g->order, bk.gpatch = g->gpatch;
+  JD_HIP(hipMemsetAsync(g->bucket, 0, (size_t)2 * g->K * sizeof(int), s));
+  JD_HIP(hipMemsetAsync(g->order, 0xFF, slots_cap * sizeof(int32_t), s));
+  const unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+  const size_t hist_bytes = (size_t)g->K * sizeof(int);
   {
     ProfScope prof(JD_KERNEL_GMM_BWD, s);
+    gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+    gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
+    gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+    GmmBwdArgs b{};
+    b.flux = flux, b.pfrag = g->pfrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
+    b.offsets = bk.offsets, b.gpatch = g->gpatch, b.K = g->K;
+    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
+    b.n_begin = n_begin, b.n_end = n_end;
+    long bwd_blocks = ((long)(slots_cap / 32) + 3) / 4;
+    const long cap = (long)g->n_cu * 3;  // 3 blocks of 4 waves per CU: one wave per SIMD x 3
+    if (bwd_blocks > cap) bwd_blocks = cap;
     gmm_bwd_max_kernel<<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
   }
   JD_LAUNCH_CHECK();

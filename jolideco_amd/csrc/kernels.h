@@ -25,6 +25,15 @@ int launch_adjoint_epilogue(const float* corr, const float* scale, float* grad, 
                             int Wp, int oy, int ox, float coef, int accumulate, hipStream_t stream);
 int launch_crop(const float* padded, float* out, int H, int W, int Wp, int oy, int ox, hipStream_t stream);
 
+// direct (MFMA Toeplitz) convolution for small PSFs (directconv.hip)
+enum { JD_CONV_FFT = 0, JD_CONV_DIRECT = 1 };
+bool direct_conv_supported(int kh, int kw);
+size_t direct_conv_fragment_floats(int kh, int kw);
+int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_adj, int kh, int kw, hipStream_t stream);
+int launch_direct_conv(const float* in, const float* in_scale, const float* afrag, float* out, const float* out_scale,
+                       int H, int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
+                       hipStream_t stream);
+
 // kernel timers (profile.hip): RAII bracket around one launch
 int prof_begin(int kernel, hipStream_t s);
 void prof_end(int slot, hipStream_t s);

@@ -89,6 +89,7 @@ extern "C" const char* jd_kernel_name(int kernel) {
     case JD_KERNEL_ADAM: return "adam_kernel";
     case JD_KERNEL_FFT_R2C: return "rocfft_r2c";
     case JD_KERNEL_FFT_C2R: return "rocfft_c2r";
+    case JD_KERNEL_DIRECT_CONV: return "direct_conv_kernel";
     default: return "?";
   }
 }

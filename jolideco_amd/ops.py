@@ -47,33 +47,57 @@ def stirling_mean(counts):
     return float(term.mean())
 
 
+CONV_MODES = {"auto": 0, "fft-exact": 1, "fft": 2, "direct": 3}  # JD_CONV_MODE_* of include/jolideco_hip.h
+
+
+def default_conv_method():
+    """Convolution method used when none is requested: "auto" (the library picks the MFMA direct
+    kernel for PSFs up to 33x33 and rocFFT otherwise) unless JOLIDECO_CONV_METHOD overrides it."""
+    import os
+
+    method = os.environ.get("JOLIDECO_CONV_METHOD", "auto")
+    if method not in CONV_MODES:
+        raise ValueError(f"JOLIDECO_CONV_METHOD={method!r}, must be one of {sorted(CONV_MODES)}")
+    return method
+
+
 class ConvPlan:
-    """FFT 'same'-convolution plan for one (H, W, kh, kw) geometry (jd_conv_plan)."""
+    """'same'-convolution plan for one (H, W, kh, kw) geometry (jd_conv_plan).
+
+    ``method``: "auto" | "fft" (rocFFT, fast padded grid) | "fft-exact" (rocFFT on the reference's
+    (H+kh-1, W+kw-1) grid) | "direct" (MFMA Toeplitz kernel, PSFs up to 33x33)."""
 
     _cache = {}
 
-    def __init__(self, H, W, kh, kw, device, exact_shape=False):
+    def __init__(self, H, W, kh, kw, device, exact_shape=False, method=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("ConvPlan needs a HIP device (no CPU fallback)")
+        if method is None:
+            method = "fft-exact" if exact_shape else default_conv_method()
+        if method not in CONV_MODES:
+            raise ValueError(f"unknown convolution method {method!r}, must be one of {sorted(CONV_MODES)}")
         handle = c_void_p()
         with torch.cuda.device(self.device):
-            check(_hip.lib().jd_conv_plan_create(H, W, kh, kw, int(exact_shape), ctypes.byref(handle)))
+            check(_hip.lib().jd_conv_plan_create(H, W, kh, kw, CONV_MODES[method], ctypes.byref(handle)))
         self._handle = handle
         shape = (c_int * 6)()
         check(_hip.lib().jd_conv_plan_shape(self._handle, shape))
         self.H, self.W, self.Hp, self.Wp, self.oy, self.ox = (int(v) for v in shape)
         self.kh, self.kw = kh, kw
         self.spectrum_size = int(_hip.lib().jd_conv_plan_spectrum_size(self._handle))
+        self.method = "direct" if _hip.lib().jd_conv_plan_method(self._handle) == 1 else "fft"
 
     @classmethod
-    def get(cls, H, W, kh, kw, device, exact_shape=False):
+    def get(cls, H, W, kh, kw, device, exact_shape=False, method=None):
         device = torch.device(device)
         if device.type == "cuda" and device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (str(device), H, W, kh, kw, bool(exact_shape))
+        if method is None:
+            method = "fft-exact" if exact_shape else default_conv_method()
+        key = (str(device), H, W, kh, kw, method)
         if key not in cls._cache:
-            cls._cache[key] = cls(H, W, kh, kw, device, exact_shape)
+            cls._cache[key] = cls(H, W, kh, kw, device, method=method)
         return cls._cache[key]
 
     @classmethod

@@ -27,7 +27,7 @@ def _trace_close(trace, arrays, prefix="trace/", rtol=2e-5):
             np.testing.assert_allclose(trace[name], ref, rtol=rtol, atol=1e-6, err_msg=name)
 
 
-def test_anchor_a_uniform_prior_128(golden):
+def test_anchor_a_uniform_prior_128(golden, conv_method):
     """BASELINE config 1 (examples/first-steps.py path): 128^2 point source, uniform prior, 50 epochs."""
     from jolideco_amd import MAPDeconvolver, SpatialFluxComponent
 
@@ -45,7 +45,7 @@ def test_anchor_a_uniform_prior_128(golden):
     np.testing.assert_allclose(res.trace_loss[-1]["total"], 2.311005, rtol=1e-5)
 
 
-def test_anchor_b_gmm_prior_sequential(golden):
+def test_anchor_b_gmm_prior_sequential(golden, conv_method):
     """64^2, 3 observations, GMM patch prior (K=8), 10 epochs = 30 steps + 10 trace draws."""
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
 

@@ -23,7 +23,7 @@ def _case(stages, name):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_fused_npred_poisson_fwd_bwd(golden, name):
+def test_fused_npred_poisson_fwd_bwd(golden, name, conv_method):
     """jd_npred_poisson_fwd_bwd == NPredModels.evaluate + PoissonNLLLoss + autograd of the reference."""
     from jolideco_amd import FluxComponents, NPredModels, SpatialFluxComponent
     from jolideco_amd.ops import stirling_mean
@@ -34,6 +34,7 @@ def test_fused_npred_poisson_fwd_bwd(golden, name):
     comps = FluxComponents()
     comps["flux"] = SpatialFluxComponent.from_numpy(flux=np.exp(sub["theta"]))
     models = NPredModels.from_dataset_numpy(dataset=data, components=comps, device=DEV)
+    assert models.plan.method == conv_method
     # edge corrected exposure (models/npred.py:108-113)
     assert rel_linf(models["flux"].exposure.cpu().numpy()[0, 0], sub["exposure_corrected"]) < 2e-6
 
@@ -59,7 +60,7 @@ def test_fused_npred_poisson_fwd_bwd(golden, name):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_autograd_seams_match_fused_path(golden, name):
+def test_autograd_seams_match_fused_path(golden, name, conv_method):
     """NPredModels.evaluate + loss_function + backward (the reference's own loop structure)."""
     from jolideco_amd import FluxComponents, PoissonLoss, SpatialFluxComponent
 
@@ -198,7 +199,7 @@ def test_gmm_estimate_log_prob_matches_sklearn_formula():
             np.testing.assert_allclose(got, sk._estimate_weighted_log_prob(X=x), rtol=2e-5, atol=2e-4)
 
 
-def test_convolve_fft_torch_known_answers():
+def test_convolve_fft_torch_known_answers(conv_method):
     """Reference test utils/tests/test_torch.py:24-41: box image * normalised box kernel."""
     from scipy.signal import convolve2d
 
@@ -255,3 +256,59 @@ def test_product_path_fails_loudly_without_gpu_tensors():
 
     with pytest.raises(RuntimeError):
         convolve_fft_torch(torch.zeros(1, 1, 8, 8), torch.ones(1, 1, 3, 3))
+
+
+@pytest.mark.parametrize(
+    "shape,kshape",
+    [((64, 64), (1, 1)), ((70, 130), (17, 17)), ((129, 67), (33, 33)), ((50, 200), (2, 31)), ((203, 61), (32, 3)),
+     ((256, 256), (5, 16))],
+)
+def test_direct_conv_matches_fft_and_float64(shape, kshape):
+    """The MFMA Toeplitz kernel, rocFFT on the fast grid and rocFFT on the reference's exact grid
+    all compute the same 'same' convolution and its adjoint (ragged tiles, even / 1-pixel PSFs)."""
+    from scipy.signal import convolve2d
+
+    from jolideco_amd.ops import ConvPlan
+
+    rs = np.random.RandomState(sum(shape) + sum(kshape))
+    image = rs.gamma(2.0, size=shape).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    psf = rs.uniform(size=kshape).astype(np.float32)
+    psf /= psf.sum()
+    grad_out = rs.normal(size=shape).astype(np.float32)
+    kh, kw = kshape
+    full = convolve2d((image * scale).astype(np.float64), psf.astype(np.float64), mode="full")
+    oy, ox = (kh - 1) // 2, (kw - 1) // 2
+    ref = full[oy : oy + shape[0], ox : ox + shape[1]]
+    t = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
+    results = {}
+    for method in ("direct", "fft", "fft-exact"):
+        plan = ConvPlan(shape[0], shape[1], kh, kw, DEV, method=method)
+        assert plan.method == ("direct" if method == "direct" else "fft")
+        khat = plan.psf_spectrum(t(psf))
+        out = plan.conv_same(t(image), t(scale), khat)
+        adj = plan.conv_same_adjoint(t(grad_out), t(scale), khat)
+        acc = torch.full(shape, 2.0, device=DEV)
+        plan.conv_same_adjoint(t(grad_out), t(scale), khat, grad_image=acc, accumulate=True)
+        torch.cuda.synchronize()
+        assert rel_linf(out.cpu().numpy(), ref) < (2e-6 if method == "direct" else 1e-5), method
+        # <conv(u), g> == <u, adj(g)>  (adjoint identity in float64 on the host)
+        lhs = float((out.double().cpu() * torch.from_numpy(grad_out).double()).sum())
+        rhs = float((torch.from_numpy(image).double() * adj.double().cpu()).sum())
+        assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs)), method
+        assert rel_linf((acc - 2.0).cpu().numpy(), adj.cpu().numpy()) < 1e-5
+        results[method] = (out.cpu().numpy(), adj.cpu().numpy())
+        plan.close()
+    for method in ("fft", "fft-exact"):
+        assert rel_linf(results[method][0], results["direct"][0]) < 1e-5
+        assert rel_linf(results[method][1], results["direct"][1]) < 1e-5
+
+
+def test_large_psf_falls_back_to_fft():
+    from jolideco_amd.ops import ConvPlan
+
+    plan = ConvPlan(96, 96, 41, 41, DEV)
+    assert plan.method == "fft"
+    plan.close()
+    with pytest.raises(RuntimeError, match="33x33"):
+        ConvPlan(96, 96, 41, 41, DEV, method="direct")
