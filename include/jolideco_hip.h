@@ -123,11 +123,15 @@ int jd_conv_same_adjoint(jd_conv_plan* plan, const float* grad_out, const float*
  * jolideco/priors/patches/gmm.py: precisions_cholesky (K, D, D) (:139-149, utils/numpy.py:16-34),
  * means_precisions_cholesky (K, D) (:217-228), const_k[k] = -0.5*D*log(2*pi) + log_det_cholesky[k]
  * + log_weights[k] (:235-240,114-117,276-281) and pixel_weights (D,) (:283-299).  D must be 64
- * (8x8 patches).  The library re-lays them out in MFMA fragment order with sqrt(pixel_weight)
- * folded into the columns. */
+ * (8x8 patches), K <= 4096.  The library re-lays them out in MFMA fragment order with
+ * sqrt(pixel_weight) folded into the columns. */
 int jd_gmm_create(int K, int D, const float* prec_chol, const float* mu_prec, const float* const_k,
                   const float* pixel_w, jd_gmm** gmm_out);
 int jd_gmm_destroy(jd_gmm* gmm);
+/* 1 when every precisions_cholesky[k] is upper triangular (what compute_precision_cholesky,
+ * utils/numpy.py:16-34, produces): the kernels then skip the all-zero 16x16 blocks (40 instead of 64
+ * MFMAs per component and 16 patches, bit-identical results); 0 = dense variant. */
+int jd_gmm_is_triangular(const jd_gmm* gmm);
 
 /* log-prior value and gradient of GMMPatchPrior.__call__ (priors/patches/core.py:189-246) with
  * IdentityImageNorm, SubtractMeanPatchNorm (utils/norms.py:97-103), cycle-spin roll by

@@ -46,6 +46,7 @@ EXPORTS = {
     "jd_poisson_nll": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "jd_gmm_create": (c_int, [c_int, c_int, fp, fp, fp, fp, POINTER(c_void_p)]),
     "jd_gmm_destroy": (c_int, [c_void_p]),
+    "jd_gmm_is_triangular": (c_int, [c_void_p]),
     "jd_gmm_prior_fwd_bwd": (
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,

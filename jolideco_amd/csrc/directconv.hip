@@ -54,16 +54,27 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   const int xin0 = x0 + a.ox_in;
 
   // ---- stage the (rows x COLS) input window, zero outside the image ------------------------
-  for (int i = threadIdx.x; i < rows * COLS; i += 256) {
-    const int r = i / COLS, c = i - r * COLS;
-    const int y = yin0 + r, x = xin0 + c;
-    float v = 0.f;
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-      const size_t off = (size_t)y * a.W + x;
-      v = a.in[off];
-      if (a.in_scale) v *= a.in_scale[off];
+  // U independent loads per thread are issued before the first one is consumed (one latency per
+  // batch instead of one per element)
+  constexpr int U = 6;
+  const int total = rows * COLS;
+  for (int base = threadIdx.x; base < total; base += 256 * U) {
+    float v[U], sc[U];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + 256 * u;
+      const int r = i / COLS, c = i - r * COLS;
+      const int y = yin0 + r, x = xin0 + c;
+      const bool inside = (i < total) && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const size_t off = inside ? (size_t)y * a.W + x : 0;
+      dst[u] = (i < total) ? r * PITCH + c : -1;
+      v[u] = inside ? a.in[off] : 0.f;
+      sc[u] = (inside && a.in_scale) ? a.in_scale[off] : 1.f;
     }
-    win[r * PITCH + c] = v;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) win[dst[u]] = v[u] * sc[u];
   }
   __syncthreads();
 
@@ -80,9 +91,11 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   // window row of output row (16 b + n) for PSF row dy is 16 b + n + (kh - 1 - dy)
   const float* bp = win + (n + a.kh - 1) * PITCH + wave * 16 + kk;
   for (int dy = 0; dy < a.kh; ++dy) {
-    if (dy + 1 < a.kh) {
+    {  // unconditional prefetch of the next PSF row (the last iteration re-reads its own row): a
+       // branch here would make the compiler drain every outstanding load (vmcnt(0))
+      const int dn = dy + 1 < a.kh ? dy + 1 : dy;
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s) a_nxt[s] = af[((dy + 1) * STEPS + s) * 64];
+      for (int s = 0; s < STEPS; ++s) a_nxt[s] = af[(dn * STEPS + s) * 64];
     }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {

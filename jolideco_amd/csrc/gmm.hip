@@ -2,20 +2,26 @@
 //
 // Forward: for every overlapping 8x8 patch x (mean subtracted) and every mixture component k
 //     y_k = x^T P_k - m_k ,  q_k = sum_j w_j y_kj^2 ,  l_k = c_k - q_k / 2 ,  v = max_k l_k | logsumexp_k l_k
-// (jolideco/priors/patches/gmm.py:262-281, priors/patches/core.py:189-246).  This is a dense
-// contraction Y^T = P'^T X^T with M = 64*K whitened coordinates, N = patches, depth 64, i.e.
-// 2*64*64 flop per (patch, component): FLOP-bound on the fp32 roof.  It runs on the exact-fp32
-// matrix cores (v_mfma_f32_32x32x2_f32: bit-for-bit an fmaf chain, same peak as the vector ALU
-// but one operand VGPR per MFMA and the VALU left free for the epilogue):
-//   * A operand = P'_k fragments (sqrt(w_j) folded into column j, fragment order prepared once on
-//     the host) streamed from L2 with 16 B/lane loads, register double-buffered;
-//   * B operand = the wave's patches, resident in VGPRs for the whole kernel (T tiles of 32);
-//   * the accumulator is initialised with -m'_k so the mean shift costs nothing;
-//   * C layout puts the patch on the lane and the whitened coordinate j in the registers, so
-//     sum_j y_j^2 is an in-lane sum + one cross-half shuffle; (Np, K) never leaves the CU.
-// Backward (max mode): only the arg-max component contributes; a second, small kernel recomputes
-// y for that component and applies P' once more, the overlap-add is done race-free and in a fixed
-// order by a gather pass (every pixel sums its <= 4 patch contributions).
+// (jolideco/priors/patches/gmm.py:262-281, priors/patches/core.py:189-246).  Per component this is a
+// 64 x 64 matrix applied to every patch: a dense contraction, FLOP-bound on the fp32 roof.  It runs on
+// the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain in pixel order):
+//   M = whitened coordinate j (four 16-blocks), N = patch (16 per MFMA), K = pixel (4 per MFMA).
+//   * P_k = (L_k^-1)^T is UPPER TRIANGULAR (jolideco/utils/numpy.py:16-34), so y_j only needs pixels
+//     i <= j: 16-block jb of the whitened coordinates needs pixel steps 0 .. 4 (jb + 1) - 1.  Skipping
+//     the all-zero blocks removes 24 of the 64 MFMAs per (component, 16 patches) and changes no bit of
+//     the result (the skipped terms are exact zeros at the END of each fmaf chain).  jd_gmm_create checks
+//     the structure; a non-triangular matrix set takes the dense variant of the same kernel;
+//   * A operand = P'_k = P_k diag(sqrt w) fragments (pixel weights folded into the columns, fragment
+//     order prepared once on the host), streamed from L2, register double-buffered across components;
+//   * B operand = mean-subtracted patches, staged once per block in LDS in fragment order;
+//   * the accumulators start at -m'_k so the mean shift costs nothing;
+//   * C layout puts the patch on the lane (n = lane & 15) and the whitened coordinate in the registers,
+//     so sum_j y_j^2 is an in-lane sum + two VALU lane swaps; (Np, K) never leaves the CU.
+// One block = 4 waves (one per SIMD) shares TB tiles of 32 patches and splits the K components four
+// ways; the partial (max, arg-max) | (max, sum-exp) results are merged through LDS in component order.
+// Backward (max mode): the patches are bucketed by arg-max component; one wave takes 32 patches that
+// share P'_k and runs y = x^T P' - m' and gamma = -P' y on the matrix cores (same block skipping);
+// the overlap-add is done race-free and in a fixed order by a gather pass.
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -25,24 +31,25 @@
 
 namespace jd {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int P = 8;    // patch edge
-constexpr int D = 64;   // features per patch
-constexpr int FRAG_FLOATS = 2048;  // one (k, row-block) A fragment: 8 x 64 lanes x float4
+constexpr int P = 8;   // patch edge
+constexpr int D = 64;  // features per patch
+// per component: A fragments [jb 4][st4 4][lane 64][e 4] (P'[pixel 16 st4 + 4 e + (lane >> 4)][16 jb + (lane & 15)])
+constexpr int AFRAG_FLOATS = 4 * 4 * 64 * 4;
 
 enum { MODE_MAX = 0, MODE_LSE = 1, MODE_DENSE = 2 };
 
 struct GmmFwdArgs {
   const float* flux;     // (H, W) image  | MODE_DENSE: (n, 64) explicit patches
-  const float* pfrag;    // K * 2 * FRAG_FLOATS
-  const float* mfrag;    // K * 2 * 2 * 16   (negated m')
+  const float* afrag;    // K * AFRAG_FLOATS
+  const float* mfrag;    // K * 64: [jb 4][g 4][r 4] = -m'[16 jb + 4 g + r]
   const float* const_k;  // K
   int K, H, W, stride, nPx, shift_y, shift_x;
   int n_begin, n_end;    // linear patch index range (row-major over the patch grid)
   int32_t* argmax_out;   // nullable (MODE_MAX)
-  float* value_patch;    // nullable: per patch v (MODE_LSE backward needs it) | MODE_DENSE: (n, K) out
-  double* partials;      // one per wave
+  float* value_patch;    // nullable: per patch v | MODE_DENSE: (n, K) out
+  double* partials;      // one per block
 };
 
 __device__ __forceinline__ int wrap(int v, int n) {
@@ -50,148 +57,234 @@ __device__ __forceinline__ int wrap(int v, int n) {
   return v < 0 ? v + n : v;
 }
 
-template <int T, int MODE>
-__global__ __launch_bounds__(256) void gmm_fwd_kernel(GmmFwdArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int h = lane >> 5, c = lane & 31;
-  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int base = a.n_begin + wave_global * (32 * T);
-  if (base >= a.n_end) return;  // whole wave idle (wave-uniform)
+__device__ __forceinline__ float f4_get(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
-  // ---- B operand: T tiles of 32 patches; lane (h, c) keeps pixels 32h .. 32h+31 of patch c ----
-  float x[T][32];
-  bool ok[T];
+// v(lane) + v(lane ^ 16) + v(lane ^ 32) + v(lane ^ 48) on every lane with the gfx950 row / half swaps
+// (VALU only; no LDS round trip like ds_bpermute)
+__device__ __forceinline__ float sum_lane_groups(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Fragments of one component held by a lane: A[jb][st4] covers pixel steps 4 st4 .. 4 st4 + 3 of
+// coordinate block jb (only st4 <= jb is non-zero for a triangular P), M[jb] the accumulator init.
+struct FragBuf {
+  float4 a[4][4];
+  float4 m[4];
+};
+
+template <bool TRI>
+__device__ __forceinline__ void load_frags(FragBuf& f, const float4* af, const float4* mf, int k) {
+  const float4* ak = af + (size_t)k * (AFRAG_FLOATS / 4);
+  const float4* mk = mf + (size_t)k * 16;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int n = base + 32 * t + c;
-    const bool valid = n < a.n_end;
-    float sum = 0.f;
-    bool sel = true;
-    if (MODE == MODE_DENSE) {
+  for (int jb = 0; jb < 4; ++jb) {
 #pragma unroll
-      for (int s = 0; s < 32; ++s) x[t][s] = valid ? a.flux[(size_t)n * D + 32 * h + s] : 0.f;
+    for (int st4 = 0; st4 < 4; ++st4)
+      if (!TRI || st4 <= jb) f.a[jb][st4] = ak[(jb * 4 + st4) * 64];
+    f.m[jb] = mk[jb * 4];
+  }
+}
+
+// x[nb * 4 + st4]: B fragments of tile t (two 16-patch halves nb) for pixel steps 4 st4 .. 4 st4 + 3
+__device__ __forceinline__ void load_x(float4 (&x)[8], const float* xs_lane, int t) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const float4*>(xs_lane + (t * 8 + q) * 256);
+}
+
+// acc[jb][nb] = -m' + sum over the pixel steps of P'^T x  (pixel order = fmaf chain order)
+template <bool TRI>
+__device__ __forceinline__ void mfma_tile(f32x4 (&acc)[4][2], const FragBuf& f, const float4 (&x)[8]) {
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) acc[jb][nb] = f32x4{f.m[jb].x, f.m[jb].y, f.m[jb].z, f.m[jb].w};
+#pragma unroll
+  for (int st = 0; st < 16; ++st)
+#pragma unroll
+    for (int jb = TRI ? st / 4 : 0; jb < 4; ++jb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        acc[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(f.a[jb][st >> 2], st & 3),
+                                                           f4_get(x[nb * 4 + (st >> 2)], st & 3), acc[jb][nb], 0, 0, 0);
+}
+
+// l = c_k - q / 2 for the two 16-patch halves of a tile, then the branch-free update of the wave's
+// running state in LDS: st[nb * 16 + n] = max, st[32 + nb * 16 + n] = arg-max | sum-exp.
+template <int MODE>
+__device__ __forceinline__ void finish_tile(const f32x4 (&acc)[4][2], float* st, float ck, int k, const GmmFwdArgs& a,
+                                            int n_first, bool writer) {
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      q0 = fmaf(acc[jb][nb][0], acc[jb][nb][0], q0), q1 = fmaf(acc[jb][nb][1], acc[jb][nb][1], q1);
+      q0 = fmaf(acc[jb][nb][2], acc[jb][nb][2], q0), q1 = fmaf(acc[jb][nb][3], acc[jb][nb][3], q1);
+    }
+    const float l = fmaf(-0.5f, sum_lane_groups(q0 + q1), ck);  // gmm.py:276-281
+    float* s0 = st + nb * 16;
+    if (MODE == MODE_MAX) {
+      const float b = s0[0], ar = s0[32];
+      const bool better = l > b;  // strict: the lowest component wins a tie, like torch.max
+      s0[0] = better ? l : b;
+      s0[32] = better ? __int_as_float(k) : ar;
+    } else if (MODE == MODE_LSE) {
+      const float b = s0[0], sm = s0[32];
+      const bool better = l > b;
+      const float e = expf(better ? b - l : l - b);
+      s0[0] = better ? l : b;
+      s0[32] = better ? fmaf(sm, e, 1.f) : sm + e;
     } else {
-      const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int yy = wrap(py * a.stride + 4 * h + r - a.shift_y, a.H);
-        const float* row = a.flux + (size_t)yy * a.W;
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-          const int xx = wrap(px * a.stride + cc - a.shift_x, a.W);
-          const float v = valid ? row[xx] : 0.f;
-          x[t][8 * r + cc] = v;
-          sum += v;
-          sel = sel && (v > -1e5f);  // patches/core.py:215
-        }
-      }
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * (1.f / 64.f);  // SubtractMeanPatchNorm, utils/norms.py:100-103
-#pragma unroll
-      for (int s = 0; s < 32; ++s) x[t][s] -= mean;
-      const int sel_other = __shfl_xor((int)sel, 32, 64);
-      sel = sel && (sel_other != 0);
+      const int n = n_first + nb * 16;
+      if (writer && n < a.n_end) a.value_patch[(size_t)n * a.K + k] = l;
     }
-    ok[t] = valid && sel;
   }
+}
 
-  float best[T], aux[T];  // MODE_MAX: best value | MODE_LSE: running max, running sum of exp
-  int arg[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) best[t] = -INFINITY, aux[t] = 0.f, arg[t] = 0;
+// One component over the block's TB tiles, software pipelined by hand: while the MFMAs of tile t
+// issue, the wave has the B operands of tile t+1 in flight from LDS and finishes tile t-1 in the VALU
+// shadow of the matrix pipe.  Every stage is one basic block (no branches), TB is even and >= 4.
+template <int TB, int MODE, bool TRI>
+__device__ __forceinline__ void sweep_tiles(const FragBuf& f, const float* xs_lane, float* st_lane, float ck, int k,
+                                            const GmmFwdArgs& a, int n_lane, bool writer) {
+  static_assert(TB >= 4 && TB % 2 == 0, "TB must be even and >= 4");
+  float4 x0[8], x1[8];
+  f32x4 acc0[4][2], acc1[4][2];
+  load_x(x0, xs_lane, 0);
+  load_x(x1, xs_lane, 1);
+  mfma_tile<TRI>(acc0, f, x0);
+  for (int t = 1; t < TB - 1; t += 2) {
+    load_x(x0, xs_lane, t + 1);
+    mfma_tile<TRI>(acc1, f, x1);
+    finish_tile<MODE>(acc0, st_lane + (t - 1) * 64, ck, k, a, n_lane + 32 * (t - 1), writer);
+    load_x(x1, xs_lane, t + 2);  // t + 2 <= TB - 1
+    mfma_tile<TRI>(acc0, f, x0);
+    finish_tile<MODE>(acc1, st_lane + t * 64, ck, k, a, n_lane + 32 * t, writer);
+  }
+  mfma_tile<TRI>(acc1, f, x1);
+  finish_tile<MODE>(acc0, st_lane + (TB - 2) * 64, ck, k, a, n_lane + 32 * (TB - 2), writer);
+  finish_tile<MODE>(acc1, st_lane + (TB - 1) * 64, ck, k, a, n_lane + 32 * (TB - 1), writer);
+}
 
-  const float4* pf = reinterpret_cast<const float4*>(a.pfrag) + lane;
-  const float4* mf = reinterpret_cast<const float4*>(a.mfrag) + h * 4;
+// LDS index (in floats) of pixel p of patch c of tile t in B-fragment order:
+// [t][nb = c / 16][st4 = p / 16][g = p % 4][n = c % 16][e = (p % 16) / 4]
+__device__ __forceinline__ int xs_index(int t, int c, int p) {
+  return (((((t * 2 + (c >> 4)) * 4 + (p >> 4)) * 4 + (p & 3)) * 16 + (c & 15)) << 2) + ((p & 15) >> 2);
+}
 
-  float4 A0[8], A1[8];
-#pragma unroll
-  for (int qd = 0; qd < 8; ++qd) A0[qd] = pf[qd * 64];
+template <int TB, int MODE, bool TRI>
+__global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                                          // TB * 2048 floats
+  float* state = lds + TB * 2048;                           // [4 waves][TB][2][32 patches]
+  int* okf = reinterpret_cast<int*>(state + 4 * TB * 64);  // [TB * 32]
+  __shared__ double red[4];
 
-  for (int k = 0; k < a.K; ++k) {
-    const float4* pk = pf + (size_t)k * (2 * FRAG_FLOATS / 4);
-    const float4* mk = mf + (size_t)k * 16;  // 2 rb * 2 h * 4 float4
-    float4 m0[4], m1[4];
-#pragma unroll
-    for (int qd = 0; qd < 8; ++qd) A1[qd] = pk[FRAG_FLOATS / 4 + qd * 64];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m0[i] = mk[i], m1[i] = mk[8 + i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile_base = a.n_begin + blockIdx.x * (TB * 32);
 
-    float q[T];
-    // ---- row block 0 (whitened coordinates j = 0..31) ----
+  // ---- stage the block's patches (mean subtracted) in MFMA B-operand order ------------------
+  {
+    const int h = lane >> 5, c = lane & 31;  // lane (h, c) gathers pixels 32 h .. 32 h + 31 of patch c
+    for (int t = wave; t < TB; t += 4) {
+      const int n = tile_base + 32 * t + c;
+      const bool valid = n < a.n_end;
+      float x[32];
+      bool sel = true;
+      if (MODE == MODE_DENSE) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[4 * i] = m0[i].x, acc[4 * i + 1] = m0[i].y, acc[4 * i + 2] = m0[i].z, acc[4 * i + 3] = m0[i].w;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const float av = (s & 3) == 0 ? A0[s >> 2].x : (s & 3) == 1 ? A0[s >> 2].y : (s & 3) == 2 ? A0[s >> 2].z : A0[s >> 2].w;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[t][s], acc, 0, 0, 0);
-      }
-      float qq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) qq = fmaf(acc[i], acc[i], qq);
-      q[t] = qq;
-    }
-    // prefetch the next component's first fragment while row block 1 computes
-    if (k + 1 < a.K) {
-#pragma unroll
-      for (int qd = 0; qd < 8; ++qd) A0[qd] = pk[2 * FRAG_FLOATS / 4 + qd * 64];
-    }
-    // ---- row block 1 (j = 32..63) ----
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      f32x16 acc;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[4 * i] = m1[i].x, acc[4 * i + 1] = m1[i].y, acc[4 * i + 2] = m1[i].z, acc[4 * i + 3] = m1[i].w;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) {
-        const float av = (s & 3) == 0 ? A1[s >> 2].x : (s & 3) == 1 ? A1[s >> 2].y : (s & 3) == 2 ? A1[s >> 2].z : A1[s >> 2].w;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[t][s], acc, 0, 0, 0);
-      }
-      float qq = q[t];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) qq = fmaf(acc[i], acc[i], qq);
-      q[t] = qq;
-    }
-    // ---- per component epilogue: l = c_k - q/2 (gmm.py:276-281), then max / online logsumexp ----
-    const float ck = a.const_k[k];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const float qf = q[t] + __shfl_xor(q[t], 32, 64);
-      const float l = fmaf(-0.5f, qf, ck);
-      if (MODE == MODE_MAX) {
-        if (l > best[t]) best[t] = l, arg[t] = k;
-      } else if (MODE == MODE_LSE) {
-        if (l > best[t]) {
-          aux[t] = aux[t] * expf(best[t] - l) + 1.f;
-          best[t] = l;
-        } else {
-          aux[t] += expf(l - best[t]);
-        }
+        for (int s = 0; s < 32; ++s) x[s] = valid ? a.flux[(size_t)n * D + 32 * h + s] : 0.f;
       } else {
-        const int n = base + 32 * t + c;
-        if (h == 0 && n < a.n_end) a.value_patch[(size_t)n * a.K + k] = l;
+        const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int yy = wrap(py * a.stride + 4 * h + r - a.shift_y, a.H);
+          const float* row = a.flux + (size_t)yy * a.W;
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) {
+            const int xx = wrap(px * a.stride + cc - a.shift_x, a.W);
+            const float v = valid ? row[xx] : 0.f;
+            x[8 * r + cc] = v;
+            sum += v;
+            sel = sel && (v > -1e5f);  // patches/core.py:215
+          }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.f / 64.f);  // SubtractMeanPatchNorm, utils/norms.py:100-103
+#pragma unroll
+        for (int s = 0; s < 32; ++s) x[s] -= mean;
+        sel = sel && (__shfl_xor((int)sel, 32, 64) != 0);
       }
+#pragma unroll
+      for (int s = 0; s < 32; ++s) xs[xs_index(t, c, 32 * h + s)] = x[s];
+      if (h == 0) okf[t * 32 + c] = (valid && sel) ? 1 : 0;
     }
   }
+  __syncthreads();
 
+  // ---- this wave's share of the components over all TB tiles ------------------------------------
+  const int g = lane >> 4, n16 = lane & 15;
+  float* st_lane = state + wave * (TB * 64) + n16;
+  if (lane < 32) {
+#pragma unroll
+    for (int t = 0; t < TB; ++t) state[wave * (TB * 64) + t * 64 + lane] = -INFINITY, state[wave * (TB * 64) + t * 64 + 32 + lane] = 0.f;
+  }
+  const int k0 = (a.K * wave) / 4, k1 = (a.K * (wave + 1)) / 4;
+  const float4* af = reinterpret_cast<const float4*>(a.afrag) + lane;
+  const float4* mf = reinterpret_cast<const float4*>(a.mfrag) + g;
+  const float* xs_lane = xs + (g * 16 + n16) * 4;
+  const int n_lane = tile_base + n16;
+  if (k0 < k1) {
+    FragBuf f0, f1;
+    load_frags<TRI>(f0, af, mf, k0);
+    for (int k = k0; k < k1; k += 2) {
+      // prefetch is unconditional (clamped): a branch would force a full vmcnt(0) drain
+      load_frags<TRI>(f1, af, mf, k + 1 < k1 ? k + 1 : k);
+      sweep_tiles<TB, MODE, TRI>(f0, xs_lane, st_lane, a.const_k[k], k, a, n_lane, g == 0);
+      load_frags<TRI>(f0, af, mf, k + 2 < k1 ? k + 2 : k);
+      if (k + 1 < k1) sweep_tiles<TB, MODE, TRI>(f1, xs_lane, st_lane, a.const_k[k + 1], k + 1, a, n_lane, g == 0);
+    }
+  }
   if (MODE == MODE_DENSE) return;
 
+  // ---- merge the four component ranges per patch (wave order = component order) ---------------
+  __syncthreads();
   double local = 0.0;
+  for (int p = threadIdx.x; p < TB * 32; p += 256) {
+    const int n = tile_base + p;
+    float b = -INFINITY, x1 = 0.f;
+    int ar = 0;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
-    const int n = base + 32 * t + c;
-    float v = best[t];
-    if (MODE == MODE_LSE) v = best[t] + logf(aux[t]);
-    if (h == 0 && n < a.n_end) {
-      if (MODE == MODE_MAX && a.argmax_out) a.argmax_out[n] = ok[t] ? arg[t] : -1;
-      if (a.value_patch) a.value_patch[n] = ok[t] ? v : NAN;
-      if (ok[t]) local += (double)v;
+    for (int w = 0; w < 4; ++w) {
+      const float bw = state[w * (TB * 64) + (p >> 5) * 64 + (p & 31)];
+      const float sw = state[w * (TB * 64) + (p >> 5) * 64 + 32 + (p & 31)];
+      if (MODE == MODE_MAX) {
+        if (bw > b) b = bw, ar = __float_as_int(sw);
+      } else if (sw > 0.f) {  // online logsumexp merge of (max, sum exp) pairs
+        if (bw > b) {
+          x1 = x1 * expf(b - bw) + sw;
+          b = bw;
+        } else {
+          x1 += sw * expf(bw - b);
+        }
+      }
+    }
+    const float v = MODE == MODE_LSE ? b + logf(x1) : b;
+    const bool ok = okf[p] != 0;
+    if (n < a.n_end) {
+      if (MODE == MODE_MAX && a.argmax_out) a.argmax_out[n] = ok ? ar : -1;
+      if (a.value_patch) a.value_patch[n] = ok ? v : NAN;
+      if (ok) local += (double)v;
     }
   }
   local = wave_sum(local);
-  if (lane == 0) a.partials[wave_global] = local;
+  if (lane == 0) red[wave] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -201,10 +294,10 @@ __global__ __launch_bounds__(256) void gmm_fwd_kernel(GmmFwdArgs a) {
 // bucket does not influence any result); buckets are padded to 32 slots.  One wave then takes a
 // 32-slot group, i.e. 32 patches that share P'_k, and runs both products on the matrix cores:
 //   Y^T = P'^T Xbar^T - m'      (as in the forward kernel)
-//   G^T = P' Y^T                (the Y accumulators ARE the B operand: lane (h, c) holds Y[j][c] for 32
-//                                values of j, and the A fragments of this product are laid out on the
-//                                host in exactly that j order, so no lane movement / LDS is needed)
-// 128 MFMAs per 32 patches instead of 2 x 16 KB of matrix reads per patch.
+//   G^T = P' Y^T                (the Y accumulators ARE the B operand: lane group g holds
+//                                Y[16 jb + 4 g + r] in register r of block jb, and the A fragments of
+//                                this product are laid out on the host in exactly that order, so no
+//                                lane movement / LDS is needed; blocks jb < ib are zero and skipped)
 // ------------------------------------------------------------------------------------------
 struct GmmBucketArgs {
   const int32_t* argmax;  // global patch index -> component or -1
@@ -296,9 +389,9 @@ __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a
 
 struct GmmBwdArgs {
   const float* flux;
-  const float* pfrag;  // as in the forward kernel
+  const float* afrag;  // as in the forward kernel
   const float* mfrag;
-  const float* gfrag;  // K * 2 * FRAG_FLOATS: A fragments of the second product
+  const float* gfrag;  // K * [ib 4][jb 4][lane 64][r 4] = P'[16 ib + (lane & 15)][16 jb + 4 (lane >> 4) + r]
   const int32_t* argmax;
   const int32_t* order;
   const int* offsets;  // offsets[K] = total slots
@@ -306,100 +399,97 @@ struct GmmBwdArgs {
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
 };
 
+template <bool TRI>
 __global__ __launch_bounds__(256) void gmm_bwd_max_kernel(GmmBwdArgs a) {
   const int lane = threadIdx.x & 63;
-  const int h = lane >> 5, c = lane & 31;
+  const int g = lane >> 4, n16 = lane & 15;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n_waves = gridDim.x * 4;
   const int n_groups = a.offsets[a.K] >> 5;
-  for (int g = wave_global; g < n_groups; g += n_waves) {
-    const int n = a.order[32 * g + c];
-    const bool valid = n >= 0;
+  for (int grp = wave_global; grp < n_groups; grp += n_waves) {
     // slot 0 of a group is always occupied (padding sits at the end of a bucket)
-    const int k = __builtin_amdgcn_readfirstlane(a.argmax[__builtin_amdgcn_readfirstlane(n)]);
-
-    // ---- B operand: pixels 32h .. 32h+31 of patch c, mean subtracted --------------------------
-    float x[32];
-    {
-      const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
+    const int k = __builtin_amdgcn_readfirstlane(a.argmax[__builtin_amdgcn_readfirstlane(a.order[32 * grp])]);
+    int n[2];
+    bool valid[2];
+    // ---- B operand: x[nb][st] = pixel 4 st + g of patch 16 nb + n16, mean subtracted ------------
+    float x[2][16];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      n[nb] = a.order[32 * grp + 16 * nb + n16];
+      valid[nb] = n[nb] >= 0;
+      const int py = valid[nb] ? n[nb] / a.nPx : 0, px = valid[nb] ? n[nb] % a.nPx : 0;
       float sum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int yy = wrap(py * a.stride + 4 * h + r - a.shift_y, a.H);
-        const float* row = a.flux + (size_t)yy * a.W;
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-          const int xx = wrap(px * a.stride + cc - a.shift_x, a.W);
-          const float v = valid ? row[xx] : 0.f;
-          x[8 * r + cc] = v;
-          sum += v;
-        }
+      for (int st = 0; st < 16; ++st) {
+        const int p = 4 * st + g;  // pixel index: row p / 8, column p % 8
+        const int yy = wrap(py * a.stride + (p >> 3) - a.shift_y, a.H);
+        const int xx = wrap(px * a.stride + (p & 7) - a.shift_x, a.W);
+        const float v = valid[nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
+        x[nb][st] = v;
+        sum += v;
       }
-      sum += __shfl_xor(sum, 32, 64);
-      const float mean = sum * (1.f / 64.f);
+      const float mean = sum_lane_groups(sum) * (1.f / 64.f);
 #pragma unroll
-      for (int s = 0; s < 32; ++s) x[s] -= mean;
+      for (int st = 0; st < 16; ++st) x[nb][st] -= mean;
     }
 
     // ---- Y^T = P'^T Xbar^T - m' ------------------------------------------------------------------
-    f32x16 y[2];
+    f32x4 y[4][2];
     {
-      const float4* pk = reinterpret_cast<const float4*>(a.pfrag) + (size_t)k * (2 * FRAG_FLOATS / 4) + lane;
-      const float4* mk = reinterpret_cast<const float4*>(a.mfrag) + (size_t)k * 16 + h * 4;
+      const float4* ak = reinterpret_cast<const float4*>(a.afrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
+      const float4* mk = reinterpret_cast<const float4*>(a.mfrag) + (size_t)k * 16 + g;
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        float4 A[8];
+      for (int jb = 0; jb < 4; ++jb) {
+        const float4 m = mk[jb * 4];
+        y[jb][0] = y[jb][1] = f32x4{m.x, m.y, m.z, m.w};
 #pragma unroll
-        for (int qd = 0; qd < 8; ++qd) A[qd] = pk[rb * (FRAG_FLOATS / 4) + qd * 64];
+        for (int st4 = 0; st4 < 4; ++st4) {
+          if (TRI && st4 > jb) continue;
+          const float4 A = ak[(jb * 4 + st4) * 64];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 m = mk[rb * 8 + i];
-          y[rb][4 * i] = m.x, y[rb][4 * i + 1] = m.y, y[rb][4 * i + 2] = m.z, y[rb][4 * i + 3] = m.w;
-        }
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-          const float av = (s & 3) == 0 ? A[s >> 2].x : (s & 3) == 1 ? A[s >> 2].y : (s & 3) == 2 ? A[s >> 2].z : A[s >> 2].w;
-          y[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x[s], y[rb], 0, 0, 0);
+            for (int nb = 0; nb < 2; ++nb)
+              y[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, e), x[nb][4 * st4 + e], y[jb][nb], 0, 0, 0);
         }
       }
     }
 
-    // ---- G^T = P' Y^T : k-step s feeds lane (h, c) value y[s >> 4][s & 15] ------------------------
-    f32x16 gacc[2];
+    // ---- G^T = P' Y^T : k-step (jb, r) feeds lane group g the value y[jb][nb][r] --------------------
+    f32x4 gacc[4][2];
     {
-      const float4* gk = reinterpret_cast<const float4*>(a.gfrag) + (size_t)k * (2 * FRAG_FLOATS / 4) + lane;
+      const float4* gk = reinterpret_cast<const float4*>(a.gfrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
-        float4 A[8];
+      for (int ib = 0; ib < 4; ++ib) {
+        gacc[ib][0] = gacc[ib][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int qd = 0; qd < 8; ++qd) A[qd] = gk[pb * (FRAG_FLOATS / 4) + qd * 64];
+        for (int jb = 0; jb < 4; ++jb) {
+          if (TRI && jb < ib) continue;
+          const float4 A = gk[(ib * 4 + jb) * 64];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) gacc[pb][i] = 0.f;
+          for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {
-          const float av = (s & 3) == 0 ? A[s >> 2].x : (s & 3) == 1 ? A[s >> 2].y : (s & 3) == 2 ? A[s >> 2].z : A[s >> 2].w;
-          gacc[pb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, y[s >> 4][s & 15], gacc[pb], 0, 0, 0);
+            for (int nb = 0; nb < 2; ++nb)
+              gacc[ib][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, r), y[jb][nb][r], gacc[ib][nb], 0, 0, 0);
         }
       }
     }
 
     // ---- gamma = -G, subtract its mean over the 64 pixels (adjoint of the mean subtraction) -------
-    float sum = 0.f;
 #pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
+    for (int nb = 0; nb < 2; ++nb) {
+      float sum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sum += gacc[pb][i];
-    sum += __shfl_xor(sum, 32, 64);
-    const float mean = sum * (1.f / 64.f);
-    if (valid) {
-      // lane (h, c) holds pixels 32 pb + 8 q + 4 h + (0..3) of its patch in gacc[pb][4 q .. 4 q + 3]
-      float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
+      for (int ib = 0; ib < 4; ++ib) sum += (gacc[ib][nb][0] + gacc[ib][nb][1]) + (gacc[ib][nb][2] + gacc[ib][nb][3]);
+      const float mean = sum_lane_groups(sum) * (1.f / 64.f);
+      if (valid[nb]) {
+        // lane (g, n16) holds pixels 16 ib + 4 g + (0..3) of its patch in gacc[ib][nb]
+        float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(n[nb] - a.n_begin) * D);
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          out[8 * pb + 2 * q + h] = make_float4(mean - gacc[pb][4 * q], mean - gacc[pb][4 * q + 1],
-                                                mean - gacc[pb][4 * q + 2], mean - gacc[pb][4 * q + 3]);
+        for (int ib = 0; ib < 4; ++ib)
+          out[4 * ib + g] = make_float4(mean - gacc[ib][nb][0], mean - gacc[ib][nb][1], mean - gacc[ib][nb][2],
+                                        mean - gacc[ib][nb][3]);
+      }
     }
   }
 }
@@ -451,7 +541,8 @@ __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
 // ==========================================================================================
 struct jd_gmm {
   int K = 0;
-  float* pfrag = nullptr;
+  bool triangular = true;  // every P_k upper triangular -> zero blocks are skipped
+  float* afrag = nullptr;
   float* mfrag = nullptr;
   float* const_k = nullptr;
   float* gfrag = nullptr;
@@ -490,53 +581,46 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
   if (!g) return fail(JD_ERR_ALLOC, "jd_gmm_create: out of host memory");
   g->K = K;
 
-  std::vector<float> pfrag((size_t)K * 2 * FRAG_FLOATS), gfrag((size_t)K * 2 * FRAG_FLOATS), mfrag((size_t)K * 64),
+  std::vector<float> afrag((size_t)K * AFRAG_FLOATS), gfrag((size_t)K * AFRAG_FLOATS), mfrag((size_t)K * 64),
       prow((size_t)D * D), mrow(D);
   double sw[D];
   for (int j = 0; j < D; ++j) sw[j] = std::sqrt((double)pixel_w[j]);
+  bool tri = true;
   for (int k = 0; k < K; ++k) {
     const float* Pk = prec_chol + (size_t)k * D * D;
     for (int i = 0; i < D; ++i)
       for (int j = 0; j < D; ++j) {
         prow[(size_t)i * D + j] = (float)((double)Pk[i * D + j] * sw[j]);  // P'[i][j] = P[i][j] * sqrt(w_j)
+        if (i > j && Pk[i * D + j] != 0.f) tri = false;
       }
     for (int j = 0; j < D; ++j) mrow[j] = (float)((double)mu_prec[(size_t)k * D + j] * sw[j]);
-    // MFMA A fragments: [k][rb][qd][lane][e] = P'[pixel 32h + 4qd + e][j = 32rb + c]
-    for (int rb = 0; rb < 2; ++rb)
-      for (int qd = 0; qd < 8; ++qd)
+    // forward A fragments [jb][st4][lane][e]: P'[pixel 16 st4 + 4 e + (lane >> 4)][16 jb + (lane & 15)]
+    for (int jb = 0; jb < 4; ++jb)
+      for (int st4 = 0; st4 < 4; ++st4)
         for (int lane = 0; lane < 64; ++lane)
           for (int e = 0; e < 4; ++e) {
-            const int hh = lane >> 5, cc = lane & 31;
-            const int pix = 32 * hh + 4 * qd + e, j = 32 * rb + cc;
-            pfrag[(((size_t)(k * 2 + rb) * 8 + qd) * 64 + lane) * 4 + e] = prow[(size_t)pix * D + j];
+            const int pix = 16 * st4 + 4 * e + (lane >> 4), j = 16 * jb + (lane & 15);
+            afrag[(size_t)k * AFRAG_FLOATS + (((jb * 4 + st4) * 64 + lane) * 4 + e)] = prow[(size_t)pix * D + j];
           }
-    // A fragments of the backward product G^T = P' Y^T: [k][pb][qd][lane][e], k-step s = 4 qd + e
-    // pairs with the Y accumulator register (rb = s >> 4, i = s & 15) of lane half hh, which holds
-    // j = 32 rb + (i & 3) + 8 (i >> 2) + 4 hh
-    for (int pb = 0; pb < 2; ++pb)
-      for (int qd = 0; qd < 8; ++qd)
+    // backward A fragments [ib][jb][lane][r]: P'[16 ib + (lane & 15)][16 jb + 4 (lane >> 4) + r]
+    for (int ib = 0; ib < 4; ++ib)
+      for (int jb = 0; jb < 4; ++jb)
         for (int lane = 0; lane < 64; ++lane)
-          for (int e = 0; e < 4; ++e) {
-            const int hh = lane >> 5, cc = lane & 31, st = 4 * qd + e;
-            const int rb = st >> 4, i = st & 15;
-            const int j = 32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hh, pix = 32 * pb + cc;
-            gfrag[(((size_t)(k * 2 + pb) * 8 + qd) * 64 + lane) * 4 + e] = prow[(size_t)pix * D + j];
+          for (int r = 0; r < 4; ++r) {
+            const int pix = 16 * ib + (lane & 15), j = 16 * jb + 4 * (lane >> 4) + r;
+            gfrag[(size_t)k * AFRAG_FLOATS + (((ib * 4 + jb) * 64 + lane) * 4 + r)] = prow[(size_t)pix * D + j];
           }
-    // accumulator init: [k][rb][h][i] = -m'[j = 32rb + (i&3) + 8(i>>2) + 4h]
-    for (int rb = 0; rb < 2; ++rb)
-      for (int hh = 0; hh < 2; ++hh)
-        for (int i = 0; i < 16; ++i) {
-          const int j = 32 * rb + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          mfrag[(((size_t)k * 2 + rb) * 2 + hh) * 16 + i] = -mrow[j];
-        }
+    // accumulator init [jb][g][r] = -m'[16 jb + 4 g + r]
+    for (int j = 0; j < D; ++j) mfrag[(size_t)k * 64 + j] = -mrow[j];
   }
+  g->triangular = tri;
   auto upload = [&](float** dst, const float* src, size_t n) -> int {
     JD_HIP(hipMalloc(dst, n * sizeof(float)));
     JD_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
     return JD_OK;
   };
   int rc;
-  if ((rc = upload(&g->pfrag, pfrag.data(), pfrag.size())) || (rc = upload(&g->mfrag, mfrag.data(), mfrag.size())) ||
+  if ((rc = upload(&g->afrag, afrag.data(), afrag.size())) || (rc = upload(&g->mfrag, mfrag.data(), mfrag.size())) ||
       (rc = upload(&g->const_k, const_k, K)) || (rc = upload(&g->gfrag, gfrag.data(), gfrag.size()))) {
     jd_gmm_destroy(g);
     return rc;
@@ -556,7 +640,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
 extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (!g) return JD_OK;
   (void)hipDeviceSynchronize();
-  for (float* p : {g->pfrag, g->mfrag, g->const_k, g->gfrag, g->gpatch})
+  for (float* p : {g->afrag, g->mfrag, g->const_k, g->gfrag, g->gpatch})
     if (p) (void)hipFree(p);
   if (g->argmax) (void)hipFree(g->argmax);
   if (g->order) (void)hipFree(g->order);
@@ -566,35 +650,61 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   return JD_OK;
 }
 
-// Pick the number of 32-patch tiles per wave so that the grid fills the 4 SIMDs of every CU.
-static int pick_tiles(long n_patches, int n_cu) {
-  if (const char* env = getenv("JD_GMM_TILES")) {  // tuning override: 1, 2 or 4
+extern "C" int jd_gmm_is_triangular(const jd_gmm* g) { return g ? (g->triangular ? 1 : 0) : -1; }
+
+// Tiles per block: the choice that minimises (rounds over the CUs) x (tiles per block); ties go to
+// the larger block (fewer fragment re-reads).
+static int pick_block_tiles(long n_patches, int n_cu) {
+  if (const char* env = getenv("JD_GMM_BLOCK_TILES")) {  // tuning override
     const int t = atoi(env);
-    if (t == 1 || t == 2 || t == 4) return t;
+    if (t == 4 || t == 8 || t == 16) return t;
   }
-  const long simds = (long)n_cu * 4;
-  for (int t : {4, 2}) {
-    const long waves = (n_patches + 32L * t - 1) / (32L * t);
-    if (waves >= 2 * simds) return t;
+  const long nt = (n_patches + 31) / 32;
+  int best_tb = 16;
+  long best_cost = -1;
+  for (int tb : {16, 8, 4}) {
+    const long blocks = (nt + tb - 1) / tb;
+    const long cost = ((blocks + n_cu - 1) / n_cu) * tb;
+    if (best_cost < 0 || cost < best_cost) best_cost = cost, best_tb = tb;
   }
-  return 1;
+  return best_tb;
 }
 
-template <int MODE>
-static int launch_fwd(const GmmFwdArgs& a, int tiles, hipStream_t s, int* n_waves_out) {
-  const long n = a.n_end - a.n_begin;
-  const long per_wave = 32L * tiles;
-  const long waves = (n + per_wave - 1) / per_wave;
-  const unsigned blocks = (unsigned)((waves + 3) / 4);
-  *n_waves_out = (int)waves;
-  ProfScope prof(JD_KERNEL_GMM_FWD, s);
-  switch (tiles) {
-    case 4: gmm_fwd_kernel<4, MODE><<<blocks, 256, 0, s>>>(a); break;
-    case 2: gmm_fwd_kernel<2, MODE><<<blocks, 256, 0, s>>>(a); break;
-    default: gmm_fwd_kernel<1, MODE><<<blocks, 256, 0, s>>>(a); break;
+template <int TB, int MODE, bool TRI>
+static int launch_fwd_tb(const GmmFwdArgs& a, unsigned blocks, hipStream_t s) {
+  const size_t lds = (size_t)(TB * 2048 + 4 * TB * 64 + TB * 32) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gmm_fwd_kernel<TB, MODE, TRI>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
   }
+  gmm_fwd_kernel<TB, MODE, TRI><<<blocks, 256, lds, s>>>(a);
   JD_LAUNCH_CHECK();
   return JD_OK;
+}
+
+// writes one fp64 partial sum per block; *n_partials = number of blocks
+template <int MODE>
+static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, int* n_partials) {
+  const long n = a.n_end - a.n_begin;
+  if (getenv("JD_GMM_DENSE")) tri = false;  // tuning / testing: force the dense variant
+  const int tb = pick_block_tiles(n, n_cu);
+  const unsigned blocks = (unsigned)((n + 32L * tb - 1) / (32L * tb));
+  *n_partials = (int)blocks;
+  ProfScope prof(JD_KERNEL_GMM_FWD, s);
+  if (tri) {
+    switch (tb) {
+      case 16: return launch_fwd_tb<16, MODE, true>(a, blocks, s);
+      case 8: return launch_fwd_tb<8, MODE, true>(a, blocks, s);
+      default: return launch_fwd_tb<4, MODE, true>(a, blocks, s);
+    }
+  }
+  switch (tb) {
+    case 16: return launch_fwd_tb<16, MODE, false>(a, blocks, s);
+    case 8: return launch_fwd_tb<8, MODE, false>(a, blocks, s);
+    default: return launch_fwd_tb<4, MODE, false>(a, blocks, s);
+  }
 }
 
 extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
@@ -618,7 +728,6 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
     return JD_OK;
   }
   const long n = n_end - n_begin;
-  const int tiles = pick_tiles(n, g->n_cu);
   int rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
   int32_t* arg = argmax_out;
@@ -627,14 +736,14 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
     arg = g->argmax;
   }
   GmmFwdArgs a{};
-  a.flux = flux, a.pfrag = g->pfrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
+  a.flux = flux, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
   a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x;
   a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = arg, a.value_patch = nullptr, a.partials = g->partials;
   int n_waves = 0;
   if (marginalize)
-    rc = launch_fwd<MODE_LSE>(a, tiles, s, &n_waves);
+    rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
   else
-    rc = launch_fwd<MODE_MAX>(a, tiles, s, &n_waves);
+    rc = launch_fwd<MODE_MAX>(a, g->triangular, g->n_cu, s, &n_waves);
   if (rc) return rc;
   if ((rc = launch_finalize_sum(g->partials, n_waves, (double)value_scale, 0.0, value_out, accumulate_value, s)))
     return rc;
@@ -658,14 +767,17 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
     gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
     gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
     GmmBwdArgs b{};
-    b.flux = flux, b.pfrag = g->pfrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
+    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
     b.offsets = bk.offsets, b.gpatch = g->gpatch, b.K = g->K;
     b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
     b.n_begin = n_begin, b.n_end = n_end;
     long bwd_blocks = ((long)(slots_cap / 32) + 3) / 4;
     const long cap = (long)g->n_cu * 3;  // 3 blocks of 4 waves per CU: one wave per SIMD x 3
     if (bwd_blocks > cap) bwd_blocks = cap;
-    gmm_bwd_max_kernel<<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
+    if (g->triangular && !getenv("JD_GMM_DENSE"))
+      gmm_bwd_max_kernel<true><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
+    else
+      gmm_bwd_max_kernel<false><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
   }
   JD_LAUNCH_CHECK();
 
@@ -690,8 +802,8 @@ extern "C" int jd_gmm_estimate_log_prob(jd_gmm* g, const float* x, int n, float*
   int rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
   GmmFwdArgs a{};
-  a.flux = x, a.pfrag = g->pfrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
+  a.flux = x, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
   a.K = g->K, a.n_begin = 0, a.n_end = n, a.value_patch = out, a.partials = g->partials;
   int n_waves = 0;
-  return launch_fwd<MODE_DENSE>(a, pick_tiles(n, g->n_cu), s, &n_waves);
+  return launch_fwd<MODE_DENSE>(a, g->triangular, g->n_cu, s, &n_waves);
 }

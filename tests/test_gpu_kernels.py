@@ -312,3 +312,55 @@ def test_large_psf_falls_back_to_fft():
     plan.close()
     with pytest.raises(RuntimeError, match="33x33"):
         ConvPlan(96, 96, 41, 41, DEV, method="direct")
+
+
+def test_gmm_triangular_skip_is_bit_identical_to_dense(golden, monkeypatch):
+    """The block-skipping (upper triangular P) and the dense variants of the GMM kernels give the
+    same bits: the skipped terms are exact zeros at the end of every fmaf chain."""
+    from jolideco_amd import _hip
+
+    stages = golden("stages")
+    name, gname = "rect80x112_psf12x16", "k5m"
+    gmm = _gmm(stages, gname)
+    handle = gmm.handle(DEV)
+    assert _hip.lib().jd_gmm_is_triangular(handle._handle) == 1
+    flux = torch.exp(torch.from_numpy(stages[f"{name}/theta"])).to(DEV)
+    H, W = flux.shape
+    scale = (16 / 64) / (H * W)
+    n_patches = ((H - 8) // 4 + 1) * ((W - 8) // 4 + 1)
+    out = {}
+    for variant in ("tri", "dense"):
+        if variant == "dense":
+            monkeypatch.setenv("JD_GMM_DENSE", "1")
+        value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+        argmax = torch.zeros(n_patches, dtype=torch.int32, device=DEV)
+        handle.prior_fwd_bwd(flux, 4, (1, -2), value, scale, grad=grad, grad_coef=scale, argmax_out=argmax)
+        lse = torch.zeros(1, device=DEV)
+        handle.prior_fwd_bwd(flux, 4, (1, -2), lse, scale, marginalize=True)
+        x = torch.from_numpy(np.random.RandomState(3).normal(size=(70, 64)).astype(np.float32)).to(DEV)
+        out[variant] = (value.cpu(), grad.cpu(), argmax.cpu(), lse.cpu(), handle.estimate_log_prob(x).cpu())
+    for a, b in zip(out["tri"], out["dense"]):
+        assert torch.equal(a, b)
+
+
+def test_gmm_non_triangular_precisions_use_the_dense_variant():
+    """A user supplied, non-triangular precisions_cholesky (the constructor accepts any matrix,
+    patches/gmm.py:64-117) must not take the block-skipping path."""
+    from jolideco_amd import _hip
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    rs = np.random.RandomState(8)
+    K = 6
+    pc = rs.normal(size=(K, 64, 64)).astype(np.float32) * 0.3 + 2 * np.eye(64, dtype=np.float32)
+    means = (0.1 * rs.normal(size=(K, 64))).astype(np.float32)
+    weights = rs.dirichlet(np.ones(K)).astype(np.float32)
+    gmm = GaussianMixtureModel(means, np.zeros((K, 64, 64), np.float32), weights, pc, meta=GaussianMixtureModelMeta(stride=4))
+    assert _hip.lib().jd_gmm_is_triangular(gmm.handle(DEV)._handle) == 0
+    x = rs.normal(size=(100, 64)).astype(np.float32)
+    got = gmm.estimate_log_prob(torch.from_numpy(x).to(DEV)).cpu().numpy()
+    w = gmm.pixel_weights_numpy.astype(np.float64)
+    ref = np.empty((100, K))
+    for k in range(K):
+        y = (x.astype(np.float64) - means[k]) @ pc[k].astype(np.float64)
+        ref[:, k] = -0.5 * (64 * np.log(2 * np.pi) + (y * y * w).sum(1)) + np.log(np.diag(pc[k])).sum() + np.log(weights[k])
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=5e-4)
