@@ -17,6 +17,9 @@
 // each MFMA needs one conflict-free ds_read_b32 (row pitch == 2 mod 4).  Cost: kh * KC/4 * 4 MFMAs of
 // 32 cycles per 1024 outputs, i.e. 17 cycles/output at 17x17 (~30 us for 2048^2 on 1024 SIMDs)
 // against ~150 us for two rocFFT transforms + the k-space multiply; the FFT path stays for large PSFs.
+#include <cstdint>
+#include <cstdlib>
+
 #include "jd_common.h"
 #include "kernels.h"
 
@@ -39,106 +42,201 @@ struct DirectConvArgs {
   int accumulate;
 };
 
-template <int KC>
+// Persistent, software pipelined: a block walks over its tiles; while the MFMAs of tile i run out of
+// LDS (image window AND Toeplitz fragments, so the matrix stream never waits on vmcnt), the loads of
+// tile i+1's window are already in flight into registers and are written to LDS after the epilogue.
+// Only the first window load and the last epilogue of a block are not overlapped with MFMA work.
+template <int KC, bool VEC>
 __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   constexpr int STEPS = KC / 4;
   constexpr int COLS = 48 + KC;    // window columns: 64 outputs + KC - 16 halo
   constexpr int PITCH = COLS + 2;  // == 2 (mod 4): the 16 rows x 2 columns of a half-wave hit 32 banks
-  extern __shared__ __attribute__((aligned(16))) float win[];
+  constexpr int NPF = (96 * COLS + 255) / 256;  // window elements per thread (kh <= 33: at most 96 rows)
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int rows = TILE - 1 + a.kh;
+  float* win = lds;                        // rows * PITCH
+  float* afl = lds + ((rows * PITCH + 3) & ~3);  // kh * STEPS * 64 Toeplitz fragments
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
-  const int rows = TILE - 1 + a.kh;
-  const int yin0 = y0 + a.oy - (a.kh - 1);
-  const int xin0 = x0 + a.ox_in;
-
-  // ---- stage the (rows x COLS) input window, zero outside the image ------------------------
-  // U independent loads per thread are issued before the first one is consumed (one latency per
-  // batch instead of one per element)
-  constexpr int U = 6;
   const int total = rows * COLS;
-  for (int base = threadIdx.x; base < total; base += 256 * U) {
-    float v[U], sc[U];
-    int dst[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base + 256 * u;
-      const int r = i / COLS, c = i - r * COLS;
-      const int y = yin0 + r, x = xin0 + c;
-      const bool inside = (i < total) && y >= 0 && y < a.H && x >= 0 && x < a.W;
-      const size_t off = inside ? (size_t)y * a.W + x : 0;
-      dst[u] = (i < total) ? r * PITCH + c : -1;
-      v[u] = inside ? a.in[off] : 0.f;
-      sc[u] = (inside && a.in_scale) ? a.in_scale[off] : 1.f;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (dst[u] >= 0) win[dst[u]] = v[u] * sc[u];
-  }
-  __syncthreads();
+  const int tiles_x = (a.W + TILE - 1) / TILE, tiles_y = (a.H + TILE - 1) / TILE;
+  const int n_tiles = tiles_x * tiles_y;
 
-  const int n = lane & 15, kk = lane >> 4;
-  f32x4 acc[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const float* af = a.afrag + lane;
-  float a_cur[STEPS], a_nxt[STEPS];
-#pragma unroll
-  for (int s = 0; s < STEPS; ++s) a_cur[s] = af[s * 64];
-
-  // window row of output row (16 b + n) for PSF row dy is 16 b + n + (kh - 1 - dy)
-  const float* bp = win + (n + a.kh - 1) * PITCH + wave * 16 + kk;
-  for (int dy = 0; dy < a.kh; ++dy) {
-    {  // unconditional prefetch of the next PSF row (the last iteration re-reads its own row): a
-       // branch here would make the compiler drain every outstanding load (vmcnt(0))
-      const int dn = dy + 1 < a.kh ? dy + 1 : dy;
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) a_nxt[s] = af[(dn * STEPS + s) * 64];
-    }
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const float bv = bp[b * 16 * PITCH + 4 * s];
-        acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[s], bv, acc[b], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < STEPS; ++s) a_cur[s] = a_nxt[s];
-    bp -= PITCH;
+  // Toeplitz fragments -> LDS (once per block; the table is a multiple of 256 floats)
+  {
+    const float4* src = reinterpret_cast<const float4*>(a.afrag);
+    float4* dst = reinterpret_cast<float4*>(afl);
+    for (int i = threadIdx.x; i < a.kh * STEPS * 16; i += 256) dst[i] = src[i];
   }
 
-  // ---- epilogue: lane holds out[y0 + 16 b + n][x0 + 16 wave + 4 kk + 0..3] -----------------------
-  const int x = x0 + wave * 16 + 4 * kk;
-  const bool vec = (a.W % 4 == 0) && (x + 3 < a.W);
+  // Prefetch registers of the NEXT tile's window.  VEC: the window columns start on a 16-byte
+  // boundary of the image rows (W % 4 == 0, ox_in % 4 == 0), so a thread moves float4 chunks that are
+  // entirely inside or entirely outside the image.  The (row, column) of a thread's chunks is fixed for
+  // the whole kernel; tiles whose window lies inside the image take a predicate-free path.
+  constexpr int C4 = COLS / 4;
+  constexpr int NPF4 = (96 * C4 + 255) / 256;
+  float4 pv4[VEC ? NPF4 : 1], ps4[VEC ? NPF4 : 1];
+  float pv[VEC ? 1 : NPF], ps[VEC ? 1 : NPF];
+  const int total4 = rows * C4;
+  int wr[VEC ? NPF4 : 1], wc[VEC ? NPF4 : 1];
+  if constexpr (VEC) {
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int y = y0 + 16 * b + n;
-    if (y >= a.H || x >= a.W) continue;
-    const size_t off = (size_t)y * a.W + x;
-    float v[4] = {acc[b][0] * a.coef, acc[b][1] * a.coef, acc[b][2] * a.coef, acc[b][3] * a.coef};
-    if (vec) {
-      if (a.out_scale) {
-        const float4 s4 = *reinterpret_cast<const float4*>(a.out_scale + off);
-        v[0] *= s4.x, v[1] *= s4.y, v[2] *= s4.z, v[3] *= s4.w;
+    for (int u = 0; u < NPF4; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      wr[u] = i < total4 ? i / C4 : -1;  // -1: this thread has no chunk u
+      wc[u] = i < total4 ? (i - (i / C4) * C4) * 4 : 0;
+    }
+  }
+  auto issue_window_loads = [&](int tile) {
+    const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
+    const int yin0 = y0 + a.oy - (a.kh - 1), xin0 = x0 + a.ox_in;
+    if constexpr (VEC) {
+      const bool interior = yin0 >= 0 && yin0 + rows <= a.H && xin0 >= 0 && xin0 + COLS <= a.W;
+      if (interior) {
+        const float* base = a.in + (size_t)yin0 * a.W + xin0;
+        const float* sbase = a.in_scale ? a.in_scale + (size_t)yin0 * a.W + xin0 : nullptr;
+#pragma unroll
+        for (int u = 0; u < NPF4; ++u) {
+          const int off = (wr[u] < 0 ? 0 : wr[u]) * a.W + wc[u];  // threads without a chunk re-read chunk 0
+          pv4[u] = *reinterpret_cast<const float4*>(base + off);
+          ps4[u] = sbase ? *reinterpret_cast<const float4*>(sbase + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NPF4; ++u) {
+          const int y = yin0 + wr[u], x = xin0 + wc[u];
+          const bool inside = wr[u] >= 0 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+          const size_t off = inside ? (size_t)y * a.W + x : 0;
+          pv4[u] = inside ? *reinterpret_cast<const float4*>(a.in + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          ps4[u] = (inside && a.in_scale) ? *reinterpret_cast<const float4*>(a.in_scale + off)
+                                          : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
       }
-      if (a.accumulate) {
-        const float4 o4 = *reinterpret_cast<const float4*>(a.out + off);
-        v[0] += o4.x, v[1] += o4.y, v[2] += o4.z, v[3] += o4.w;
-      }
-      *reinterpret_cast<float4*>(a.out + off) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (x + i >= a.W) break;
-        float r = v[i];
-        if (a.out_scale) r *= a.out_scale[off + i];
-        if (a.accumulate) r += a.out[off + i];
-        a.out[off + i] = r;
+      for (int u = 0; u < NPF; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int r = i / COLS, c = i - r * COLS;
+        const int y = yin0 + r, x = xin0 + c;
+        const bool inside = (i < total) && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const size_t off = inside ? (size_t)y * a.W + x : 0;
+        pv[u] = inside ? a.in[off] : 0.f;
+        ps[u] = (inside && a.in_scale) ? a.in_scale[off] : 1.f;
       }
     }
+  };
+  auto store_window = [&]() {
+    if constexpr (VEC) {
+#pragma unroll
+      for (int u = 0; u < NPF4; ++u) {
+        if (wr[u] >= 0) {  // PITCH is even: 8-byte aligned pairs
+          float2* dst = reinterpret_cast<float2*>(win + wr[u] * PITCH + wc[u]);
+          dst[0] = make_float2(pv4[u].x * ps4[u].x, pv4[u].y * ps4[u].y);
+          dst[1] = make_float2(pv4[u].z * ps4[u].z, pv4[u].w * ps4[u].w);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int r = i / COLS, c = i - r * COLS;
+        if (i < total) win[r * PITCH + c] = pv[u] * ps[u];
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < n_tiles) issue_window_loads(tile);
+  const int n = lane & 15, kk = lane >> 4;
+  while (tile < n_tiles) {
+    store_window();
+    __syncthreads();
+    const int next = tile + gridDim.x;
+    if (next < n_tiles) issue_window_loads(next);  // in flight during the MFMA phase below
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // window row of output row (16 b + n) for PSF row dy is 16 b + n + (kh - 1 - dy).  The operands of
+    // PSF row dy + 1 are read from LDS while the MFMAs of row dy issue (register double buffer, the
+    // loop is unrolled by two so no copies are needed); reads past the last row are clamped.
+    const float* bp = win + (n + a.kh - 1) * PITCH + wave * 16 + kk;
+    const float* ap = afl + lane;
+    float a0[STEPS], a1[STEPS], b0[STEPS][4], b1[STEPS][4];
+    auto load_row = [&](float (&av)[STEPS], float (&bv)[STEPS][4], int dy) {
+      const int d = dy < a.kh ? dy : a.kh - 1;
+      const float* app = ap + d * (STEPS * 64);
+      const float* bpp = bp - d * PITCH;
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        av[s] = app[s * 64];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) bv[s][b] = bpp[b * 16 * PITCH + 4 * s];
+      }
+    };
+    auto mfma_row = [&](const float (&av)[STEPS], const float (&bv)[STEPS][4]) {
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s][b], acc[b], 0, 0, 0);
+    };
+    load_row(a0, b0, 0);
+    for (int dy = 0; dy < a.kh; dy += 2) {
+      // sched_barrier: keep the LDS reads of the next row AHEAD of this row's MFMAs (the scheduler
+      // otherwise sinks them to just before their use and exposes the LDS latency)
+      load_row(a1, b1, dy + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_row(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_row(a0, b0, dy + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (dy + 1 < a.kh) mfma_row(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue: lane holds out[y0 + 16 b + n][x0 + 16 wave + 4 kk + 0..3] ---------------------
+    const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
+    const int x = x0 + wave * 16 + 4 * kk;
+    const bool vec = (a.W % 4 == 0) && (x + 3 < a.W);
+    if (vec) {
+      // all loads of the four row groups are issued before the first one is consumed: one memory
+      // round trip per tile instead of eight dependent ones
+      float4 s4[4], o4[4];
+      bool live[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int y = y0 + 16 * b + n;
+        live[b] = y < a.H;
+        const size_t off = (size_t)(live[b] ? y : y0) * a.W + x;  // row y0 always exists
+        s4[b] = a.out_scale ? *reinterpret_cast<const float4*>(a.out_scale + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+        o4[b] = a.accumulate ? *reinterpret_cast<const float4*>(a.out + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (!live[b]) continue;
+        const size_t off = (size_t)(y0 + 16 * b + n) * a.W + x;
+        *reinterpret_cast<float4*>(a.out + off) =
+            make_float4(fmaf(acc[b][0] * a.coef, s4[b].x, o4[b].x), fmaf(acc[b][1] * a.coef, s4[b].y, o4[b].y),
+                        fmaf(acc[b][2] * a.coef, s4[b].z, o4[b].z), fmaf(acc[b][3] * a.coef, s4[b].w, o4[b].w));
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int y = y0 + 16 * b + n;
+        if (y >= a.H || x >= a.W) continue;
+        const size_t off = (size_t)y * a.W + x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (x + i >= a.W) break;
+          const float sc = a.out_scale ? a.out_scale[off + i] : 1.f;
+          const float ov = a.accumulate ? a.out[off + i] : 0.f;
+          a.out[off + i] = fmaf(acc[b][i] * a.coef, sc, ov);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading the window before it is overwritten
+    tile = next;
   }
 }
 
@@ -171,12 +269,46 @@ int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_a
   return JD_OK;
 }
 
+static int g_conv_n_cu = 0;
+
 template <int KC>
 static int launch_kc(const DirectConvArgs& a, hipStream_t stream) {
   constexpr int PITCH = 48 + KC + 2;
-  const size_t lds = (size_t)(TILE - 1 + a.kh) * PITCH * sizeof(float);
-  dim3 grid((a.W + TILE - 1) / TILE, (a.H + TILE - 1) / TILE);
-  direct_conv_kernel<KC><<<grid, 256, lds, stream>>>(a);
+  const int rows = TILE - 1 + a.kh;
+  const size_t lds = (size_t)(((rows * PITCH + 3) & ~3) + a.kh * (KC / 4) * 64) * sizeof(float);
+  static int configured_bytes = 0;
+  if ((int)lds > configured_bytes) {
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, false>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured_bytes = (int)lds;
+  }
+  if (!g_conv_n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    g_conv_n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                      ? prop.multiProcessorCount
+                      : 256;
+  }
+  const int n_tiles = ((a.W + TILE - 1) / TILE) * ((a.H + TILE - 1) / TILE);
+  // persistent grid: as many blocks as fit at once (LDS bound, at most 2 per CU: 2 waves per SIMD)
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  if (const char* env = getenv("JD_CONV_BLOCKS_PER_CU")) {  // tuning override
+    const int v = atoi(env);
+    if (v >= 1 && v <= 8) per_cu = v;
+  }
+  int grid = g_conv_n_cu * per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  const bool vec = (a.W % 4 == 0) && (a.ox_in % 4 == 0) &&
+                   (reinterpret_cast<uintptr_t>(a.in) % 16 == 0) &&
+                   (!a.in_scale || reinterpret_cast<uintptr_t>(a.in_scale) % 16 == 0);
+  if (vec)
+    direct_conv_kernel<KC, true><<<grid, 256, lds, stream>>>(a);
+  else
+    direct_conv_kernel<KC, false><<<grid, 256, lds, stream>>>(a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
