@@ -102,20 +102,37 @@ __device__ __forceinline__ void mfma_tile(f32x4 (&acc)[4][2], const FragBuf& f, 
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) acc[jb][nb] = f32x4{f.m[jb].x, f.m[jb].y, f.m[jb].z, f.m[jb].w};
 #pragma unroll
-  for (int st = 0; st < 16; ++st)
+  for (int st = 0; st < 16; ++st) {
 #pragma unroll
     for (int jb = TRI ? st / 4 : 0; jb < 4; ++jb)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb)
         acc[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(f.a[jb][st >> 2], st & 3),
                                                            f4_get(x[nb * 4 + (st >> 2)], st & 3), acc[jb][nb], 0, 0, 0);
+  }
 }
 
-// l = c_k - q / 2 for the two 16-patch halves of a tile, then the branch-free update of the wave's
-// running state in LDS: st[nb * 16 + n] = max, st[32 + nb * 16 + n] = arg-max | sum-exp.
+// Running state of the two 16-patch halves of a tile in LDS: st[nb * 16 + n] = max,
+// st[32 + nb * 16 + n] = arg-max | sum-exp.  It is read BEFORE the MFMAs of the stage are issued so that
+// the LDS latency is off the critical path of finish_tile.
+struct TileState {
+  float b[2], s[2];
+};
+
 template <int MODE>
-__device__ __forceinline__ void finish_tile(const f32x4 (&acc)[4][2], float* st, float ck, int k, const GmmFwdArgs& a,
-                                            int n_first, bool writer) {
+__device__ __forceinline__ TileState read_state(const float* st) {
+  TileState ts;
+  if (MODE != MODE_DENSE) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) ts.b[nb] = st[nb * 16], ts.s[nb] = st[32 + nb * 16];
+  }
+  return ts;
+}
+
+// l = c_k - q / 2 for the two 16-patch halves of a tile, then the branch-free update of the state.
+template <int MODE>
+__device__ __forceinline__ void finish_tile(const f32x4 (&acc)[4][2], const TileState& ts, float* st, float ck, int k,
+                                            const GmmFwdArgs& a, int n_first, bool writer) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     float q0 = 0.f, q1 = 0.f;
@@ -127,12 +144,11 @@ __device__ __forceinline__ void finish_tile(const f32x4 (&acc)[4][2], float* st,
     const float l = fmaf(-0.5f, sum_lane_groups(q0 + q1), ck);  // gmm.py:276-281
     float* s0 = st + nb * 16;
     if (MODE == MODE_MAX) {
-      const float b = s0[0], ar = s0[32];
-      const bool better = l > b;  // strict: the lowest component wins a tie, like torch.max
-      s0[0] = better ? l : b;
-      s0[32] = better ? __int_as_float(k) : ar;
+      const bool better = l > ts.b[nb];  // strict: the lowest component wins a tie, like torch.max
+      s0[0] = better ? l : ts.b[nb];
+      s0[32] = better ? __int_as_float(k) : ts.s[nb];
     } else if (MODE == MODE_LSE) {
-      const float b = s0[0], sm = s0[32];
+      const float b = ts.b[nb], sm = ts.s[nb];
       const bool better = l > b;
       const float e = expf(better ? b - l : l - b);
       s0[0] = better ? l : b;
@@ -157,16 +173,20 @@ __device__ __forceinline__ void sweep_tiles(const FragBuf& f, const float* xs_la
   load_x(x1, xs_lane, 1);
   mfma_tile<TRI>(acc0, f, x0);
   for (int t = 1; t < TB - 1; t += 2) {
+    const TileState s0 = read_state<MODE>(st_lane + (t - 1) * 64);
     load_x(x0, xs_lane, t + 1);
     mfma_tile<TRI>(acc1, f, x1);
-    finish_tile<MODE>(acc0, st_lane + (t - 1) * 64, ck, k, a, n_lane + 32 * (t - 1), writer);
+    finish_tile<MODE>(acc0, s0, st_lane + (t - 1) * 64, ck, k, a, n_lane + 32 * (t - 1), writer);
+    const TileState s1 = read_state<MODE>(st_lane + t * 64);
     load_x(x1, xs_lane, t + 2);  // t + 2 <= TB - 1
     mfma_tile<TRI>(acc0, f, x0);
-    finish_tile<MODE>(acc1, st_lane + t * 64, ck, k, a, n_lane + 32 * t, writer);
+    finish_tile<MODE>(acc1, s1, st_lane + t * 64, ck, k, a, n_lane + 32 * t, writer);
   }
+  const TileState s0 = read_state<MODE>(st_lane + (TB - 2) * 64);
+  const TileState s1 = read_state<MODE>(st_lane + (TB - 1) * 64);
   mfma_tile<TRI>(acc1, f, x1);
-  finish_tile<MODE>(acc0, st_lane + (TB - 2) * 64, ck, k, a, n_lane + 32 * (TB - 2), writer);
-  finish_tile<MODE>(acc1, st_lane + (TB - 1) * 64, ck, k, a, n_lane + 32 * (TB - 1), writer);
+  finish_tile<MODE>(acc0, s0, st_lane + (TB - 2) * 64, ck, k, a, n_lane + 32 * (TB - 2), writer);
+  finish_tile<MODE>(acc1, s1, st_lane + (TB - 1) * 64, ck, k, a, n_lane + 32 * (TB - 1), writer);
 }
 
 // LDS index (in floats) of pixel p of patch c of tile t in B-fragment order:
