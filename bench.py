@@ -143,7 +143,7 @@ def main():
     world = dist_ctx.world_size
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 

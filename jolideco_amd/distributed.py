@@ -61,9 +61,13 @@ def init_from_env(backend=None):
         return DistContext()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # JOLIDECO_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a single-GPU box; gloo
+        # stages device tensors through the host); the production backend is RCCL ("nccl")
+        backend = os.environ.get("JOLIDECO_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if not dist.is_initialized():
         kwargs = {}

@@ -121,7 +121,9 @@ class TotalLoss:
         """Column layout of the reference's trace table (jolideco/loss.py:192-210)."""
         names = ["total", "datasets-total", "priors-total"]
         names += [f"prior-{name}" for name in self.prior_loss.priors]
-        names += [f"dataset-{name}" for name in self.poisson_loss.names_all]
+        # in a sharded joint fit a rank holds only its own datasets but the trace lists all of them
+        names_d = getattr(self.poisson_loss, "names_all_global", None) or self.poisson_loss.names_all
+        names += [f"dataset-{name}" for name in names_d]
         if self.poisson_loss_validation:
             names += ["datasets-validation-total"]
         names += ["filename"]
