@@ -45,7 +45,7 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 =
 PATCH, D, STRIDE = 8, 64, 4
 
 
-def build_session(cfg_name, device, seed=0):
+def build_session(cfg_name, device, seed=0, dist=None):
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
     from jolideco_amd.data import synthetic_gmm, synthetic_observations
     from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
@@ -56,7 +56,7 @@ def build_session(cfg_name, device, seed=0):
     gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=STRIDE))
     comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
     deconvolver = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="joint")
-    return deconvolver.session(datasets, components=comp)
+    return deconvolver.session(datasets, components=comp, dist=dist)
 
 
 def host_cores(cap=16):
@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="tuning only: time rank 0's share of an N-rank joint step in ONE process, without the "
+                         "collective (the printed value is NOT a benchmark result)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -149,7 +152,12 @@ def main():
 
     H, W, n_obs, K = CONFIGS[args.config]
     log(f"building {args.config}: {H}x{W}, {n_obs} obs, K={K} on {device}")
-    session = build_session(args.config, device)
+    fake = None
+    if args.shard_of > 1:
+        from jolideco_amd.distributed import DistContext
+
+        fake = DistContext(rank=0, world_size=args.shard_of, dry_run=True)
+    session = build_session(args.config, device, dist=fake)
     torch.cuda.synchronize(device)
     log("session ready; warm-up")
 
@@ -189,6 +197,8 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     n_py, n_px = (H - PATCH) // STRIDE + 1, (W - PATCH) // STRIDE + 1
     rows = dist_ctx.shard_range(n_py) if world > 1 else (0, n_py)
+    if fake is not None:
+        rows = fake.shard_range(n_py)
     np_local = (rows[1] - rows[0]) * n_px
 
     def avg_ms(name):
@@ -232,7 +242,8 @@ def main():
     roofline = roof_poi if dominant == "poisson_fused" else roof_gmm
 
     out = {
-        "metric": "MAP iters/sec at 2048x2048, 8-obs joint fit" if args.config == "c3" else f"MAP iters/sec ({args.config})",
+        "metric": ("MAP iters/sec at 2048x2048, 8-obs joint fit" if args.config == "c3" else f"MAP iters/sec ({args.config})")
+        + (f" [TUNING: rank 0 of {args.shard_of}, no collective]" if args.shard_of > 1 else ""),
         "value": args.steps / elapsed,
         "unit": "iters/s",
         "n_gpus": world,

@@ -227,7 +227,7 @@ class MAPDeconvolver:
         with torch.cuda.device(self.device):
             return self._run(datasets, datasets_validation, components, components_init, dist)
 
-    def session(self, datasets, datasets_validation=None, components=None):
+    def session(self, datasets, datasets_validation=None, components=None, dist=None):
         """Set up a fit without running it: uploads the datasets, builds the FFT plans / kernel
         spectra / GMM handles and returns a `FitSession` whose ``epoch()`` enqueues one epoch of
         the fit on the current HIP stream (used by `run` and by bench.py)."""
@@ -236,7 +236,7 @@ class MAPDeconvolver:
         components = FluxComponents(components)
         _hip.lib()
         with torch.cuda.device(self.device):
-            return FitSession(self, datasets, datasets_validation, components, DistContext.current())
+            return FitSession(self, datasets, datasets_validation, components, dist or DistContext.current())
 
     def _run(self, datasets, datasets_validation, components, components_init, dist):
         from tqdm.auto import tqdm

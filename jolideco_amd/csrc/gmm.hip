@@ -68,6 +68,32 @@ __device__ __forceinline__ float sum_lane_groups(float v) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// Patch mean with ONE summation order shared by the forward staging and the backward kernels:
+//   S_g = (sum of pixels 4 st + g, st = 0..7 in order) + (the same for st = 8..15),  g = 0..3
+//   mean = ((S_0 + S_1) + (S_2 + S_3)) / 64
+// y = xbar^T P' is sensitive to the mean at the 1e-4 level (the columns of P' do not sum to zero), so
+// the backward kernels must subtract the same bits or the recomputed log-likelihoods (and with them
+// the logsumexp responsibilities) would not match the forward pass.
+// Backward form: lane group g holds x[st] = pixel 4 st + g of its patch.
+__device__ __forceinline__ float patch_mean_groups(const float (&x)[16]) {
+  float lo = x[0], hi = x[8];
+#pragma unroll
+  for (int st = 1; st < 8; ++st) lo += x[st], hi += x[8 + st];
+  return sum_lane_groups(lo + hi) * (1.f / 64.f);
+}
+// Forward staging form: lane half h holds x[s] = pixel 32 h + s, i.e. steps st = 8 h .. 8 h + 7 of every g.
+__device__ __forceinline__ float patch_mean_halves(const float (&x)[32]) {
+  float t[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float sg = x[g];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) sg += x[4 * k + g];
+    t[g] = sg + __shfl_xor(sg, 32, 64);
+  }
+  return ((t[0] + t[1]) + (t[2] + t[3])) * (1.f / 64.f);
+}
+
 // Fragments of one component held by a lane: A[jb][st4] covers pixel steps 4 st4 .. 4 st4 + 3 of
 // coordinate block jb (only st4 <= jb is non-zero for a triangular P), M[jb] the accumulator init.
 struct FragBuf {
@@ -219,7 +245,6 @@ __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
         for (int s = 0; s < 32; ++s) x[s] = valid ? a.flux[(size_t)n * D + 32 * h + s] : 0.f;
       } else {
         const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
-        float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int yy = wrap(py * a.stride + 4 * h + r - a.shift_y, a.H);
@@ -229,12 +254,10 @@ __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
             const int xx = wrap(px * a.stride + cc - a.shift_x, a.W);
             const float v = valid ? row[xx] : 0.f;
             x[8 * r + cc] = v;
-            sum += v;
             sel = sel && (v > -1e5f);  // patches/core.py:215
           }
         }
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.f / 64.f);  // SubtractMeanPatchNorm, utils/norms.py:100-103
+        const float mean = patch_mean_halves(x);  // SubtractMeanPatchNorm, utils/norms.py:100-103
 #pragma unroll
         for (int s = 0; s < 32; ++s) x[s] -= mean;
         sel = sel && (__shfl_xor((int)sel, 32, 64) != 0);
@@ -438,17 +461,14 @@ __global__ __launch_bounds__(256) void gmm_bwd_max_kernel(GmmBwdArgs a) {
       n[nb] = a.order[32 * grp + 16 * nb + n16];
       valid[nb] = n[nb] >= 0;
       const int py = valid[nb] ? n[nb] / a.nPx : 0, px = valid[nb] ? n[nb] % a.nPx : 0;
-      float sum = 0.f;
 #pragma unroll
       for (int st = 0; st < 16; ++st) {
         const int p = 4 * st + g;  // pixel index: row p / 8, column p % 8
         const int yy = wrap(py * a.stride + (p >> 3) - a.shift_y, a.H);
         const int xx = wrap(px * a.stride + (p & 7) - a.shift_x, a.W);
-        const float v = valid[nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
-        x[nb][st] = v;
-        sum += v;
+        x[nb][st] = valid[nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
       }
-      const float mean = sum_lane_groups(sum) * (1.f / 64.f);
+      const float mean = patch_mean_groups(x[nb]);
 #pragma unroll
       for (int st = 0; st < 16; ++st) x[nb][st] -= mean;
     }
@@ -515,6 +535,148 @@ __global__ __launch_bounds__(256) void gmm_bwd_max_kernel(GmmBwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward, marginalized (logsumexp) mode: d v / d xbar = sum_k r_k gamma_k with the responsibilities
+// r_k = exp(l_k - v) (v = logsumexp from the forward pass) and gamma_k = -P'_k y_k.  One wave owns
+// GRP groups of 32 patches and walks over ALL components: Y as in the forward kernel, the columns
+// of Y scaled by r_k (per patch = per lane), then G += P'_k (r_k Y) accumulated over k in registers.
+// Twice the matrix work of the forward pass; fragments are streamed from L2, register double-buffered.
+// ------------------------------------------------------------------------------------------
+struct GmmBwdLseArgs {
+  const float* flux;
+  const float* afrag;
+  const float* mfrag;
+  const float* gfrag;
+  const float* const_k;
+  const float* value_patch;  // logsumexp per patch (global patch index), NaN for filtered patches
+  float* gpatch;             // (n_end - n_begin) * 64
+  int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+};
+
+struct GFrag {
+  float4 a[4][4];  // [ib][jb]
+};
+
+template <bool TRI>
+__device__ __forceinline__ void load_gfrags(GFrag& f, const float4* gf, int k) {
+  const float4* gk = gf + (size_t)k * (AFRAG_FLOATS / 4);
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+      if (!TRI || jb >= ib) f.a[ib][jb] = gk[(ib * 4 + jb) * 64];
+}
+
+template <bool TRI, int GRP>
+__device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr, float ck, const float4 (&x)[GRP][8],
+                                              const float (&v)[GRP][2], f32x4 (&G)[GRP][4][2]) {
+#pragma unroll
+  for (int gi = 0; gi < GRP; ++gi) {
+    f32x4 y[4][2];
+    mfma_tile<TRI>(y, f, x[gi]);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        q0 = fmaf(y[jb][nb][0], y[jb][nb][0], q0), q1 = fmaf(y[jb][nb][1], y[jb][nb][1], q1);
+        q0 = fmaf(y[jb][nb][2], y[jb][nb][2], q0), q1 = fmaf(y[jb][nb][3], y[jb][nb][3], q1);
+      }
+      const float l = fmaf(-0.5f, sum_lane_groups(q0 + q1), ck);
+      const float r = (v[gi][nb] == v[gi][nb]) ? expf(l - v[gi][nb]) : 0.f;  // NaN marks a filtered patch
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[jb][nb][e] *= r;
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+      for (int jb = TRI ? ib : 0; jb < 4; ++jb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            G[gi][ib][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(gfr.a[ib][jb], e), y[jb][nb][e], G[gi][ib][nb], 0, 0, 0);
+  }
+}
+
+template <bool TRI, int GRP>
+__global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, n16 = lane & 15;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
+  const int n_groups = (a.n_end - a.n_begin + 31) / 32;
+  const float4* af = reinterpret_cast<const float4*>(a.afrag) + lane;
+  const float4* mf = reinterpret_cast<const float4*>(a.mfrag) + g;
+  const float4* gf = reinterpret_cast<const float4*>(a.gfrag) + lane;
+  for (int grp0 = wave_global * GRP; grp0 < n_groups; grp0 += n_waves * GRP) {
+    int n[GRP][2];
+    bool valid[GRP][2];
+    float v[GRP][2];
+    float4 x[GRP][8];
+    f32x4 G[GRP][4][2];
+#pragma unroll
+    for (int gi = 0; gi < GRP; ++gi)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        n[gi][nb] = a.n_begin + (grp0 + gi) * 32 + nb * 16 + n16;
+        valid[gi][nb] = n[gi][nb] < a.n_end;
+        v[gi][nb] = valid[gi][nb] ? a.value_patch[n[gi][nb]] : NAN;
+        const int py = valid[gi][nb] ? n[gi][nb] / a.nPx : 0, px = valid[gi][nb] ? n[gi][nb] % a.nPx : 0;
+        float xv[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+          const int p = 4 * st + g;
+          const int yy = wrap(py * a.stride + (p >> 3) - a.shift_y, a.H);
+          const int xx = wrap(px * a.stride + (p & 7) - a.shift_x, a.W);
+          xv[st] = valid[gi][nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
+        }
+        const float mean = patch_mean_groups(xv);
+#pragma unroll
+        for (int st4 = 0; st4 < 4; ++st4)
+          x[gi][nb * 4 + st4] = make_float4(xv[4 * st4] - mean, xv[4 * st4 + 1] - mean, xv[4 * st4 + 2] - mean,
+                                            xv[4 * st4 + 3] - mean);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) G[gi][ib][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+
+    FragBuf f0, f1;
+    GFrag g0, g1;
+    load_frags<TRI>(f0, af, mf, 0);
+    load_gfrags<TRI>(g0, gf, 0);
+    for (int k = 0; k < a.K; k += 2) {
+      const int kn = k + 1 < a.K ? k + 1 : k;
+      load_frags<TRI>(f1, af, mf, kn);
+      load_gfrags<TRI>(g1, gf, kn);
+      lse_component<TRI, GRP>(f0, g0, a.const_k[k], x, v, G);
+      const int kn2 = k + 2 < a.K ? k + 2 : k;
+      load_frags<TRI>(f0, af, mf, kn2);
+      load_gfrags<TRI>(g0, gf, kn2);
+      if (k + 1 < a.K) lse_component<TRI, GRP>(f1, g1, a.const_k[k + 1], x, v, G);
+    }
+
+    // gamma = -G, minus its mean over the 64 pixels (adjoint of the patch-mean subtraction)
+#pragma unroll
+    for (int gi = 0; gi < GRP; ++gi)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        float sum = 0.f;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) sum += (G[gi][ib][nb][0] + G[gi][ib][nb][1]) + (G[gi][ib][nb][2] + G[gi][ib][nb][3]);
+        const float mean = sum_lane_groups(sum) * (1.f / 64.f);
+        if (valid[gi][nb]) {
+          float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(n[gi][nb] - a.n_begin) * D);
+#pragma unroll
+          for (int ib = 0; ib < 4; ++ib)
+            out[4 * ib + g] = make_float4(mean - G[gi][ib][nb][0], mean - G[gi][ib][nb][1], mean - G[gi][ib][nb][2],
+                                          mean - G[gi][ib][nb][3]);
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Overlap-add gather: every pixel of the rolled frame sums the contributions of the patches that
 // cover it in a fixed order (no float atomics), un-rolls and accumulates into grad.
 // ------------------------------------------------------------------------------------------
@@ -574,6 +736,8 @@ struct jd_gmm {
   size_t order_cap = 0;
   float* gpatch = nullptr;
   size_t gpatch_cap = 0;
+  float* vpatch = nullptr;  // logsumexp per patch (marginalized backward)
+  size_t vpatch_cap = 0;
   double* partials = nullptr;
   size_t partials_cap = 0;
   int n_cu = 256;
@@ -660,7 +824,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
 extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (!g) return JD_OK;
   (void)hipDeviceSynchronize();
-  for (float* p : {g->afrag, g->mfrag, g->const_k, g->gfrag, g->gpatch})
+  for (float* p : {g->afrag, g->mfrag, g->const_k, g->gfrag, g->gpatch, g->vpatch})
     if (p) (void)hipFree(p);
   if (g->argmax) (void)hipFree(g->argmax);
   if (g->order) (void)hipFree(g->order);
@@ -734,8 +898,6 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   JD_REQUIRE(g && flux && value_out, "jd_gmm_prior_fwd_bwd: null argument");
   JD_REQUIRE(H >= P && W >= P, "jd_gmm_prior_fwd_bwd: image (%d, %d) smaller than a patch", H, W);
   JD_REQUIRE(stride >= 1 && stride <= P, "jd_gmm_prior_fwd_bwd: stride = %d not in [1, 8]", stride);
-  JD_REQUIRE(!(marginalize && grad_flux_accum),
-             "jd_gmm_prior_fwd_bwd: the gradient of the marginalized (logsumexp) prior is not implemented");
   const int nPy = (H - P) / stride + 1, nPx = (W - P) / stride + 1;
   JD_REQUIRE((long)nPy * nPx < (1L << 31), "jd_gmm_prior_fwd_bwd: too many patches");
   if (patch_row_end < 0) patch_row_end = nPy;
@@ -759,6 +921,10 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   a.flux = flux, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
   a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x;
   a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = arg, a.value_patch = nullptr, a.partials = g->partials;
+  if (marginalize && grad_flux_accum) {
+    if ((rc = grow(&g->vpatch, &g->vpatch_cap, (size_t)nPy * nPx))) return rc;
+    a.value_patch = g->vpatch;
+  }
   int n_waves = 0;
   if (marginalize)
     rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
@@ -770,6 +936,24 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   if (!grad_flux_accum) return JD_OK;
 
   if ((rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;
+  if (marginalize) {
+    GmmBwdLseArgs b{};
+    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
+    b.value_patch = g->vpatch, b.gpatch = g->gpatch, b.K = g->K;
+    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
+    b.n_begin = n_begin, b.n_end = n_end;
+    const long groups = (n + 31) / 32;
+    long blocks = (groups + 2 * 4 - 1) / (2 * 4);  // 2 groups per wave, 4 waves per block
+    if (blocks > g->n_cu) blocks = g->n_cu;       // one block per CU (one wave per SIMD), grid-stride over the rest
+    {
+      ProfScope prof(JD_KERNEL_GMM_BWD, s);
+      if (g->triangular && !getenv("JD_GMM_DENSE"))
+        gmm_bwd_lse_kernel<true, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+      else
+        gmm_bwd_lse_kernel<false, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+    }
+    JD_LAUNCH_CHECK();
+  } else {
   const size_t slots_cap = (size_t)n + 32 * (size_t)g->K;
   if ((rc = grow(&g->order, &g->order_cap, slots_cap))) return rc;
   // ---- bucket the patches by arg-max component -------------------------------------------------
@@ -800,6 +984,7 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
       gmm_bwd_max_kernel<false><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
   }
   JD_LAUNCH_CHECK();
+  }
 
   GmmGatherArgs ga{};
   ga.gpatch = g->gpatch, ga.grad = grad_flux_accum, ga.H = H, ga.W = W, ga.stride = stride, ga.nPx = nPx, ga.nPy = nPy;

@@ -19,10 +19,13 @@ __all__ = ["DistContext", "init_from_env"]
 class DistContext:
     """Rank / world size and the two sharding rules + the gradient all-reduce."""
 
-    def __init__(self, rank=0, world_size=1, group=None):
+    def __init__(self, rank=0, world_size=1, group=None, dry_run=False):
         self.rank = rank
         self.world_size = world_size
         self.group = group
+        # dry_run: shard like rank `rank` of `world_size` but skip the collectives (single-process
+        # timing of one rank's share of the step, bench.py --shard-of)
+        self.dry_run = dry_run
 
     @classmethod
     def current(cls):
@@ -43,12 +46,12 @@ class DistContext:
 
     def all_reduce_sum(self, buffer):
         """In-place sum all-reduce of one flat tensor (a no-op for a single process)."""
-        if self.world_size > 1:
+        if self.world_size > 1 and not self.dry_run:
             dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=self.group)
         return buffer
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.world_size > 1 and not self.dry_run:
             dist.barrier(group=self.group)
 
 

@@ -281,8 +281,6 @@ class GMMPatchPriorFunction(torch.autograd.Function):
         value = torch.empty(1, dtype=torch.float32, device=image.device)
         grad = None
         if flux.requires_grad:
-            if marginalize:
-                raise NotImplementedError("gradient of the marginalized GMM prior is not implemented yet")
             grad = torch.zeros(image.shape[-2:], dtype=torch.float32, device=image.device)
         handle.prior_fwd_bwd(
             image.reshape(image.shape[-2:]), stride, shifts, value, value_scale, grad=grad, grad_coef=value_scale,

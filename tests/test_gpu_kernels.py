@@ -132,7 +132,10 @@ def test_gmm_prior_max_value_grad_argmax(golden, name, gname):
 
 @pytest.mark.parametrize("name", CASES[:3])
 def test_gmm_prior_marginalized_value(golden, name):
-    """logsumexp mode forward value (priors/patches/core.py:242-243)."""
+    """logsumexp mode (priors/patches/core.py:242-243): forward value and gradient
+    (sum_k responsibility_k * gamma_k).  The fixture's flux is float32(gamma * 3) while the kernels see
+    exp(log(.)), a <= 1 ulp difference that the responsibilities of near-tie components amplify to
+    ~1e-4 (the CPU oracle shows the same deviation, tests/test_oracle_golden.py), hence 5e-4."""
     stages = golden("stages")
     for gname in ("k16", "k5m"):
         handle = _gmm(stages, gname).handle(DEV)
@@ -143,6 +146,10 @@ def test_gmm_prior_marginalized_value(golden, name):
             value = torch.zeros(1, device=DEV)
             handle.prior_fwd_bwd(flux, 4, shifts, value, scale, marginalize=True)
             np.testing.assert_allclose(float(value), float(stages[f"{key}/value"]), rtol=3e-6)
+            value2, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+            handle.prior_fwd_bwd(flux, 4, shifts, value2, scale, grad=grad, grad_coef=scale, marginalize=True)
+            assert torch.equal(value, value2)
+            assert rel_linf(grad.cpu().numpy(), stages[f"{key}/grad_flux"]) < 5e-4
 
 
 def test_gmm_prior_patch_row_shards_sum_to_whole(golden):
@@ -364,3 +371,60 @@ def test_gmm_non_triangular_precisions_use_the_dense_variant():
         y = (x.astype(np.float64) - means[k]) @ pc[k].astype(np.float64)
         ref[:, k] = -0.5 * (64 * np.log(2 * np.pi) + (y * y * w).sum(1)) + np.log(np.diag(pc[k])).sum() + np.log(weights[k])
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=5e-4)
+
+
+def test_gmm_prior_marginalized_gradient_exact_inputs():
+    """logsumexp gradient against the CPU oracle on bit-identical inputs (no exp(log(.)) round trip).
+    Tolerance 5e-5 instead of the 1e-5 of the max mode: the responsibilities exponentiate the ABSOLUTE
+    fp32 error of the log-likelihoods (|l| ~ 1e2..1e3, so ~1e-5 per component whatever the summation
+    order), which no fp32 implementation can avoid; measured 1.9e-5 here."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+    from oracle import cpu_ref
+
+    rs = np.random.RandomState(12)
+    means, covs, weights = synthetic_gmm(9, 64, seed=6)
+    means = 0.05 * rs.normal(size=means.shape)
+    flux_np = (rs.gamma(3, size=(70, 91)) * 2).astype(np.float32)
+    gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+    value_o, grad_o, _ = cpu_ref.gmm_prior_value_and_grad(flux_np, gmm_o, 4, (-1, 2), marginalize=True)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+    handle = gmm.handle(DEV)
+    flux = torch.from_numpy(flux_np).to(DEV)
+    scale = (16 / 64) / flux.numel()
+    value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+    handle.prior_fwd_bwd(flux, 4, (-1, 2), value, scale, grad=grad, grad_coef=scale, marginalize=True)
+    np.testing.assert_allclose(float(value), value_o, rtol=3e-6)
+    assert rel_linf(grad.cpu().numpy(), grad_o) < 5e-5
+    # patch-row shards accumulate to the same gradient
+    n_rows = (70 - 8) // 4 + 1
+    pv, pg = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+    for lo, hi in ((0, 6), (6, 6), (6, n_rows)):
+        handle.prior_fwd_bwd(flux, 4, (-1, 2), pv, scale, grad=pg, grad_coef=scale, marginalize=True,
+                             patch_rows=(lo, hi), accumulate_value=True)
+    np.testing.assert_allclose(float(pv), float(value), rtol=1e-6)
+    assert rel_linf(pg.cpu().numpy(), grad.cpu().numpy()) < 1e-6
+
+
+def test_marginalized_prior_fit_matches_oracle():
+    """A short sequential fit with GMMPatchPrior(marginalize=True) against oracle/cpu_ref.py."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+    from jolideco_amd.data import point_source_gauss_psf, synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+    from oracle import cpu_ref
+
+    rs = np.random.RandomState(5)
+    datasets = {f"o{i}": point_source_gauss_psf(shape=(40, 48), sigma_psf=2 + i, random_state=rs) for i in range(2)}
+    for d in datasets.values():
+        d.pop("flux")
+    flux_init = rs.gamma(30, size=(40, 48))
+    means, covs, weights = synthetic_gmm(6, 64, seed=3)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+    comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm, marginalize=True))
+    res = MAPDeconvolver(n_epochs=4, display_progress=False, device=DEV).run(datasets, components=comp)
+    gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+    final, trace = cpu_ref.map_fit_sequential(
+        datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o, marginalize=True)}, n_epochs=4
+    )
+    assert rel_linf(res.flux_total, final["flux"]) < 5e-5  # see the tolerance note above
+    np.testing.assert_allclose(res.trace_loss[-1]["total"], trace[-1]["total"], rtol=2e-5)
