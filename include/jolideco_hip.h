@@ -98,14 +98,18 @@ int jd_conv_same(jd_conv_plan* plan, const float* image, const float* scale_imag
  * grad_flux[c]  <- (accumulate ? += : =) grad_scale * E_c * corr(psf_c, g * [conv_c >= 0]),
  *                  g = (1 - c/(n+eps)) / (H*W);  pass grad_flux == NULL for a forward-only
  *                  evaluation (PoissonLoss.evaluate, loss.py:56-71).
- * npred_out     optional (H, W) output of the total predicted counts.
+ * npred_out     optional output of the total predicted counts (counts grid).
+ * upsampling    u >= 1: flux_c, exposure_c and grad_flux_c live on the plan's (H, W) grid, background,
+ *               counts and npred_out on (H/u, W/u); the convolution is sum-pooled u x u before the clip
+ *               (models/npred.py:181-184, `upsampling_factor`).  The PSF given to jd_conv_psf_spectrum and
+ *               the exposure must already be up-sampled (models/npred.py:96-106 does that at setup).
  * `stirling_mean` = mean([c>1] * (c*log c - c + 0.5*log(2*pi*c))) is flux independent and is
  * supplied by the caller (computed once per dataset). */
 int jd_npred_poisson_fwd_bwd(jd_conv_plan* plan, int n_comp, const float* const* flux,
                              const float* const* exposure, const float* const* khat,
                              const float* background, const float* counts, float stirling_mean,
                              float eps, float* loss_out, float* const* grad_flux, int accumulate,
-                             float grad_scale, float* npred_out, void* stream);
+                             float grad_scale, float* npred_out, int upsampling, void* stream);
 
 /* Same chain split at the reference's object seams, for callers that keep the reference's own
  * loop structure (autograd.Function wrappers in jolideco_amd/ops.py):

@@ -217,6 +217,67 @@ int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stre
   return JD_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// K3 with sum-pooling (upsampling_factor u > 1, jolideco/models/npred.py:181-184): one thread per
+// COUNTS pixel sums the u x u block of every component's convolution, clips, adds the background,
+// accumulates the Poisson NLL and replicates g = d loss / d npred into the u x u block of g_c (the
+// adjoint of the sum-pool), masked where the pooled value was clipped.  The padding of the g buffers
+// (FFT method) is already zero: K1 rewrote the whole padded grid before the forward transform.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void poisson_pooled_kernel(PoissonArgs a) {
+  __shared__ double smem[BLOCK / 64];
+  const int u = a.up;
+  const int Hd = a.H / u, Wd = a.W / u;
+  const int y = blockIdx.y;
+  const int x = blockIdx.x * BLOCK + threadIdx.x;
+  double local = 0.0;
+  if (y < Hd && x < Wd) {
+    const size_t off = (size_t)y * Wd + x;
+    float pooled[JD_MAX_COMPONENTS];
+    float n = 0.f;
+#pragma unroll
+    for (int k = 0; k < JD_MAX_COMPONENTS; ++k) {
+      if (k >= a.n_comp) break;
+      float acc = 0.f;
+      for (int dy = 0; dy < u; ++dy) {
+        const float* row = a.conv[k] + (size_t)(y * u + dy + a.oy) * a.Wp + (x * u + a.ox);
+        for (int dx = 0; dx < u; ++dx) acc += row[dx];
+      }
+      pooled[k] = acc;
+      n += fmaxf(acc, 0.f);  // clip per component after pooling (npred.py:181-191)
+    }
+    n += a.background[off];
+    const float c = a.counts[off];
+    const float ne = n + a.eps;
+    local = (double)(n - c * logf(ne));
+    const float g = (1.f - c / ne) * a.inv_n;
+    if (a.npred_out) a.npred_out[off] = n;
+    if (a.write_grad) {
+#pragma unroll
+      for (int k = 0; k < JD_MAX_COMPONENTS; ++k) {
+        if (k >= a.n_comp) break;
+        const float gk = pooled[k] >= 0.f ? g : 0.f;
+        for (int dy = 0; dy < u; ++dy) {
+          float* row = a.g[k] + (size_t)(y * u + dy) * a.Wp + (size_t)x * u;
+          for (int dx = 0; dx < u; ++dx) row[dx] = gk;
+        }
+      }
+    }
+  }
+  const double total = block_sum<BLOCK>(local, smem);
+  if (threadIdx.x == 0) a.partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
+}
+
+int launch_poisson_pooled(const PoissonArgs& a, int* n_partials, hipStream_t stream) {
+  const int Hd = a.H / a.up, Wd = a.W / a.up;
+  dim3 grid((Wd + BLOCK - 1) / BLOCK, Hd);
+  *n_partials = grid.x * grid.y;
+  ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
+  poisson_pooled_kernel<<<grid, BLOCK, 0, stream>>>(a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
 int poisson_fused_max_partials(int Hp, int Wp) { return ((Wp + BLOCK - 1) / BLOCK) * Hp; }
 
 // ------------------------------------------------------------------------------------------

@@ -260,9 +260,12 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
                                         const float* const* exposure, const float* const* khat,
                                         const float* background, const float* counts, float stirling_mean,
                                         float eps, float* loss_out, float* const* grad_flux, int accumulate,
-                                        float grad_scale, float* npred_out, void* stream) {
+                                        float grad_scale, float* npred_out, int upsampling, void* stream) {
   JD_REQUIRE(p && flux && exposure && khat && background && counts && loss_out,
              "jd_npred_poisson_fwd_bwd: null argument");
+  JD_REQUIRE(upsampling >= 1 && upsampling <= 8 && p->H % upsampling == 0 && p->W % upsampling == 0,
+             "jd_npred_poisson_fwd_bwd: upsampling = %d must be in [1, 8] and divide the flux grid (%d, %d)",
+             upsampling, p->H, p->W);
   JD_REQUIRE(n_comp >= 1 && n_comp <= JD_MAX_COMPONENTS, "jd_npred_poisson_fwd_bwd: n_comp = %d not in [1, %d]",
              n_comp, JD_MAX_COMPONENTS);
   for (int c = 0; c < n_comp; ++c) {
@@ -286,11 +289,14 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
   a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = p->partials;
   a.n_comp = n_comp, a.H = p->H, a.W = p->W, a.Hp = p->Hp, a.Wp = p->Wp, a.oy = p->py, a.ox = p->px;
   a.eps = eps;
-  const double n_pix = (double)p->H * (double)p->W;
+  a.up = upsampling;
+  // the loss is the mean over the COUNTS pixels (loss.py:35-37)
+  const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   a.inv_n = (float)(1.0 / n_pix);
   a.write_grad = grad_flux ? 1 : 0;
   int n_partials = 0;
-  if ((rc = launch_poisson_fused(a, &n_partials, s))) return rc;
+  if ((rc = upsampling > 1 ? launch_poisson_pooled(a, &n_partials, s) : launch_poisson_fused(a, &n_partials, s)))
+    return rc;
   if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
     return rc;
   if (!grad_flux) return JD_OK;

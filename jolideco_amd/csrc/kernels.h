@@ -11,15 +11,17 @@ struct PoissonArgs {
   const float* counts;
   float* npred_out;  // nullable
   double* partials;
-  int n_comp, H, W, Hp, Wp, oy, ox;
+  int n_comp, H, W, Hp, Wp, oy, ox;  // (H, W): the conv / flux grid; counts live on (H / up, W / up)
   float eps, inv_n;
   int write_grad;
+  int up;  // up-sampling factor of the flux grid w.r.t. the counts grid (1 = none)
 };
 
 int launch_pad_mul(const float* image, const float* scale, float* padded, int H, int W, int Hp, int Wp,
                    hipStream_t stream);
 int launch_cmul(float2* spec, const float2* khat, size_t n, bool conj, hipStream_t stream);
 int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stream);
+int launch_poisson_pooled(const PoissonArgs& a, int* n_partials, hipStream_t stream);
 int poisson_fused_max_partials(int Hp, int Wp);
 int launch_adjoint_epilogue(const float* corr, const float* scale, float* grad, int H, int W, int Hp,
                             int Wp, int oy, int ox, float coef, int accumulate, hipStream_t stream);

@@ -26,7 +26,7 @@ class SpatialFluxComponent(nn.Module):
     use_log_flux : bool
         Optimise log(flux) (only True is implemented).
     upsampling_factor : int
-        Only 1 is implemented.
+        Up-sampling factor of the flux grid w.r.t. the counts grid (None / 1 = none).
     prior : `Prior`
         Prior of this component (default uniform).
     frozen : bool
@@ -51,8 +51,8 @@ class SpatialFluxComponent(nn.Module):
             raise ValueError(f"Flux tensor must be four dimensional. Got {flux_upsampled.ndim}")
         if not use_log_flux:
             raise NotImplementedError("use_log_flux=False is not implemented in jolideco_amd")
-        if upsampling_factor not in (None, 1):
-            raise NotImplementedError("upsampling_factor != 1 is not implemented in jolideco_amd yet")
+        if upsampling_factor is not None and (int(upsampling_factor) != upsampling_factor or upsampling_factor < 1):
+            raise ValueError(f"upsampling_factor must be a positive integer, got {upsampling_factor}")
         flux_upsampled = torch.log(flux_upsampled.to(torch.float32))
         self._flux_upsampled = nn.Parameter(flux_upsampled)
         self._flux_upsampled_error = flux_upsampled_error
@@ -62,17 +62,25 @@ class SpatialFluxComponent(nn.Module):
             )
         self.mask = mask
         self._use_log_flux = True
-        self.upsampling_factor = 1
+        self.upsampling_factor = None if upsampling_factor is None else int(upsampling_factor)
         self.prior = prior if prior is not None else UniformPrior()
         self.frozen = frozen
         self._wcs = wcs
 
     @classmethod
     def from_numpy(cls, flux, mask=None, **kwargs):
-        """Create from a 2-D numpy flux image (reference: models/core.py:505-540)."""
+        """Create from a 2-D numpy flux image on the counts grid; with ``upsampling_factor`` the flux
+        (and mask) are bilinearly up-sampled first (reference: models/core.py:505-540)."""
+        import torch.nn.functional as F
+
+        upsampling_factor = kwargs.get("upsampling_factor", None)
         flux = torch.from_numpy(np.asarray(flux)[np.newaxis, np.newaxis].astype(np.float32))
+        if upsampling_factor:
+            flux = F.interpolate(flux, scale_factor=upsampling_factor, mode="bilinear")
         if mask is not None:
             mask = torch.from_numpy(np.asarray(mask)[np.newaxis, np.newaxis].astype(bool))
+            if upsampling_factor:
+                mask = F.interpolate(mask.type(torch.float32), scale_factor=upsampling_factor, mode="bilinear") > 0.5
         return cls(flux_upsampled=flux, mask=mask, **kwargs)
 
     @classmethod
@@ -110,7 +118,13 @@ class SpatialFluxComponent(nn.Module):
 
     @property
     def flux(self):
-        return self.flux_upsampled
+        """Flux on the counts grid: sum-pool of the up-sampled flux (models/core.py:596-607)."""
+        import torch.nn.functional as F
+
+        flux = self.flux_upsampled
+        if self.upsampling_factor:
+            flux = F.avg_pool2d(flux, kernel_size=self.upsampling_factor, divisor_override=1)
+        return flux
 
     @property
     def flux_upsampled_error(self):
@@ -127,7 +141,7 @@ class SpatialFluxComponent(nn.Module):
     def to_dict(self, include_data=None):
         data = {
             "use_log_flux": True,
-            "upsampling_factor": 1,
+            "upsampling_factor": self.upsampling_factor,
             "frozen": self.frozen,
             "prior": self.prior.to_dict(),
         }

@@ -43,10 +43,16 @@ class NPredModel(nn.Module):
         self.upsampling_factor = upsampling_factor
 
     @property
-    def shape(self):
+    def shape_upsampled(self):
         return tuple(self.exposure.shape)
 
-    shape_upsampled = shape
+    @property
+    def shape(self):
+        shape = list(self.shape_upsampled)
+        if self.upsampling_factor:
+            shape[-1] //= self.upsampling_factor
+            shape[-2] //= self.upsampling_factor
+        return tuple(shape)
 
     @classmethod
     def from_numpy(cls, exposure, psf, upsampling_factor=None, correct_exposure_edges=True, device="cuda",
@@ -56,13 +62,19 @@ class NPredModel(nn.Module):
 
         ``kernel_shape`` (KH, KW) >= psf.shape embeds the PSF in a larger zero array such that the
         'same' crop is unchanged; it lets all components of a dataset share one FFT plan."""
-        if upsampling_factor not in (None, 1):
-            raise NotImplementedError("upsampling_factor != 1 is not implemented in jolideco_amd yet")
         device = torch.device(device)
-        exposure_t = _to_device_image(exposure, device)
         psf = np.asarray(psf, dtype=np.float32)
         if kernel_shape is not None and tuple(kernel_shape) != psf.shape:
             psf = embed_kernel(psf, kernel_shape)
+        exposure = np.ascontiguousarray(exposure, dtype=np.float32)
+        if upsampling_factor:
+            # setup-time bilinear up-sampling on the host, PSF divided by u^2 (models/npred.py:96-106)
+            import torch.nn.functional as F
+
+            up = lambda a: F.interpolate(torch.from_numpy(a)[None, None], scale_factor=upsampling_factor, mode="bilinear")[0, 0]  # noqa: E731
+            exposure = up(exposure).numpy()
+            psf = (up(np.ascontiguousarray(psf)) / upsampling_factor**2).numpy()
+        exposure_t = _to_device_image(exposure, device)
         psf_t = _to_device_image(psf, device)
         H, W = exposure_t.shape
         kh, kw = psf_t.shape
@@ -87,6 +99,10 @@ class NPredModel(nn.Module):
         if psf_scale is not None:
             raise NotImplementedError("psf_scale calibration is not implemented in jolideco_amd")
         conv = ConvSameFunction.apply(flux, self.exposure, self.khat, self.plan)
+        if self.upsampling_factor:
+            import torch.nn.functional as F
+
+            conv = F.avg_pool2d(conv, kernel_size=self.upsampling_factor, divisor_override=1)
         return torch.clip(conv, 0, torch.inf)
 
 
@@ -119,6 +135,9 @@ class NPredModels(nn.ModuleDict):
         for name in components.keys():
             psf = dataset["psf"]
             psfs[name] = np.asarray(psf[name] if isinstance(psf, dict) else psf)
+        factors = {c.upsampling_factor or 1 for c in components.values()}
+        if len(factors) != 1:
+            raise NotImplementedError("all components of a fit must share one upsampling_factor in jolideco_amd")
         kernel_shape = (max(p.shape[0] for p in psfs.values()), max(p.shape[1] for p in psfs.values()))
         for name, component in components.items():
             model = NPredModel.from_numpy(
@@ -145,4 +164,5 @@ class NPredModels(nn.ModuleDict):
             fluxes=list(fluxes), exposures=[m.exposure for m in models], khats=[m.khat for m in models],
             background=self.background, counts=counts, stirling=stirling, loss_out=loss_out, grads=grads,
             accumulate=accumulate, grad_scale=grad_scale, npred_out=npred_out,
+            upsampling=models[0].upsampling_factor or 1,
         )

@@ -149,7 +149,7 @@ class ConvPlan:
 
     def npred_poisson_fwd_bwd(
         self, fluxes, exposures, khats, background, counts, stirling, loss_out, grads=None, accumulate=False,
-        grad_scale=1.0, npred_out=None, eps=POISSON_EPS,
+        grad_scale=1.0, npred_out=None, eps=POISSON_EPS, upsampling=1,
     ):
         """Fused forward model + Poisson NLL (+ gradient) of one dataset; see include/jolideco_hip.h."""
         n = len(fluxes)
@@ -162,7 +162,7 @@ class ConvPlan:
                 self._handle, n, ptr_array(fluxes), ptr_array(exposures), ptr_array(khats), ptr(background),
                 ptr(counts), c_float(stirling), c_float(eps), ptr(loss_out),
                 ptr_array(grads) if grads is not None else None, int(accumulate), c_float(grad_scale),
-                ptr(npred_out), stream_ptr(background.device),
+                ptr(npred_out), int(upsampling), stream_ptr(background.device),
             )
         )
 

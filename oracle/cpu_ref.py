@@ -47,18 +47,32 @@ def edge_corrected_exposure(exposure, psf):
     return exposure / convolve_fft(torch.ones_like(exposure), psf)
 
 
-def npred_component(flux, exposure, psf):
-    """clip(conv_same(flux * exposure, psf), 0, inf): jolideco/models/npred.py:160-191 at
-    upsampling_factor=1 / rmf=None (the pool at :181-184 is the identity for kernel 1)."""
-    return torch.clip(convolve_fft(flux * exposure, psf), 0, torch.inf)
+def npred_component(flux, exposure, psf, upsampling_factor=None):
+    """clip(sum_pool_u(conv_same(flux * exposure, psf)), 0, inf): jolideco/models/npred.py:160-191
+    (rmf=None).  `exposure` / `psf` are the (already up-sampled) buffers of `upsample_setup`."""
+    npred = convolve_fft(flux * exposure, psf)
+    if upsampling_factor:
+        npred = F.avg_pool2d(npred, kernel_size=upsampling_factor, divisor_override=1)  # npred.py:181-184
+    return torch.clip(npred, 0, torch.inf)
 
 
-def npred_total(fluxes, exposures, psfs, background):
+def upsample_setup(tensor, upsampling_factor, is_psf):
+    """Bilinear up-sampling of exposure / PSF at setup, PSF divided by u^2:
+    jolideco/models/npred.py:96-106."""
+    if upsampling_factor:
+        tensor = F.interpolate(tensor, scale_factor=upsampling_factor, mode="bilinear")
+        if is_psf:
+            tensor = tensor / upsampling_factor**2
+    return tensor
+
+
+def npred_total(fluxes, exposures, psfs, background, upsampling_factors=None):
     """sum_c npred_c + background, accumulated into zeros in component order, background last:
     jolideco/models/npred.py:210-261 (no calibration)."""
     total = torch.zeros(background.shape)
-    for flux, exposure, psf in zip(fluxes, exposures, psfs):
-        total += npred_component(flux, exposure, psf)
+    ups = upsampling_factors or [None] * len(fluxes)
+    for flux, exposure, psf, u in zip(fluxes, exposures, psfs, ups):
+        total += npred_component(flux, exposure, psf, u)
     total += background
     return total
 
@@ -290,18 +304,20 @@ class DatasetRef:
 
     counts: torch.Tensor  # (1,1,H,W)
     background: torch.Tensor
-    exposures: list  # per component, edge-corrected
-    psfs: list  # per component (1,1,kh,kw)
+    exposures: list  # per component, edge-corrected (up-sampled when the component is)
+    psfs: list  # per component (1,1,kh,kw) (up-sampled, / u^2)
+    upsampling_factors: list = None  # per component: None or int
 
     @classmethod
-    def from_numpy(cls, dataset, component_names):
+    def from_numpy(cls, dataset, component_names, upsampling_factors=None):
         exposures, psfs = [], []
-        for name in component_names:
+        ups = upsampling_factors or [None] * len(component_names)
+        for name, u in zip(component_names, ups):
             psf = dataset["psf"]
             if isinstance(psf, dict):
                 psf = psf[name]
-            psf_t = torch.from_numpy(psf[np.newaxis, np.newaxis])
-            exp_t = torch.from_numpy(dataset["exposure"][np.newaxis, np.newaxis])
+            psf_t = upsample_setup(torch.from_numpy(psf[np.newaxis, np.newaxis]), u, is_psf=True)
+            exp_t = upsample_setup(torch.from_numpy(dataset["exposure"][np.newaxis, np.newaxis]), u, is_psf=False)
             exposures.append(edge_corrected_exposure(exp_t, psf_t))
             psfs.append(psf_t)
         return cls(
@@ -309,19 +325,30 @@ class DatasetRef:
             background=torch.from_numpy(dataset["background"][np.newaxis, np.newaxis]),
             exposures=exposures,
             psfs=psfs,
+            upsampling_factors=list(ups),
         )
 
     def npred(self, fluxes):
-        return npred_total(fluxes, self.exposures, self.psfs, self.background)
+        return npred_total(fluxes, self.exposures, self.psfs, self.background, self.upsampling_factors)
 
     def loss(self, fluxes):
         return poisson_nll(self.npred(fluxes), self.counts)
 
 
-def log_flux_parameter(flux_init):
-    """theta = log(float32(flux)) as a (1,1,H,W) leaf: jolideco/models/core.py:399-402,505-540."""
+def log_flux_parameter(flux_init, upsampling_factor=None):
+    """theta = log(float32(flux)) as a (1,1,H,W) leaf, bilinearly up-sampled first when the component
+    is: jolideco/models/core.py:399-402,505-540."""
     flux = torch.from_numpy(flux_init[np.newaxis, np.newaxis].astype(np.float32))
+    if upsampling_factor:
+        flux = F.interpolate(flux, scale_factor=upsampling_factor, mode="bilinear")
     return torch.log(flux).requires_grad_(True)
+
+
+def downsampled_flux(flux_upsampled, upsampling_factor=None):
+    """SpatialFluxComponent.flux: sum-pool of the up-sampled flux, jolideco/models/core.py:596-607."""
+    if upsampling_factor:
+        return F.avg_pool2d(flux_upsampled, kernel_size=upsampling_factor, divisor_override=1)
+    return flux_upsampled
 
 
 def to_flux(theta, mask=None):
@@ -356,6 +383,7 @@ def map_fit_sequential(
     datasets_validation=None,
     masks=None,
     record_steps=False,
+    upsampling_factors=None,
 ):
     """The reference optimisation loop: one Adam step per dataset on
     L_d - beta * logprior / n_datasets, then a no-grad trace row evaluated on the STALE fluxes
@@ -367,16 +395,17 @@ def map_fit_sequential(
     """
     names_c = list(flux_inits)
     names_d = list(datasets)
-    thetas = [log_flux_parameter(flux_inits[n]) for n in names_c]
+    ups = [(upsampling_factors or {}).get(n) for n in names_c]
+    thetas = [log_flux_parameter(flux_inits[n], u) for n, u in zip(names_c, ups)]
     masks = masks or {}
     mask_t = [
         None if masks.get(n) is None else torch.from_numpy(masks[n][np.newaxis, np.newaxis].astype(bool))
         for n in names_c
     ]
-    data = [DatasetRef.from_numpy(datasets[n], names_c) for n in names_d]
+    data = [DatasetRef.from_numpy(datasets[n], names_c, ups) for n in names_d]
     data_val = None
     if datasets_validation:
-        data_val = [DatasetRef.from_numpy(d, names_c) for d in datasets_validation.values()]
+        data_val = [DatasetRef.from_numpy(d, names_c, ups) for d in datasets_validation.values()]
     optimizer = torch.optim.Adam(thetas, lr=learning_rate)
     prior_list = [priors[n] for n in names_c]
     n_datasets = len(data)
@@ -407,6 +436,7 @@ def map_fit_sequential(
                 loss_val = [d.loss(fluxes).item() for d in data_val]
         trace.append(_trace_row(names_d, names_c, loss_datasets, loss_priors, beta, loss_val))
 
+    # `final` holds the UP-SAMPLED fluxes (== the fluxes when upsampling_factor is None)
     final = {n: to_flux(t, m).detach().numpy()[0, 0] for n, t, m in zip(names_c, thetas, mask_t)}
     if record_steps:
         return final, trace, steps

@@ -232,6 +232,56 @@ def reference_test_cases():
     print("reference_test_cases ok")
 
 
+def upsampling_case():
+    """The reference's up-sampling known-answer test (jolideco/tests/test_core.py:99-124): disk
+    datasets, flux component with upsampling_factor=2, uniform prior, 100 epochs; plus a short
+    fit with a GMM prior on the up-sampled flux and an odd factor (3)."""
+    rs = np.random.RandomState(642020)
+    datasets_disk = {f"{i}": disk_source_gauss_psf(random_state=rs) for i in range(3)}
+    flux_init = np.random.RandomState(642020).gamma(20, size=(32, 32))
+    comps = FluxComponents()
+    comps["flux-1"] = SpatialFluxComponent.from_numpy(flux=flux_init, upsampling_factor=2, prior=UniformPrior())
+    res = MAPDeconvolver(n_epochs=100, learning_rate=0.1, display_progress=False).run(
+        datasets=datasets_disk, components=comps
+    )
+    assert res.flux_upsampled_total.shape == (64, 64)
+    assert np.isclose(res.flux_total[12, 12], 3.565998, rtol=1e-3) and np.isclose(res.flux_total[0, 0], 1.605782, rtol=1e-3)
+    assert np.isclose(res.trace_loss[-1]["total"], 5.844786, rtol=1e-3)
+    final, trace = cpu_ref.map_fit_sequential(
+        datasets_disk, {"flux-1": flux_init}, {"flux-1": cpu_ref.UniformPriorRef()}, n_epochs=100,
+        upsampling_factors={"flux-1": 2},
+    )
+    assert np.array_equal(final["flux-1"], res.flux_upsampled_total), np.abs(final["flux-1"] - res.flux_upsampled_total).max()
+    assert trace[-1]["total"] == res.trace_loss[-1]["total"]
+    out = {"flux_init": flux_init, "u2/flux_upsampled_final": res.flux_upsampled_total, "u2/flux_final": res.flux_total}
+    out.update({f"u2/{k}": v for k, v in trace_to_arrays(res.trace_loss).items()})
+    out.update({f"disk/{k}": v for k, v in pack_datasets(datasets_disk).items()})
+
+    # GMM prior on the up-sampled flux, factor 3, 2 observations with a small 5x5 PSF
+    rs = np.random.RandomState(31)
+    means, covs, weights = cpu_ref.synthetic_gmm(6, 64, seed=8)
+    shape = (24, 28)
+    datasets = {f"o{i}": scene(shape, asym_psf((5, 5), 1.0 + 0.2 * i, 1.3), rs, n_points=3, bkg=1.0) for i in range(2)}
+    init3 = rs.gamma(30, size=shape)
+    comps = FluxComponents()
+    comps["flux"] = SpatialFluxComponent.from_numpy(
+        flux=init3, upsampling_factor=3, prior=GMMPatchPrior(gmm=ref_gmm(means, covs, weights))
+    )
+    res3 = MAPDeconvolver(n_epochs=5, display_progress=False).run(datasets=datasets, components=comps)
+    gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+    final, trace = cpu_ref.map_fit_sequential(
+        datasets, {"flux": init3}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o)}, n_epochs=5, upsampling_factors={"flux": 3}
+    )
+    assert np.array_equal(final["flux"], res3.flux_upsampled_total)
+    assert trace[-1]["total"] == res3.trace_loss[-1]["total"]
+    out.update({"u3/flux_init": init3, "u3/flux_upsampled_final": res3.flux_upsampled_total, "u3/flux_final": res3.flux_total,
+                "u3/gmm_means": means, "u3/gmm_covariances": covs, "u3/gmm_weights": weights})
+    out.update({f"u3/{k}": v for k, v in pack_datasets(datasets).items()})
+    out.update({f"u3/{k}": v for k, v in trace_to_arrays(res3.trace_loss).items()})
+    np.savez_compressed(OUT / "upsampling.npz", **out)
+    print("upsampling_case ok", res.flux_total[12, 12], res3.trace_loss[-1]["total"])
+
+
 def stage_vectors():
     """Per-stage vectors: npred / loss / dL/dtheta and GMM prior value / grad / arg-max for
     several shapes incl. non-square images, even-sized and asymmetric PSFs, sizes that leave a
@@ -419,12 +469,16 @@ def joint_and_multi():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "upsampling":  # add this fixture without touching the others
+        upsampling_case()
+        sys.exit(0)
     rng_draws()
     anchor_a()
     anchor_b()
     reference_test_cases()
     stage_vectors()
     joint_and_multi()
+    upsampling_case()
     import os
 
     for f in sorted(OUT.glob("*.npz")):

@@ -208,3 +208,42 @@ def test_mask_and_frozen_component():
     np.testing.assert_array_equal(res.components["b"]._flux_upsampled.detach().cpu().numpy(), theta_b0)
     np.testing.assert_allclose(fl["b"], b0, rtol=1e-6)  # exp() evaluated on the device
     assert len(res.trace_loss) == 5 and np.all(np.diff(res.trace_loss["total"]) < 0)
+
+
+def test_upsampling_factor_2_reference_known_answers(golden):
+    """The reference's up-sampling test (jolideco/tests/test_core.py:99-124): flux grid 2x the counts
+    grid, PSF / exposure bilinearly up-sampled at setup, sum-pooled npred.  The 34x34 up-sampled PSF
+    takes the rocFFT path."""
+    from jolideco_amd import FluxComponents, MAPDeconvolver, SpatialFluxComponent, UniformPrior
+
+    u = golden("upsampling")
+    datasets = unpack_datasets(u, "disk/data/")
+    comps = FluxComponents()
+    comps["flux-1"] = SpatialFluxComponent.from_numpy(flux=u["flux_init"], upsampling_factor=2, prior=UniformPrior())
+    res = MAPDeconvolver(n_epochs=100, learning_rate=0.1, display_progress=False, device=DEV).run(datasets, components=comps)
+    assert res.flux_upsampled_total.shape == (64, 64) and res.flux_total.shape == (32, 32)
+    assert res.components["flux-1"].upsampling_factor == 2
+    np.testing.assert_allclose(res.flux_total[12, 12], 3.565998, rtol=1e-3)
+    np.testing.assert_allclose(res.flux_total[0, 0], 1.605782, rtol=1e-3)
+    row = res.trace_loss[-1]
+    np.testing.assert_allclose(row["total"], 5.844786, rtol=1e-3)
+    np.testing.assert_allclose(row["dataset-0"], 1.946759, rtol=1e-3)
+    np.testing.assert_allclose(row["dataset-1"], 1.958015, rtol=1e-3)
+    np.testing.assert_allclose(row["dataset-2"], 1.940012, rtol=1e-3)
+    assert rel_linf(res.flux_upsampled_total, u["u2/flux_upsampled_final"]) < 1e-4  # 300 Adam steps
+    assert rel_linf(res.flux_total, u["u2/flux_final"]) < 1e-4
+    _trace_close(res.trace_loss, u, prefix="u2/trace/")
+
+
+def test_upsampling_factor_3_gmm_prior(golden, conv_method):
+    """Odd factor, GMM prior evaluated on the up-sampled flux, 15x15 up-sampled PSF (both methods)."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+
+    u = golden("upsampling")
+    datasets = unpack_datasets(u, "u3/data/")
+    gmm = _gmm(u["u3/gmm_means"], u["u3/gmm_covariances"], u["u3/gmm_weights"])
+    comp = SpatialFluxComponent.from_numpy(flux=u["u3/flux_init"], upsampling_factor=3, prior=GMMPatchPrior(gmm=gmm))
+    res = MAPDeconvolver(n_epochs=5, display_progress=False, device=DEV).run(datasets, components=comp)
+    assert rel_linf(res.flux_upsampled_total, u["u3/flux_upsampled_final"]) < 1e-5
+    assert rel_linf(res.flux_total, u["u3/flux_final"]) < 1e-5
+    _trace_close(res.trace_loss, u, prefix="u3/trace/")

@@ -205,3 +205,31 @@ def test_two_components_per_component_psf(golden):
     assert rel_linf(final["extended"], j["multi/final/extended"]) < TOL
     assert rel_linf(final["points"], j["multi/final/points"]) < TOL
     _trace_close(trace, j, prefix="multi/trace/")
+
+
+def test_upsampling_known_answers(golden):
+    """upsampling_factor=2 (the reference's own test, jolideco/tests/test_core.py:99-124) and an odd
+    factor 3 with a GMM prior on the up-sampled flux."""
+    u = golden("upsampling")
+    disk = unpack_datasets(u, "disk/data/")
+    final, trace = cpu_ref.map_fit_sequential(
+        disk, {"flux-1": u["flux_init"]}, {"flux-1": cpu_ref.UniformPriorRef()}, n_epochs=100,
+        upsampling_factors={"flux-1": 2},
+    )
+    assert final["flux-1"].shape == (64, 64)
+    assert rel_linf(final["flux-1"], u["u2/flux_upsampled_final"]) < TOL
+    flux = cpu_ref.downsampled_flux(torch.from_numpy(final["flux-1"])[None, None], 2).numpy()[0, 0]
+    assert rel_linf(flux, u["u2/flux_final"]) < TOL
+    np.testing.assert_allclose(flux[12, 12], 3.565998, rtol=1e-3)  # test_core.py:117-124
+    np.testing.assert_allclose(flux[0, 0], 1.605782, rtol=1e-3)
+    np.testing.assert_allclose(trace[-1]["total"], 5.844786, rtol=1e-3)
+    np.testing.assert_allclose(trace[-1]["dataset-0"], 1.946759, rtol=1e-3)
+    _trace_close(trace, u, prefix="u2/trace/")
+
+    gmm = cpu_ref.GMM.from_numpy(u["u3/gmm_means"], u["u3/gmm_covariances"], u["u3/gmm_weights"], stride=4)
+    final, trace = cpu_ref.map_fit_sequential(
+        unpack_datasets(u, "u3/data/"), {"flux": u["u3/flux_init"]}, {"flux": cpu_ref.GMMPatchPriorRef(gmm)},
+        n_epochs=5, upsampling_factors={"flux": 3},
+    )
+    assert rel_linf(final["flux"], u["u3/flux_upsampled_final"]) < TOL
+    _trace_close(trace, u, prefix="u3/trace/")
