@@ -16,7 +16,9 @@ rows): strong scaling.  All inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step (the GMM
 forward kernel: fp32 matrix-core roof), `roofline_poisson` the fused Poisson pass (HBM roof), both
-from hipEvent pairs recorded by the library around every launch inside the timed region.
+from hipEvent pairs recorded by the library around every launch of every 4th step of the timed region
+(bracketing every launch of every step costs ~4 % of the step).  `--config c2|c4|c5` run the other
+BASELINE configurations (parity-test cases; the default c3 is the one the metric is quoted on).
 `cpu_baseline` times oracle/cpu_ref.py (the PyTorch-CPU restatement of the reference) on a bounded
 sample on rank 0 at N = 1.
 """
@@ -39,10 +41,12 @@ CONFIGS = {
     "c2": (1024, 1024, 1, 128),
     "c3": (2048, 2048, 8, 128),
     "c4": (4096, 4096, 1, 128),
+    "c5": (2048, 2048, 16, 128),  # two flux components: "extended" (GMM prior) + "points" (inverse-gamma prior)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 PATCH, D, STRIDE = 8, 64, 4
+PROFILE_EVERY = 4  # steps of the timed region whose kernels are timed with hipEvent pairs: 0, 4, 8, ...
 
 
 def build_session(cfg_name, device, seed=0, dist=None):
@@ -55,6 +59,18 @@ def build_session(cfg_name, device, seed=0, dist=None):
     means, covs, weights = synthetic_gmm(K, D, seed=0)
     gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=STRIDE))
     comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+    if cfg_name == "c5":
+        from jolideco_amd import FluxComponents, InverseGammaPrior
+        from jolideco_amd.data import gaussian_kernel
+
+        comps = FluxComponents()
+        comps["extended"] = comp
+        comps["points"] = SpatialFluxComponent.from_numpy(
+            flux=0.05 * flux_init, prior=InverseGammaPrior(alpha=10, beta=1.5)
+        )
+        for i, d in enumerate(datasets.values()):  # per-component PSFs: the point sources see a sharper core
+            d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
+        comp = comps
     deconvolver = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="joint")
     return deconvolver.session(datasets, components=comp, dist=dist)
 
@@ -168,9 +184,12 @@ def main():
     torch.cuda.synchronize(device)
 
     log("timed region")
+    # kernel timers: hipEvent pairs around every launch of every PROFILE_EVERY-th step of the timed
+    # region (a pair costs ~2 us of stream time, ~4 % of the step if every launch is bracketed)
     _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        _hip.profile_pause(i % PROFILE_EVERY != 0)
         session.epoch()
     torch.cuda.synchronize(device)
     dist_ctx.barrier()
@@ -237,7 +256,8 @@ def main():
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes,
         }
-    kernel_ms_per_step = {k: (v[0] / args.steps) for k, v in prof.items() if v[1]}
+    n_profiled = len(range(0, args.steps, PROFILE_EVERY))
+    kernel_ms_per_step = {k: (v[0] / n_profiled) for k, v in prof.items() if v[1]}
     dominant = max(kernel_ms_per_step, key=kernel_ms_per_step.get) if kernel_ms_per_step else None
     roofline = roof_poi if dominant == "poisson_fused" else roof_gmm
 

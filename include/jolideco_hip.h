@@ -204,6 +204,8 @@ enum {
 };
 int jd_profile_enable(int capacity);
 int jd_profile_disable(void);
+/* pause (1) / resume (0) the timers without resetting them: lets a caller time a sample of its steps */
+int jd_profile_pause(int paused);
 int jd_profile_read(int kernel, double* total_ms, long long* launches);
 const char* jd_kernel_name(int kernel);
 

@@ -66,6 +66,7 @@ EXPORTS = {
     "jd_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
     "jd_profile_enable": (c_int, [c_int]),
     "jd_profile_disable": (c_int, []),
+    "jd_profile_pause": (c_int, [c_int]),
     "jd_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_longlong)]),
     "jd_kernel_name": (c_char_p, [c_int]),
 }
@@ -100,6 +101,11 @@ def lib():
 def profile_enable(capacity=8192):
     """Start timing the library's kernels with hipEvent pairs on their launch stream."""
     check(lib().jd_profile_enable(int(capacity)))
+
+
+def profile_pause(paused=True):
+    """Pause / resume the kernel timers (recorded pairs are kept)."""
+    check(lib().jd_profile_pause(int(bool(paused))))
 
 
 def profile_read():

@@ -61,6 +61,13 @@ extern "C" int jd_profile_disable(void) {
   return JD_OK;
 }
 
+extern "C" int jd_profile_pause(int paused) {
+  // keeps the recorded pairs; launches issued while paused are simply not timed (a benchmark can
+  // sample every n-th step and keep the event overhead out of the others)
+  g_enabled = !paused && !g_pairs.empty();
+  return JD_OK;
+}
+
 extern "C" int jd_profile_read(int kernel, double* total_ms, long long* launches) {
   JD_REQUIRE(total_ms && launches, "jd_profile_read: null argument");
   JD_REQUIRE(kernel >= 0 && kernel < JD_KERNEL_COUNT, "jd_profile_read: unknown kernel id %d", kernel);

@@ -104,3 +104,36 @@ def test_joint_step_2048_8obs_runs_and_decreases_the_loss():
         assert np.all(np.diff(total) < 0)
         totals.append(vals)
     assert np.array_equal(totals[0], totals[1])
+
+
+def test_config5_two_components_16_observations():
+    """BASELINE config 5 at full size: 2 flux components with their own PSFs and priors, 16
+    observations, joint step.  Finite, decreasing objective; sharding 2 ways (observations + prior rows,
+    element-wise prior on rank 0 only) reproduces the unsharded gradient buffer."""
+    import bench
+    from jolideco_amd.distributed import DistContext
+
+    session = bench.build_session("c5", torch.device(DEV))
+    assert session.n_c == 2 and session.n_d == 16
+    rows = []
+    for _ in range(3):
+        session.epoch()
+        rows.append(session.scalars.clone())
+    torch.cuda.synchronize()
+    vals = torch.stack(rows).cpu().numpy()
+    assert np.isfinite(vals).all()
+    total = vals[:, :16].sum(1) - vals[:, 16:18].sum(1)
+    assert np.all(np.diff(total) < 0)
+    del session
+
+    # gradient of one joint step: whole == sum of the 2 rank shares (dry-run contexts, same theta)
+    grads = []
+    for ctx in (None, DistContext(0, 2, dry_run=True), DistContext(1, 2, dry_run=True)):
+        sess = bench.build_session("c5", torch.device(DEV), dist=ctx)
+        sess.cfg._optimizer_step = lambda states, step: None  # keep the gradient buffer, do not update
+        sess.epoch()
+        torch.cuda.synchronize()
+        grads.append(sess.comm.clone())
+        del sess
+    whole, part = grads[0], grads[1] + grads[2]
+    assert rel_linf(part.cpu().numpy(), whole.cpu().numpy()) < 2e-6
