@@ -111,6 +111,23 @@ int jd_npred_poisson_fwd_bwd(jd_conv_plan* plan, int n_comp, const float* const*
                              float eps, float* loss_out, float* const* grad_flux, int accumulate,
                              float grad_scale, float* npred_out, int upsampling, void* stream);
 
+/* The same with the per-dataset calibration of NPredCalibration (models/npred.py:298-402,225-237):
+ *   shift_xy             device [2] = {shift_x, shift_y} in COUNTS pixels or NULL: every flux_c is shifted
+ *                        (bilinear, zero padding = shift_image_torch, utils/torch.py:196-223) before the
+ *                        exposure / PSF are applied; scale = upsampling
+ *   log_background_norm  device [1] or NULL: background * exp(.)
+ *   grad_shift_xy        device [2] or NULL  <- grad_scale * d loss / d shift_xy   (summed over components)
+ *   grad_log_background_norm  device [1] or NULL  <- grad_scale * d loss / d log_background_norm
+ * The parameters are read from device memory so that a fit never synchronises on them.  The caller
+ * decides whether the shift is active (the reference skips it -- and its gradient -- while it is ~0). */
+int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* plan, int n_comp, const float* const* flux,
+                                        const float* const* exposure, const float* const* khat,
+                                        const float* background, const float* counts, float stirling_mean,
+                                        float eps, float* loss_out, float* const* grad_flux, int accumulate,
+                                        float grad_scale, float* npred_out, int upsampling, const float* shift_xy,
+                                        const float* log_background_norm, float* grad_shift_xy,
+                                        float* grad_log_background_norm, void* stream);
+
 /* Same chain split at the reference's object seams, for callers that keep the reference's own
  * loop structure (autograd.Function wrappers in jolideco_amd/ops.py):
  * conv_padded[c] are plan-owned buffers exposed through jd_conv_plan_conv_buffer. */

@@ -5,7 +5,14 @@ ctypes (`jolideco_amd._hip`).  PyTorch provides device memory, streams and `torc
 """
 from .core import MAPDeconvolver, MAPDeconvolverResult
 from .loss import PoissonLoss, PriorLoss, TotalLoss
-from .models import FluxComponents, NPredModel, NPredModels, SpatialFluxComponent
+from .models import (
+    FluxComponents,
+    NPredCalibration,
+    NPredCalibrations,
+    NPredModel,
+    NPredModels,
+    SpatialFluxComponent,
+)
 from .priors import (
     ExponentialPrior,
     GaussianMixtureModel,
@@ -27,6 +34,8 @@ __all__ = [
     "SpatialFluxComponent",
     "NPredModel",
     "NPredModels",
+    "NPredCalibration",
+    "NPredCalibrations",
     "GaussianMixtureModel",
     "GMMPatchPrior",
     "UniformPrior",

@@ -206,8 +206,9 @@ class MAPDeconvolver:
         datasets_validation : dict of [str, dict]
             Validation datasets (trace column and early stopping only).
         components : `FluxComponents` or `SpatialFluxComponent`
-        calibrations : None
-            `NPredCalibrations` are not implemented.
+        calibrations : `NPredCalibrations`
+            Per-dataset calibrations (sub-pixel shift, background norm, PSF scale), trained with the
+            fluxes; keys are dataset names.
 
         Returns
         -------
@@ -215,19 +216,19 @@ class MAPDeconvolver:
         """
         if self.stop_early and datasets_validation is None:
             raise ValueError("Early stopping requires providing test datasets")
-        if calibrations is not None:
-            raise NotImplementedError("NPredCalibrations are not implemented in jolideco_amd yet")
         if isinstance(components, SpatialFluxComponent):
             components = {self._default_flux_component: components}
         components = FluxComponents(components)
         components_init = copy.deepcopy(components)
+        calibrations_init = copy.deepcopy(calibrations) if calibrations is not None else None
 
         _hip.lib()  # fail loudly before touching anything if the extension is missing
         dist = DistContext.current()
         with torch.cuda.device(self.device):
-            return self._run(datasets, datasets_validation, components, components_init, dist)
+            return self._run(datasets, datasets_validation, components, components_init, dist, calibrations,
+                             calibrations_init)
 
-    def session(self, datasets, datasets_validation=None, components=None, dist=None):
+    def session(self, datasets, datasets_validation=None, components=None, dist=None, calibrations=None):
         """Set up a fit without running it: uploads the datasets, builds the FFT plans / kernel
         spectra / GMM handles and returns a `FitSession` whose ``epoch()`` enqueues one epoch of
         the fit on the current HIP stream (used by `run` and by bench.py)."""
@@ -236,12 +237,14 @@ class MAPDeconvolver:
         components = FluxComponents(components)
         _hip.lib()
         with torch.cuda.device(self.device):
-            return FitSession(self, datasets, datasets_validation, components, dist or DistContext.current())
+            return FitSession(self, datasets, datasets_validation, components, dist or DistContext.current(),
+                              calibrations)
 
-    def _run(self, datasets, datasets_validation, components, components_init, dist):
+    def _run(self, datasets, datasets_validation, components, components_init, dist, calibrations=None,
+             calibrations_init=None):
         from tqdm.auto import tqdm
 
-        session = FitSession(self, datasets, datasets_validation, components, dist)
+        session = FitSession(self, datasets, datasets_validation, components, dist, calibrations)
         total_loss = session.total_loss
         n_d, n_c, n_val = session.n_d, session.n_c, session.n_val
         trace_dev = torch.zeros((self.n_epochs, session.scalars.numel()), dtype=torch.float32, device=self.device)
@@ -279,8 +282,8 @@ class MAPDeconvolver:
             components=session.components,
             components_init=components_init,
             trace_loss=trace,
-            calibrations=None,
-            calibrations_init=None,
+            calibrations=calibrations,
+            calibrations_init=calibrations_init,
             wcs=None,
         )
 
@@ -313,9 +316,11 @@ class FitSession:
     ``scalars`` holds the epoch's [dataset losses (global order) | log-priors | validation losses].
     """
 
-    def __init__(self, deconvolver, datasets, datasets_validation, components, dist):
+    def __init__(self, deconvolver, datasets, datasets_validation, components, dist, calibrations=None):
         self.cfg = deconvolver
         self.dist = dist
+        if calibrations is not None and deconvolver.fit_mode == "joint" and dist.world_size > 1:
+            raise NotImplementedError("NPredCalibrations in a sharded joint fit are not implemented in jolideco_amd")
         device = deconvolver.device
         self.components = components = components.to(device)
         self.joint = deconvolver.fit_mode == "joint"
@@ -334,8 +339,21 @@ class FitSession:
             datasets_validation=datasets_validation,
             components=components,
             beta=deconvolver.beta,
+            calibrations=calibrations,
             device=device,
         )
+        # One small Adam per calibrated dataset, stepped when (and only when) that dataset took part in
+        # the step: exactly what the reference's single optimizer does, because torch.optim.Adam keeps
+        # per-parameter state and skips parameters whose grad is None (jolideco/core.py:197-204,215,229).
+        self.cal_optimizers = []
+        for models in self.total_loss.poisson_loss.npred_models_all:
+            cal = models.calibration
+            params = [] if cal is None else [p for p in cal.parameters() if p.requires_grad]
+            opt = None
+            if params:
+                kwargs = dict(deconvolver.optimizer_kwargs)
+                opt = (torch.optim.Adam if deconvolver.optimizer_type == "adam" else torch.optim.SGD)(params, **kwargs)
+            self.cal_optimizers.append(opt)
         # the trace always has one column per GLOBAL dataset
         self.total_loss.poisson_loss.names_all_global = names_all
         self.priors = list(self.total_loss.prior_loss.priors.values())
@@ -360,6 +378,16 @@ class FitSession:
     def _slot(self, i):
         return self.scalars[i : i + 1]
 
+    def _cal_zero_grad(self, li):
+        opt = self.cal_optimizers[li]
+        if opt is not None:
+            opt.zero_grad(set_to_none=True)
+
+    def _cal_step(self, li):
+        opt = self.cal_optimizers[li]
+        if opt is not None:
+            opt.step()
+
     def _prior_rows(self, prior, state):
         if self.joint and self.dist.world_size > 1 and prior.shardable:
             return self.dist.shard_range(prior.n_patch_rows(state.shape))
@@ -377,6 +405,7 @@ class FitSession:
                 self.scalars.zero_()
             first = True
             for gslot, li in self.local_idx:
+                self._cal_zero_grad(li)
                 total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
                 first = False
             if first:
@@ -393,17 +422,21 @@ class FitSession:
                 dist.all_reduce_sum(self.comm)
             self.step += 1
             cfg._optimizer_step(states, self.step)
+            for _, li in self.local_idx:
+                self._cal_step(li)
         else:
             # ---- the reference loop: one step per dataset (core.py:214-229) -------------------
             for gslot, li in self.local_idx:
                 fluxes = [st.flux_cur for st in states]
                 grads = [st.grad for st in states]
+                self._cal_zero_grad(li)
                 total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
                 coef = -float(cfg.beta) / total_loss.prior_weight
                 for ci, (st, prior) in enumerate(zip(states, priors)):
                     prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef)
                 self.step += 1
                 cfg._optimizer_step(states, self.step)
+                self._cal_step(li)
             # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------------
             stale = [st.flux_prev for st in states]
             for gslot, li in self.local_idx:

@@ -133,7 +133,8 @@ template <int VEC, int ROWS>
 __global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
   __shared__ double smem[BLOCK / 64];
   const int x0 = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
-  double local = 0.0;
+  double local = 0.0, local_b = 0.0;
+  const float bkg_norm = a.log_bkg_norm ? expf(a.log_bkg_norm[0]) : 1.f;  // NPredCalibration.background_norm
   // ROWS rows per thread: every load of the thread is issued before the first one is consumed
   // (ROWS x (2 + n_comp) x 16 B in flight per lane)
   float b[ROWS][VEC], c[ROWS][VEC], conv[ROWS][JD_MAX_COMPONENTS][VEC];
@@ -185,10 +186,12 @@ __global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        n[i] += b[r][i];  // background added last, un-convolved (npred.py:234-261)
+        const float bi = a.log_bkg_norm ? b[r][i] * bkg_norm : b[r][i];
+        n[i] += bi;  // background added last, un-convolved (npred.py:234-261)
         const float ne = n[i] + a.eps;
         local += (double)(n[i] - c[r][i] * logf(ne));
         g[i] = (1.f - c[r][i] / ne) * a.inv_n;
+        local_b += (double)(g[i] * bi);
       }
       if (a.npred_out) {
         const size_t off = (size_t)y * a.W + x0;
@@ -217,6 +220,11 @@ __global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
 
   const double total = block_sum<BLOCK>(local, smem);
   if (threadIdx.x == 0) a.partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
+  if (a.partials_b) {  // wave-uniform: only with a calibration
+    __syncthreads();
+    const double total_b = block_sum<BLOCK>(local_b, smem);
+    if (threadIdx.x == 0) a.partials_b[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total_b;
+  }
 }
 
 int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stream) {
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(BLOCK) void poisson_pooled_kernel(PoissonArgs a) {
   const int Hd = a.H / u, Wd = a.W / u;
   const int y = blockIdx.y;
   const int x = blockIdx.x * BLOCK + threadIdx.x;
-  double local = 0.0;
+  double local = 0.0, local_b = 0.0;
   if (y < Hd && x < Wd) {
     const size_t off = (size_t)y * Wd + x;
     float pooled[JD_MAX_COMPONENTS];
@@ -273,11 +281,13 @@ __global__ __launch_bounds__(BLOCK) void poisson_pooled_kernel(PoissonArgs a) {
       pooled[k] = acc;
       n += fmaxf(acc, 0.f);  // clip per component after pooling (npred.py:181-191)
     }
-    n += a.background[off];
+    const float bi = a.log_bkg_norm ? a.background[off] * expf(a.log_bkg_norm[0]) : a.background[off];
+    n += bi;
     const float c = a.counts[off];
     const float ne = n + a.eps;
     local = (double)(n - c * logf(ne));
     const float g = (1.f - c / ne) * a.inv_n;
+    local_b = (double)(g * bi);
     if (a.npred_out) a.npred_out[off] = n;
     if (a.write_grad) {
 #pragma unroll
@@ -293,6 +303,11 @@ __global__ __launch_bounds__(BLOCK) void poisson_pooled_kernel(PoissonArgs a) {
   }
   const double total = block_sum<BLOCK>(local, smem);
   if (threadIdx.x == 0) a.partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
+  if (a.partials_b) {
+    __syncthreads();
+    const double total_b = block_sum<BLOCK>(local_b, smem);
+    if (threadIdx.x == 0) a.partials_b[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total_b;
+  }
 }
 
 int launch_poisson_pooled(const PoissonArgs& a, int* n_partials, hipStream_t stream) {

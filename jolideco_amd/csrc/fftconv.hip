@@ -30,6 +30,11 @@ struct jd_conv_plan {
   float2* spec = nullptr;
   double* partials = nullptr;
   int partials_cap = 0;
+  // calibration work space (allocated on first use): shifted flux / gradient w.r.t. the shifted flux per
+  // component on the (H, W) flux grid, partial sums of the background-norm and shift gradients
+  float* shifted[JD_MAX_COMPONENTS] = {nullptr};
+  float* gshift[JD_MAX_COMPONENTS] = {nullptr};
+  double* partials_cal = nullptr;
 };
 
 namespace jd {
@@ -52,6 +57,22 @@ static int ensure_component_buffers(jd_conv_plan* p, int n_comp) {
   for (int c = 0; c < n_comp; ++c) {
     if (!p->pad[c]) JD_HIP(hipMalloc(&p->pad[c], bytes));
     if (!p->conv[c]) JD_HIP(hipMalloc(&p->conv[c], bytes));
+  }
+  return JD_OK;
+}
+
+static int ensure_calibration_buffers(jd_conv_plan* p, int n_comp, bool shift) {
+  if (!p->partials_cal) {
+    const size_t n = (size_t)(p->partials_cap > 2 * shift_bwd_max_blocks(p->H, p->W) ? p->partials_cap
+                                                                                    : 2 * shift_bwd_max_blocks(p->H, p->W));
+    JD_HIP(hipMalloc(&p->partials_cal, n * sizeof(double)));
+  }
+  if (shift) {
+    const size_t bytes = (size_t)p->H * p->W * sizeof(float);
+    for (int c = 0; c < n_comp; ++c) {
+      if (!p->shifted[c]) JD_HIP(hipMalloc(&p->shifted[c], bytes));
+      if (!p->gshift[c]) JD_HIP(hipMalloc(&p->gshift[c], bytes));
+    }
   }
   return JD_OK;
 }
@@ -199,9 +220,12 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
   if (p->work) (void)hipFree(p->work);
   if (p->spec) (void)hipFree(p->spec);
   if (p->partials) (void)hipFree(p->partials);
+  if (p->partials_cal) (void)hipFree(p->partials_cal);
   for (int c = 0; c < JD_MAX_COMPONENTS; ++c) {
     if (p->pad[c]) (void)hipFree(p->pad[c]);
     if (p->conv[c]) (void)hipFree(p->conv[c]);
+    if (p->shifted[c]) (void)hipFree(p->shifted[c]);
+    if (p->gshift[c]) (void)hipFree(p->gshift[c]);
   }
   delete p;
   return JD_OK;
@@ -256,29 +280,45 @@ extern "C" int jd_conv_same_adjoint(jd_conv_plan* p, const float* grad_out, cons
   return corr_backward_into(p, 0, khat, scale_image, grad_image, 1.f, accumulate, s);
 }
 
-extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,
-                                        const float* const* exposure, const float* const* khat,
-                                        const float* background, const float* counts, float stirling_mean,
-                                        float eps, float* loss_out, float* const* grad_flux, int accumulate,
-                                        float grad_scale, float* npred_out, int upsampling, void* stream) {
-  JD_REQUIRE(p && flux && exposure && khat && background && counts && loss_out,
-             "jd_npred_poisson_fwd_bwd: null argument");
+namespace {
+struct Calibration {
+  const float* shift_xy = nullptr;      // device [2] = {x, y}; null: no shift
+  float shift_scale = 1.f;              // up-sampling factor (shift is given in counts pixels)
+  const float* log_bkg_norm = nullptr;  // device [1]; null: background unscaled
+  float* grad_shift_xy = nullptr;       // device [2], overwritten; null: not wanted
+  float* grad_log_bkg_norm = nullptr;   // device [1], overwritten; null: not wanted
+};
+}  // namespace
+
+static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, const float* const* flux,
+                              const float* const* exposure, const float* const* khat, const float* background,
+                              const float* counts, float stirling_mean, float eps, float* loss_out,
+                              float* const* grad_flux, int accumulate, float grad_scale, float* npred_out,
+                              int upsampling, const Calibration& cal, void* stream) {
+  JD_REQUIRE(p && flux && exposure && khat && background && counts && loss_out, "%s: null argument", who);
   JD_REQUIRE(upsampling >= 1 && upsampling <= 8 && p->H % upsampling == 0 && p->W % upsampling == 0,
-             "jd_npred_poisson_fwd_bwd: upsampling = %d must be in [1, 8] and divide the flux grid (%d, %d)",
-             upsampling, p->H, p->W);
-  JD_REQUIRE(n_comp >= 1 && n_comp <= JD_MAX_COMPONENTS, "jd_npred_poisson_fwd_bwd: n_comp = %d not in [1, %d]",
-             n_comp, JD_MAX_COMPONENTS);
+             "%s: upsampling = %d must be in [1, 8] and divide the flux grid (%d, %d)", who, upsampling, p->H, p->W);
+  JD_REQUIRE(n_comp >= 1 && n_comp <= JD_MAX_COMPONENTS, "%s: n_comp = %d not in [1, %d]", who, n_comp,
+             JD_MAX_COMPONENTS);
   for (int c = 0; c < n_comp; ++c) {
-    JD_REQUIRE(flux[c] && khat[c], "jd_npred_poisson_fwd_bwd: flux[%d] or khat[%d] is null", c, c);
-    if (grad_flux) JD_REQUIRE(grad_flux[c], "jd_npred_poisson_fwd_bwd: grad_flux[%d] is null", c);
+    JD_REQUIRE(flux[c] && khat[c], "%s: flux[%d] or khat[%d] is null", who, c, c);
+    if (grad_flux) JD_REQUIRE(grad_flux[c], "%s: grad_flux[%d] is null", who, c);
   }
   hipStream_t s = as_stream(stream);
   int rc = ensure_component_buffers(p, n_comp);
   if (rc) return rc;
+  const bool calibrated = cal.shift_xy || cal.log_bkg_norm;
+  if (calibrated && (rc = ensure_calibration_buffers(p, n_comp, cal.shift_xy != nullptr))) return rc;
 
-  // forward model per component (models/npred.py:175-179)
-  for (int c = 0; c < n_comp; ++c)
-    if ((rc = conv_forward(p, c, flux[c], exposure[c], khat[c], s))) return rc;
+  // forward model per component (models/npred.py:175-179), after the calibration shift (:225-232)
+  for (int c = 0; c < n_comp; ++c) {
+    const float* in = flux[c];
+    if (cal.shift_xy) {
+      if ((rc = launch_shift_fwd(flux[c], p->shifted[c], p->H, p->W, cal.shift_xy, cal.shift_scale, s))) return rc;
+      in = p->shifted[c];
+    }
+    if ((rc = conv_forward(p, c, in, exposure[c], khat[c], s))) return rc;
+  }
 
   // fused clip + background + NLL + gradient (models/npred.py:191,254-261; loss.py:35-37)
   PoissonArgs a{};
@@ -290,6 +330,8 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
   a.n_comp = n_comp, a.H = p->H, a.W = p->W, a.Hp = p->Hp, a.Wp = p->Wp, a.oy = p->py, a.ox = p->px;
   a.eps = eps;
   a.up = upsampling;
+  a.log_bkg_norm = cal.log_bkg_norm;
+  a.partials_b = (cal.log_bkg_norm && cal.grad_log_bkg_norm && grad_flux) ? p->partials_cal : nullptr;
   // the loss is the mean over the COUNTS pixels (loss.py:35-37)
   const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   a.inv_n = (float)(1.0 / n_pix);
@@ -300,9 +342,50 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
   if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
     return rc;
   if (!grad_flux) return JD_OK;
+  if (a.partials_b &&
+      (rc = launch_finalize_sum(p->partials_cal, n_partials, (double)grad_scale, 0.0, cal.grad_log_bkg_norm, 0, s)))
+    return rc;
 
-  // adjoint: d loss / d flux_c = E_c * corr(psf_c, g_c)
-  for (int c = 0; c < n_comp; ++c)
-    if ((rc = corr_backward_into(p, c, khat[c], exposure[c], grad_flux[c], grad_scale, accumulate, s))) return rc;
+  // adjoint: d loss / d flux_c = [shift^T] ( E_c * corr(psf_c, g_c) )
+  for (int c = 0; c < n_comp; ++c) {
+    if (!cal.shift_xy) {
+      if ((rc = corr_backward_into(p, c, khat[c], exposure[c], grad_flux[c], grad_scale, accumulate, s))) return rc;
+      continue;
+    }
+    if ((rc = corr_backward_into(p, c, khat[c], exposure[c], p->gshift[c], grad_scale, 0, s))) return rc;
+    int n_blocks = 0;
+    if ((rc = launch_shift_bwd(flux[c], p->gshift[c], grad_flux[c], accumulate, p->H, p->W, cal.shift_xy,
+                               cal.shift_scale, p->partials_cal, &n_blocks, s)))
+      return rc;
+    if (cal.grad_shift_xy &&
+        (rc = launch_finalize_multi(p->partials_cal, n_blocks, 2, 1.0, cal.grad_shift_xy, c > 0, s)))
+      return rc;
+  }
   return JD_OK;
+}
+
+extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,
+                                        const float* const* exposure, const float* const* khat,
+                                        const float* background, const float* counts, float stirling_mean,
+                                        float eps, float* loss_out, float* const* grad_flux, int accumulate,
+                                        float grad_scale, float* npred_out, int upsampling, void* stream) {
+  return npred_poisson_impl("jd_npred_poisson_fwd_bwd", p, n_comp, flux, exposure, khat, background, counts,
+                            stirling_mean, eps, loss_out, grad_flux, accumulate, grad_scale, npred_out, upsampling,
+                            Calibration{}, stream);
+}
+
+extern "C" int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,
+                                                   const float* const* exposure, const float* const* khat,
+                                                   const float* background, const float* counts,
+                                                   float stirling_mean, float eps, float* loss_out,
+                                                   float* const* grad_flux, int accumulate, float grad_scale,
+                                                   float* npred_out, int upsampling, const float* shift_xy,
+                                                   const float* log_background_norm, float* grad_shift_xy,
+                                                   float* grad_log_background_norm, void* stream) {
+  Calibration cal;
+  cal.shift_xy = shift_xy, cal.shift_scale = (float)upsampling, cal.log_bkg_norm = log_background_norm;
+  cal.grad_shift_xy = grad_shift_xy, cal.grad_log_bkg_norm = grad_log_background_norm;
+  return npred_poisson_impl("jd_npred_poisson_calibrated_fwd_bwd", p, n_comp, flux, exposure, khat, background, counts,
+                            stirling_mean, eps, loss_out, grad_flux, accumulate, grad_scale, npred_out, upsampling, cal,
+                            stream);
 }

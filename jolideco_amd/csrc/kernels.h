@@ -15,6 +15,10 @@ struct PoissonArgs {
   float eps, inv_n;
   int write_grad;
   int up;  // up-sampling factor of the flux grid w.r.t. the counts grid (1 = none)
+  // calibration (models/npred.py:234-237): background * exp(*log_bkg_norm); partials_b receives the
+  // block sums of g * background * norm = d loss / d log_bkg_norm.  Both null without a calibration.
+  const float* log_bkg_norm;
+  double* partials_b;
 };
 
 int launch_pad_mul(const float* image, const float* scale, float* padded, int H, int W, int Hp, int Wp,
@@ -26,6 +30,16 @@ int poisson_fused_max_partials(int Hp, int Wp);
 int launch_adjoint_epilogue(const float* corr, const float* scale, float* grad, int H, int W, int Hp,
                             int Wp, int oy, int ox, float coef, int accumulate, hipStream_t stream);
 int launch_crop(const float* padded, float* out, int H, int W, int Wp, int oy, int ox, hipStream_t stream);
+
+// sub-pixel shift of the calibration (shift.hip): out = bilinear(in, y + scale * shift[1], x + scale * shift[0])
+int launch_shift_fwd(const float* in, float* out, int H, int W, const float* shift_xy, float scale, hipStream_t stream);
+// grad_in (+)= adjoint(gs);  partials[2 * b + {0, 1}] = block sums of d/d shift_{x, y} (already times scale)
+int launch_shift_bwd(const float* in, const float* gs, float* grad_in, int accumulate, int H, int W,
+                     const float* shift_xy, float scale, double* partials, int* n_blocks, hipStream_t stream);
+int shift_bwd_max_blocks(int H, int W);
+// out[i] = [out[i] +] scale * sum_b partials[n_out * b + i]   (i < n_out; one fixed-order pass)
+int launch_finalize_multi(const double* partials, int n_blocks, int n_out, double scale, float* out, int accumulate,
+                          hipStream_t stream);
 
 // direct (MFMA Toeplitz) convolution for small PSFs (directconv.hip)
 enum { JD_CONV_FFT = 0, JD_CONV_DIRECT = 1 };

@@ -1,0 +1,120 @@
+// Sub-pixel shift of a flux image, the dataset calibration of jolideco/models/npred.py:298-402:
+// `shift_image_torch` (jolideco/utils/torch.py:196-223) = affine_grid + grid_sample (bilinear, zero
+// padding, align_corners=False) with a pure translation.  In pixel units the sample point of output
+// pixel (i, j) is (i + scale * shift_y, j + scale * shift_x), so the integer offsets and the
+// bilinear weights are the same for every pixel.  The shift is read from DEVICE memory (it is a
+// trainable parameter that changes every step without the host looking at it).
+#include "jd_common.h"
+#include "kernels.h"
+
+namespace jd {
+
+struct ShiftGeom {
+  int fy, fx;          // integer parts
+  float wy0, wy1, wx0, wx1;  // weights of rows fy, fy + 1 / columns fx, fx + 1
+};
+
+__device__ __forceinline__ ShiftGeom shift_geom(const float* shift_xy, float scale) {
+  const float sx = scale * shift_xy[0], sy = scale * shift_xy[1];
+  const float flx = floorf(sx), fly = floorf(sy);
+  ShiftGeom g;
+  g.fx = (int)flx, g.fy = (int)fly;
+  g.wx1 = sx - flx, g.wx0 = 1.f - g.wx1;
+  g.wy1 = sy - fly, g.wy0 = 1.f - g.wy1;
+  return g;
+}
+
+__device__ __forceinline__ float at(const float* img, int H, int W, int y, int x) {
+  return (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void shift_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
+                                                        int W, const float* __restrict__ shift_xy, float scale) {
+  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= W) return;
+  const ShiftGeom g = shift_geom(shift_xy, scale);
+  const int y0 = y + g.fy, x0 = x + g.fx;
+  // same association as grid_sample: nw * (w_x0 w_y0) + ne * (w_x1 w_y0) + sw * (w_x0 w_y1) + se * (w_x1 w_y1)
+  out[(size_t)y * W + x] = at(in, H, W, y0, x0) * (g.wx0 * g.wy0) + at(in, H, W, y0, x0 + 1) * (g.wx1 * g.wy0) +
+                           at(in, H, W, y0 + 1, x0) * (g.wx0 * g.wy1) + at(in, H, W, y0 + 1, x0 + 1) * (g.wx1 * g.wy1);
+}
+
+// Backward of the shift for one image:
+//   grad_in[p][q] (+)= sum_{a,b} w_a^y w_b^x gs[p - fy - a][q - fx - b]         (adjoint, gather form)
+//   d/d shift_x = scale * sum_ij gs[i][j] * ((in[y0][x0+1] - in[y0][x0]) w_y0 + (in[y0+1][x0+1] - in[y0+1][x0]) w_y1)
+//   d/d shift_y analogous; zero padding outside the image (grid_sample's in-bounds checks).
+__global__ __launch_bounds__(256) void shift_bwd_kernel(const float* __restrict__ in, const float* __restrict__ gs,
+                                                        float* __restrict__ grad_in, int accumulate, int H, int W,
+                                                        const float* __restrict__ shift_xy, float scale,
+                                                        double* __restrict__ partials) {
+  __shared__ double smem[256 / 64];
+  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  const ShiftGeom g = shift_geom(shift_xy, scale);
+  double dsx = 0.0, dsy = 0.0;
+  if (x < W) {
+    const int py = y - g.fy, px = x - g.fx;
+    float v = at(gs, H, W, py, px) * (g.wx0 * g.wy0) + at(gs, H, W, py, px - 1) * (g.wx1 * g.wy0) +
+              at(gs, H, W, py - 1, px) * (g.wx0 * g.wy1) + at(gs, H, W, py - 1, px - 1) * (g.wx1 * g.wy1);
+    const size_t off = (size_t)y * W + x;
+    if (accumulate) v += grad_in[off];
+    grad_in[off] = v;
+    // derivative of OUTPUT pixel (y, x) w.r.t. the sample position
+    const int y0 = y + g.fy, x0 = x + g.fx;
+    const float nw = at(in, H, W, y0, x0), ne = at(in, H, W, y0, x0 + 1);
+    const float sw = at(in, H, W, y0 + 1, x0), se = at(in, H, W, y0 + 1, x0 + 1);
+    const float go = gs[off];
+    dsx = (double)(go * ((ne - nw) * g.wy0 + (se - sw) * g.wy1));
+    dsy = (double)(go * ((sw - nw) * g.wx0 + (se - ne) * g.wx1));
+  }
+  const double tx = block_sum<256>(dsx, smem);
+  __syncthreads();
+  const double ty = block_sum<256>(dsy, smem);
+  if (threadIdx.x == 0) {
+    const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partials[2 * b] = tx * (double)scale;
+    partials[2 * b + 1] = ty * (double)scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void finalize_multi_kernel(const double* __restrict__ partials, int n_blocks, int n_out,
+                                                             double scale, float* __restrict__ out, int accumulate) {
+  __shared__ double smem[256 / 64];
+  for (int i = 0; i < n_out; ++i) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < n_blocks; b += 256) acc += partials[(size_t)n_out * b + i];
+    const double total = block_sum<256>(acc, smem);
+    if (threadIdx.x == 0) {
+      double v = scale * total;
+      if (accumulate) v += (double)out[i];
+      out[i] = (float)v;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_shift_fwd(const float* in, float* out, int H, int W, const float* shift_xy, float scale, hipStream_t stream) {
+  dim3 grid((W + 255) / 256, H);
+  shift_fwd_kernel<<<grid, 256, 0, stream>>>(in, out, H, W, shift_xy, scale);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+int shift_bwd_max_blocks(int H, int W) { return ((W + 255) / 256) * H; }
+
+int launch_shift_bwd(const float* in, const float* gs, float* grad_in, int accumulate, int H, int W,
+                     const float* shift_xy, float scale, double* partials, int* n_blocks, hipStream_t stream) {
+  dim3 grid((W + 255) / 256, H);
+  *n_blocks = grid.x * grid.y;
+  shift_bwd_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+int launch_finalize_multi(const double* partials, int n_blocks, int n_out, double scale, float* out, int accumulate,
+                          hipStream_t stream) {
+  finalize_multi_kernel<<<1, 256, 0, stream>>>(partials, n_blocks, n_out, scale, out, accumulate);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+}  // namespace jd

@@ -82,11 +82,12 @@ class PoissonLoss:
 
     @classmethod
     def from_datasets(cls, datasets, components, calibrations=None, device=TORCH_DEFAULT_DEVICE):
-        if calibrations:
-            raise NotImplementedError("NPredCalibrations are not implemented in jolideco_amd yet")
         npred_models_all, counts_all = [], []
         for name, dataset in datasets.items():
-            models = NPredModels.from_dataset_numpy(dataset=dataset, components=components, device=device)
+            calibration = calibrations[name] if calibrations else None  # KeyError for an unknown name, like the reference
+            models = NPredModels.from_dataset_numpy(
+                dataset=dataset, components=components, calibration=calibration, device=device
+            )
             npred_models_all.append(models)
             counts = torch.from_numpy(np.ascontiguousarray(dataset["counts"], dtype=np.float32)[None, None])
             counts_all.append(counts.to(device))

@@ -1,4 +1,4 @@
 from .core import FluxComponents, SpatialFluxComponent
-from .npred import NPredModel, NPredModels
+from .npred import NPredCalibration, NPredCalibrations, NPredModel, NPredModels
 
-__all__ = ["FluxComponents", "SpatialFluxComponent", "NPredModel", "NPredModels"]
+__all__ = ["FluxComponents", "SpatialFluxComponent", "NPredModel", "NPredModels", "NPredCalibration", "NPredCalibrations"]

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ..ops import ConvPlan, ConvSameFunction
 
-__all__ = ["NPredModel", "NPredModels"]
+__all__ = ["NPredModel", "NPredModels", "NPredCalibration", "NPredCalibrations"]
 
 
 def _to_device_image(array, device):
@@ -56,7 +56,7 @@ class NPredModel(nn.Module):
 
     @classmethod
     def from_numpy(cls, exposure, psf, upsampling_factor=None, correct_exposure_edges=True, device="cuda",
-                   kernel_shape=None):
+                   kernel_shape=None, psf_scale=None):
         """Upload one dataset's exposure and PSF, compute K-hat once and apply the reference's
         edge correction exposure / conv(1, psf) (models/npred.py:66-115) on the device.
 
@@ -81,8 +81,14 @@ class NPredModel(nn.Module):
         plan = ConvPlan.get(H, W, kh, kw, device)
         khat = plan.psf_spectrum(psf_t)
         if correct_exposure_edges:
+            # the edge correction uses the UN-rescaled PSF (models/npred.py:108-113 runs before any calibration)
             weights = plan.conv_same(torch.ones_like(exposure_t), None, khat)
             exposure_t = exposure_t / weights
+        if psf_scale is not None:
+            rescaled = rescale_psf(psf, psf_scale)
+            if rescaled is not psf:
+                psf_t = _to_device_image(rescaled, device)
+                khat = plan.psf_spectrum(psf_t)
         return cls(
             exposure=exposure_t[None, None], psf=psf_t[None, None], plan=plan, khat=khat,
             upsampling_factor=upsampling_factor,
@@ -106,17 +112,104 @@ class NPredModel(nn.Module):
         return torch.clip(conv, 0, torch.inf)
 
 
+def rescale_psf(psf, factor):
+    """Setup-time `rescale_image_torch` (jolideco/utils/torch.py:172-193) of a (kh, kw) PSF on the host:
+    the PSF scale of a calibration is not trainable (npred.py:333-334), so the rescaled PSF is a
+    constant of the fit."""
+    import torch.nn.functional as F
+
+    factor = torch.as_tensor(float(factor))
+    if torch.isclose(factor, torch.tensor(1.0)):
+        return psf
+    image = torch.from_numpy(np.ascontiguousarray(psf, dtype=np.float32))[None, None]
+    theta = torch.cat([torch.eye(2) / factor, torch.tensor([[0.0], [0.0]])], dim=1)[None]
+    grid = F.affine_grid(theta=theta, size=image.size(), align_corners=False)
+    return F.grid_sample(image, grid=grid, align_corners=False)[0, 0].numpy()
+
+
+class NPredCalibration(nn.Module):
+    """Dataset calibration parameters (reference: jolideco/models/npred.py:298-402).
+
+    Attributes
+    ----------
+    shift_xy : `~torch.nn.Parameter`  (1, 2) shift in x / y direction in counts pixels, trainable
+    background_norm : background normalisation, trainable as its logarithm
+    psf_scale : PSF scale (not trainable, applied once at setup)
+    frozen : bool, exclude the calibration from the optimisation (it is still applied)
+    weight : likelihood weight (stored; the fit loop of the reference does not use it either)
+    """
+
+    def __init__(self, shift_x=0.0, shift_y=0.0, background_norm=1.0, psf_scale=1.0, frozen=False, weight=1.0):
+        super().__init__()
+        self.shift_xy = nn.Parameter(torch.tensor([[shift_x, shift_y]], dtype=torch.float32))
+        self._background_norm = nn.Parameter(torch.log(torch.tensor([background_norm], dtype=torch.float32)))
+        self.psf_scale = nn.Parameter(torch.tensor([psf_scale], dtype=torch.float32), requires_grad=False)
+        self.frozen = frozen
+        self.weight = weight
+
+    @property
+    def background_norm(self):
+        return torch.exp(self._background_norm)
+
+    @property
+    def shift_is_active(self):
+        """The reference applies the shift -- and propagates a gradient to it -- only while it is not
+        close to zero (`shift_image_torch`, utils/torch.py:211): a shift initialised at exactly 0 never
+        moves.  Evaluated once at setup from the host copy of the initial value."""
+        shift = self.shift_xy.detach().cpu()
+        return not bool(torch.all(torch.isclose(shift, torch.zeros_like(shift))))
+
+    def parameters(self, recurse=True):
+        return [] if self.frozen else super().parameters(recurse)
+
+    def to_dict(self):
+        shift_xy = self.shift_xy.detach().cpu().numpy()
+        return {
+            "shift_x": shift_xy[0, 0].item(),
+            "shift_y": shift_xy[0, 1].item(),
+            "background_norm": self.background_norm.detach().cpu().numpy().item(),
+            "psf_scale": self.psf_scale.detach().cpu().numpy().item(),
+            "frozen": self.frozen,
+            "weight": float(self.weight),
+        }
+
+    @classmethod
+    def from_dict(cls, data):
+        return cls(**data)
+
+
+class NPredCalibrations(nn.ModuleDict):
+    """Calibrations by dataset name (reference: jolideco/models/npred.py:405-510)."""
+
+    def parameters(self, recurse=True):
+        parameters = []
+        for model in self.values():
+            if not model.frozen:
+                parameters.extend(list(model.parameters()))
+        return parameters
+
+    def to_dict(self):
+        return {name: model.to_dict() for name, model in self.items()}
+
+    @classmethod
+    def from_dict(cls, data):
+        return cls([(name, NPredCalibration.from_dict(d)) for name, d in data.items()])
+
+
 class NPredModels(nn.ModuleDict):
-    """All component models of one dataset plus its background."""
+    """All component models of one dataset plus its background (and its calibration)."""
 
     def __init__(self, background, calibration=None, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if calibration is not None:
-            raise NotImplementedError("NPredCalibration is not implemented in jolideco_amd yet")
         self.register_buffer("background", background)
-        self.calibration = None
+        # not registered as a sub-module: a ModuleDict iterates its modules as flux component models
+        object.__setattr__(self, "calibration", calibration)
 
     def evaluate_per_component(self, fluxes):
+        if self.calibration is not None:
+            raise NotImplementedError(
+                "the autograd seam NPredModels.evaluate does not apply calibrations; use fwd_bwd (the fit loop does)"
+            )
         npreds = {name: model(flux=flux) for (name, model), flux in zip(self.items(), fluxes)}
         npreds["background"] = self.background
         return npreds
@@ -139,13 +232,16 @@ class NPredModels(nn.ModuleDict):
         if len(factors) != 1:
             raise NotImplementedError("all components of a fit must share one upsampling_factor in jolideco_amd")
         kernel_shape = (max(p.shape[0] for p in psfs.values()), max(p.shape[1] for p in psfs.values()))
+        psf_scale = None if calibration is None else float(calibration.psf_scale.detach().cpu())
         for name, component in components.items():
             model = NPredModel.from_numpy(
                 exposure=dataset["exposure"], psf=psfs[name], upsampling_factor=component.upsampling_factor,
-                device=device, kernel_shape=kernel_shape,
+                device=device, kernel_shape=kernel_shape, psf_scale=psf_scale,
             )
             values.append((name, model))
         background = _to_device_image(dataset["background"], device)[None, None]
+        if calibration is not None:
+            calibration = calibration.to(device)
         return cls(background, calibration, values)
 
     # fused path ----------------------------------------------------------------------------
@@ -160,9 +256,35 @@ class NPredModels(nn.ModuleDict):
                 npred_out=None):
         """One fused C-ABI call: forward model + Poisson NLL (+ d loss / d flux_c)."""
         models = list(self.values())
+        cal = self.calibration
+        calibration = None
+        if cal is not None:
+            # device pointers of the calibration parameters; gradients land in `.grad` (allocated here, so
+            # a parameter that takes no part keeps grad None and the optimizer skips it, as in the reference)
+            want_grad = grads is not None and not cal.frozen
+            shift = cal.shift_xy if self.shift_active else None
+            if want_grad:
+                if shift is not None and cal.shift_xy.grad is None:
+                    cal.shift_xy.grad = torch.zeros_like(cal.shift_xy)
+                if cal._background_norm.grad is None:
+                    cal._background_norm.grad = torch.zeros_like(cal._background_norm)
+            calibration = (
+                None if shift is None else shift.data,
+                cal._background_norm.data,
+                cal.shift_xy.grad if (want_grad and shift is not None) else None,
+                cal._background_norm.grad if want_grad else None,
+            )
         self.plan.npred_poisson_fwd_bwd(
             fluxes=list(fluxes), exposures=[m.exposure for m in models], khats=[m.khat for m in models],
             background=self.background, counts=counts, stirling=stirling, loss_out=loss_out, grads=grads,
             accumulate=accumulate, grad_scale=grad_scale, npred_out=npred_out,
-            upsampling=models[0].upsampling_factor or 1,
+            upsampling=models[0].upsampling_factor or 1, calibration=calibration,
         )
+
+    @property
+    def shift_active(self):
+        if self.calibration is None:
+            return False
+        if not hasattr(self, "_shift_active"):
+            self._shift_active = self.calibration.shift_is_active
+        return self._shift_active

@@ -149,7 +149,7 @@ class ConvPlan:
 
     def npred_poisson_fwd_bwd(
         self, fluxes, exposures, khats, background, counts, stirling, loss_out, grads=None, accumulate=False,
-        grad_scale=1.0, npred_out=None, eps=POISSON_EPS, upsampling=1,
+        grad_scale=1.0, npred_out=None, eps=POISSON_EPS, upsampling=1, calibration=None,
     ):
         """Fused forward model + Poisson NLL (+ gradient) of one dataset; see include/jolideco_hip.h."""
         n = len(fluxes)
@@ -157,6 +157,19 @@ class ConvPlan:
             raise ValueError("fluxes, exposures and khats must have the same length")
         for f in fluxes:
             self._check_image(f, "flux")
+        if calibration is not None:
+            # (shift_xy | None, log_background_norm, grad_shift_xy | None, grad_log_background_norm | None)
+            shift, log_norm, grad_shift, grad_log_norm = calibration
+            check(
+                _hip.lib().jd_npred_poisson_calibrated_fwd_bwd(
+                    self._handle, n, ptr_array(fluxes), ptr_array(exposures), ptr_array(khats), ptr(background),
+                    ptr(counts), c_float(stirling), c_float(eps), ptr(loss_out),
+                    ptr_array(grads) if grads is not None else None, int(accumulate), c_float(grad_scale),
+                    ptr(npred_out), int(upsampling), ptr(shift), ptr(log_norm), ptr(grad_shift), ptr(grad_log_norm),
+                    stream_ptr(background.device),
+                )
+            )
+            return
         check(
             _hip.lib().jd_npred_poisson_fwd_bwd(
                 self._handle, n, ptr_array(fluxes), ptr_array(exposures), ptr_array(khats), ptr(background),

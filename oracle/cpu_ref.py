@@ -66,6 +66,56 @@ def upsample_setup(tensor, upsampling_factor, is_psf):
     return tensor
 
 
+def shift_image(image, shift_xy, scale=1):
+    """Sub-pixel shift through affine_grid / grid_sample (bilinear, zero padding, align_corners=False);
+    the identity -- and no gradient to `shift_xy` -- when the shift is close to zero:
+    jolideco/utils/torch.py:196-223 (`shift_image_torch`)."""
+    if shift_xy is None or torch.all(torch.isclose(shift_xy, torch.zeros_like(shift_xy))):
+        return image
+    size = image.size()
+    scale = 2 * scale / torch.tensor([[size[-1]], [size[-2]]])
+    theta = torch.cat([torch.eye(2), scale * shift_xy.T], dim=1)[None]
+    grid = F.affine_grid(theta=theta, size=size)
+    return F.grid_sample(image, grid=grid)
+
+
+def rescale_image(image, factor):
+    """jolideco/utils/torch.py:172-193 (`rescale_image_torch`): identity for factor None / ~1."""
+    if factor is None or torch.isclose(factor, torch.tensor(1.0)):
+        return image
+    theta = torch.cat([torch.eye(2) / factor, torch.tensor([[0], [0]])], dim=1)[None]
+    grid = F.affine_grid(theta=theta, size=image.size())
+    return F.grid_sample(image, grid=grid)
+
+
+@dataclass
+class CalibrationRef:
+    """Parameters of jolideco/models/npred.py:298-402 (`NPredCalibration`)."""
+
+    shift_xy: torch.Tensor  # (1, 2) [x, y], trainable
+    log_background_norm: torch.Tensor  # (1,), trainable
+    psf_scale: torch.Tensor  # (1,), requires_grad=False
+    frozen: bool = False
+
+    @classmethod
+    def create(cls, shift_x=0.0, shift_y=0.0, background_norm=1.0, psf_scale=1.0, frozen=False):
+        return cls(
+            shift_xy=torch.tensor([[float(shift_x), float(shift_y)]], requires_grad=True),
+            log_background_norm=torch.log(torch.tensor([float(background_norm)])).requires_grad_(True),
+            psf_scale=torch.tensor([float(psf_scale)]),
+            frozen=frozen,
+        )
+
+    def parameters(self):
+        return [] if self.frozen else [self.shift_xy, self.log_background_norm]
+
+    def to_dict(self):
+        return {
+            "shift_x": float(self.shift_xy[0, 0]), "shift_y": float(self.shift_xy[0, 1]),
+            "background_norm": float(torch.exp(self.log_background_norm)), "psf_scale": float(self.psf_scale),
+        }
+
+
 def npred_total(fluxes, exposures, psfs, background, upsampling_factors=None):
     """sum_c npred_c + background, accumulated into zeros in component order, background last:
     jolideco/models/npred.py:210-261 (no calibration)."""
@@ -307,9 +357,10 @@ class DatasetRef:
     exposures: list  # per component, edge-corrected (up-sampled when the component is)
     psfs: list  # per component (1,1,kh,kw) (up-sampled, / u^2)
     upsampling_factors: list = None  # per component: None or int
+    calibration: CalibrationRef = None
 
     @classmethod
-    def from_numpy(cls, dataset, component_names, upsampling_factors=None):
+    def from_numpy(cls, dataset, component_names, upsampling_factors=None, calibration=None):
         exposures, psfs = [], []
         ups = upsampling_factors or [None] * len(component_names)
         for name, u in zip(component_names, ups):
@@ -326,10 +377,18 @@ class DatasetRef:
             exposures=exposures,
             psfs=psfs,
             upsampling_factors=list(ups),
+            calibration=calibration,
         )
 
     def npred(self, fluxes):
-        return npred_total(fluxes, self.exposures, self.psfs, self.background, self.upsampling_factors)
+        cal = self.calibration
+        if cal is None:
+            return npred_total(fluxes, self.exposures, self.psfs, self.background, self.upsampling_factors)
+        # jolideco/models/npred.py:210-239: shift every flux, rescale the PSF, scale the background
+        fluxes = [shift_image(f, cal.shift_xy, scale=u) for f, u in zip(fluxes, self.upsampling_factors)]
+        psfs = [rescale_image(p, cal.psf_scale) for p in self.psfs]
+        background = self.background * torch.exp(cal.log_background_norm)
+        return npred_total(fluxes, self.exposures, psfs, background, self.upsampling_factors)
 
     def loss(self, fluxes):
         return poisson_nll(self.npred(fluxes), self.counts)
@@ -384,6 +443,7 @@ def map_fit_sequential(
     masks=None,
     record_steps=False,
     upsampling_factors=None,
+    calibrations=None,
 ):
     """The reference optimisation loop: one Adam step per dataset on
     L_d - beta * logprior / n_datasets, then a no-grad trace row evaluated on the STALE fluxes
@@ -402,11 +462,15 @@ def map_fit_sequential(
         None if masks.get(n) is None else torch.from_numpy(masks[n][np.newaxis, np.newaxis].astype(bool))
         for n in names_c
     ]
-    data = [DatasetRef.from_numpy(datasets[n], names_c, ups) for n in names_d]
+    calibrations = calibrations or {}
+    data = [DatasetRef.from_numpy(datasets[n], names_c, ups, calibrations.get(n)) for n in names_d]
     data_val = None
     if datasets_validation:
-        data_val = [DatasetRef.from_numpy(d, names_c, ups) for d in datasets_validation.values()]
-    optimizer = torch.optim.Adam(thetas, lr=learning_rate)
+        data_val = [DatasetRef.from_numpy(d, names_c, ups, calibrations.get(n)) for n, d in datasets_validation.items()]
+    parameters = list(thetas)
+    for cal in calibrations.values():  # jolideco/core.py:197-200
+        parameters.extend(cal.parameters())
+    optimizer = torch.optim.Adam(parameters, lr=learning_rate)
     prior_list = [priors[n] for n in names_c]
     n_datasets = len(data)
     trace, steps = [], []

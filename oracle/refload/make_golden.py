@@ -282,6 +282,59 @@ def upsampling_case():
     print("upsampling_case ok", res.flux_total[12, 12], res3.trace_loss[-1]["total"])
 
 
+def calibration_case():
+    """Fits with NPredCalibrations (jolideco/models/npred.py:298-510): trainable sub-pixel shift and
+    background norm per dataset, a fixed PSF scale, one frozen calibration; upsampling_factor 1 and 2."""
+    from jolideco.models import NPredCalibration, NPredCalibrations
+
+    out = {}
+    for tag, u, n_epochs in (("u1", 1, 8), ("u2", 2, 5)):
+        rs = np.random.RandomState(40 + u)
+        shape = (40, 44)
+        datasets = {f"o{i}": scene(shape, asym_psf((7, 7), 1.1 + 0.2 * i, 1.4), rs, n_points=4, bkg=0.8 + 0.1 * i) for i in range(3)}
+        flux_init = rs.gamma(30, size=shape)
+        means, covs, weights = cpu_ref.synthetic_gmm(6, 64, seed=9)
+        spec = {
+            "o0": dict(shift_x=0.3, shift_y=-0.2, background_norm=1.2, psf_scale=1.0),
+            "o1": dict(shift_x=0.0, shift_y=0.0, background_norm=0.9, psf_scale=1.1),  # shift stays exactly 0
+            "o2": dict(shift_x=-0.45, shift_y=0.6, background_norm=1.0, psf_scale=1.0, frozen=True),
+        }
+        cals = NPredCalibrations()
+        for name, kw in spec.items():
+            cals[name] = NPredCalibration(**kw)
+        comps = FluxComponents()
+        comps["flux"] = SpatialFluxComponent.from_numpy(
+            flux=flux_init, upsampling_factor=u, prior=GMMPatchPrior(gmm=ref_gmm(means, covs, weights))
+        )
+        res = MAPDeconvolver(n_epochs=n_epochs, display_progress=False).run(datasets=datasets, components=comps, calibrations=cals)
+        cal_final = {name: c.to_dict() for name, c in res.calibrations.items()}
+
+        gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+        cals_o = {name: cpu_ref.CalibrationRef.create(**kw) for name, kw in spec.items()}
+        final, trace = cpu_ref.map_fit_sequential(
+            datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o)}, n_epochs=n_epochs,
+            upsampling_factors={"flux": u}, calibrations=cals_o,
+        )
+        assert np.array_equal(final["flux"], res.flux_upsampled_total), np.abs(final["flux"] - res.flux_upsampled_total).max()
+        assert trace[-1]["total"] == res.trace_loss[-1]["total"]
+        for name in spec:
+            for key, value in cals_o[name].to_dict().items():
+                assert value == cal_final[name][key], (name, key, value, cal_final[name][key])
+        assert cal_final["o1"]["shift_x"] == 0.0 and cal_final["o0"]["shift_x"] != 0.3 and cal_final["o2"]["shift_x"] == np.float32(-0.45)
+
+        out.update({f"{tag}/flux_init": flux_init, f"{tag}/flux_upsampled_final": res.flux_upsampled_total,
+                    f"{tag}/gmm_means": means, f"{tag}/gmm_covariances": covs, f"{tag}/gmm_weights": weights})
+        out.update({f"{tag}/{k}": v for k, v in pack_datasets(datasets).items()})
+        out.update({f"{tag}/{k}": v for k, v in trace_to_arrays(res.trace_loss).items()})
+        for name, kw in spec.items():
+            out[f"{tag}/cal_init/{name}"] = np.array([kw["shift_x"], kw["shift_y"], kw["background_norm"], kw["psf_scale"],
+                                                      float(kw.get("frozen", False))])
+            d = cal_final[name]
+            out[f"{tag}/cal_final/{name}"] = np.array([d["shift_x"], d["shift_y"], d["background_norm"], d["psf_scale"]])
+        print("calibration_case", tag, "ok", cal_final["o0"], res.trace_loss[-1]["total"])
+    np.savez_compressed(OUT / "calibration.npz", **out)
+
+
 def stage_vectors():
     """Per-stage vectors: npred / loss / dL/dtheta and GMM prior value / grad / arg-max for
     several shapes incl. non-square images, even-sized and asymmetric PSFs, sizes that leave a
@@ -472,6 +525,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "upsampling":  # add this fixture without touching the others
         upsampling_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "calibration":
+        calibration_case()
+        sys.exit(0)
     rng_draws()
     anchor_a()
     anchor_b()
@@ -479,6 +535,7 @@ if __name__ == "__main__":
     stage_vectors()
     joint_and_multi()
     upsampling_case()
+    calibration_case()
     import os
 
     for f in sorted(OUT.glob("*.npz")):

@@ -247,3 +247,75 @@ def test_upsampling_factor_3_gmm_prior(golden, conv_method):
     assert rel_linf(res.flux_upsampled_total, u["u3/flux_upsampled_final"]) < 1e-5
     assert rel_linf(res.flux_total, u["u3/flux_final"]) < 1e-5
     _trace_close(res.trace_loss, u, prefix="u3/trace/")
+
+
+@pytest.mark.parametrize("tag,u,n_epochs", [("u1", 1, 8), ("u2", 2, 5)])
+def test_calibrations_match_the_reference(golden, tag, u, n_epochs, conv_method):
+    """Fits with NPredCalibrations against the live-reference fixture: sub-pixel shift (bilinear, trained),
+    background norm (trained), PSF scale (fixed), a zero shift that must stay exactly zero, a frozen
+    calibration.  Tolerance 1e-4: grid_sample's own pixel-coordinate rounding (W * 2^-24 px) and the Adam
+    steps on the three scalars amplify fp32 differences beyond the 1e-5 of the pure flux path."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent
+
+    c = golden("calibration")
+    datasets = unpack_datasets(c, f"{tag}/data/")
+    gmm = _gmm(c[f"{tag}/gmm_means"], c[f"{tag}/gmm_covariances"], c[f"{tag}/gmm_weights"])
+    cals = NPredCalibrations()
+    for name in datasets:
+        sx, sy, norm, psf_scale, frozen = (float(v) for v in c[f"{tag}/cal_init/{name}"])
+        cals[name] = NPredCalibration(shift_x=sx, shift_y=sy, background_norm=norm, psf_scale=psf_scale, frozen=bool(frozen))
+    comp = SpatialFluxComponent.from_numpy(flux=c[f"{tag}/flux_init"], upsampling_factor=u, prior=GMMPatchPrior(gmm=gmm))
+    res = MAPDeconvolver(n_epochs=n_epochs, display_progress=False, device=DEV).run(
+        datasets, components=comp, calibrations=cals
+    )
+    err = rel_linf(res.flux_upsampled_total, c[f"{tag}/flux_upsampled_final"])
+    print("calibrated fit rel Linf", tag, err)
+    assert err < 1e-4
+    _trace_close(res.trace_loss, c, prefix=f"{tag}/trace/", rtol=1e-4)
+    for name in datasets:
+        d = res.calibrations[name].to_dict()
+        got = np.array([d["shift_x"], d["shift_y"], d["background_norm"], d["psf_scale"]])
+        np.testing.assert_allclose(got, c[f"{tag}/cal_final/{name}"], rtol=2e-4, atol=2e-5, err_msg=name)
+    assert res.calibrations["o1"].to_dict()["shift_x"] == 0.0
+    assert res.calibrations_init["o0"].to_dict()["shift_x"] == pytest.approx(0.3)
+    np.testing.assert_allclose(res.calibrations["o2"].to_dict()["shift_y"], 0.6, rtol=1e-6)  # frozen
+
+
+def test_shift_kernel_matches_grid_sample():
+    """jd shift forward / adjoint / shift gradient against torch's affine_grid + grid_sample on the CPU."""
+    import torch.nn.functional as F
+
+    from jolideco_amd import FluxComponents, NPredCalibration, NPredModels, SpatialFluxComponent
+    from jolideco_amd.data import gaussian_kernel
+    from jolideco_amd.ops import stirling_mean
+    from oracle import cpu_ref
+
+    rs = np.random.RandomState(2)
+    shape = (37, 52)
+    data = {
+        "counts": rs.poisson(4.0, size=shape).astype(np.float32),
+        "psf": gaussian_kernel(1.2, (5, 5)).astype(np.float32),
+        "exposure": rs.uniform(0.5, 1.5, size=shape).astype(np.float32),
+        "background": rs.uniform(0.5, 1.0, size=shape).astype(np.float32),
+    }
+    flux_np = (rs.gamma(2.0, size=shape) * 2).astype(np.float32)
+    # (an exactly integer shift sits on a kink of the bilinear interpolant: grid_sample's one-sided
+    # derivative there depends on the rounding of its normalised coordinates, so it is not tested)
+    for sx, sy in ((0.3, -0.2), (-1.6, 2.25), (3.01, 0.5)):
+        cal_o = cpu_ref.CalibrationRef.create(sx, sy, 1.3, 1.0)
+        d = cpu_ref.DatasetRef.from_numpy(data, ["flux"], [1], cal_o)
+        flux_t = torch.from_numpy(flux_np)[None, None].requires_grad_(True)
+        loss_o = d.loss((flux_t,))
+        loss_o.backward()
+
+        cal = NPredCalibration(shift_x=sx, shift_y=sy, background_norm=1.3)
+        comps = FluxComponents()
+        comps["flux"] = SpatialFluxComponent.from_numpy(flux=flux_np, upsampling_factor=1)
+        models = NPredModels.from_dataset_numpy(dataset=data, components=comps, calibration=cal, device=DEV)
+        flux = torch.from_numpy(flux_np).to(DEV)
+        loss, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+        models.fwd_bwd([flux], torch.from_numpy(data["counts"]).to(DEV), stirling_mean(data["counts"]), loss, grads=[grad])
+        np.testing.assert_allclose(float(loss), float(loss_o), rtol=5e-6)
+        assert rel_linf(grad.cpu().numpy(), flux_t.grad.numpy()[0, 0]) < 2e-5
+        np.testing.assert_allclose(cal.shift_xy.grad.cpu().numpy(), cal_o.shift_xy.grad.numpy(), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(cal._background_norm.grad.cpu().numpy(), cal_o.log_background_norm.grad.numpy(), rtol=2e-5)

@@ -233,3 +233,27 @@ def test_upsampling_known_answers(golden):
     )
     assert rel_linf(final["flux"], u["u3/flux_upsampled_final"]) < TOL
     _trace_close(trace, u, prefix="u3/trace/")
+
+
+@pytest.mark.parametrize("tag,u,n_epochs", [("u1", 1, 8), ("u2", 2, 5)])
+def test_calibrations(golden, tag, u, n_epochs):
+    """NPredCalibrations (jolideco/models/npred.py:298-510): trainable shift + background norm, fixed PSF
+    scale, a shift that starts at exactly 0 (never moves: shift_image_torch bypass) and a frozen one."""
+    c = golden("calibration")
+    datasets = unpack_datasets(c, f"{tag}/data/")
+    gmm = cpu_ref.GMM.from_numpy(c[f"{tag}/gmm_means"], c[f"{tag}/gmm_covariances"], c[f"{tag}/gmm_weights"], stride=4)
+    cals = {}
+    for name in datasets:
+        sx, sy, norm, psf_scale, frozen = c[f"{tag}/cal_init/{name}"]
+        cals[name] = cpu_ref.CalibrationRef.create(sx, sy, norm, psf_scale, bool(frozen))
+    final, trace = cpu_ref.map_fit_sequential(
+        datasets, {"flux": c[f"{tag}/flux_init"]}, {"flux": cpu_ref.GMMPatchPriorRef(gmm)}, n_epochs=n_epochs,
+        upsampling_factors={"flux": u}, calibrations=cals,
+    )
+    assert rel_linf(final["flux"], c[f"{tag}/flux_upsampled_final"]) < TOL
+    _trace_close(trace, c, prefix=f"{tag}/trace/")
+    for name in datasets:
+        d = cals[name].to_dict()
+        got = np.array([d["shift_x"], d["shift_y"], d["background_norm"], d["psf_scale"]])
+        np.testing.assert_allclose(got, c[f"{tag}/cal_final/{name}"], rtol=1e-5, atol=1e-7)
+    assert cals["o1"].to_dict()["shift_x"] == 0.0  # bypassed shift gets no gradient
