@@ -181,8 +181,9 @@ int jd_elementwise_prior_fwd_bwd(int kind, const float* flux, size_t n, float al
                                  float* grad_flux_accum, void* stream);
 
 /* Parameter update -------------------------------------------------------------------------
- * flux = exp(theta) [* mask]   (SpatialFluxComponent.flux_upsampled, models/core.py:583-594) */
-int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, void* stream);
+ * flux = exp(theta) [* mask]   (SpatialFluxComponent.flux_upsampled, models/core.py:583-594);
+ * use_log_flux == 0: flux = theta [* mask] (the parameter is the flux itself, no positivity). */
+int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, int use_log_flux, void* stream);
 
 /* One torch.optim.Adam step (jolideco/core.py:39-42,229) on theta with the chain rule of
  * models/core.py:588-592 fused in: g_theta = grad_flux * flux_in.  Writes theta, exp_avg,
@@ -194,10 +195,10 @@ int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_
 int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux, float* exp_avg,
                  float* exp_avg_sq, const float* mask, size_t n, float step_size, float beta1,
                  float beta2, float one_minus_beta1, float one_minus_beta2, float bias2_sqrt, float eps,
-                 int zero_grad, void* stream);
+                 int zero_grad, int use_log_flux, void* stream);
 /* plain SGD (core.py:41): theta -= lr * grad_flux * flux_in */
 int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
-                const float* mask, size_t n, float lr, int zero_grad, void* stream);
+                const float* mask, size_t n, float lr, int zero_grad, int use_log_flux, void* stream);
 
 /* Kernel timers -----------------------------------------------------------------------------
  * New (the reference has no profiler hooks).  After jd_profile_enable(n) the

@@ -62,13 +62,13 @@ EXPORTS = {
         c_int,
         [c_int, c_void_p, c_size_t, c_float, c_float, c_float, c_void_p, c_float, c_void_p, c_void_p],
     ),
-    "jd_flux_from_theta": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "jd_flux_from_theta": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "jd_adam_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
-         c_float, c_float, c_float, c_float, c_int, c_void_p],
+         c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
     ),
-    "jd_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_void_p]),
+    "jd_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_int, c_void_p]),
     "jd_profile_enable": (c_int, [c_int]),
     "jd_profile_disable": (c_int, []),
     "jd_profile_pause": (c_int, [c_int]),

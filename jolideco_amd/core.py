@@ -60,11 +60,21 @@ class _ComponentState:
         self.exp_avg = torch.zeros_like(self.theta)
         self.exp_avg_sq = torch.zeros_like(self.theta)
         self.frozen = component.frozen
+        self.use_log_flux = bool(component.use_log_flux)
+        # reference quirk: with use_log_flux=False and no mask `flux_upsampled` IS the
+        # parameter tensor, which the optimizer updates in place, so the per-epoch trace sees the POST-step flux
+        self.trace_sees_current = (not self.use_log_flux) and self.mask is None
         check(
             _hip.lib().jd_flux_from_theta(
-                ptr(self.theta), ptr(self.mask), ptr(self.flux[0]), self.theta.numel(), stream_ptr(theta.device)
+                ptr(self.theta), ptr(self.mask), ptr(self.flux[0]), self.theta.numel(), int(self.use_log_flux),
+                stream_ptr(theta.device),
             )
         )
+
+    @property
+    def flux_trace(self):
+        """Flux the reference's `append_trace` evaluates (jolideco/core.py:247)."""
+        return self.flux_cur if self.trace_sees_current else self.flux_prev
 
     @property
     def flux_cur(self):
@@ -184,14 +194,14 @@ class MAPDeconvolver:
                     lib.jd_adam_step(
                         ptr(st.theta), ptr(st.flux_cur), ptr(st.flux[1 - st.cur]), ptr(st.grad), ptr(st.exp_avg),
                         ptr(st.exp_avg_sq), ptr(st.mask), n, step_size, beta1, beta2, 1 - beta1, 1 - beta2, bias2_sqrt, eps, 1,
-                        stream,
+                        int(st.use_log_flux), stream,
                     )
                 )
             else:
                 check(
                     lib.jd_sgd_step(
                         ptr(st.theta), ptr(st.flux_cur), ptr(st.flux[1 - st.cur]), ptr(st.grad), ptr(st.mask), n, lr,
-                        1, stream,
+                        1, int(st.use_log_flux), stream,
                     )
                 )
             st.cur = 1 - st.cur
@@ -438,14 +448,14 @@ class FitSession:
                 cfg._optimizer_step(states, self.step)
                 self._cal_step(li)
             # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------------
-            stale = [st.flux_prev for st in states]
+            stale = [st.flux_trace for st in states]
             for gslot, li in self.local_idx:
                 total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
             for ci, (st, prior) in enumerate(zip(states, priors)):
-                prior.device_fwd_bwd(st.flux_prev, slot(n_d + ci))
+                prior.device_fwd_bwd(st.flux_trace, slot(n_d + ci))
         if self.n_val:
             # validation losses on the same fluxes the trace row refers to
-            vfl = [st.flux_prev for st in states]
+            vfl = [st.flux_prev if self.joint else st.flux_trace for st in states]
             for vi in range(self.n_val):
                 total_loss.poisson_loss_validation.fwd_bwd(vi, vfl, slot(n_d + n_c + vi))
 

@@ -406,6 +406,7 @@ struct AdamArgs {
   size_t n;
   float step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, lr;
   int zero_grad, sgd;
+  int linear;  // use_log_flux=False: theta IS the flux (models/core.py:586-594), no exp / chain rule
 };
 
 __device__ inline void adam_update(float& th, float& m, float& v, float g, const AdamArgs& a) {
@@ -449,9 +450,10 @@ __global__ __launch_bounds__(BLOCK) void adam_kernel(AdamArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      // d flux / d theta = exp(theta) * mask = flux  (models/core.py:588-592)
-      adam_update(th[k], m[k], v[k], gf[k] * f[k], a);
-      f[k] = expf(th[k]);
+      // d flux / d theta = exp(theta) * mask = flux  (models/core.py:588-592); linear: = mask
+      const float dfdth = a.linear ? (a.mask ? mk[k] : 1.f) : f[k];
+      adam_update(th[k], m[k], v[k], gf[k] * dfdth, a);
+      f[k] = a.linear ? th[k] : expf(th[k]);
       if (a.mask) f[k] *= mk[k];
     }
     if constexpr (VEC == 4) {
@@ -487,10 +489,10 @@ static int launch_adam(const AdamArgs& a, hipStream_t stream) {
 
 __global__ __launch_bounds__(BLOCK) void flux_from_theta_kernel(const float* __restrict__ theta,
                                                                const float* __restrict__ mask,
-                                                               float* __restrict__ flux, size_t n) {
+                                                               float* __restrict__ flux, size_t n, int linear) {
   const size_t stride = (size_t)gridDim.x * BLOCK;
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-    float f = expf(theta[i]);
+    float f = linear ? theta[i] : expf(theta[i]);
     if (mask) f *= mask[i];
     flux[i] = f;
   }
@@ -575,11 +577,12 @@ extern "C" int jd_elementwise_prior_fwd_bwd(int kind, const float* flux, size_t 
   return launch_finalize_sum(g_partials, (int)blocks, 1.0 / (double)n, (double)log_const, value_out, 0, s);
 }
 
-extern "C" int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, void* stream) {
+extern "C" int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, int use_log_flux,
+                                  void* stream) {
   JD_REQUIRE(theta && flux && n > 0, "jd_flux_from_theta: null argument or n == 0");
   size_t blocks = (n + BLOCK - 1) / BLOCK;
   if (blocks > 8192) blocks = 8192;
-  flux_from_theta_kernel<<<(unsigned)blocks, BLOCK, 0, as_stream(stream)>>>(theta, mask, flux, n);
+  flux_from_theta_kernel<<<(unsigned)blocks, BLOCK, 0, as_stream(stream)>>>(theta, mask, flux, n, use_log_flux ? 0 : 1);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -587,19 +590,20 @@ extern "C" int jd_flux_from_theta(const float* theta, const float* mask, float* 
 extern "C" int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
                             float* exp_avg, float* exp_avg_sq, const float* mask, size_t n, float step_size,
                             float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
-                            float bias2_sqrt, float eps, int zero_grad, void* stream) {
+                            float bias2_sqrt, float eps, int zero_grad, int use_log_flux, void* stream) {
   JD_REQUIRE(theta && flux_in && flux_out && grad_flux && exp_avg && exp_avg_sq && n > 0,
              "jd_adam_step: null argument or n == 0");
   AdamArgs a{theta, flux_in, flux_out, grad_flux, exp_avg, exp_avg_sq, mask, n,
-             step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, 0.f, zero_grad, 0};
+             step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, 0.f, zero_grad, 0,
+             use_log_flux ? 0 : 1};
   return launch_adam(a, as_stream(stream));
 }
 
 extern "C" int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
-                           const float* mask, size_t n, float lr, int zero_grad, void* stream) {
+                           const float* mask, size_t n, float lr, int zero_grad, int use_log_flux, void* stream) {
   JD_REQUIRE(theta && flux_in && flux_out && grad_flux && n > 0, "jd_sgd_step: null argument or n == 0");
   AdamArgs a{theta, flux_in, flux_out, grad_flux, nullptr, nullptr, mask, n,
-             0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, lr, zero_grad, 1};
+             0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, lr, zero_grad, 1, use_log_flux ? 0 : 1};
   return launch_adam(a, as_stream(stream));
 }
 

@@ -394,13 +394,15 @@ class DatasetRef:
         return poisson_nll(self.npred(fluxes), self.counts)
 
 
-def log_flux_parameter(flux_init, upsampling_factor=None):
-    """theta = log(float32(flux)) as a (1,1,H,W) leaf, bilinearly up-sampled first when the component
-    is: jolideco/models/core.py:399-402,505-540."""
+def log_flux_parameter(flux_init, upsampling_factor=None, use_log_flux=True):
+    """theta = log(float32(flux)) (or the flux itself for use_log_flux=False) as a (1,1,H,W) leaf,
+    bilinearly up-sampled first when the component is: jolideco/models/core.py:399-402,505-540."""
     flux = torch.from_numpy(flux_init[np.newaxis, np.newaxis].astype(np.float32))
     if upsampling_factor:
         flux = F.interpolate(flux, scale_factor=upsampling_factor, mode="bilinear")
-    return torch.log(flux).requires_grad_(True)
+    if use_log_flux:
+        flux = torch.log(flux)
+    return flux.requires_grad_(True)
 
 
 def downsampled_flux(flux_upsampled, upsampling_factor=None):
@@ -410,9 +412,11 @@ def downsampled_flux(flux_upsampled, upsampling_factor=None):
     return flux_upsampled
 
 
-def to_flux(theta, mask=None):
-    """exp(theta) [* mask]: jolideco/models/core.py:583-594."""
-    flux = torch.exp(theta)
+def to_flux(theta, mask=None, use_log_flux=True):
+    """exp(theta) [* mask]: jolideco/models/core.py:583-594.  With use_log_flux=False and no mask the
+    PARAMETER ITSELF is returned, like the reference: the optimizer then updates the "flux" of the last
+    step in place and the per-epoch trace sees the post-step values."""
+    flux = torch.exp(theta) if use_log_flux else theta
     if mask is not None:
         flux = flux * mask
     return flux
@@ -444,6 +448,7 @@ def map_fit_sequential(
     record_steps=False,
     upsampling_factors=None,
     calibrations=None,
+    use_log_flux=True,
 ):
     """The reference optimisation loop: one Adam step per dataset on
     L_d - beta * logprior / n_datasets, then a no-grad trace row evaluated on the STALE fluxes
@@ -456,7 +461,7 @@ def map_fit_sequential(
     names_c = list(flux_inits)
     names_d = list(datasets)
     ups = [(upsampling_factors or {}).get(n) for n in names_c]
-    thetas = [log_flux_parameter(flux_inits[n], u) for n, u in zip(names_c, ups)]
+    thetas = [log_flux_parameter(flux_inits[n], u, use_log_flux) for n, u in zip(names_c, ups)]
     masks = masks or {}
     mask_t = [
         None if masks.get(n) is None else torch.from_numpy(masks[n][np.newaxis, np.newaxis].astype(bool))
@@ -478,7 +483,7 @@ def map_fit_sequential(
     for _ in range(n_epochs):
         for d in data:
             optimizer.zero_grad()
-            fluxes = tuple(to_flux(t, m) for t, m in zip(thetas, mask_t))
+            fluxes = tuple(to_flux(t, m, use_log_flux) for t, m in zip(thetas, mask_t))
             loss = d.loss(fluxes)
             loss_prior = sum(p(f) for f, p in zip(fluxes, prior_list))
             total = loss - beta * loss_prior / n_datasets
@@ -501,7 +506,7 @@ def map_fit_sequential(
         trace.append(_trace_row(names_d, names_c, loss_datasets, loss_priors, beta, loss_val))
 
     # `final` holds the UP-SAMPLED fluxes (== the fluxes when upsampling_factor is None)
-    final = {n: to_flux(t, m).detach().numpy()[0, 0] for n, t, m in zip(names_c, thetas, mask_t)}
+    final = {n: to_flux(t, m, use_log_flux).detach().numpy()[0, 0] for n, t, m in zip(names_c, thetas, mask_t)}
     if record_steps:
         return final, trace, steps
     return final, trace

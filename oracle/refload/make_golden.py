@@ -335,6 +335,39 @@ def calibration_case():
     np.savez_compressed(OUT / "calibration.npz", **out)
 
 
+def linear_flux_case():
+    """use_log_flux=False (models/core.py:399-402,583-594): the parameter is the flux itself; without a
+    mask the trace sees the post-step flux (the parameter object is what `to_flux_tuple` returns)."""
+    out = {}
+    for tag, with_mask in (("nomask", False), ("mask", True)):
+        rs = np.random.RandomState(51)
+        shape = (36, 40)
+        datasets = {f"o{i}": scene(shape, asym_psf((7, 7), 1.2 + 0.2 * i, 1.5), rs, n_points=3, bkg=1.0) for i in range(2)}
+        flux_init = rs.gamma(30, size=shape)
+        mask = np.ones(shape, dtype=bool)
+        mask[:, :6] = False
+        means, covs, weights = cpu_ref.synthetic_gmm(5, 64, seed=12)
+        comps = FluxComponents()
+        comps["flux"] = SpatialFluxComponent.from_numpy(
+            flux=flux_init, mask=mask if with_mask else None, use_log_flux=False,
+            prior=GMMPatchPrior(gmm=ref_gmm(means, covs, weights)),
+        )
+        res = MAPDeconvolver(n_epochs=6, display_progress=False).run(datasets=datasets, components=comps)
+        gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+        final, trace = cpu_ref.map_fit_sequential(
+            datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o)}, n_epochs=6,
+            masks={"flux": mask} if with_mask else None, use_log_flux=False,
+        )
+        assert np.array_equal(final["flux"], res.flux_total), np.abs(final["flux"] - res.flux_total).max()
+        assert trace[-1]["total"] == res.trace_loss[-1]["total"], (trace[-1]["total"], res.trace_loss[-1]["total"])
+        out.update({f"{tag}/flux_init": flux_init, f"{tag}/flux_final": res.flux_total, f"{tag}/mask": mask,
+                    f"{tag}/gmm_means": means, f"{tag}/gmm_covariances": covs, f"{tag}/gmm_weights": weights})
+        out.update({f"{tag}/{k}": v for k, v in pack_datasets(datasets).items()})
+        out.update({f"{tag}/{k}": v for k, v in trace_to_arrays(res.trace_loss).items()})
+        print("linear_flux_case", tag, "ok", res.trace_loss[-1]["total"], res.flux_total.min())
+    np.savez_compressed(OUT / "linear_flux.npz", **out)
+
+
 def stage_vectors():
     """Per-stage vectors: npred / loss / dL/dtheta and GMM prior value / grad / arg-max for
     several shapes incl. non-square images, even-sized and asymmetric PSFs, sizes that leave a
@@ -528,6 +561,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "calibration":
         calibration_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "linear_flux":
+        linear_flux_case()
+        sys.exit(0)
     rng_draws()
     anchor_a()
     anchor_b()
@@ -536,6 +572,7 @@ if __name__ == "__main__":
     joint_and_multi()
     upsampling_case()
     calibration_case()
+    linear_flux_case()
     import os
 
     for f in sorted(OUT.glob("*.npz")):

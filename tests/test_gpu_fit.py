@@ -348,3 +348,20 @@ def test_long_trajectory_drift_100_epochs():
     rel_total = abs(res.trace_loss[-1]["total"] - trace[-1]["total"]) / abs(trace[-1]["total"])
     print(f"100-epoch drift: flux rel Linf = {err:.3e}, final total loss rel = {rel_total:.3e}")
     assert err < 1e-5 and rel_total < 1e-5  # measured on MI355X: 4.5e-7 / 7.5e-8
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_linear_flux_parameter(golden, tag):
+    """use_log_flux=False (the parameter is the flux itself) against the live-reference fixture, incl. the
+    reference's trace quirk: post-step flux in the trace without a mask, stale flux with one."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+
+    g = golden("linear_flux")
+    gmm = _gmm(g[f"{tag}/gmm_means"], g[f"{tag}/gmm_covariances"], g[f"{tag}/gmm_weights"])
+    comp = SpatialFluxComponent.from_numpy(
+        flux=g[f"{tag}/flux_init"], mask=g[f"{tag}/mask"] if tag == "mask" else None, use_log_flux=False,
+        prior=GMMPatchPrior(gmm=gmm),
+    )
+    res = MAPDeconvolver(n_epochs=6, display_progress=False, device=DEV).run(unpack_datasets(g, f"{tag}/data/"), components=comp)
+    assert rel_linf(res.flux_total, g[f"{tag}/flux_final"]) < 1e-5
+    _trace_close(res.trace_loss, g, prefix=f"{tag}/trace/")

@@ -251,7 +251,7 @@ def test_adam_step_matches_torch_optim():
         grad = torch.from_numpy(g).to(DEV)
         ss, b2 = adam_bias_terms(step, 0.1, 0.9, 0.999)
         check(_hip.lib().jd_adam_step(ptr(theta), ptr(flux), ptr(flux2), ptr(grad), ptr(m), ptr(v), None, n, ss, 0.9,
-                                      0.999, 1 - 0.9, 1 - 0.999, b2, 1e-8, 1, stream_ptr()))
+                                      0.999, 1 - 0.9, 1 - 0.999, b2, 1e-8, 1, 1, stream_ptr()))
         flux, flux2 = flux2, flux
         assert float(grad.abs().max()) == 0.0
         np.testing.assert_allclose(theta.cpu().numpy(), ref_p.detach().numpy(), rtol=2e-6, atol=2e-6)

@@ -160,8 +160,8 @@ def test_unsupported_options_raise_instead_of_silently_differing():
         jd.GMMPatchPrior(gmm=gmm, jitter=True)
     with pytest.raises(NotImplementedError):
         jd.GMMPatchPrior(gmm=gmm, cycle_spin_subpix=True)
-    with pytest.raises(NotImplementedError):
-        jd.SpatialFluxComponent.from_numpy(np.ones((8, 8)), use_log_flux=False)
+    lin = jd.SpatialFluxComponent.from_numpy(np.full((8, 8), 3.0), use_log_flux=False)
+    assert not lin.use_log_flux and torch.allclose(lin._flux_upsampled, torch.full((1, 1, 8, 8), 3.0))
     with pytest.raises(ValueError):
         jd.MAPDeconvolver(optimizer_type="lbfgs", device="cuda")
     with pytest.raises(ValueError):

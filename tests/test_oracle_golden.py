@@ -257,3 +257,17 @@ def test_calibrations(golden, tag, u, n_epochs):
         got = np.array([d["shift_x"], d["shift_y"], d["background_norm"], d["psf_scale"]])
         np.testing.assert_allclose(got, c[f"{tag}/cal_final/{name}"], rtol=1e-5, atol=1e-7)
     assert cals["o1"].to_dict()["shift_x"] == 0.0  # bypassed shift gets no gradient
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_linear_flux_parameter(golden, tag):
+    """use_log_flux=False incl. the reference's trace quirk (post-step flux without a mask, stale flux with one)."""
+    g = golden("linear_flux")
+    gmm = cpu_ref.GMM.from_numpy(g[f"{tag}/gmm_means"], g[f"{tag}/gmm_covariances"], g[f"{tag}/gmm_weights"], stride=4)
+    masks = {"flux": g[f"{tag}/mask"]} if tag == "mask" else None
+    final, trace = cpu_ref.map_fit_sequential(
+        unpack_datasets(g, f"{tag}/data/"), {"flux": g[f"{tag}/flux_init"]}, {"flux": cpu_ref.GMMPatchPriorRef(gmm)},
+        n_epochs=6, masks=masks, use_log_flux=False,
+    )
+    assert rel_linf(final["flux"], g[f"{tag}/flux_final"]) < TOL
+    _trace_close(trace, g, prefix=f"{tag}/trace/")
