@@ -129,12 +129,14 @@ int launch_cmul(float2* spec, const float2* khat, size_t n, bool conj, hipStream
 // (zeros outside (H, W)) so the buffer is directly the input of the adjoint R2C.
 // Algorithmic bytes: 16 B/pixel for one component (conv, background, counts in; g out).
 // ------------------------------------------------------------------------------------------
-template <int VEC, int ROWS>
+// CAL: a dataset calibration is present (background norm read from device memory, second partial sum
+// for its gradient); a compile-time switch so that the plain pass carries none of it.
+template <int VEC, int ROWS, bool CAL>
 __global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
   __shared__ double smem[BLOCK / 64];
   const int x0 = (blockIdx.x * BLOCK + threadIdx.x) * VEC;
   double local = 0.0, local_b = 0.0;
-  const float bkg_norm = a.log_bkg_norm ? expf(a.log_bkg_norm[0]) : 1.f;  // NPredCalibration.background_norm
+  const float bkg_norm = (CAL && a.log_bkg_norm) ? expf(a.log_bkg_norm[0]) : 1.f;  // NPredCalibration.background_norm
   // ROWS rows per thread: every load of the thread is issued before the first one is consumed
   // (ROWS x (2 + n_comp) x 16 B in flight per lane)
   float b[ROWS][VEC], c[ROWS][VEC], conv[ROWS][JD_MAX_COMPONENTS][VEC];
@@ -186,12 +188,12 @@ __global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const float bi = a.log_bkg_norm ? b[r][i] * bkg_norm : b[r][i];
+        const float bi = (CAL && a.log_bkg_norm) ? b[r][i] * bkg_norm : b[r][i];
         n[i] += bi;  // background added last, un-convolved (npred.py:234-261)
         const float ne = n[i] + a.eps;
         local += (double)(n[i] - c[r][i] * logf(ne));
         g[i] = (1.f - c[r][i] / ne) * a.inv_n;
-        local_b += (double)(g[i] * bi);
+        if (CAL) local_b += (double)(g[i] * bi);
       }
       if (a.npred_out) {
         const size_t off = (size_t)y * a.W + x0;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
 
   const double total = block_sum<BLOCK>(local, smem);
   if (threadIdx.x == 0) a.partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
-  if (a.partials_b) {  // wave-uniform: only with a calibration
+  if (CAL && a.partials_b) {  // wave-uniform
     __syncthreads();
     const double total_b = block_sum<BLOCK>(local_b, smem);
     if (threadIdx.x == 0) a.partials_b[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total_b;
@@ -240,14 +242,19 @@ int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stre
   dim3 grid((span + per_block - 1) / per_block, (rows + rows_per_block - 1) / rows_per_block);
   *n_partials = grid.x * grid.y;
   ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
-  if (!vec)
-    poisson_fused_kernel<1, 1><<<grid, BLOCK, 0, stream>>>(a);
+  const bool cal = a.log_bkg_norm != nullptr;
+  if (!vec && cal)
+    poisson_fused_kernel<1, 1, true><<<grid, BLOCK, 0, stream>>>(a);
+  else if (!vec)
+    poisson_fused_kernel<1, 1, false><<<grid, BLOCK, 0, stream>>>(a);
+  else if (cal)
+    poisson_fused_kernel<4, 1, true><<<grid, BLOCK, 0, stream>>>(a);
   else if (rows_per_block == 4)
-    poisson_fused_kernel<4, 4><<<grid, BLOCK, 0, stream>>>(a);
+    poisson_fused_kernel<4, 4, false><<<grid, BLOCK, 0, stream>>>(a);
   else if (rows_per_block == 2)
-    poisson_fused_kernel<4, 2><<<grid, BLOCK, 0, stream>>>(a);
+    poisson_fused_kernel<4, 2, false><<<grid, BLOCK, 0, stream>>>(a);
   else
-    poisson_fused_kernel<4, 1><<<grid, BLOCK, 0, stream>>>(a);
+    poisson_fused_kernel<4, 1, false><<<grid, BLOCK, 0, stream>>>(a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
