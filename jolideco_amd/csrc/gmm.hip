@@ -138,6 +138,24 @@ __device__ __forceinline__ void mfma_tile(f32x4 (&acc)[4][2], const FragBuf& f, 
   }
 }
 
+// Sum of the 16 squared whitened coordinates a lane holds for 16-patch half nb, on v_pk_fma_f32: fp32
+// MFMA and fp32 VALU share the SIMD's FMA lanes (tools/mfma_valu_overlap.hip: every v_fma_f32 beside a
+// v_mfma_f32_16x16x4_f32 costs ~5.3 cycles of the wave, a packed one ~6.3 for two fmas), so the epilogue is
+// priced per instruction and packing halves its biggest part.  Same summation order in forward and
+// backward kernels (the logsumexp responsibilities rely on identical log-likelihoods).
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+__device__ __forceinline__ float sum_squares(const f32x4 (&acc)[4][2], int nb) {
+  f32x2 q = {0.f, 0.f};
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    const f32x2 lo = {acc[jb][nb][0], acc[jb][nb][1]}, hi = {acc[jb][nb][2], acc[jb][nb][3]};
+    q = __builtin_elementwise_fma(lo, lo, q);
+    q = __builtin_elementwise_fma(hi, hi, q);
+  }
+  return q[0] + q[1];
+}
+
 // Running state of the two 16-patch halves of a tile in LDS: st[nb * 16 + n] = max,
 // st[32 + nb * 16 + n] = arg-max | sum-exp.  It is read BEFORE the MFMAs of the stage are issued so that
 // the LDS latency is off the critical path of finish_tile.
@@ -161,13 +179,7 @@ __device__ __forceinline__ void finish_tile(const f32x4 (&acc)[4][2], const Tile
                                             const GmmFwdArgs& a, int n_first, bool writer) {
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
-    float q0 = 0.f, q1 = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      q0 = fmaf(acc[jb][nb][0], acc[jb][nb][0], q0), q1 = fmaf(acc[jb][nb][1], acc[jb][nb][1], q1);
-      q0 = fmaf(acc[jb][nb][2], acc[jb][nb][2], q0), q1 = fmaf(acc[jb][nb][3], acc[jb][nb][3], q1);
-    }
-    const float l = fmaf(-0.5f, sum_lane_groups(q0 + q1), ck);  // gmm.py:276-281
+    const float l = fmaf(-0.5f, sum_lane_groups(sum_squares(acc, nb)), ck);  // gmm.py:276-281
     float* s0 = st + nb * 16;
     if (MODE == MODE_MAX) {
       const bool better = l > ts.b[nb];  // strict: the lowest component wins a tie, like torch.max
@@ -575,13 +587,7 @@ __device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr
     mfma_tile<TRI>(y, f, x[gi]);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      float q0 = 0.f, q1 = 0.f;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        q0 = fmaf(y[jb][nb][0], y[jb][nb][0], q0), q1 = fmaf(y[jb][nb][1], y[jb][nb][1], q1);
-        q0 = fmaf(y[jb][nb][2], y[jb][nb][2], q0), q1 = fmaf(y[jb][nb][3], y[jb][nb][3], q1);
-      }
-      const float l = fmaf(-0.5f, sum_lane_groups(q0 + q1), ck);
+      const float l = fmaf(-0.5f, sum_lane_groups(sum_squares(y, nb)), ck);
       const float r = (v[gi][nb] == v[gi][nb]) ? expf(l - v[gi][nb]) : 0.f;  // NaN marks a filtered patch
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb)
