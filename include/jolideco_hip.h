@@ -52,7 +52,7 @@ const char* jd_target_arch(void);
  * crop offset is the reference's `_centered` offset ((kh-1)/2, (kw-1)/2) (utils/torch.py:337-344).
  * Two methods compute the same function:
  *   FFT    rocFFT R2C / k-space multiply / C2R on a zero padded (Hp, Wp) grid, Hp >= H+kh-1,
- *          Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5,7-smooth, Wp % 4 == 0) sizes
+ *          Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5-smooth, Wp % 4 == 0) sizes
  *          (JD_CONV_MODE_FFT_EXACT forces the reference's own grid (H+kh-1, W+kw-1));
  *   DIRECT the sum over PSF taps on the fp32 matrix cores (exact fmaf chain), PSFs up to 33x33;
  *          padding, exposure scaling and crop are folded into the kernel (csrc/directconv.hip).
