@@ -110,12 +110,14 @@ class MAPDeconvolver:
     optimizer_kwargs : dict
         ``lr``, and for Adam ``betas`` and ``eps``.
     checkpoint_path : str
-        Not implemented (the reference writes ASDF files).
+        Directory for per-epoch checkpoints (``checkpoint-epoch-<n>.fits``; the reference writes the
+        same content as ASDF, which is not available here).  Forces one device->host copy per epoch.
     fit_mode : {"sequential", "joint"}
         See the module docstring.
     """
 
     _default_flux_component = "flux"
+    _default_checkpoint_filename = "checkpoint-epoch-{epoch}.fits"
 
     def __init__(
         self,
@@ -157,8 +159,9 @@ class MAPDeconvolver:
         if unknown:
             raise NotImplementedError(f"optimizer_kwargs {sorted(unknown)} are not implemented in jolideco_amd")
         if checkpoint_path is not None:
-            raise NotImplementedError("checkpoints (ASDF) are not implemented in jolideco_amd")
-        self.checkpoint_path = None
+            checkpoint_path = Path(checkpoint_path)
+            checkpoint_path.mkdir(exist_ok=True, parents=True)
+        self.checkpoint_path = checkpoint_path
         if fit_mode not in FIT_MODES:
             raise ValueError(f"Unknown fit_mode: {fit_mode}, must be one of {FIT_MODES}")
         self.fit_mode = fit_mode
@@ -260,7 +263,9 @@ class MAPDeconvolver:
         trace_dev = torch.zeros((self.n_epochs, session.scalars.numel()), dtype=torch.float32, device=self.device)
         n_epochs_run = 0
         host_rows = []
+        filenames = []
         disable = not self.display_progress
+        write_checkpoints = self.checkpoint_path is not None and dist.rank == 0
         with tqdm(total=self.n_epochs * len(datasets), disable=disable) as pbar:
             for epoch in range(self.n_epochs):
                 pbar.set_description(f"Epoch {epoch + 1}")
@@ -269,10 +274,29 @@ class MAPDeconvolver:
                 trace_dev[epoch].copy_(session.scalars)
                 n_epochs_run = epoch + 1
 
+                filename = ""
+                if write_checkpoints:
+                    # like the reference (core.py:234-245): written before this epoch's trace row exists
+                    filename = self._default_checkpoint_filename.format(epoch=epoch)
+                    while len(host_rows) < epoch:
+                        i = len(host_rows)
+                        host_rows.append(self._row(total_loss, trace_dev[i].cpu().numpy(), n_d, n_c, n_val, filenames[i]))
+                    trace_so_far = total_loss.trace.copy()
+                    for row in host_rows[:epoch]:
+                        trace_so_far.add_row(row)
+                    checkpoint = MAPDeconvolverResult(
+                        config=self.to_dict(), trace_loss=trace_so_far, components=session.components,
+                        calibrations=calibrations,
+                    )
+                    log.info(f"Writing checkpoint to {self.checkpoint_path / filename}")
+                    checkpoint.write(filename=self.checkpoint_path / filename)
+                filenames.append(filename)
+
                 if self.stop_early or self.display_progress:
                     # the only per-epoch device->host sync, and only when the caller asked for it
                     while len(host_rows) < n_epochs_run:
-                        host_rows.append(self._row(total_loss, trace_dev[len(host_rows)].cpu().numpy(), n_d, n_c, n_val))
+                        i = len(host_rows)
+                        host_rows.append(self._row(total_loss, trace_dev[i].cpu().numpy(), n_d, n_c, n_val, filenames[i]))
                     row = host_rows[-1]
                     if self.stop_early and n_epochs_run > self.stop_early_n_average:
                         recent = [r["datasets-validation-total"] for r in host_rows[-self.stop_early_n_average :]]
@@ -285,7 +309,7 @@ class MAPDeconvolver:
         trace = total_loss.trace
         values = trace_dev[:n_epochs_run].cpu().numpy()
         for epoch in range(n_epochs_run):
-            trace.add_row(self._row(total_loss, values[epoch], n_d, n_c, n_val))
+            trace.add_row(self._row(total_loss, values[epoch], n_d, n_c, n_val, filenames[epoch]))
 
         return MAPDeconvolverResult(
             config=self.to_dict(),
@@ -298,7 +322,7 @@ class MAPDeconvolver:
         )
 
     @staticmethod
-    def _row(total_loss, values, n_d, n_c, n_val):
+    def _row(total_loss, values, n_d, n_c, n_val, filename=""):
         names_d = getattr(total_loss.poisson_loss, "names_all_global", total_loss.poisson_loss.names_all)
         loss_datasets = [float(v) for v in values[:n_d]]
         loss_priors = [float(v) for v in values[n_d : n_d + n_c]]
@@ -307,7 +331,7 @@ class MAPDeconvolver:
         local = total_loss.poisson_loss.names_all
         total_loss.poisson_loss.names_all = names_d
         try:
-            return total_loss.make_row(loss_datasets, loss_priors, "", loss_val)
+            return total_loss.make_row(loss_datasets, loss_priors, filename, loss_val)
         finally:
             total_loss.poisson_loss.names_all = local
 
@@ -503,61 +527,101 @@ class MAPDeconvolverResult:
     def config(self):
         return self._config
 
+    @property
+    def checkpoint_path(self):
+        """Path to checkpoints"""
+        return Path(self.config.get("checkpoint_path", None))
+
+    def read_checkpoint(self, epoch):
+        """Read the checkpoint of an epoch (reference: core.py:329-343) -> `MAPDeconvolverResult`."""
+        filename = self.checkpoint_path / str(self.trace_loss["filename"][epoch])
+        return self.__class__.read(filename=filename)
+
+    @property
+    def config_table(self):
+        """Configuration as a one-row table (reference: core.py:425-433)."""
+        from .utils.io.fits import config_to_table
+
+        return config_to_table(self.config)
+
     def write(self, filename, overwrite=False, format=None):
-        """Write fluxes and the loss trace to a numpy ``.npz`` archive.  The reference's FITS / ASDF
-        writers (jolideco/utils/io) need astropy / asdf and are out of scope."""
-        filename = Path(filename)
-        if format not in (None, "npz"):
-            raise NotImplementedError(f"format {format!r} is not implemented in jolideco_amd (use 'npz')")
-        if filename.exists() and not overwrite:
-            raise OSError(f"{filename} exists")
-        arrays = {f"flux/{name}": flux for name, flux in self.components.to_numpy().items()}
-        for name, component in self.components.items():
-            arrays[f"meta/{name}"] = np.array(
-                [component.upsampling_factor or 0, int(component.use_log_flux), int(component.frozen)]
-            )
-        for name in self.trace_loss.colnames:
-            if name != "filename":
-                arrays[f"trace/{name}"] = self.trace_loss[name]
-        if self.calibrations is not None:
-            for name, cal in self.calibrations.to_dict().items():
-                arrays[f"calibration/{name}"] = np.array(
-                    [cal["shift_x"], cal["shift_y"], cal["background_norm"], cal["psf_scale"], float(cal["frozen"])]
-                )
-        np.savez_compressed(filename, **arrays)
+        """Write the result to file.
+
+        format : {"fits", "npz"}
+            "fits" is the reference's layout (jolideco/utils/io/fits.py:421-459), readable by the
+            reference; "npz" a compact numpy archive (fluxes, trace, calibrations).  Default: from the
+            file suffix.  "asdf" raises (package not available).
+        """
+        from .utils.io import IO_FORMATS_MAP_RESULT_WRITE, get_writer
+
+        registry = dict(IO_FORMATS_MAP_RESULT_WRITE, npz=_write_map_result_to_npz)
+        if format is None and Path(filename).suffix == ".npz":
+            format = "npz"
+        writer = get_writer(filename=filename, format=format, registry=registry)
+        writer(result=self, filename=filename, overwrite=overwrite)
 
     @classmethod
     def read(cls, filename, format=None):
-        """Read a result written by `write` (numpy ``.npz``): fluxes (priors are not stored and default to
-        uniform), loss trace and calibrations."""
-        from .models import NPredCalibration, NPredCalibrations
-        from .utils.table import TraceTable
+        """Read a result written by `write` (or, for "fits", by the reference)."""
+        from .utils.io import IO_FORMATS_MAP_RESULT_READ, get_reader
 
-        if format not in (None, "npz"):
-            raise NotImplementedError(f"format {format!r} is not implemented in jolideco_amd (use 'npz')")
-        data = dict(np.load(filename))
-        components = FluxComponents()
-        for key, flux in data.items():
-            if key.startswith("flux/"):
-                name = key[len("flux/"):]
-                up, use_log, frozen = (int(v) for v in data.get(f"meta/{name}", np.array([0, 1, 0])))
-                component = SpatialFluxComponent(
-                    flux_upsampled=torch.from_numpy(np.asarray(flux, dtype=np.float32))[None, None],
-                    use_log_flux=bool(use_log), upsampling_factor=up or None, frozen=bool(frozen),
-                )
-                components[name] = component
-        names = [key[len("trace/"):] for key in data if key.startswith("trace/")]
-        trace = TraceTable(names=names + ["filename"])
-        n_rows = len(data[f"trace/{names[0]}"]) if names else 0
-        for i in range(n_rows):
-            row = {name: float(data[f"trace/{name}"][i]) for name in names}
-            row["filename"] = ""
-            trace.add_row(row)
-        calibrations = None
-        cal_keys = [key for key in data if key.startswith("calibration/")]
-        if cal_keys:
-            calibrations = NPredCalibrations()
-            for key in cal_keys:
-                sx, sy, norm, psf_scale, frozen = (float(v) for v in data[key])
-                calibrations[key[len("calibration/"):]] = NPredCalibration(sx, sy, norm, psf_scale, bool(frozen))
-        return cls(config={}, components=components, trace_loss=trace, calibrations=calibrations)
+        registry = dict(IO_FORMATS_MAP_RESULT_READ, npz=_read_map_result_from_npz)
+        if format is None and Path(filename).suffix == ".npz":
+            format = "npz"
+        reader = get_reader(filename=filename, format=format, registry=registry)
+        return reader(filename=filename)
+
+
+def _write_map_result_to_npz(result, filename, overwrite):
+    """Fluxes, loss trace and calibrations as a numpy ``.npz`` archive."""
+    filename = Path(filename)
+    if filename.exists() and not overwrite:
+        raise OSError(f"{filename} exists")
+    arrays = {f"flux/{name}": flux for name, flux in result.components.to_numpy().items()}
+    for name, component in result.components.items():
+        arrays[f"meta/{name}"] = np.array(
+            [component.upsampling_factor or 0, int(component.use_log_flux), int(component.frozen)]
+        )
+    for name in result.trace_loss.colnames:
+        if name != "filename":
+            arrays[f"trace/{name}"] = result.trace_loss[name]
+    if result.calibrations is not None:
+        for name, cal in result.calibrations.to_dict().items():
+            arrays[f"calibration/{name}"] = np.array(
+                [cal["shift_x"], cal["shift_y"], cal["background_norm"], cal["psf_scale"], float(cal["frozen"])]
+            )
+    np.savez_compressed(filename, **arrays)
+
+
+def _read_map_result_from_npz(filename):
+    """Read an ``.npz`` result: fluxes (priors are not stored and default to uniform), loss trace and
+    calibrations."""
+    from .models import NPredCalibration, NPredCalibrations
+    from .utils.table import TraceTable
+
+    data = dict(np.load(filename))
+    components = FluxComponents()
+    for key, flux in data.items():
+        if key.startswith("flux/"):
+            name = key[len("flux/"):]
+            up, use_log, frozen = (int(v) for v in data.get(f"meta/{name}", np.array([0, 1, 0])))
+            component = SpatialFluxComponent(
+                flux_upsampled=torch.from_numpy(np.asarray(flux, dtype=np.float32))[None, None],
+                use_log_flux=bool(use_log), upsampling_factor=up or None, frozen=bool(frozen),
+            )
+            components[name] = component
+    names = [key[len("trace/"):] for key in data if key.startswith("trace/")]
+    trace = TraceTable(names=names + ["filename"])
+    n_rows = len(data[f"trace/{names[0]}"]) if names else 0
+    for i in range(n_rows):
+        row = {name: float(data[f"trace/{name}"][i]) for name in names}
+        row["filename"] = ""
+        trace.add_row(row)
+    calibrations = None
+    cal_keys = [key for key in data if key.startswith("calibration/")]
+    if cal_keys:
+        calibrations = NPredCalibrations()
+        for key in cal_keys:
+            sx, sy, norm, psf_scale, frozen = (float(v) for v in data[key])
+            calibrations[key[len("calibration/"):]] = NPredCalibration(sx, sy, norm, psf_scale, bool(frozen))
+    return MAPDeconvolverResult(config={}, components=components, trace_loss=trace, calibrations=calibrations)

@@ -5,13 +5,37 @@ that inspects `.parameters()` keeps working.  During a fit the parameter, its fl
 gradient accumulator and the optimizer moments live on the HIP device and are updated by the fused
 kernels (csrc/elementwise.hip); `flux_upsampled` is the autograd-visible `exp(theta) [* mask]`.
 """
+import logging
+from pathlib import Path
+
 import numpy as np
 import torch
 import torch.nn as nn
 
 from ..priors import Prior, Priors, UniformPrior
+from ..priors.patches.gmm import GMMNotAvailableError
+from ..utils.io import (
+    IO_FORMATS_FLUX_COMPONENT_READ,
+    IO_FORMATS_FLUX_COMPONENT_WRITE,
+    IO_FORMATS_FLUX_COMPONENTS_READ,
+    IO_FORMATS_FLUX_COMPONENTS_WRITE,
+    get_reader,
+    get_writer,
+)
 
 __all__ = ["SpatialFluxComponent", "FluxComponents"]
+
+log = logging.getLogger(__name__)
+
+
+def parse_flux_tensor(value, cls):
+    """A flux given as a file name, a 2-D numpy array or a tensor -> (1, 1, H, W) float32 tensor
+    (reference: models/core.py:41-51)."""
+    if isinstance(value, (str, Path)):
+        return cls.read(Path(value)).flux_upsampled.detach()
+    if not isinstance(value, torch.Tensor):
+        return torch.from_numpy(np.asarray(value)[np.newaxis, np.newaxis].astype(np.float32))
+    return value
 
 
 class SpatialFluxComponent(nn.Module):
@@ -151,6 +175,36 @@ class SpatialFluxComponent(nn.Module):
                 data["mask"] = self.mask.cpu().numpy()
         return data
 
+    @classmethod
+    def from_dict(cls, data):
+        """Create from `to_dict` output or a file header (reference: models/core.py:455-487).  A GMM
+        prior whose model is not in the user's GMM library cannot be rebuilt from its name: the
+        component is then created with a uniform prior and a warning."""
+        kwargs = dict(data)
+        prior_data = kwargs.pop("prior", None)
+        if prior_data:
+            try:
+                kwargs["prior"] = Prior.from_dict(prior_data)
+            except GMMNotAvailableError as error:
+                log.warning(f"{error}; the component gets a uniform prior instead of {prior_data.get('type')}")
+        kwargs["flux_upsampled"] = parse_flux_tensor(kwargs["flux_upsampled"], cls)
+        if "flux_upsampled_error" in kwargs:
+            kwargs["flux_upsampled_error"] = parse_flux_tensor(kwargs["flux_upsampled_error"], cls)
+        if "mask" in kwargs:
+            kwargs["mask"] = torch.from_numpy(np.asarray(kwargs["mask"]).astype(bool))
+        kwargs.pop("shape", None)
+        return cls(**kwargs)
+
+    @classmethod
+    def read(cls, filename, format=None):
+        """Read a flux component; format : {"fits", "yaml"} (default: from the suffix)."""
+        return get_reader(filename, format, IO_FORMATS_FLUX_COMPONENT_READ)(filename)
+
+    def write(self, filename, format=None, overwrite=False, **kwargs):
+        """Write the flux component; format : {"fits", "yaml"} (default: from the suffix)."""
+        writer = get_writer(filename, format, IO_FORMATS_FLUX_COMPONENT_WRITE)
+        return writer(flux_component=self, filename=filename, overwrite=overwrite, **kwargs)
+
 
 class FluxComponents(nn.ModuleDict):
     """Dict of flux components (reference: models/core.py:720-842)."""
@@ -197,3 +251,17 @@ class FluxComponents(nn.ModuleDict):
 
     def to_dict(self, include_data=None):
         return {name: c.to_dict(include_data=include_data) for name, c in self.items()}
+
+    @classmethod
+    def from_dict(cls, data):
+        return cls([(name, SpatialFluxComponent.from_dict(d)) for name, d in data.items()])
+
+    @classmethod
+    def read(cls, filename, format=None):
+        """Read flux components; format : {"fits", "yaml"} (default: from the suffix)."""
+        return get_reader(filename, format, IO_FORMATS_FLUX_COMPONENTS_READ)(filename)
+
+    def write(self, filename, overwrite=False, format=None, **kwargs):
+        """Write flux components; format : {"fits", "yaml"} (default: from the suffix)."""
+        writer = get_writer(filename, format, IO_FORMATS_FLUX_COMPONENTS_WRITE)
+        return writer(flux_components=self, filename=filename, overwrite=overwrite, **kwargs)

@@ -175,7 +175,8 @@ class NPredCalibration(nn.Module):
 
     @classmethod
     def from_dict(cls, data):
-        return cls(**data)
+        kwargs = {key: (bool(value) if key == "frozen" else float(value)) for key, value in data.items()}
+        return cls(**kwargs)
 
 
 class NPredCalibrations(nn.ModuleDict):
@@ -194,6 +195,20 @@ class NPredCalibrations(nn.ModuleDict):
     @classmethod
     def from_dict(cls, data):
         return cls([(name, NPredCalibration.from_dict(d)) for name, d in data.items()])
+
+    @classmethod
+    def read(cls, filename, format=None):
+        """Read calibrations; format : {"yaml", "fits"} (reference: npred.py:466-486)."""
+        from ..utils.io import IO_FORMATS_NPRED_CALIBRATIONS_READ, get_reader
+
+        return get_reader(filename, format, IO_FORMATS_NPRED_CALIBRATIONS_READ)(filename)
+
+    def write(self, filename, format=None, overwrite=False, **kwargs):
+        """Write calibrations; format : {"yaml", "fits"} (reference: npred.py:488-510)."""
+        from ..utils.io import IO_FORMATS_NPRED_CALIBRATIONS_WRITE, get_writer
+
+        writer = get_writer(filename, format, IO_FORMATS_NPRED_CALIBRATIONS_WRITE)
+        return writer(npred_calibrations=self, filename=filename, overwrite=overwrite, **kwargs)
 
 
 class NPredModels(nn.ModuleDict):

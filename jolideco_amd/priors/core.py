@@ -54,6 +54,8 @@ class Prior(nn.Module):
         kwargs = dict(data)
         if "type" in kwargs:
             type_ = kwargs.pop("type")
+            if type_ not in PRIOR_REGISTRY:
+                raise NotImplementedError(f"prior {type_!r} is not implemented in jolideco_amd")
             return PRIOR_REGISTRY[type_].from_dict(kwargs)
         return cls(**kwargs)
 

@@ -1,12 +1,16 @@
 """GMM patch prior (reference: jolideco/priors/patches/core.py:30-246)."""
+import logging
+
 import torch
 
-from ...utils.norms import IdentityImageNorm, SubtractMeanPatchNorm
+from ...utils.norms import IdentityImageNorm, ImageNorm, PatchNorm, SubtractMeanPatchNorm
 from ...utils.torch import TORCH_DEFAULT_DEVICE, cycle_spin_shifts, get_default_generator
 from ..core import Prior
 from .gmm import GaussianMixtureModel
 
 __all__ = ["GMMPatchPrior"]
+
+log = logging.getLogger(__name__)
 
 
 class GMMPatchPrior(Prior):
@@ -111,4 +115,18 @@ class GMMPatchPrior(Prior):
             gmm=self.gmm.to_dict(), norm=self.norm.to_dict(), patch_norm=self.patch_norm.to_dict(),
             device=str(self.device),
         )
+        if self.marginalize:
+            data["marginalize"] = True
         return data
+
+    @classmethod
+    def from_dict(cls, data):
+        """Rebuild from `to_dict` output / a file header (patches/core.py:110-121): the GMM is looked up
+        by name in the user's GMM library."""
+        kwargs = dict(data)
+        kwargs.pop("type", None)
+        kwargs["gmm"] = GaussianMixtureModel.from_dict(kwargs.pop("gmm"))
+        kwargs["norm"] = ImageNorm.from_dict(kwargs.pop("norm", {"type": "identity"}))
+        if "patch_norm" in kwargs:
+            kwargs["patch_norm"] = PatchNorm.from_dict(kwargs["patch_norm"])
+        return cls(**kwargs)

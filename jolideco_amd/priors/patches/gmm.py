@@ -3,9 +3,14 @@
 Constants are prepared on the host in float64/float32 exactly as the reference does (scipy
 Cholesky -> precision Cholesky -> fp32), then handed to the HIP library which lays them out in
 MFMA fragment order.  The trained GMM libraries of the reference ("zoran-weiss", ...) are external
-data files that are not part of this repository: use `from_numpy`.
+data files that are not part of this repository: `from_registry` / `read` load them from
+``$JOLIDECO_GMM_LIBRARY`` exactly as the reference does (gmm.py:301-391,493-508) when the user has them;
+`from_numpy` takes explicit arrays.
 """
+import json
+import os
 from dataclasses import dataclass, field
+from pathlib import Path
 from typing import Optional
 
 import numpy as np
@@ -14,7 +19,11 @@ import torch
 from ...utils.norms import PatchNorm, SubtractMeanPatchNorm
 from ...utils.numpy import compute_precision_cholesky, get_pixel_weights
 
-__all__ = ["GaussianMixtureModel", "GaussianMixtureModelMeta"]
+__all__ = ["GaussianMixtureModel", "GaussianMixtureModelMeta", "GMMNotAvailableError"]
+
+
+class GMMNotAvailableError(ValueError):
+    """The named GMM is not in the user's GMM library (or there is no library)."""
 
 
 @dataclass
@@ -24,6 +33,24 @@ class GaussianMixtureModelMeta:
 
     stride: Optional[int] = None
     patch_norm: PatchNorm = field(default_factory=SubtractMeanPatchNorm)
+
+    @classmethod
+    def from_table(cls, table):
+        """Meta data of a GMM table file: patch norm from the ``PNPTYPE`` keyword, stride = half the
+        patch edge (jolideco/priors/patches/gmm.py:38-61)."""
+        patch_norm = PatchNorm.from_dict({"type": table.meta.get("PNPTYPE", "subtract-mean")})
+        npix = int(table["means"].shape[-1] ** 0.5)
+        return cls(stride=npix // 2, patch_norm=patch_norm)
+
+
+def get_gmm_registry():
+    """Index of the user's GMM library: ``$JOLIDECO_GMM_LIBRARY/jolideco-gmm-library-index.json``
+    (jolideco/priors/patches/gmm.py:493-508; read on demand here, at import time there)."""
+    path = Path(os.path.expandvars("$JOLIDECO_GMM_LIBRARY/jolideco-gmm-library-index.json"))
+    if not path.exists():
+        return {}
+    with path.open() as f:
+        return json.load(f)
 
 
 class GaussianMixtureModel:
@@ -39,6 +66,7 @@ class GaussianMixtureModel:
         self.weights_numpy = np.asarray(weights, dtype=np.float32)
         self.precisions_cholesky_numpy = np.asarray(precisions_cholesky, dtype=np.float32)
         self.meta = meta or GaussianMixtureModelMeta()
+        self.registry_name = None
         self._handles = {}
 
     @classmethod
@@ -59,10 +87,66 @@ class GaussianMixtureModel:
 
     @classmethod
     def from_registry(cls, name, **kwargs):
-        raise NotImplementedError(
-            "the trained GMM library files of the reference are external data that is not available here; "
-            "construct the model with GaussianMixtureModel.from_numpy(means, covariances, weights)"
+        """Load a trained GMM by its name in the user's library index (gmm.py:301-335)."""
+        registry = get_gmm_registry()
+        if name not in registry:
+            raise GMMNotAvailableError(
+                f"Not a supported GMM {name}, choose from {list(registry)} (the index is "
+                "$JOLIDECO_GMM_LIBRARY/jolideco-gmm-library-index.json; the library files are external data)"
+            )
+        kwargs.update(registry[name])
+        gmm = cls.read(**kwargs)
+        gmm.registry_name = name
+        return gmm
+
+    @classmethod
+    def read(cls, filename, format="epll-matlab", **kwargs):
+        """Read a trained GMM (gmm.py:336-391).
+
+        format : {"epll-matlab", "epll-matlab-16x16", "table"}
+            Zoran & Weiss EPLL ``.mat`` files (through scipy.io) or a FITS table with ``means`` (K, D),
+            ``weights`` (K,) and ``covariances`` (K, D, D) columns.
+        """
+        filename = str(Path(os.path.expandvars(str(filename))))
+        if format in ("epll-matlab", "epll-matlab-16x16"):
+            import scipy.io as sio
+
+            record = sio.loadmat(filename)["GS" if format == "epll-matlab" else "GMM"]
+            covariances = record["covs"][0][0].T
+            weights = record["mixweights"][0][0][:, 0]
+            if format == "epll-matlab":
+                means = record["means"][0][0].T
+                meta = GaussianMixtureModelMeta(stride=4, patch_norm=SubtractMeanPatchNorm())
+            else:
+                means = np.zeros((200, 256))
+                meta = GaussianMixtureModelMeta(stride=8, patch_norm=SubtractMeanPatchNorm())
+        elif format == "table":
+            from ...utils.io._fitsfile import read_fits
+
+            tables = [hdu.data for hdu in read_fits(filename) if hdu.kind == "bintable"]
+            if not tables:
+                raise ValueError(f"{filename} holds no table")
+            table = tables[0]
+            means, weights, covariances = table["means"], table["weights"], table["covariances"]
+            meta = GaussianMixtureModelMeta.from_table(table)
+        else:
+            raise ValueError(f"Not a supported format {format}")
+        return cls.from_numpy(means=means, covariances=covariances, weights=weights, meta=meta, **kwargs)
+
+    def write(self, filename, overwrite=False):
+        """Write the model as a FITS table that `read(format="table")` -- of this package and of the
+        reference -- loads back."""
+        from ...utils.io._fitsfile import HDU, FitsTable, write_fits
+
+        table = FitsTable(
+            {
+                "means": self.means_numpy.astype(np.float64),
+                "weights": self.weights_numpy.astype(np.float64),
+                "covariances": self.covariances_numpy.astype(np.float64),
+            },
+            meta={"PNPTYPE": self.meta.patch_norm.to_dict()["type"]},
         )
+        write_fits(filename, [HDU(kind="primary"), HDU(table, name="GMM")], overwrite=overwrite)
 
     @property
     def n_components(self):
@@ -137,4 +221,12 @@ class GaussianMixtureModel:
         return self
 
     def to_dict(self):
+        """``{"type": <name in the GMM library>}`` like the reference (gmm.py:458-471); a model built from
+        explicit arrays has no name and is recorded as "custom" with its size."""
+        if self.registry_name is not None:
+            return {"type": self.registry_name}
         return {"type": "custom", "n_components": int(self.n_components), "n_features": int(self.n_features)}
+
+    @classmethod
+    def from_dict(cls, data):
+        return cls.from_registry(name=data["type"])
