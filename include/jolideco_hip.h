@@ -56,22 +56,34 @@ const char* jd_target_arch(void);
  *          (JD_CONV_MODE_FFT_EXACT forces the reference's own grid (H+kh-1, W+kw-1));
  *   DIRECT the sum over PSF taps on the fp32 matrix cores (exact fmaf chain), PSFs up to 33x33;
  *          padding, exposure scaling and crop are folded into the kernel (csrc/directconv.hip).
- * JD_CONV_MODE_AUTO picks DIRECT when the PSF is small enough for it to be faster. */
+ *   SEPARABLE for a PSF that is a sum of at most 3 outer products u_r v_r^T (a sampled Gaussian is 1, a
+ *          double Gaussian 2): a row pass and a column pass of kh + kw taps per rank instead of kh * kw,
+ *          PSFs up to 68x68 (csrc/sepconv.hip).  Whether a PSF qualifies is decided by
+ *          jd_psf_separable_rank() / jd_conv_psf_spectrum(); a PSF that does not is an error for such a plan.
+ * JD_CONV_MODE_AUTO picks DIRECT when the PSF is small enough for it to be faster than FFT; it never picks
+ * SEPARABLE, because the choice depends on the PSF values, which a plan does not know: the caller asks
+ * jd_psf_separable_rank() and requests JD_CONV_MODE_SEPARABLE (jolideco_amd.NPredModel does). */
 enum {
   JD_CONV_MODE_AUTO = 0,
   JD_CONV_MODE_FFT_EXACT = 1,
   JD_CONV_MODE_FFT = 2,
-  JD_CONV_MODE_DIRECT = 3
+  JD_CONV_MODE_DIRECT = 3,
+  JD_CONV_MODE_SEPARABLE = 4
 };
+/* Rank R (1..3) of the outer-product decomposition of a (kh, kw) PSF given in HOST memory, or 0 when the PSF
+ * is not that low-rank to within `tol` (sum |psf - sum_r u_r v_r^T| <= tol * sum |psf|; tol <= 0 selects the
+ * default 3e-7, a few fp32 ulps) or larger than 68x68.  Host-only analysis, no device work. */
+int jd_psf_separable_rank(const float* psf_host, int kh, int kw, float tol);
 int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_conv_plan** plan_out);
 int jd_conv_plan_destroy(jd_conv_plan* plan);
 /* shape[0..5] = {H, W, Hp, Wp, oy, ox}; (Hp, Wp) = (H, W) for the direct method */
 int jd_conv_plan_shape(const jd_conv_plan* plan, int* shape6);
-/* 0 = FFT, 1 = DIRECT */
+/* 0 = FFT, 1 = DIRECT, 2 = SEPARABLE */
 int jd_conv_plan_method(const jd_conv_plan* plan);
 /* HALF the number of floats of one per-(dataset, component) kernel operator buffer `khat`:
  * FFT: complex64 elements of the kernel spectrum, Hp * (Wp/2 + 1); DIRECT: floats of one Toeplitz
- * fragment table (the buffer holds the forward and the adjoint table). */
+ * fragment table (the buffer holds the forward and the adjoint table); SEPARABLE: the rank and the row /
+ * column taps of both directions (a few hundred floats). */
 size_t jd_conv_plan_spectrum_size(const jd_conv_plan* plan);
 
 /* Kernel operator of one PSF, computed ONCE per (dataset, component) and cached by the caller in
@@ -218,7 +230,8 @@ enum {
   JD_KERNEL_FFT_R2C = 8,         /* rocFFT real forward transform (all its kernels) */
   JD_KERNEL_FFT_C2R = 9,         /* rocFFT real inverse transform (all its kernels) */
   JD_KERNEL_DIRECT_CONV = 10,    /* MFMA Toeplitz convolution / correlation (small PSFs) */
-  JD_KERNEL_COUNT = 11
+  JD_KERNEL_SEP_CONV = 11,       /* separable (low-rank PSF) convolution / correlation */
+  JD_KERNEL_COUNT = 12
 };
 int jd_profile_enable(int capacity);
 int jd_profile_disable(void);

@@ -35,6 +35,7 @@ EXPORTS = {
     "jd_conv_plan_shape": (c_int, [c_void_p, POINTER(c_int)]),
     "jd_conv_plan_spectrum_size": (c_size_t, [c_void_p]),
     "jd_conv_plan_method": (c_int, [c_void_p]),
+    "jd_psf_separable_rank": (c_int, [c_void_p, c_int, c_int, c_float]),
     "jd_conv_psf_spectrum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jd_conv_same": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jd_conv_same_adjoint": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -78,7 +79,7 @@ EXPORTS = {
 
 KERNEL_IDS = {
     "poisson_fused": 0, "gmm_fwd": 1, "gmm_bwd": 2, "gmm_gather": 3, "pad_mul": 4, "cmul": 5,
-    "adjoint_epilogue": 6, "adam": 7, "fft_r2c": 8, "fft_c2r": 9, "direct_conv": 10,
+    "adjoint_epilogue": 6, "adam": 7, "fft_r2c": 8, "fft_c2r": 9, "direct_conv": 10, "sep_conv": 11,
 }
 
 _lib = None

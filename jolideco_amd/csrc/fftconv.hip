@@ -20,7 +20,8 @@
 
 struct jd_conv_plan {
   int H = 0, W = 0, kh = 0, kw = 0, Hp = 0, Wp = 0, oy = 0, ox = 0;
-  int method = jd::JD_CONV_FFT;  // JD_CONV_FFT: rocFFT on the padded (Hp, Wp) grid | JD_CONV_DIRECT: MFMA Toeplitz
+  // JD_CONV_FFT: rocFFT on the padded (Hp, Wp) grid | JD_CONV_DIRECT: MFMA Toeplitz | JD_CONV_SEPARABLE: row + column pass
+  int method = jd::JD_CONV_FFT;
   int py = 0, px = 0;        // offset of the (H, W) image inside the conv / pad buffers (FFT: oy, ox; direct: 0)
   size_t nspec = 0;  // complex elements of one spectrum (direct: floats of one Toeplitz fragment table)
   rocfft_plan fwd = nullptr, inv = nullptr;
@@ -97,6 +98,9 @@ static int conv_forward(jd_conv_plan* p, int c, const float* image, const float*
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0,
                               1.f, 0, stream);
+  if (p->method == JD_CONV_SEPARABLE)
+    return launch_sep_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0,
+                           stream);
   int rc = launch_pad_mul(image, scale, p->pad[c], p->H, p->W, p->Hp, p->Wp, stream);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream))) return rc;
@@ -121,6 +125,9 @@ static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const f
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(p->pad[c], nullptr, khat + p->nspec, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                               1, coef, accumulate, stream);
+  if (p->method == JD_CONV_SEPARABLE)
+    return launch_sep_conv(p->pad[c], nullptr, khat, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1, coef,
+                           accumulate, stream);
   int rc = corr_backward(p, c, khat, stream);
   if (rc) return rc;
   return launch_adjoint_epilogue(p->conv[c], scale, grad, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox, coef, accumulate,
@@ -142,17 +149,21 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
   JD_REQUIRE(H > 0 && W > 0 && kh > 0 && kw > 0, "jd_conv_plan_create: non-positive shape (%d,%d,%d,%d)", H,
              W, kh, kw);
   JD_REQUIRE((long)H * W < (1L << 31), "jd_conv_plan_create: image too large");
-  JD_REQUIRE(mode >= JD_CONV_MODE_AUTO && mode <= JD_CONV_MODE_DIRECT, "jd_conv_plan_create: unknown mode %d", mode);
+  JD_REQUIRE(mode >= JD_CONV_MODE_AUTO && mode <= JD_CONV_MODE_SEPARABLE, "jd_conv_plan_create: unknown mode %d", mode);
+  JD_REQUIRE(mode != JD_CONV_MODE_SEPARABLE || sep_conv_supported(kh, kw),
+             "jd_conv_plan_create: the separable method supports PSFs up to %dx%d, got %dx%d", SEP_MAX_K, SEP_MAX_K, kh, kw);
   JD_REQUIRE(mode != JD_CONV_MODE_DIRECT || direct_conv_supported(kh, kw),
              "jd_conv_plan_create: the direct method supports PSFs up to 33x33, got %dx%d", kh, kw);
   const bool exact_shape = mode == JD_CONV_MODE_FFT_EXACT;
-  if (mode == JD_CONV_MODE_DIRECT || (mode == JD_CONV_MODE_AUTO && direct_conv_supported(kh, kw))) {
+  if (mode == JD_CONV_MODE_SEPARABLE || mode == JD_CONV_MODE_DIRECT ||
+      (mode == JD_CONV_MODE_AUTO && direct_conv_supported(kh, kw))) {
+    // both work on the unpadded (H, W) grid: no FFT plans, only the image-sized work buffers
     jd_conv_plan* p = new (std::nothrow) jd_conv_plan();
     if (!p) return fail(JD_ERR_ALLOC, "jd_conv_plan_create: out of host memory");
-    p->method = JD_CONV_DIRECT;
+    p->method = mode == JD_CONV_MODE_SEPARABLE ? JD_CONV_SEPARABLE : JD_CONV_DIRECT;
     p->H = H, p->W = W, p->kh = kh, p->kw = kw, p->Hp = H, p->Wp = W;
     p->oy = (kh - 1) / 2, p->ox = (kw - 1) / 2, p->py = 0, p->px = 0;
-    p->nspec = direct_conv_fragment_floats(kh, kw);
+    p->nspec = p->method == JD_CONV_SEPARABLE ? (sep_conv_operator_floats() + 1) / 2 : direct_conv_fragment_floats(kh, kw);
     p->partials_cap = poisson_fused_max_partials(H, W);
     int rc = JD_OK;
     if (hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
@@ -250,10 +261,27 @@ extern "C" size_t jd_conv_plan_spectrum_size(const jd_conv_plan* p) { return p ?
 
 extern "C" int jd_conv_plan_method(const jd_conv_plan* p) { return p ? p->method : -1; }
 
+extern "C" int jd_psf_separable_rank(const float* psf_host, int kh, int kw, float tol) {
+  if (!psf_host || !sep_conv_supported(kh, kw)) return 0;
+  return sep_factorize(psf_host, kh, kw, tol > 0.f ? (double)tol : SEP_DEFAULT_TOL, nullptr, nullptr);
+}
+
 extern "C" int jd_conv_psf_spectrum(jd_conv_plan* p, const float* psf, float* khat, void* stream) {
   JD_REQUIRE(p && psf && khat, "jd_conv_psf_spectrum: null argument");
   hipStream_t s = as_stream(stream);
   if (p->method == JD_CONV_DIRECT) return launch_toeplitz_fragments(psf, khat, khat + p->nspec, p->kh, p->kw, s);
+  if (p->method == JD_CONV_SEPARABLE) {
+    // setup-time only: the factorisation runs on the host (a PSF is a few KB), so this call synchronises
+    std::vector<float> host((size_t)p->kh * p->kw), op;
+    JD_HIP(hipMemcpyAsync(host.data(), psf, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    JD_HIP(hipStreamSynchronize(s));
+    const int rank = sep_build_operator(host.data(), p->kh, p->kw, p->oy, p->ox, SEP_DEFAULT_TOL, &op);
+    JD_REQUIRE(rank > 0, "jd_conv_psf_spectrum: the %dx%d PSF is not a sum of <= %d outer products to %.0e of its sum "
+               "(ask jd_psf_separable_rank() first); use JD_CONV_MODE_AUTO", p->kh, p->kw, SEP_MAX_RANK, SEP_DEFAULT_TOL);
+    JD_HIP(hipMemcpyAsync(khat, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    JD_HIP(hipStreamSynchronize(s));
+    return JD_OK;
+  }
   int rc = launch_pad_mul(psf, nullptr, p->pad[0], p->kh, p->kw, p->Hp, p->Wp, s);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[0], p->spec, s))) return rc;
@@ -272,6 +300,8 @@ extern "C" int jd_conv_same(jd_conv_plan* p, const float* image, const float* sc
   hipStream_t s = as_stream(stream);
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(image, scale_image, khat, out, nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0, s);
+  if (p->method == JD_CONV_SEPARABLE)
+    return launch_sep_conv(image, scale_image, khat, out, nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0, s);
   int rc = conv_forward(p, 0, image, scale_image, khat, s);
   if (rc) return rc;
   return launch_crop(p->conv[0], out, p->H, p->W, p->Wp, p->oy, p->ox, s);
@@ -284,6 +314,9 @@ extern "C" int jd_conv_same_adjoint(jd_conv_plan* p, const float* grad_out, cons
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(grad_out, nullptr, khat + p->nspec, grad_image, scale_image, p->H, p->W, p->kh, p->kw,
                               p->oy, p->ox, 1, 1.f, accumulate, s);
+  if (p->method == JD_CONV_SEPARABLE)
+    return launch_sep_conv(grad_out, nullptr, khat, grad_image, scale_image, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1,
+                           1.f, accumulate, s);
   int rc = launch_pad_mul(grad_out, nullptr, p->pad[0], p->H, p->W, p->Hp, p->Wp, s);
   if (rc) return rc;
   return corr_backward_into(p, 0, khat, scale_image, grad_image, 1.f, accumulate, s);

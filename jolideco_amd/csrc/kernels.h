@@ -1,5 +1,6 @@
 // Internal launch prototypes shared between the translation units of libjolideco_hip.so.
 #pragma once
+#include <vector>
 #include "jd_common.h"
 
 namespace jd {
@@ -42,13 +43,23 @@ int launch_finalize_multi(const double* partials, int n_blocks, int n_out, doubl
                           hipStream_t stream);
 
 // direct (MFMA Toeplitz) convolution for small PSFs (directconv.hip)
-enum { JD_CONV_FFT = 0, JD_CONV_DIRECT = 1 };
+enum { JD_CONV_FFT = 0, JD_CONV_DIRECT = 1, JD_CONV_SEPARABLE = 2 };
 bool direct_conv_supported(int kh, int kw);
 size_t direct_conv_fragment_floats(int kh, int kw);
 int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_adj, int kh, int kw, hipStream_t stream);
 int launch_direct_conv(const float* in, const float* in_scale, const float* afrag, float* out, const float* out_scale,
                        int H, int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
                        hipStream_t stream);
+
+// separable (low-rank PSF) convolution (sepconv.hip)
+constexpr int SEP_MAX_K = 68, SEP_MAX_RANK = 3;
+constexpr double SEP_DEFAULT_TOL = 3e-7;  // residual sum|psf - sum_r u_r v_r^T| <= tol * sum|psf|  (~5 fp32 ulps)
+bool sep_conv_supported(int kh, int kw);
+size_t sep_conv_operator_floats();
+int sep_factorize(const float* psf_host, int kh, int kw, double tol, std::vector<double>* u, std::vector<double>* v);
+int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op);
+int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
+                    int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream);
 
 // kernel timers (profile.hip): RAII bracket around one launch
 int prof_begin(int kernel, hipStream_t s);

@@ -99,6 +99,7 @@ extern "C" const char* jd_kernel_name(int kernel) {
     case JD_KERNEL_FFT_R2C: return "rocfft_r2c";
     case JD_KERNEL_FFT_C2R: return "rocfft_c2r";
     case JD_KERNEL_DIRECT_CONV: return "direct_conv_kernel";
+    case JD_KERNEL_SEP_CONV: return "sep_conv_kernel";
     default: return "?";
   }
 }

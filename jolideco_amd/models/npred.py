@@ -9,7 +9,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..ops import ConvPlan, ConvSameFunction
+from ..ops import ConvPlan, ConvSameFunction, default_conv_method, psf_separable_rank
+
+SEPARABLE_MAX_EDGE = 68  # SEP_MAX_K of csrc/kernels.h
 
 __all__ = ["NPredModel", "NPredModels", "NPredCalibration", "NPredCalibrations"]
 
@@ -56,12 +58,15 @@ class NPredModel(nn.Module):
 
     @classmethod
     def from_numpy(cls, exposure, psf, upsampling_factor=None, correct_exposure_edges=True, device="cuda",
-                   kernel_shape=None, psf_scale=None):
+                   kernel_shape=None, psf_scale=None, allow_separable=True):
         """Upload one dataset's exposure and PSF, compute K-hat once and apply the reference's
         edge correction exposure / conv(1, psf) (models/npred.py:66-115) on the device.
 
         ``kernel_shape`` (KH, KW) >= psf.shape embeds the PSF in a larger zero array such that the
-        'same' crop is unchanged; it lets all components of a dataset share one FFT plan."""
+        'same' crop is unchanged; it lets all components of a dataset share one FFT plan.
+
+        With the convolution method "auto" a PSF that is a sum of at most three outer products (every sampled
+        Gaussian is one) takes the separable kernel (csrc/sepconv.hip) unless ``allow_separable`` is False."""
         device = torch.device(device)
         psf = np.asarray(psf, dtype=np.float32)
         if kernel_shape is not None and tuple(kernel_shape) != psf.shape:
@@ -78,17 +83,20 @@ class NPredModel(nn.Module):
         psf_t = _to_device_image(psf, device)
         H, W = exposure_t.shape
         kh, kw = psf_t.shape
-        plan = ConvPlan.get(H, W, kh, kw, device)
+        rescaled = rescale_psf(psf, psf_scale) if psf_scale is not None else psf
+        method = default_conv_method()
+        if method == "auto" and allow_separable and max(kh, kw) <= SEPARABLE_MAX_EDGE:
+            if psf_separable_rank(psf) and (rescaled is psf or psf_separable_rank(rescaled)):
+                method = "separable"
+        plan = ConvPlan.get(H, W, kh, kw, device, method=method)
         khat = plan.psf_spectrum(psf_t)
         if correct_exposure_edges:
             # the edge correction uses the UN-rescaled PSF (models/npred.py:108-113 runs before any calibration)
             weights = plan.conv_same(torch.ones_like(exposure_t), None, khat)
             exposure_t = exposure_t / weights
-        if psf_scale is not None:
-            rescaled = rescale_psf(psf, psf_scale)
-            if rescaled is not psf:
-                psf_t = _to_device_image(rescaled, device)
-                khat = plan.psf_spectrum(psf_t)
+        if rescaled is not psf:
+            psf_t = _to_device_image(rescaled, device)
+            khat = plan.psf_spectrum(psf_t)
         return cls(
             exposure=exposure_t[None, None], psf=psf_t[None, None], plan=plan, khat=khat,
             upsampling_factor=upsampling_factor,
@@ -248,12 +256,17 @@ class NPredModels(nn.ModuleDict):
             raise NotImplementedError("all components of a fit must share one upsampling_factor in jolideco_amd")
         kernel_shape = (max(p.shape[0] for p in psfs.values()), max(p.shape[1] for p in psfs.values()))
         psf_scale = None if calibration is None else float(calibration.psf_scale.detach().cpu())
-        for name, component in components.items():
-            model = NPredModel.from_numpy(
-                exposure=dataset["exposure"], psf=psfs[name], upsampling_factor=component.upsampling_factor,
-                device=device, kernel_shape=kernel_shape, psf_scale=psf_scale,
-            )
-            values.append((name, model))
+        for allow_separable in (True, False):
+            values = []
+            for name, component in components.items():
+                model = NPredModel.from_numpy(
+                    exposure=dataset["exposure"], psf=psfs[name], upsampling_factor=component.upsampling_factor,
+                    device=device, kernel_shape=kernel_shape, psf_scale=psf_scale, allow_separable=allow_separable,
+                )
+                values.append((name, model))
+            # one fused call per dataset = one plan: if only some of the component PSFs are separable, none uses it
+            if len({id(model.plan) for _, model in values}) <= 1:
+                break
         background = _to_device_image(dataset["background"], device)[None, None]
         if calibration is not None:
             calibration = calibration.to(device)

@@ -47,12 +47,25 @@ def stirling_mean(counts):
     return float(term.mean())
 
 
-CONV_MODES = {"auto": 0, "fft-exact": 1, "fft": 2, "direct": 3}  # JD_CONV_MODE_* of include/jolideco_hip.h
+CONV_MODES = {"auto": 0, "fft-exact": 1, "fft": 2, "direct": 3, "separable": 4}  # JD_CONV_MODE_* (jolideco_hip.h)
+CONV_METHOD_NAMES = {0: "fft", 1: "direct", 2: "separable"}  # jd_conv_plan_method
+
+
+def psf_separable_rank(psf, tol=0.0):
+    """Number of outer products (1..3) that reproduce a host PSF array to a few fp32 ulps, 0 if it is not
+    that low-rank (jd_psf_separable_rank).  A sampled Gaussian is 1."""
+    import numpy as np
+
+    psf = np.ascontiguousarray(psf, dtype=np.float32)
+    if psf.ndim != 2:
+        raise ValueError(f"psf must be two dimensional, got shape {psf.shape}")
+    return int(_hip.lib().jd_psf_separable_rank(psf.ctypes.data, psf.shape[0], psf.shape[1], float(tol)))
 
 
 def default_conv_method():
-    """Convolution method used when none is requested: "auto" (the library picks the MFMA direct
-    kernel for PSFs up to 33x33 and rocFFT otherwise) unless JOLIDECO_CONV_METHOD overrides it."""
+    """Convolution method used when none is requested: "auto" (the separable kernel when the PSF is a sum
+    of at most three outer products, else the MFMA direct kernel for PSFs up to 33x33, else rocFFT) unless
+    JOLIDECO_CONV_METHOD overrides it."""
     import os
 
     method = os.environ.get("JOLIDECO_CONV_METHOD", "auto")
@@ -65,7 +78,8 @@ class ConvPlan:
     """'same'-convolution plan for one (H, W, kh, kw) geometry (jd_conv_plan).
 
     ``method``: "auto" | "fft" (rocFFT, fast padded grid) | "fft-exact" (rocFFT on the reference's
-    (H+kh-1, W+kw-1) grid) | "direct" (MFMA Toeplitz kernel, PSFs up to 33x33)."""
+    (H+kh-1, W+kw-1) grid) | "direct" (MFMA Toeplitz kernel, PSFs up to 33x33) | "separable" (row + column
+    pass for low-rank PSFs, `psf_separable_rank`; `psf_spectrum` raises for a PSF that is not)."""
 
     _cache = {}
 
@@ -86,7 +100,7 @@ class ConvPlan:
         self.H, self.W, self.Hp, self.Wp, self.oy, self.ox = (int(v) for v in shape)
         self.kh, self.kw = kh, kw
         self.spectrum_size = int(_hip.lib().jd_conv_plan_spectrum_size(self._handle))
-        self.method = "direct" if _hip.lib().jd_conv_plan_method(self._handle) == 1 else "fft"
+        self.method = CONV_METHOD_NAMES[_hip.lib().jd_conv_plan_method(self._handle)]
 
     @classmethod
     def get(cls, H, W, kh, kw, device, exact_shape=False, method=None):

@@ -34,7 +34,10 @@ def test_fused_npred_poisson_fwd_bwd(golden, name, conv_method):
     comps = FluxComponents()
     comps["flux"] = SpatialFluxComponent.from_numpy(flux=np.exp(sub["theta"]))
     models = NPredModels.from_dataset_numpy(dataset=data, components=comps, device=DEV)
-    assert models.plan.method == conv_method
+    from conftest import expected_plan_method
+    from jolideco_amd.ops import psf_separable_rank
+
+    assert models.plan.method == expected_plan_method(conv_method, psf_separable_rank(np.asarray(data["psf"])) > 0)
     # edge corrected exposure (models/npred.py:108-113)
     assert rel_linf(models["flux"].exposure.cpu().numpy()[0, 0], sub["exposure_corrected"]) < 2e-6
 
@@ -309,6 +312,81 @@ def test_direct_conv_matches_fft_and_float64(shape, kshape):
     for method in ("fft", "fft-exact"):
         assert rel_linf(results[method][0], results["direct"][0]) < 1e-5
         assert rel_linf(results[method][1], results["direct"][1]) < 1e-5
+
+
+def _gauss(n, sigma, offset=0.0):
+    x = np.arange(n) - (n - 1) / 2 - offset
+    return np.exp(-0.5 * (x / sigma) ** 2)
+
+
+@pytest.mark.parametrize(
+    "shape,kshape,rank",
+    [((70, 130), (17, 17), 1), ((129, 67), (33, 33), 2), ((50, 200), (2, 31), 1), ((203, 61), (32, 3), 3),
+     ((256, 256), (13, 16), 1), ((64, 64), (1, 1), 1), ((96, 260), (34, 34), 1), ((40, 40), (68, 5), 2),
+     ((31, 33), (25, 25), 3)],
+)
+def test_separable_conv_matches_direct_and_float64(shape, kshape, rank):
+    """Low-rank PSFs (sums of `rank` outer products, asymmetric and off-centre on purpose): the separable kernel
+    computes the same 'same' convolution and adjoint as float64 scipy and as the MFMA / rocFFT paths -- ragged
+    tiles, even sizes, widths that need the alignment shift, images narrower than one tile, W % 4 != 0."""
+    from scipy.signal import convolve2d
+
+    from jolideco_amd.ops import ConvPlan, psf_separable_rank
+
+    kh, kw = kshape
+    rs = np.random.RandomState(sum(shape) + sum(kshape) + rank)
+    psf = np.zeros(kshape)
+    for r in range(rank):
+        u = _gauss(kh, 1.0 + 2.0 * r, 0.4 * r) * (1 + 0.3 * np.tanh(np.arange(kh) - kh / 2))
+        v = _gauss(kw, 1.5 + 1.5 * r, -0.7 * r) * (1 + 0.2 * np.sin(np.arange(kw)))
+        psf += rs.uniform(0.3, 1.0) * np.outer(u, v)
+    psf = (psf / psf.sum()).astype(np.float32)
+    assert psf_separable_rank(psf) == min(rank, kh, kw)
+    image = rs.gamma(2.0, size=shape).astype(np.float32)
+    scale = rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    grad_out = rs.normal(size=shape).astype(np.float32)
+    oy, ox = (kh - 1) // 2, (kw - 1) // 2
+    ref = convolve2d((image * scale).astype(np.float64), psf.astype(np.float64), mode="full")[oy : oy + shape[0], ox : ox + shape[1]]
+    # adjoint in float64: correlation, then the exposure
+    pad = np.zeros((shape[0] + kh - 1, shape[1] + kw - 1))
+    pad[oy : oy + shape[0], ox : ox + shape[1]] = grad_out
+    ref_adj = convolve2d(pad, psf[::-1, ::-1].astype(np.float64), mode="valid") * scale
+    t = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
+
+    plan = ConvPlan(shape[0], shape[1], kh, kw, DEV, method="separable")
+    assert plan.method == "separable" and (plan.Hp, plan.Wp) == shape
+    khat = plan.psf_spectrum(t(psf))
+    out = plan.conv_same(t(image), t(scale), khat)
+    adj = plan.conv_same_adjoint(t(grad_out), t(scale), khat)
+    acc = torch.full(shape, 2.0, device=DEV)
+    plan.conv_same_adjoint(t(grad_out), t(scale), khat, grad_image=acc, accumulate=True)
+    no_scale = plan.conv_same(t(image), None, khat)
+    torch.cuda.synchronize()
+    assert rel_linf(out.cpu().numpy(), ref) < 2e-6
+    assert rel_linf(adj.cpu().numpy(), ref_adj) < 2e-6
+    assert rel_linf((acc - 2.0).cpu().numpy(), ref_adj) < 2e-6
+    ref_ns = convolve2d(image.astype(np.float64), psf.astype(np.float64), mode="full")[oy : oy + shape[0], ox : ox + shape[1]]
+    assert rel_linf(no_scale.cpu().numpy(), ref_ns) < 2e-6
+    plan.close()
+    other = ConvPlan(shape[0], shape[1], kh, kw, DEV, method="auto")  # direct up to 33x33, rocFFT beyond
+    khat_o = other.psf_spectrum(t(psf))
+    assert rel_linf(other.conv_same(t(image), t(scale), khat_o).cpu().numpy(), out.cpu().numpy()) < 1e-5
+    assert rel_linf(other.conv_same_adjoint(t(grad_out), t(scale), khat_o).cpu().numpy(), adj.cpu().numpy()) < 1e-5
+    other.close()
+
+
+def test_separable_plan_refuses_a_general_psf():
+    from jolideco_amd.ops import ConvPlan, psf_separable_rank
+
+    rs = np.random.RandomState(0)
+    psf = rs.uniform(size=(9, 9)).astype(np.float32)
+    assert psf_separable_rank(psf) == 0
+    plan = ConvPlan(32, 32, 9, 9, DEV, method="separable")
+    with pytest.raises(RuntimeError, match="outer products"):
+        plan.psf_spectrum(torch.from_numpy(psf).to(DEV))
+    plan.close()
+    with pytest.raises(RuntimeError, match="68x68"):
+        ConvPlan(96, 96, 69, 3, DEV, method="separable")
 
 
 def test_large_psf_falls_back_to_fft():
