@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-general-psf", action="store_true",
+                    help="skip the extra run that convolves the PSFs as general (not separable) kernels")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="tuning only: time rank 0's share of an N-rank joint step in ONE process, without the "
                          "collective (the printed value is NOT a benchmark result)")
@@ -312,6 +314,47 @@ def main():
         "kernel_ms_per_step": kernel_ms_per_step,
         "dominant_kernel": dominant,
     }
+    # which convolution the fit used: Gaussian PSFs are rank 1, so "auto" takes the separable kernel
+    methods = sorted({m.plan.method for m in session.total_loss.poisson_loss.npred_models_all})
+    out["config"]["conv_method"] = "+".join(methods)
+    # convolution kernel, HBM bound: forward reads flux + exposure and writes the convolution (12 B/pixel), the
+    # adjoint reads g + exposure + the gradient accumulator and writes it back (16 B/pixel): 14 B/pixel on average
+    conv_key = "sep_conv" if "sep_conv" in kernel_ms_per_step else "direct_conv" if "direct_conv" in kernel_ms_per_step else None
+    if conv_key:
+        conv_ms, conv_n = avg_ms(conv_key)
+        conv_bytes = 14 * H * W
+        achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
+        out["roofline_conv"] = {
+            "kernel": _hip.lib().jd_kernel_name(_hip.KERNEL_IDS[conv_key]).decode(), "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "avg_launch_ms": conv_ms, "launches": conv_n, "bytes_per_launch": conv_bytes,
+        }
+    # The same fit with the PSF treated as a general (not low-rank) kernel, i.e. what an instrument PSF that is not
+    # a sum of <= 3 outer products gets: MFMA Toeplitz convolution.  Reported next to the headline, never as it.
+    if world == 1 and fake is None and "separable" in methods and not args.no_general_psf:
+        log("general-PSF run (JOLIDECO_CONV_METHOD=direct)")
+        previous = os.environ.get("JOLIDECO_CONV_METHOD")
+        os.environ["JOLIDECO_CONV_METHOD"] = "direct"
+        try:
+            general = build_session(args.config, device)
+            for _ in range(args.warmup):
+                general.epoch()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                general.epoch()
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            out["general_psf"] = {
+                "value": args.steps / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / args.steps,
+                "conv_method": "direct", "note": "same workload with the PSFs convolved as general 17x17 kernels",
+            }
+            del general
+        finally:
+            if previous is None:
+                os.environ.pop("JOLIDECO_CONV_METHOD", None)
+            else:
+                os.environ["JOLIDECO_CONV_METHOD"] = previous
     log("gpu result: " + json.dumps(out))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)

@@ -10,11 +10,13 @@
 // low-rank kernels; it refuses anything whose residual exceeds a few fp32 ulps of the PSF sum, so a PSF that is
 // not separable never takes this path).
 //
-// Kernel: one 32 x 128 output tile per block.  The input window (tile + halo, times the exposure, zero outside
-// the image) is staged once in LDS; the row pass writes an intermediate (window rows x 128) image back to LDS, the
-// column pass reads it and adds into per-thread accumulators that persist over the ranks; the epilogue applies
-// coef * out_scale and stores / accumulates.  Both passes are register blocked 8 outputs x 4 taps, so one LDS
-// read feeds ~3 FMAs and the taps stay runtime values (no template per PSF size).
+// Kernel: one 32 x 64 output tile per block of 256 threads, ~30 KB of LDS (5 blocks per CU).  The input window
+// (tile + halo, times the exposure, zero outside the image) is staged once in LDS; the row pass writes an
+// intermediate (window rows x 64) image back to LDS, the column pass reads it and adds into per-thread
+// accumulators that persist over the ranks; the epilogue applies coef * out_scale and stores / accumulates.  Both
+// passes are register blocked (8 outputs x 4 taps / 4 x 4) and use packed fp32 FMAs (v_pk_fma_f32: the row pass on
+// two image rows, the column pass on two neighbouring columns), so one LDS read feeds ~5 FMAs; the taps stay
+// runtime values (no template per PSF size).
 #include <cmath>
 #include <vector>
 
@@ -25,13 +27,15 @@ namespace jd {
 
 namespace {
 
-constexpr int TY = 32, TX = 64, THREADS = 256, STAGE_BATCH = 5;
+constexpr int TY = 32, TX = 64, THREADS = 256, STAGE_BATCH = 3;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct SepGeom {
   int khp, kwp;    // padded tap counts (multiples of 4): rows / columns
   int oy0, ox0;    // image offset of window (row 0, col 0) relative to the tile origin
   int shiftx;      // zero taps prepended to the column taps so that ox0 is a multiple of 4
-  int rows, pitch; // LDS window: rows = TY + khp - 1, pitch = TX + kwp rounded so that pitch / 4 is odd
+  int rpairs;      // window row PAIRS: ceil((TY + khp - 1) / 2)
+  int pitch;       // window columns per row (>= TX + kwp), pitch % 4 == 2 (bank spread of the row-pair reads)
 };
 
 inline SepGeom sep_geom(int kh, int kw, int oy, int ox, bool adjoint) {
@@ -43,9 +47,8 @@ inline SepGeom sep_geom(int kh, int kw, int oy, int ox, bool adjoint) {
   g.ox0 = ox0 - g.shiftx;
   g.khp = (kh + 3) / 4 * 4;
   g.kwp = (kw + g.shiftx + 3) / 4 * 4;
-  g.rows = TY + g.khp - 1;
-  g.pitch = TX + g.kwp;
-  if ((g.pitch / 4) % 2 == 0) g.pitch += 4;
+  g.rpairs = (TY + g.khp) / 2;  // khp is a multiple of 4: (TY + khp - 1 + 1) / 2
+  g.pitch = TX + g.kwp + 2;
   return g;
 }
 
@@ -56,20 +59,25 @@ struct SepArgs {
   float* out;
   const float* out_scale;
   int H, W, tiles_x, n_tiles;
-  int khp, kwp, oy0, ox0, rows, pitch, taps_off;
+  int khp, kwp, oy0, ox0, rpairs, pitch, taps_off;
   float coef;
   int accumulate;
 };
 
-template <bool VEC>
+// LDS images:
+//   win  [rpairs][pitch][2]  the input window with two image rows interleaved per column, so that one ds_read_b128
+//                            yields the operand pairs (row 2p, row 2p+1) of two columns for v_pk_fma_f32
+//   hbuf [2 * rpairs][TX]    the row-pass result, plain row-major: the column pass packs two neighbouring x
+template <bool VEC, bool IN_SCALE>
 __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   extern __shared__ float4 lds4[];
   float* win = reinterpret_cast<float*>(lds4);
-  float* hbuf = win + a.rows * a.pitch;
-  float* taps = hbuf + a.rows * TX;  // per rank: khp row taps then kwp column taps
+  float* hbuf = win + a.rpairs * a.pitch * 2;
+  float* taps = hbuf + 2 * a.rpairs * TX;  // per rank: khp row taps then kwp column taps
   const int tid = threadIdx.x;
   const int rank = (int)a.op[0];
   const int tap_stride = a.khp + a.kwp;
+  const int nrows = 2 * a.rpairs;
 
   // consecutive tiles on one XCD (blockIdx % 8) are neighbours in the image: their halos hit in that XCD's L2
   const int per_xcd = (a.n_tiles + 7) / 8;
@@ -79,38 +87,56 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
 
   for (int i = tid; i < rank * tap_stride; i += THREADS) taps[i] = a.op[a.taps_off + i];
 
-  // ---- stage the window: rows x (pitch) floats, image * in_scale, zero outside ---------------------------
+  // ---- stage the window: image * in_scale, zero outside -----------------------------------------------------
   const int gy0 = Y0 + a.oy0, gx0 = X0 + a.ox0;
   if (VEC) {
-    // all loads of a batch are issued before the first LDS store: one exposed memory latency per batch, not per load
+    // One item = 4 columns of BOTH rows of a row pair: two float4 loads (+ two of the exposure), two ds_write_b128
+    // of the interleaved (row 2p, row 2p+1) pairs.  All loads of a thread are issued before its first LDS store, so
+    // a tile exposes one memory latency; lanes outside the image load element 0 and select zero (no branches).
     const int nv = (TX + a.kwp) / 4;  // float4 per row actually needed
-    const int total = a.rows * nv;
+    const int total = a.rpairs * nv;
+    const int step_r = THREADS / nv, step_c = THREADS % nv;  // (row pair, float4 column) advance of i += THREADS
+    int rp = tid / nv, cv = tid - rp * nv;
     for (int base = tid; base < total; base += STAGE_BATCH * THREADS) {
-      float4 v[STAGE_BATCH], sc[STAGE_BATCH];
+      float4 va[STAGE_BATCH], vb[STAGE_BATCH], sa[STAGE_BATCH], sb[STAGE_BATCH];
       int dst[STAGE_BATCH];
+      bool oka[STAGE_BATCH], okb[STAGE_BATCH];
 #pragma unroll
       for (int b = 0; b < STAGE_BATCH; ++b) {
-        const int i = base + b * THREADS;
-        const int r = i / nv, cv = i - r * nv;
-        const int gy = gy0 + r, gx = gx0 + 4 * cv;
-        dst[b] = i < total ? r * a.pitch + 4 * cv : -1;
-        v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-        sc[b] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (i < total && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {  // gx, W multiples of 4: never partial
-          const size_t off = (size_t)gy * a.W + gx;
-          v[b] = *reinterpret_cast<const float4*>(a.in + off);
-          if (a.in_scale) sc[b] = *reinterpret_cast<const float4*>(a.in_scale + off);
+        const int gy = gy0 + 2 * rp, gx = gx0 + 4 * cv;
+        const bool inx = rp < a.rpairs && gx >= 0 && gx < a.W;  // gx, W multiples of 4: never partial
+        dst[b] = rp < a.rpairs ? (rp * a.pitch + 4 * cv) * 2 : -1;
+        oka[b] = inx && gy >= 0 && gy < a.H;
+        okb[b] = inx && gy + 1 >= 0 && gy + 1 < a.H;
+        const size_t offa = oka[b] ? (size_t)gy * a.W + gx : 0, offb = okb[b] ? (size_t)(gy + 1) * a.W + gx : 0;
+        va[b] = *reinterpret_cast<const float4*>(a.in + offa);
+        vb[b] = *reinterpret_cast<const float4*>(a.in + offb);
+        if (IN_SCALE) {
+          sa[b] = *reinterpret_cast<const float4*>(a.in_scale + offa);
+          sb[b] = *reinterpret_cast<const float4*>(a.in_scale + offb);
         }
+        rp += step_r, cv += step_c;
+        if (cv >= nv) cv -= nv, ++rp;
       }
 #pragma unroll
-      for (int b = 0; b < STAGE_BATCH; ++b)
-        if (dst[b] >= 0)
-          *reinterpret_cast<float4*>(win + dst[b]) =
-              make_float4(v[b].x * sc[b].x, v[b].y * sc[b].y, v[b].z * sc[b].z, v[b].w * sc[b].w);
+      for (int b = 0; b < STAGE_BATCH; ++b) {
+        float4 x = va[b], y = vb[b];
+        if (IN_SCALE) {
+          x.x *= sa[b].x, x.y *= sa[b].y, x.z *= sa[b].z, x.w *= sa[b].w;
+          y.x *= sb[b].x, y.y *= sb[b].y, y.z *= sb[b].z, y.w *= sb[b].w;
+        }
+        if (!oka[b]) x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!okb[b]) y = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dst[b] >= 0) {
+          float4* d = reinterpret_cast<float4*>(win + dst[b]);
+          d[0] = make_float4(x.x, y.x, x.y, y.y);
+          d[1] = make_float4(x.z, y.z, x.w, y.w);
+        }
+      }
     }
   } else {
     const int nc = TX + a.kwp;
-    const int total = a.rows * nc;
+    const int total = nrows * nc;
     for (int i = tid; i < total; i += THREADS) {
       const int r = i / nc, c = i - r * nc;
       const int gy = gy0 + r, gx = gx0 + c;
@@ -118,32 +144,33 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
       if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
         const size_t off = (size_t)gy * a.W + gx;
         v = a.in[off];
-        if (a.in_scale) v *= a.in_scale[off];
+        if (IN_SCALE) v *= a.in_scale[off];
       }
-      win[r * a.pitch + c] = v;
+      win[((r >> 1) * a.pitch + c) * 2 + (r & 1)] = v;
     }
   }
 
-  constexpr int COL_ITEMS = TX * (TY / 8) / THREADS;  // column-pass items (one x, 8 rows) per thread
-  static_assert(COL_ITEMS * THREADS == TX * (TY / 8), "tile / block shape");
-  float acc[COL_ITEMS][8];
-#pragma unroll
-  for (int m = 0; m < COL_ITEMS; ++m)
-#pragma unroll
-    for (int c = 0; c < 8; ++c) acc[m][c] = 0.f;
-
+  // column-pass item of this thread: outputs (y0 .. y0+3, x and x+1)
+  static_assert((TX / 2) * (TY / 4) == THREADS, "tile / block shape");
+  const int cx = (tid % (TX / 2)) * 2, cy = (tid / (TX / 2)) * 4;
+  const int gx = X0 + cx;
+  v2f acc[4], oscale[4], oprev[4];
   // epilogue operands are requested now, so that their latency hides behind the two passes
-  float oscale[COL_ITEMS][8], oprev[COL_ITEMS][8];
 #pragma unroll
-  for (int m = 0; m < COL_ITEMS; ++m) {
-    const int item = tid + m * THREADS;
-    const int gx = X0 + item % TX, y0 = Y0 + (item / TX) * 8;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const bool ok = gx < a.W && y0 + c < a.H;
-      const size_t off = ok ? (size_t)(y0 + c) * a.W + gx : 0;
-      oscale[m][c] = (ok && a.out_scale) ? a.out_scale[off] : 1.f;
-      oprev[m][c] = (ok && a.accumulate) ? a.out[off] : 0.f;
+  for (int c = 0; c < 4; ++c) {
+    acc[c] = v2f{0.f, 0.f};
+    oscale[c] = v2f{1.f, 1.f};
+    oprev[c] = v2f{0.f, 0.f};
+    const int gy = Y0 + cy + c;
+    if (gy >= a.H || gx >= a.W) continue;
+    const size_t off = (size_t)gy * a.W + gx;
+    if (VEC) {  // W even, bases 16-byte aligned: the pair is an aligned float2 inside the image
+      if (a.out_scale) oscale[c] = *reinterpret_cast<const v2f*>(a.out_scale + off);
+      if (a.accumulate) oprev[c] = *reinterpret_cast<const v2f*>(a.out + off);
+    } else {
+      const bool two = gx + 1 < a.W;
+      if (a.out_scale) oscale[c] = v2f{a.out_scale[off], two ? a.out_scale[off + 1] : 1.f};
+      if (a.accumulate) oprev[c] = v2f{a.out[off], two ? a.out[off + 1] : 0.f};
     }
   }
 
@@ -151,62 +178,65 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
     __syncthreads();  // window (r == 0) / previous column pass done with hbuf (r > 0); taps visible
     const float* tu = taps + r * tap_stride;
     const float* tv = tu + a.khp;
-    // ---- row pass: hbuf[row][x] = sum_t tv[t] * win[row][x + t] -----------------------------------------
-    for (int item = tid; item < a.rows * (TX / 8); item += THREADS) {
-      const int row = item / (TX / 8), x0 = (item % (TX / 8)) * 8;
-      const float* w = win + row * a.pitch + x0;
-      float h[8];
+    // ---- row pass, two rows at once: hbuf[row][x] = sum_t tv[t] * win[row][x + t] ---------------------------
+    for (int item = tid; item < a.rpairs * (TX / 8); item += THREADS) {
+      const int rp = item / (TX / 8), x0 = (item % (TX / 8)) * 8;
+      const float* w = win + (rp * a.pitch + x0) * 2;
+      v2f h[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) h[c] = 0.f;
+      for (int c = 0; c < 8; ++c) h[c] = v2f{0.f, 0.f};
       for (int q = 0; q < a.kwp; q += 4) {
         const float4 t4 = *reinterpret_cast<const float4*>(tv + q);
-        const float4 w0 = *reinterpret_cast<const float4*>(w + q);
-        const float4 w1 = *reinterpret_cast<const float4*>(w + q + 4);
-        const float4 w2 = *reinterpret_cast<const float4*>(w + q + 8);
-        const float ww[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
         const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+        v2f ww[12];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int k = 0; k < 6; ++k) {
+          const float4 two = *reinterpret_cast<const float4*>(w + (q + 2 * k) * 2);
+          ww[2 * k] = v2f{two.x, two.y};
+          ww[2 * k + 1] = v2f{two.z, two.w};
+        }
 #pragma unroll
-          for (int c = 0; c < 8; ++c) h[c] = fmaf(tt[e], ww[c + e], h[c]);
+        for (int e = 0; e < 4; ++e) {
+          const v2f t2 = v2f{tt[e], tt[e]};
+#pragma unroll
+          for (int c = 0; c < 8; ++c) h[c] = __builtin_elementwise_fma(t2, ww[c + e], h[c]);
+        }
       }
-      float4* dst = reinterpret_cast<float4*>(hbuf + row * TX + x0);
-      dst[0] = make_float4(h[0], h[1], h[2], h[3]);
-      dst[1] = make_float4(h[4], h[5], h[6], h[7]);
+      float* d0 = hbuf + (2 * rp) * TX + x0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d0[c] = h[c].x, d0[TX + c] = h[c].y;
     }
     __syncthreads();
-    // ---- column pass: acc[y][x] += sum_t tu[t] * hbuf[y + t][x] ------------------------------------------
+    // ---- column pass, two columns at once: acc[y][x] += sum_t tu[t] * hbuf[y + t][x] -------------------------
+    const float* hcol = hbuf + cy * TX + cx;
+    for (int q = 0; q < a.khp; q += 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(tu + q);
+      const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+      v2f hh[7];
 #pragma unroll
-    for (int m = 0; m < COL_ITEMS; ++m) {
-      const int item = tid + m * THREADS;
-      const int x = item % TX, y0 = (item / TX) * 8;
-      const float* hcol = hbuf + y0 * TX + x;
-      for (int q = 0; q < a.khp; q += 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(tu + q);
-        const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
-        float hh[11];
+      for (int k = 0; k < 7; ++k) hh[k] = *reinterpret_cast<const v2f*>(hcol + (q + k) * TX);
 #pragma unroll
-        for (int k = 0; k < 11; ++k) hh[k] = hcol[(q + k) * TX];
+      for (int e = 0; e < 4; ++e) {
+        const v2f t2 = v2f{tt[e], tt[e]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int c = 0; c < 8; ++c) acc[m][c] = fmaf(tt[e], hh[c + e], acc[m][c]);
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(t2, hh[c + e], acc[c]);
       }
     }
   }
 
-  // ---- epilogue: out (+)= coef * out_scale * acc ---------------------------------------------------------
+  // ---- epilogue: out = [out +] coef * out_scale * acc -------------------------------------------------------
+  if (gx >= a.W) return;
 #pragma unroll
-  for (int m = 0; m < COL_ITEMS; ++m) {
-    const int item = tid + m * THREADS;
-    const int gx = X0 + item % TX, y0 = Y0 + (item / TX) * 8;
-    if (gx >= a.W) continue;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int gy = y0 + c;
-      if (gy >= a.H) break;
-      const size_t off = (size_t)gy * a.W + gx;
-      a.out[off] = oprev[m][c] + a.coef * acc[m][c] * oscale[m][c];
+  for (int c = 0; c < 4; ++c) {
+    const int gy = Y0 + cy + c;
+    if (gy >= a.H) break;
+    const size_t off = (size_t)gy * a.W + gx;
+    const v2f res = oprev[c] + a.coef * acc[c] * oscale[c];
+    if (VEC) {
+      *reinterpret_cast<v2f*>(a.out + off) = res;
+    } else {
+      a.out[off] = res.x;
+      if (gx + 1 < a.W) a.out[off + 1] = res.y;
     }
   }
 }
@@ -292,18 +322,21 @@ int launch_sep_conv(const float* in, const float* in_scale, const float* op, flo
   a.H = H, a.W = W;
   a.tiles_x = (W + TX - 1) / TX;
   a.n_tiles = a.tiles_x * ((H + TY - 1) / TY);
-  a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rows = g.rows, a.pitch = g.pitch;
+  a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rpairs = g.rpairs, a.pitch = g.pitch;
   a.taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
   a.coef = coef, a.accumulate = accumulate;
-  const size_t lds = ((size_t)g.rows * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
+  const size_t lds = ((size_t)2 * g.rpairs * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
   const int blocks = ((a.n_tiles + 7) / 8) * 8;
   auto aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = W % 4 == 0 && aligned(in) && aligned(in_scale);
-  auto kernel = vec ? sep_conv_kernel<true> : sep_conv_kernel<false>;
-  static size_t lds_set[2] = {0, 0};
-  if (lds > 64 * 1024 && lds > lds_set[vec]) {
+  const int variant = (vec ? 2 : 0) + (in_scale ? 1 : 0);
+  void (*const kernels[4])(SepArgs) = {sep_conv_kernel<false, false>, sep_conv_kernel<false, true>,
+                                       sep_conv_kernel<true, false>, sep_conv_kernel<true, true>};
+  auto kernel = kernels[variant];
+  static size_t lds_set[4] = {0, 0, 0, 0};
+  if (lds > 64 * 1024 && lds > lds_set[variant]) {
     JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set[vec] = lds;
+    lds_set[variant] = lds;
   }
   ProfScope prof(JD_KERNEL_SEP_CONV, stream);
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds, stream, a);
