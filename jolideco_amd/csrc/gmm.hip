@@ -40,6 +40,23 @@ constexpr int AFRAG_FLOATS = 4 * 4 * 64 * 4;
 
 enum { MODE_MAX = 0, MODE_LSE = 1, MODE_DENSE = 2 };
 
+__host__ __device__ inline unsigned long long best_key(float l, int k) {
+  unsigned u = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  u = __float_as_uint(l);
+#else
+  memcpy(&u, &l, 4);
+#endif
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotonic map float -> uint
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)k);
+}
+__device__ inline float best_value(unsigned long long key) {
+  unsigned u = (unsigned)(key >> 32);
+  u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+  return __uint_as_float(u);
+}
+__device__ inline int best_component(unsigned long long key) { return (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu)); }
+
 struct GmmFwdArgs {
   const float* flux;     // (H, W) image  | MODE_DENSE: (n, 64) explicit patches
   const float* afrag;    // K * AFRAG_FLOATS
@@ -50,6 +67,8 @@ struct GmmFwdArgs {
   int32_t* argmax_out;   // nullable (MODE_MAX)
   float* value_patch;    // nullable: per patch v | MODE_DENSE: (n, K) out
   double* partials;      // one per block
+  const int* run_flag;   // nullable: the kernel returns at once while *run_flag == 0 (fallback of the screened path)
+  unsigned long long* best_out;  // nullable (MODE_MAX): per patch (max, arg-max) key, 0 for a filtered patch
 };
 
 __device__ __forceinline__ int wrap(int v, int n) {
@@ -235,6 +254,7 @@ __device__ __forceinline__ int xs_index(int t, int c, int p) {
 
 template <int TB, int MODE, bool TRI>
 __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
+  if (a.run_flag && *a.run_flag == 0) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                                          // TB * 2048 floats
   float* state = lds + TB * 2048;                           // [4 waves][TB][2][32 patches]
@@ -272,7 +292,10 @@ __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
         const float mean = patch_mean_halves(x);  // SubtractMeanPatchNorm, utils/norms.py:100-103
 #pragma unroll
         for (int s = 0; s < 32; ++s) x[s] -= mean;
-        sel = sel && (__shfl_xor((int)sel, 32, 64) != 0);
+        // NOT `sel && shfl(...)`: the short circuit would keep the lanes with sel == false out of the exchange and the
+        // other half of the patch would read a stale register
+        const int sel_other = __shfl_xor((int)sel, 32, 64);
+        sel = sel && sel_other != 0;
       }
 #pragma unroll
       for (int s = 0; s < 32; ++s) xs[xs_index(t, c, 32 * h + s)] = x[s];
@@ -332,6 +355,7 @@ __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
     const bool ok = okf[p] != 0;
     if (n < a.n_end) {
       if (MODE == MODE_MAX && a.argmax_out) a.argmax_out[n] = ok ? ar : -1;
+      if (MODE == MODE_MAX && a.best_out) a.best_out[n] = ok ? best_key(b, ar) : 0ull;
       if (a.value_patch) a.value_patch[n] = ok ? v : NAN;
       if (ok) local += (double)v;
     }
@@ -425,7 +449,7 @@ __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a
       kk[i] = a.argmax[n];
       if (kk[i] >= 0) {
         rank[i] = atomicAdd(&hist[kk[i]], 1);
-      } else {  // filtered patch (patches/core.py:215-216): no gradient
+      } else if (a.gpatch) {  // filtered patch (patches/core.py:215-216): no gradient
         float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
         for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -686,6 +710,319 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
 // Overlap-add gather: every pixel of the rolled frame sums the contributions of the patches that
 // cover it in a fixed order (no float atomics), un-rolls and accumulates into grad.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Screened arg-max (max mode, zero-mean mixtures): the same result as gmm_fwd_kernel<MODE_MAX>, bit for bit,
+// for a fraction of the fp32 matrix work.
+//
+//   1. SCREEN (gmm_screen_kernel): every (patch, component) log-likelihood is first evaluated APPROXIMATELY with
+//      one bf16 MFMA product, ytilde = bf16(xbar)^T bf16(P'_k) (fp32 accumulate; v_mfma_f32_32x32x16_bf16 runs at
+//      16x the rate of the fp32-input MFMA), together with a rigorous bound on its distance to the fp32 value:
+//        |ytilde_j - y_j| <= eps |xbar| |P'_k[:, j]|,   eps = 2^-7 + 2^-16 + accumulation  (two bf16 roundings)
+//        |ltilde - l|     <= B = sqrt(2 qtilde) e + e^2 / 2 (+ fp32 rounding slack),  e = eps |xbar| |P'_k|_F
+//      (Cauchy-Schwarz twice; qtilde = sum_j ytilde_j^2 / 2).  Sweep 1 over the components finds
+//      L = max_k (ltilde - B), a lower bound of the true maximum; sweep 2 keeps the components with
+//      ltilde + B >= L.  Every other component is provably below the maximum.  Typically 2-5 of 128 survive.
+//   2. The surviving (patch, component) pairs are counting-sorted by component (the bucket kernels of the
+//      backward pass).
+//   3. EXACT (gmm_exact_kernel): groups of 32 pairs that share P'_k are evaluated with the SAME fp32 MFMA chain,
+//      mean order and epilogue as gmm_fwd_kernel (bit-identical l), and merged per patch with a 64-bit atomic max
+//      on (l, lowest k wins ties) -- order independent, so the result is deterministic.
+//   4. gmm_best_kernel decodes (max, arg-max) per patch and sums the values in a fixed order.
+// Anything unusual -- a non-finite screening value, more survivors than the per-wave list holds -- raises a
+// device flag; the dense fp32 kernel then runs (it is always enqueued and returns at once when the flag is clear)
+// and overwrites the per-patch results.  No host synchronisation anywhere.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int SCREEN_T = 4;        // tiles of 32 patches per wave
+constexpr int SCREEN_CAP = 1536;   // survivor pairs a wave can record (128 patches: 12 per patch)
+constexpr int A16_BLOCKS = 6;      // non-zero (32 coordinates x 16 pixels) blocks of an upper triangular P'
+constexpr float SCREEN_EPS = 0.0079f;
+
+struct GmmScreenArgs {
+  const float* flux;
+  const uint4* afrag16;  // K * A16_BLOCKS * 64 lanes * 8 bf16
+  const float* const_k;  // K
+  const float* efro_k;   // K: SCREEN_EPS * |P'_k|_F (rounded up)
+  int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+  unsigned long long* best;  // per patch (global index): initialised here
+  int32_t* pair_n;           // [waves][SCREEN_CAP] survivor patch (global index)
+  int32_t* pair_k;           // [waves][SCREEN_CAP] survivor component, -1 = empty (pre-filled by the caller)
+  int* flag;                 // != 0: fall back to the dense kernel
+};
+
+struct ScreenFrags {
+  bf16x8 a[A16_BLOCKS];
+};
+
+__device__ __forceinline__ void load_frags16(ScreenFrags& f, const uint4* af, int k) {
+  const uint4* ak = af + (size_t)k * (A16_BLOCKS * 64);
+#pragma unroll
+  for (int b = 0; b < A16_BLOCKS; ++b) {
+    const uint4 v = ak[b * 64];
+    f.a[b] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+
+// ytilde for one tile: coordinate block 0 (j < 32) needs pixel steps 0, 1; block 1 all four
+__device__ __forceinline__ void mfma_screen(f32x16 (&acc)[2], const ScreenFrags& f, const bf16x8 (&x)[4]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], x[0], zero, 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], x[0], zero, 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], x[1], acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[3], x[1], acc[1], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[4], x[2], acc[1], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[5], x[3], acc[1], 0, 0, 0);
+}
+
+// (ltilde, B) of the lane's patch from the two accumulator blocks
+__device__ __forceinline__ void screen_bounds(const f32x16 (&acc)[2], float ck, float e, float& l, float& B) {
+  f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 v = {acc[b][r], acc[b][r + 1]};
+      q2 = __builtin_elementwise_fma(v, v, q2);
+    }
+  float q = q2[0] + q2[1];
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q), __float_as_uint(q), false, false);
+  q = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // both lane halves of the patch
+  l = fmaf(-0.5f, q, ck);
+  // |l - ltilde| <= sqrt(q) e + e^2 / 2, inflated for the fp32 rounding of q, l and of this expression itself
+  B = fmaf(__builtin_sqrtf(q), e, 0.5f * e * e) * 1.001f + 2e-5f * q + 1e-6f * fabsf(ck) + 1e-30f;
+}
+
+template <int SWEEP>
+__device__ __forceinline__ void screen_finish(const f32x16 (&acc)[2], float ck, float efro, float xn, bool ok, float& L,
+                                              int n, int k, int lane, int seg, int& cnt, bool& trouble,
+                                              const GmmScreenArgs& a) {
+  float l, B;
+  screen_bounds(acc, ck, efro * xn, l, B);
+  if (SWEEP == 0) {
+    trouble = trouble || (ok && !(fabsf(l) < 3.0e38f));  // NaN / inf: do not trust the screen
+    L = fmaxf(L, l - B);
+  } else {
+    const bool cand = ok && lane < 32 && (l + B >= L);
+    const unsigned long long mask = __ballot(cand);
+    if (mask) {
+      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (cand && pos < SCREEN_CAP) {
+        a.pair_n[seg + pos] = n;
+        a.pair_k[seg + pos] = k;
+      }
+      cnt += __popcll(mask);
+    }
+  }
+}
+
+template <int SWEEP>
+__device__ __forceinline__ void screen_sweep(const GmmScreenArgs& a, const uint4* af, const uint4* xs_lane, const float (&xn)[SCREEN_T],
+                                             const bool (&ok)[SCREEN_T], float (&L)[SCREEN_T], const int (&nidx)[SCREEN_T],
+                                             int lane, int seg, int& cnt, bool& trouble) {
+  static_assert(SCREEN_T == 4, "the pipeline below is written for 4 tiles");
+  ScreenFrags f0, f1;
+  load_frags16(f0, af, 0);
+  bf16x8 x[4];
+  f32x16 acc[SCREEN_T][2];
+  auto load_x16 = [&](int t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(bf16x8, xs_lane[(t * 4 + s) * 64]);
+  };
+  // prologue: tiles 0, 1 of component 0
+  load_x16(0);
+  mfma_screen(acc[0], f0, x);
+  load_x16(1);
+  mfma_screen(acc[1], f0, x);
+  for (int k = 0; k < a.K; ++k) {
+    const float ck = a.const_k[k], ef = a.efro_k[k];
+    const int kn = k + 1 < a.K ? k + 1 : k;
+    load_frags16(f1, af, kn);  // unconditional (clamped) prefetch of the next component
+    // tiles 2, 3 of k on the matrix pipe while tiles 0, 1 of k finish in its shadow
+    load_x16(2);
+    mfma_screen(acc[2], f0, x);
+    screen_finish<SWEEP>(acc[0], ck, ef, xn[0], ok[0], L[0], nidx[0], k, lane, seg, cnt, trouble, a);
+    load_x16(3);
+    mfma_screen(acc[3], f0, x);
+    screen_finish<SWEEP>(acc[1], ck, ef, xn[1], ok[1], L[1], nidx[1], k, lane, seg, cnt, trouble, a);
+    // tiles 0, 1 of k + 1 while tiles 2, 3 of k finish
+    load_x16(0);
+    mfma_screen(acc[0], f1, x);
+    screen_finish<SWEEP>(acc[2], ck, ef, xn[2], ok[2], L[2], nidx[2], k, lane, seg, cnt, trouble, a);
+    load_x16(1);
+    mfma_screen(acc[1], f1, x);
+    screen_finish<SWEEP>(acc[3], ck, ef, xn[3], ok[3], L[3], nidx[3], k, lane, seg, cnt, trouble, a);
+#pragma unroll
+    for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
+  __shared__ uint4 xs[4][SCREEN_T * 4 * 64];  // per wave: [tile][pixel step][lane] = 8 bf16 (B fragment)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = blockIdx.x * 4 + wave;
+  const int base = a.n_begin + wave_global * (SCREEN_T * 32);
+  const int h = lane >> 5, c = lane & 31;  // lane (h, c): image rows 2 s + h (pixel step s) of patch c
+  float xn[SCREEN_T], L[SCREEN_T];
+  bool ok[SCREEN_T];
+  int nidx[SCREEN_T];
+#pragma unroll
+  for (int t = 0; t < SCREEN_T; ++t) {
+    const int n = base + 32 * t + c;
+    const bool valid = n < a.n_end;
+    const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
+    float x[32];
+    bool sel = true;
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int yy = wrap(py * a.stride + 2 * s + h - a.shift_y, a.H);
+      const float* row = a.flux + (size_t)yy * a.W;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int xx = wrap(px * a.stride + e - a.shift_x, a.W);
+        const float v = valid ? row[xx] : 0.f;
+        x[8 * s + e] = v;
+        sum += v;
+        sel = sel && (v > -1e5f);  // patches/core.py:215
+      }
+    }
+    const float mean = (sum + __shfl_xor(sum, 32, 64)) * (1.f / 64.f);
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) x[i] -= mean, n2 = fmaf(x[i], x[i], n2);
+    n2 += __shfl_xor(n2, 32, 64);
+    const int sel_other = __shfl_xor((int)sel, 32, 64);  // unconditional: see gmm_fwd_kernel
+    sel = sel && sel_other != 0;
+    xn[t] = __builtin_sqrtf(n2) * 1.001f;
+    ok[t] = valid && sel;
+    nidx[t] = n;
+    L[t] = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)x[8 * s + e];
+      xs[wave][(t * 4 + s) * 64 + lane] = __builtin_bit_cast(uint4, v);
+    }
+    if (h == 0 && valid) a.best[n] = ok[t] ? best_key(-INFINITY, 0) : 0ull;
+  }
+  // (wave-private LDS: written and read by the same wave, program order suffices)
+  const uint4* af = a.afrag16 + lane;
+  const uint4* xs_lane = &xs[wave][lane];
+  const int seg = wave_global * SCREEN_CAP;
+  int cnt = 0;
+  bool trouble = false;
+  screen_sweep<0>(a, af, xs_lane, xn, ok, L, nidx, lane, seg, cnt, trouble);
+  screen_sweep<1>(a, af, xs_lane, xn, ok, L, nidx, lane, seg, cnt, trouble);
+  if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
+    if (lane == 0) atomicOr(a.flag, 1);
+  }
+}
+
+struct GmmExactArgs {
+  const float* flux;
+  const float* afrag;
+  const float* mfrag;
+  const float* const_k;
+  const int32_t* pair_n;
+  const int32_t* pair_k;
+  const int32_t* order;  // bucket slot -> pair slot, -1 = padding
+  const int* offsets;    // offsets[K] = total bucket slots
+  const int* flag;
+  unsigned long long* best;
+  int K, H, W, stride, nPx, shift_y, shift_x;
+};
+
+// l(n, k) exactly as gmm_fwd_kernel computes it (same mean order, same MFMA chains, same epilogue), for groups of 32
+// surviving pairs that share the component; merged per patch with an order-independent atomic max.
+template <bool TRI>
+__global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
+  if (*a.flag != 0) return;  // the dense kernel takes over
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, n16 = lane & 15;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
+  const int n_groups = a.offsets[a.K] >> 5;
+  for (int grp = wave_global; grp < n_groups; grp += n_waves) {
+    const int k = __builtin_amdgcn_readfirstlane(a.pair_k[__builtin_amdgcn_readfirstlane(a.order[32 * grp])]);
+    const float ck = a.const_k[k];
+    int n[2];
+    bool valid[2];
+    float x[2][16];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const int slot = a.order[32 * grp + 16 * nb + n16];
+      valid[nb] = slot >= 0;
+      n[nb] = valid[nb] ? a.pair_n[slot] : 0;
+      const int py = n[nb] / a.nPx, px = n[nb] % a.nPx;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        const int p = 4 * st + g;
+        const int yy = wrap(py * a.stride + (p >> 3) - a.shift_y, a.H);
+        const int xx = wrap(px * a.stride + (p & 7) - a.shift_x, a.W);
+        x[nb][st] = valid[nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
+      }
+      const float mean = patch_mean_groups(x[nb]);
+#pragma unroll
+      for (int st = 0; st < 16; ++st) x[nb][st] -= mean;
+    }
+    f32x4 y[4][2];
+    const float4* ak = reinterpret_cast<const float4*>(a.afrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
+    const float4* mk = reinterpret_cast<const float4*>(a.mfrag) + (size_t)k * 16 + g;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      const float4 m = mk[jb * 4];
+      y[jb][0] = y[jb][1] = f32x4{m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int st4 = 0; st4 < 4; ++st4) {
+        if (TRI && st4 > jb) continue;
+        const float4 A = ak[(jb * 4 + st4) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            y[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, e), x[nb][4 * st4 + e], y[jb][nb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const float l = fmaf(-0.5f, sum_lane_groups(sum_squares(y, nb)), ck);  // = finish_tile of the forward kernel
+      if (g == 0 && valid[nb] && l > -INFINITY) atomicMax(a.best + n[nb], best_key(l, k));  // NaN never wins (l > b)
+    }
+  }
+}
+
+struct GmmBestArgs {
+  const unsigned long long* best;
+  int n_begin, n_end;
+  int32_t* argmax_out;  // nullable
+  double* partials;     // one per block
+};
+
+constexpr int BEST_CHUNK = 1024;
+
+__global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
+  __shared__ double red[4];
+  const int base = a.n_begin + blockIdx.x * BEST_CHUNK;
+  double local = 0.0;
+#pragma unroll
+  for (int i = 0; i < BEST_CHUNK / 256; ++i) {
+    const int n = base + i * 256 + threadIdx.x;
+    if (n < a.n_end) {
+      const unsigned long long key = a.best[n];
+      const bool ok = key != 0ull;
+      if (a.argmax_out) a.argmax_out[n] = ok ? best_component(key) : -1;
+      if (ok) local += (double)best_value(key);
+    }
+  }
+  local = wave_sum(local);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 struct GmmGatherArgs {
   const float* gpatch;
   float* grad;
@@ -747,6 +1084,17 @@ struct jd_gmm {
   double* partials = nullptr;
   size_t partials_cap = 0;
   int n_cu = 256;
+  // screened arg-max (zero-mean, upper triangular mixtures): bf16 fragments, bound constants, work space
+  bool screen_ok = false;
+  uint4* afrag16 = nullptr;
+  float* efro_k = nullptr;
+  unsigned long long* best = nullptr;
+  size_t best_cap = 0;
+  int32_t* pair_n = nullptr;  // pair_k follows at pair_n + pair_cap
+  size_t pair_cap = 0;
+  int32_t* pair_order = nullptr;
+  size_t pair_order_cap = 0;
+  int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | cursor (K) | offsets (K + 1)
 };
 
 using namespace jd;
@@ -804,6 +1152,40 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     for (int j = 0; j < D; ++j) mfrag[(size_t)k * 64 + j] = -mrow[j];
   }
   g->triangular = tri;
+  // screening operands: bf16(P') in 32x32x16 A-fragment order, blocks (jb, s) = (0,0) (0,1) (1,0) (1,1) (1,2) (1,3):
+  // lane l holds A[row l & 31][k = 8 (l >> 5) + e] = P'[pixel 16 s + 8 (l >> 5) + e][32 jb + (l & 31)]
+  bool zero_means = true;
+  for (size_t i = 0; i < (size_t)K * D; ++i) zero_means = zero_means && mu_prec[i] == 0.f;
+  std::vector<uint16_t> a16;
+  std::vector<float> efro;
+  if (tri && zero_means) {
+    auto to_bf16 = [](float f) -> uint16_t {  // round to nearest even
+      uint32_t u;
+      memcpy(&u, &f, 4);
+      if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);
+      return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    };
+    static const int blk_jb[A16_BLOCKS] = {0, 0, 1, 1, 1, 1}, blk_s[A16_BLOCKS] = {0, 1, 0, 1, 2, 3};
+    a16.resize((size_t)K * A16_BLOCKS * 64 * 8);
+    efro.resize(K);
+    for (int k = 0; k < K; ++k) {
+      const float* Pk = prec_chol + (size_t)k * D * D;
+      double fro = 0.0;
+      for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+          const float v = (float)((double)Pk[i * D + j] * sw[j]);
+          fro += (double)v * v;
+        }
+      efro[k] = (float)(std::sqrt(fro) * (double)SCREEN_EPS * (1.0 + 1e-6));
+      for (int b = 0; b < A16_BLOCKS; ++b)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int e = 0; e < 8; ++e) {
+            const int pix = 16 * blk_s[b] + 8 * (lane >> 5) + e, j = 32 * blk_jb[b] + (lane & 31);
+            const float v = (float)((double)Pk[pix * D + j] * sw[j]);
+            a16[(((size_t)k * A16_BLOCKS + b) * 64 + lane) * 8 + e] = to_bf16(v);
+          }
+    }
+  }
   auto upload = [&](float** dst, const float* src, size_t n) -> int {
     JD_HIP(hipMalloc(dst, n * sizeof(float)));
     JD_HIP(hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
@@ -819,6 +1201,16 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     jd_gmm_destroy(g);
     return fail(JD_ERR_ALLOC, "jd_gmm_create: hipMalloc of the bucket counters failed");
   }
+  if (!a16.empty()) {
+    if (hipMalloc(&g->afrag16, a16.size() * sizeof(uint16_t)) != hipSuccess ||
+        hipMemcpy(g->afrag16, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
+        (rc = upload(&g->efro_k, efro.data(), efro.size())) ||
+        hipMalloc(&g->screen_ctl, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess) {
+      jd_gmm_destroy(g);
+      return fail(JD_ERR_ALLOC, "jd_gmm_create: allocation of the screening operands failed");
+    }
+    g->screen_ok = true;
+  }
   int dev = 0;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
@@ -833,6 +1225,12 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   for (float* p : {g->afrag, g->mfrag, g->const_k, g->gfrag, g->gpatch, g->vpatch})
     if (p) (void)hipFree(p);
   if (g->argmax) (void)hipFree(g->argmax);
+  if (g->afrag16) (void)hipFree(g->afrag16);
+  if (g->efro_k) (void)hipFree(g->efro_k);
+  if (g->best) (void)hipFree(g->best);
+  if (g->pair_n) (void)hipFree(g->pair_n);
+  if (g->pair_order) (void)hipFree(g->pair_order);
+  if (g->screen_ctl) (void)hipFree(g->screen_ctl);
   if (g->order) (void)hipFree(g->order);
   if (g->bucket) (void)hipFree(g->bucket);
   if (g->partials) (void)hipFree(g->partials);
@@ -897,6 +1295,83 @@ static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, in
   }
 }
 
+// Max mode through the bf16 screen (see gmm_screen_kernel): fills a.argmax_out (if any) and one fp64 partial sum per
+// 1024 patches, exactly the numbers gmm_fwd_kernel<MODE_MAX> produces.
+static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials) {
+  const long n = a.n_end - a.n_begin;
+  const long waves = (n + SCREEN_T * 32 - 1) / (SCREEN_T * 32);
+  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  const size_t slots = (size_t)blocks * 4 * SCREEN_CAP;          // survivor pair slots
+  const size_t bucket_slots = slots + 32 * (size_t)g->K;         // padded bucket slots
+  int rc;
+  if ((rc = grow(&g->best, &g->best_cap, (size_t)a.n_end))) return rc;
+  if ((rc = grow(&g->pair_n, &g->pair_cap, 2 * slots))) return rc;
+  if ((rc = grow(&g->pair_order, &g->pair_order_cap, bucket_slots))) return rc;
+  if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
+  int32_t* pair_n = g->pair_n;
+  int32_t* pair_k = g->pair_n + slots;
+  int* flag = g->screen_ctl;
+  JD_HIP(hipMemsetAsync(g->screen_ctl, 0, (size_t)(2 * g->K + 1) * sizeof(int), s));
+  JD_HIP(hipMemsetAsync(pair_k, 0xFF, slots * sizeof(int32_t), s));
+  JD_HIP(hipMemsetAsync(g->pair_order, 0xFF, bucket_slots * sizeof(int32_t), s));
+
+  ProfScope prof(JD_KERNEL_GMM_FWD, s);
+  GmmScreenArgs sc{};
+  sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k;
+  sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
+  sc.n_begin = a.n_begin, sc.n_end = a.n_end;
+  sc.best = g->best, sc.pair_n = pair_n, sc.pair_k = pair_k, sc.flag = flag;
+  gmm_screen_kernel<<<blocks, 256, 0, s>>>(sc);
+  JD_LAUNCH_CHECK();
+
+  // counting sort of the survivor slots by component (the slot index plays the role of the patch index)
+  GmmBucketArgs bk{};
+  bk.argmax = pair_k, bk.n_begin = 0, bk.n_end = (int)slots, bk.K = g->K;
+  bk.counts = g->screen_ctl + 1, bk.cursor = g->screen_ctl + 1 + g->K, bk.offsets = g->screen_ctl + 1 + 2 * g->K;
+  bk.order = g->pair_order, bk.gpatch = nullptr;
+  const unsigned chunks = (unsigned)((slots + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+  const size_t hist_bytes = (size_t)g->K * sizeof(int);
+  gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+  gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
+  gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+  JD_LAUNCH_CHECK();
+
+  GmmExactArgs ex{};
+  ex.flux = a.flux, ex.afrag = g->afrag, ex.mfrag = g->mfrag, ex.const_k = g->const_k;
+  ex.pair_n = pair_n, ex.pair_k = pair_k, ex.order = g->pair_order, ex.offsets = bk.offsets, ex.flag = flag;
+  ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
+  ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
+  long ex_blocks = (long)(bucket_slots / 32 + 3) / 4;
+  if (ex_blocks > (long)g->n_cu * 3) ex_blocks = (long)g->n_cu * 3;
+  gmm_exact_kernel<true><<<(unsigned)ex_blocks, 256, 0, s>>>(ex);
+  JD_LAUNCH_CHECK();
+
+  // fallback: the dense fp32 kernel, gated on the device flag (returns at once in the normal case)
+  GmmFwdArgs dense = a;
+  dense.run_flag = flag, dense.best_out = g->best, dense.argmax_out = nullptr, dense.value_patch = nullptr;
+  int dense_partials = 0;
+  {
+    const int tb = pick_block_tiles(n, g->n_cu);
+    const unsigned dblocks = (unsigned)((n + 32L * tb - 1) / (32L * tb));
+    dense_partials = (int)dblocks;
+    (void)dense_partials;
+    switch (tb) {
+      case 16: rc = launch_fwd_tb<16, MODE_MAX, true>(dense, dblocks, s); break;
+      case 8: rc = launch_fwd_tb<8, MODE_MAX, true>(dense, dblocks, s); break;
+      default: rc = launch_fwd_tb<4, MODE_MAX, true>(dense, dblocks, s); break;
+    }
+    if (rc) return rc;
+  }
+
+  GmmBestArgs be{};
+  be.best = g->best, be.n_begin = a.n_begin, be.n_end = a.n_end, be.argmax_out = a.argmax_out, be.partials = g->partials;
+  const unsigned best_blocks = (unsigned)((n + BEST_CHUNK - 1) / BEST_CHUNK);
+  gmm_best_kernel<<<best_blocks, 256, 0, s>>>(be);
+  JD_LAUNCH_CHECK();
+  *n_partials = (int)best_blocks;
+  return JD_OK;
+}
+
 extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
                                     int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                                     float value_scale, float* value_out, int accumulate_value, float grad_coef,
@@ -932,8 +1407,12 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
     a.value_patch = g->vpatch;
   }
   int n_waves = 0;
+  const char* screen_var = getenv("JD_GMM_SCREEN");  // "0" forces the dense fp32 kernel (testing / tuning)
+  const bool screen_env = !(screen_var && atoi(screen_var) == 0);
   if (marginalize)
     rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
+  else if (g->screen_ok && screen_env && !getenv("JD_GMM_DENSE"))
+    rc = screened_forward(g, a, s, &n_waves);
   else
     rc = launch_fwd<MODE_MAX>(a, g->triangular, g->n_cu, s, &n_waves);
   if (rc) return rc;
