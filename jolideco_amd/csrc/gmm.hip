@@ -71,9 +71,12 @@ struct GmmFwdArgs {
   unsigned long long* best_out;  // nullable (MODE_MAX): per patch (max, arg-max) key, 0 for a filtered patch
 };
 
+// v mod n for -n <= v < 2 n: the host normalises the cycle-spin shifts to [0, n), so every coordinate
+// (pixel inside the image) - shift is in (-n, n); an integer division here costs ~20 instructions per pixel and
+// made the gather the bottleneck of the bucketed kernels.
 __device__ __forceinline__ int wrap(int v, int n) {
-  v %= n;
-  return v < 0 ? v + n : v;
+  v = v < 0 ? v + n : v;
+  return v >= n ? v - n : v;
 }
 
 __device__ __forceinline__ float f4_get(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
@@ -385,24 +388,43 @@ struct GmmBucketArgs {
   int* cursor;    // K      (zeroed by the caller)
   int* offsets;   // K + 1  exclusive scan of the padded counts; offsets[K] = total slots
   int32_t* order; // slot -> global patch index, -1 for padding (pre-filled with -1 by the caller)
-  float* gpatch;  // rows of filtered patches (argmax < 0) are zeroed here
+  float* gpatch;  // rows of filtered patches (argmax < 0) are zeroed here (nullable)
+  // screened forward pass only (seg_cnt != nullptr): the elements are candidate records in per-wave segments of
+  // seg_cap slots of which the first seg_cnt[segment] are used; a record counts only if its upper bound still
+  // reaches the final lower bound of its patch
+  const int* seg_cnt;
+  int seg_cap;
+  const int32_t* rec_n;
+  const float* rec_ub;
+  const float* lfinal;
 };
+
+// component of element n, or -1 if it takes no part
+__device__ __forceinline__ int bucket_key(const GmmBucketArgs& a, int n) {
+  if (n >= a.n_end) return -2;
+  if (a.seg_cnt) {
+    if (n % a.seg_cap >= a.seg_cnt[n / a.seg_cap]) return -2;
+    if (!(a.rec_ub[n] >= a.lfinal[a.rec_n[n]])) return -2;
+  }
+  return a.argmax[n];
+}
+__device__ __forceinline__ bool bucket_block_empty(const GmmBucketArgs& a, int base) {
+  return a.seg_cnt && base < a.n_end && base % a.seg_cap >= a.seg_cnt[base / a.seg_cap];  // BUCKET_CHUNK divides seg_cap
+}
 
 constexpr int BUCKET_CHUNK = 1024;  // patches per block (4 per thread)
 constexpr int BUCKET_MAX_K = 4096;  // LDS histogram capacity
 
 __global__ __launch_bounds__(256) void gmm_bucket_count_kernel(GmmBucketArgs a) {
   extern __shared__ int hist[];
+  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
+  if (bucket_block_empty(a, base)) return;
   for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
   __syncthreads();
-  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
 #pragma unroll
   for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
-    const int n = base + i * 256 + threadIdx.x;
-    if (n < a.n_end) {
-      const int k = a.argmax[n];
-      if (k >= 0) atomicAdd(&hist[k], 1);
-    }
+    const int k = bucket_key(a, base + i * 256 + threadIdx.x);
+    if (k >= 0) atomicAdd(&hist[k], 1);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < a.K; k += 256)
@@ -437,22 +459,20 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
 
 __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a) {
   extern __shared__ int hist[];  // [0, K): block-local counts, then the block's base inside each bucket
+  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
+  if (bucket_block_empty(a, base)) return;
   for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
   __syncthreads();
-  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
   int kk[BUCKET_CHUNK / 256], rank[BUCKET_CHUNK / 256];
 #pragma unroll
   for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
     const int n = base + i * 256 + threadIdx.x;
-    kk[i] = -2;
-    if (n < a.n_end) {
-      kk[i] = a.argmax[n];
-      if (kk[i] >= 0) {
-        rank[i] = atomicAdd(&hist[kk[i]], 1);
-      } else if (a.gpatch) {  // filtered patch (patches/core.py:215-216): no gradient
-        float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
-        for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    kk[i] = bucket_key(a, n);
+    if (kk[i] >= 0) {
+      rank[i] = atomicAdd(&hist[kk[i]], 1);
+    } else if (kk[i] == -1 && a.gpatch) {  // filtered patch (patches/core.py:215-216): no gradient
+      float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
+      for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   __syncthreads();
@@ -736,9 +756,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int SCREEN_T = 4;        // tiles of 32 patches per wave
-constexpr int SCREEN_CAP = 1536;   // survivor pairs a wave can record (128 patches: 12 per patch)
+constexpr int SCREEN_CAP = 4096;   // candidate records a wave can hold (128 patches: 32 per patch); multiple of BUCKET_CHUNK
 constexpr int A16_BLOCKS = 6;      // non-zero (32 coordinates x 16 pixels) blocks of an upper triangular P'
 constexpr float SCREEN_EPS = 0.0079f;
+constexpr int KORDER_MAX_K = 1024;  // the popularity order of the components is maintained up to this K
 
 struct GmmScreenArgs {
   const float* flux;
@@ -746,9 +767,13 @@ struct GmmScreenArgs {
   const float* const_k;  // K
   const float* efro_k;   // K: SCREEN_EPS * |P'_k|_F (rounded up)
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+  const int* korder;         // K: the order in which the components are visited (most popular first)
   unsigned long long* best;  // per patch (global index): initialised here
-  int32_t* pair_n;           // [waves][SCREEN_CAP] survivor patch (global index)
-  int32_t* pair_k;           // [waves][SCREEN_CAP] survivor component, -1 = empty (pre-filled by the caller)
+  float* lfinal;             // per patch: max_k (ltilde - B), a lower bound of the true maximum
+  int32_t* rec_n;            // [waves][SCREEN_CAP] candidate records: patch (global index),
+  int32_t* rec_k;            //                     component,
+  float* rec_ub;             //                     upper bound ltilde + B
+  int* seg_cnt;              // [waves] records used
   int* flag;                 // != 0: fall back to the dense kernel
 };
 
@@ -776,8 +801,8 @@ __device__ __forceinline__ void mfma_screen(f32x16 (&acc)[2], const ScreenFrags&
   acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[5], x[3], acc[1], 0, 0, 0);
 }
 
-// (ltilde, B) of the lane's patch from the two accumulator blocks
-__device__ __forceinline__ void screen_bounds(const f32x16 (&acc)[2], float ck, float e, float& l, float& B) {
+// q = sum_j ytilde_j^2 of the lane's patch from the two accumulator blocks (both lane halves)
+__device__ __forceinline__ float screen_q(const f32x16 (&acc)[2]) {
   f32x2 q2 = {0.f, 0.f};
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -786,85 +811,51 @@ __device__ __forceinline__ void screen_bounds(const f32x16 (&acc)[2], float ck, 
       const f32x2 v = {acc[b][r], acc[b][r + 1]};
       q2 = __builtin_elementwise_fma(v, v, q2);
     }
-  float q = q2[0] + q2[1];
+  const float q = q2[0] + q2[1];
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q), __float_as_uint(q), false, false);
-  q = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // both lane halves of the patch
-  l = fmaf(-0.5f, q, ck);
-  // |l - ltilde| <= sqrt(q) e + e^2 / 2, inflated for the fp32 rounding of q, l and of this expression itself
-  B = fmaf(__builtin_sqrtf(q), e, 0.5f * e * e) * 1.001f + 2e-5f * q + 1e-6f * fabsf(ck) + 1e-30f;
+  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-template <int SWEEP>
-__device__ __forceinline__ void screen_finish(const f32x16 (&acc)[2], float ck, float efro, float xn, bool ok, float& L,
-                                              int n, int k, int lane, int seg, int& cnt, bool& trouble,
-                                              const GmmScreenArgs& a) {
-  float l, B;
-  screen_bounds(acc, ck, efro * xn, l, B);
-  if (SWEEP == 0) {
-    trouble = trouble || (ok && !(fabsf(l) < 3.0e38f));  // NaN / inf: do not trust the screen
-    L = fmaxf(L, l - B);
-  } else {
-    const bool cand = ok && lane < 32 && (l + B >= L);
-    const unsigned long long mask = __ballot(cand);
-    if (mask) {
-      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-      if (cand && pos < SCREEN_CAP) {
-        a.pair_n[seg + pos] = n;
-        a.pair_k[seg + pos] = k;
-      }
-      cnt += __popcll(mask);
+// One (tile, component): ltilde = ck - q / 2 and the bound
+//   |l - ltilde| <= sqrt(q) e + e^2 / 2,  e = eps |xbar| |P'_k|_F
+// inflated for the fp32 rounding of q, l, the hardware square root (1 ulp) and of this expression itself:
+//   B = sqrt(q) * e1 + 2e-5 q + c2,   e1 = 1.001 e,   c2 = 0.5 e1^2 + 1e-6 |ck| + 1e-30.
+// ONE sweep over the components: a component is recorded while its upper bound reaches the running lower bound L of
+// the maximum; records made before L rose are dropped later (bucket_key) against the final L.  Visiting the
+// components most-popular-first makes L rise early, so few stale records are written.
+// The issue slots beside the MFMAs are the budget (about six 4-cycle VALU instructions hide per 32-cycle MFMA).
+__device__ __forceinline__ void screen_finish(const f32x16 (&acc)[2], float ck, float ack, float hef2, float efro, float xn,
+                                              float xn2, bool ok, float& L, float& qacc, int n, int k, int lane, int seg,
+                                              int& cnt, const GmmScreenArgs& a) {
+  const float q = screen_q(acc);
+  qacc += q;  // a NaN / inf anywhere ends up here and raises the fallback flag
+  const float e1 = efro * xn;            // efro carries eps and the factor 1.001
+  const float c2 = fmaf(hef2, xn2, ack);  // hef2 = efro^2 / 2
+  const float l = fmaf(-0.5f, q, ck);
+  const float B = fmaf(__builtin_amdgcn_sqrtf(q), e1, fmaf(2e-5f, q, c2));
+  const float ub = l + B;
+  const bool cand = ok && lane < 32 && ub >= L;
+  L = fmaxf(L, l - B);
+  const unsigned long long mask = __ballot(cand);
+  if (mask) {
+    const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+    if (cand && pos < SCREEN_CAP) {
+      a.rec_n[seg + pos] = n;
+      a.rec_k[seg + pos] = k;
+      a.rec_ub[seg + pos] = ub;
     }
-  }
-}
-
-template <int SWEEP>
-__device__ __forceinline__ void screen_sweep(const GmmScreenArgs& a, const uint4* af, const uint4* xs_lane, const float (&xn)[SCREEN_T],
-                                             const bool (&ok)[SCREEN_T], float (&L)[SCREEN_T], const int (&nidx)[SCREEN_T],
-                                             int lane, int seg, int& cnt, bool& trouble) {
-  static_assert(SCREEN_T == 4, "the pipeline below is written for 4 tiles");
-  ScreenFrags f0, f1;
-  load_frags16(f0, af, 0);
-  bf16x8 x[4];
-  f32x16 acc[SCREEN_T][2];
-  auto load_x16 = [&](int t) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(bf16x8, xs_lane[(t * 4 + s) * 64]);
-  };
-  // prologue: tiles 0, 1 of component 0
-  load_x16(0);
-  mfma_screen(acc[0], f0, x);
-  load_x16(1);
-  mfma_screen(acc[1], f0, x);
-  for (int k = 0; k < a.K; ++k) {
-    const float ck = a.const_k[k], ef = a.efro_k[k];
-    const int kn = k + 1 < a.K ? k + 1 : k;
-    load_frags16(f1, af, kn);  // unconditional (clamped) prefetch of the next component
-    // tiles 2, 3 of k on the matrix pipe while tiles 0, 1 of k finish in its shadow
-    load_x16(2);
-    mfma_screen(acc[2], f0, x);
-    screen_finish<SWEEP>(acc[0], ck, ef, xn[0], ok[0], L[0], nidx[0], k, lane, seg, cnt, trouble, a);
-    load_x16(3);
-    mfma_screen(acc[3], f0, x);
-    screen_finish<SWEEP>(acc[1], ck, ef, xn[1], ok[1], L[1], nidx[1], k, lane, seg, cnt, trouble, a);
-    // tiles 0, 1 of k + 1 while tiles 2, 3 of k finish
-    load_x16(0);
-    mfma_screen(acc[0], f1, x);
-    screen_finish<SWEEP>(acc[2], ck, ef, xn[2], ok[2], L[2], nidx[2], k, lane, seg, cnt, trouble, a);
-    load_x16(1);
-    mfma_screen(acc[1], f1, x);
-    screen_finish<SWEEP>(acc[3], ck, ef, xn[3], ok[3], L[3], nidx[3], k, lane, seg, cnt, trouble, a);
-#pragma unroll
-    for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
+    cnt += __popcll(mask);
   }
 }
 
 __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
+  static_assert(SCREEN_T == 4, "the pipeline below is written for 4 tiles");
   __shared__ uint4 xs[4][SCREEN_T * 4 * 64];  // per wave: [tile][pixel step][lane] = 8 bf16 (B fragment)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
   const int base = a.n_begin + wave_global * (SCREEN_T * 32);
   const int h = lane >> 5, c = lane & 31;  // lane (h, c): image rows 2 s + h (pixel step s) of patch c
-  float xn[SCREEN_T], L[SCREEN_T];
+  float xn[SCREEN_T], xn2[SCREEN_T], L[SCREEN_T], qacc[SCREEN_T];
   bool ok[SCREEN_T];
   int nidx[SCREEN_T];
 #pragma unroll
@@ -895,10 +886,12 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     n2 += __shfl_xor(n2, 32, 64);
     const int sel_other = __shfl_xor((int)sel, 32, 64);  // unconditional: see gmm_fwd_kernel
     sel = sel && sel_other != 0;
-    xn[t] = __builtin_sqrtf(n2) * 1.001f;
+    xn[t] = __builtin_sqrtf(n2) * 1.0001f;
+    xn2[t] = xn[t] * xn[t];
     ok[t] = valid && sel;
     nidx[t] = n;
     L[t] = -INFINITY;
+    qacc[t] = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       bf16x8 v;
@@ -913,11 +906,68 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   const uint4* xs_lane = &xs[wave][lane];
   const int seg = wave_global * SCREEN_CAP;
   int cnt = 0;
+
+  ScreenFrags f0, f1;
+  bf16x8 x[4];
+  f32x16 acc[SCREEN_T][2];
+  auto load_x16 = [&](int t) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(bf16x8, xs_lane[(t * 4 + s) * 64]);
+  };
+  int k_next = a.korder[0];
+  float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next];
+  load_frags16(f0, af, k_next);
+  // prologue: tiles 0, 1 of the first component
+  load_x16(0);
+  mfma_screen(acc[0], f0, x);
+  load_x16(1);
+  mfma_screen(acc[1], f0, x);
+  for (int kk = 0; kk < a.K; ++kk) {
+    const int k = k_next;
+    const float ck = ck_next, ef = ef_next;
+    const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f), hef2 = 0.5f * ef * ef;
+    k_next = a.korder[kk + 1 < a.K ? kk + 1 : kk];  // scalar loads one component ahead of their use
+    ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next];
+    load_frags16(f1, af, k_next);  // unconditional (clamped) prefetch of the next component
+    // tiles 2, 3 of k on the matrix pipe while tiles 0, 1 of k finish in its shadow
+    load_x16(2);
+    mfma_screen(acc[2], f0, x);
+    screen_finish(acc[0], ck, ack, hef2, ef, xn[0], xn2[0], ok[0], L[0], qacc[0], nidx[0], k, lane, seg, cnt, a);
+    load_x16(3);
+    mfma_screen(acc[3], f0, x);
+    screen_finish(acc[1], ck, ack, hef2, ef, xn[1], xn2[1], ok[1], L[1], qacc[1], nidx[1], k, lane, seg, cnt, a);
+    // tiles 0, 1 of the next component while tiles 2, 3 of k finish
+    load_x16(0);
+    mfma_screen(acc[0], f1, x);
+    screen_finish(acc[2], ck, ack, hef2, ef, xn[2], xn2[2], ok[2], L[2], qacc[2], nidx[2], k, lane, seg, cnt, a);
+    load_x16(1);
+    mfma_screen(acc[1], f1, x);
+    screen_finish(acc[3], ck, ack, hef2, ef, xn[3], xn2[3], ok[3], L[3], qacc[3], nidx[3], k, lane, seg, cnt, a);
+#pragma unroll
+    for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
+  }
   bool trouble = false;
-  screen_sweep<0>(a, af, xs_lane, xn, ok, L, nidx, lane, seg, cnt, trouble);
-  screen_sweep<1>(a, af, xs_lane, xn, ok, L, nidx, lane, seg, cnt, trouble);
+#pragma unroll
+  for (int t = 0; t < SCREEN_T; ++t) {
+    trouble = trouble || (ok[t] && !(qacc[t] < 3.0e38f));
+    if (h == 0 && nidx[t] < a.n_end) a.lfinal[nidx[t]] = L[t];
+  }
+  if (lane == 0) a.seg_cnt[wave_global] = cnt < SCREEN_CAP ? cnt : SCREEN_CAP;
   if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
     if (lane == 0) atomicOr(a.flag, 1);
+  }
+}
+
+// Order of the components for the NEXT call: most survivors first (ties: lowest index), from this call's buckets.
+__global__ __launch_bounds__(256) void gmm_korder_kernel(const int* counts, int K, int* korder) {
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const int ck = counts[k];
+    int rank = 0;
+    for (int j = 0; j < K; ++j) {
+      const int cj = counts[j];
+      rank += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
+    }
+    korder[rank] = k;
   }
 }
 
@@ -926,47 +976,81 @@ struct GmmExactArgs {
   const float* afrag;
   const float* mfrag;
   const float* const_k;
-  const int32_t* pair_n;
-  const int32_t* pair_k;
-  const int32_t* order;  // bucket slot -> pair slot, -1 = padding
-  const int* offsets;    // offsets[K] = total bucket slots
+  const int32_t* rec_n;
+  const int32_t* order;   // bucket slot -> record slot (only the first counts[k] slots of a bucket are written)
+  const int* counts;      // K
+  const int* offsets;     // K + 1, offsets[K] = total (padded) bucket slots
   const int* flag;
   unsigned long long* best;
   int K, H, W, stride, nPx, shift_y, shift_x;
 };
 
+struct __attribute__((packed, aligned(4))) F4U {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
+  float x, y, z, w;
+};
+
+constexpr int EXACT_PITCH = 68;  // floats per staged patch (64 + pad: 16-byte aligned rows, 2-way bank spread)
+
 // l(n, k) exactly as gmm_fwd_kernel computes it (same mean order, same MFMA chains, same epilogue), for groups of 32
-// surviving pairs that share the component; merged per patch with an order-independent atomic max.
+// surviving records that share the component; merged per patch with an order-independent atomic max.  The patches
+// of a group are fetched with 16-byte row segments into a wave-private LDS image (the per-pixel gather of the
+// backward kernel costs 4x the memory instructions) and read back in B-operand order.
 template <bool TRI>
 __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
   if (*a.flag != 0) return;  // the dense kernel takes over
-  const int lane = threadIdx.x & 63;
+  __shared__ __attribute__((aligned(16))) float stage[4][32 * EXACT_PITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, n16 = lane & 15;
-  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave_global = blockIdx.x * 4 + wave;
   const int n_waves = gridDim.x * 4;
   const int n_groups = a.offsets[a.K] >> 5;
+  float* st = stage[wave];
   for (int grp = wave_global; grp < n_groups; grp += n_waves) {
-    const int k = __builtin_amdgcn_readfirstlane(a.pair_k[__builtin_amdgcn_readfirstlane(a.order[32 * grp])]);
+    // bucket of this group: the last k with offsets[k] <= 32 grp (buckets are padded to 32, so a group never straddles)
+    int lo = 0, hi = a.K;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (a.offsets[mid] <= 32 * grp) lo = mid; else hi = mid;
+    }
+    const int k = lo;
+    const int nvalid = a.counts[k] - (32 * grp - a.offsets[k]);  // >= 1
     const float ck = a.const_k[k];
+    // ---- stage: lane (q = lane / 2, hh = lane % 2) fetches columns 4 hh .. 4 hh + 3 of the 8 rows of record q
+    {
+      const int q = lane >> 1, hh = lane & 1;
+      const bool have = q < nvalid;
+      const int n = have ? a.rec_n[a.order[32 * grp + q]] : 0;
+      const int py = n / a.nPx, px = n - py * a.nPx;
+      const int x0 = px * a.stride + 4 * hh - a.shift_x;  // in (-W, W)
+      const bool straight = x0 >= 0 && x0 + 3 < a.W;
+      const int xw[4] = {wrap(x0, a.W), wrap(x0 + 1, a.W), wrap(x0 + 2, a.W), wrap(x0 + 3, a.W)};
+      float4 rows[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float* row = a.flux + (size_t)wrap(py * a.stride + r - a.shift_y, a.H) * a.W;
+        if (straight) {
+          const F4U v = *reinterpret_cast<const F4U*>(row + x0);
+          rows[r] = make_float4(v.x, v.y, v.z, v.w);
+        } else {
+          rows[r] = make_float4(row[xw[0]], row[xw[1]], row[xw[2]], row[xw[3]]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) *reinterpret_cast<float4*>(st + q * EXACT_PITCH + 8 * r + 4 * hh) = rows[r];
+    }
     int n[2];
     bool valid[2];
     float x[2][16];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      const int slot = a.order[32 * grp + 16 * nb + n16];
-      valid[nb] = slot >= 0;
-      n[nb] = valid[nb] ? a.pair_n[slot] : 0;
-      const int py = n[nb] / a.nPx, px = n[nb] % a.nPx;
+      const int q = 16 * nb + n16;
+      valid[nb] = q < nvalid;
+      n[nb] = valid[nb] ? a.rec_n[a.order[32 * grp + q]] : 0;
 #pragma unroll
-      for (int st = 0; st < 16; ++st) {
-        const int p = 4 * st + g;
-        const int yy = wrap(py * a.stride + (p >> 3) - a.shift_y, a.H);
-        const int xx = wrap(px * a.stride + (p & 7) - a.shift_x, a.W);
-        x[nb][st] = valid[nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
-      }
+      for (int s4 = 0; s4 < 16; ++s4) x[nb][s4] = valid[nb] ? st[q * EXACT_PITCH + 4 * s4 + g] : 0.f;
       const float mean = patch_mean_groups(x[nb]);
 #pragma unroll
-      for (int st = 0; st < 16; ++st) x[nb][st] -= mean;
+      for (int s4 = 0; s4 < 16; ++s4) x[nb][s4] -= mean;
     }
     f32x4 y[4][2];
     const float4* ak = reinterpret_cast<const float4*>(a.afrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
@@ -1090,10 +1174,15 @@ struct jd_gmm {
   float* efro_k = nullptr;
   unsigned long long* best = nullptr;
   size_t best_cap = 0;
-  int32_t* pair_n = nullptr;  // pair_k follows at pair_n + pair_cap
-  size_t pair_cap = 0;
-  int32_t* pair_order = nullptr;
-  size_t pair_order_cap = 0;
+  float* lfinal = nullptr;
+  size_t lfinal_cap = 0;
+  int32_t* rec = nullptr;  // candidate records: patch | component | upper bound (as float), `slots` each
+  size_t rec_cap = 0;
+  int32_t* rec_order = nullptr;
+  size_t rec_order_cap = 0;
+  int* seg_cnt = nullptr;
+  size_t seg_cnt_cap = 0;
+  int* korder = nullptr;      // K: visiting order of the components (most survivors in the previous call first)
   int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | cursor (K) | offsets (K + 1)
 };
 
@@ -1176,7 +1265,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
           const float v = (float)((double)Pk[i * D + j] * sw[j]);
           fro += (double)v * v;
         }
-      efro[k] = (float)(std::sqrt(fro) * (double)SCREEN_EPS * (1.0 + 1e-6));
+      efro[k] = (float)(std::sqrt(fro) * (double)SCREEN_EPS * 1.0011);  // includes the 1.001 inflation of the bound
       for (int b = 0; b < A16_BLOCKS; ++b)
         for (int lane = 0; lane < 64; ++lane)
           for (int e = 0; e < 8; ++e) {
@@ -1205,9 +1294,16 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     if (hipMalloc(&g->afrag16, a16.size() * sizeof(uint16_t)) != hipSuccess ||
         hipMemcpy(g->afrag16, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
         (rc = upload(&g->efro_k, efro.data(), efro.size())) ||
-        hipMalloc(&g->screen_ctl, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess) {
+        hipMalloc(&g->screen_ctl, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess ||
+        hipMalloc(&g->korder, (size_t)K * sizeof(int)) != hipSuccess) {
       jd_gmm_destroy(g);
       return fail(JD_ERR_ALLOC, "jd_gmm_create: allocation of the screening operands failed");
+    }
+    std::vector<int> identity(K);
+    for (int k = 0; k < K; ++k) identity[k] = k;
+    if (hipMemcpy(g->korder, identity.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+      jd_gmm_destroy(g);
+      return fail(JD_ERR_HIP, "jd_gmm_create: upload of the component order failed");
     }
     g->screen_ok = true;
   }
@@ -1228,8 +1324,11 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->afrag16) (void)hipFree(g->afrag16);
   if (g->efro_k) (void)hipFree(g->efro_k);
   if (g->best) (void)hipFree(g->best);
-  if (g->pair_n) (void)hipFree(g->pair_n);
-  if (g->pair_order) (void)hipFree(g->pair_order);
+  if (g->lfinal) (void)hipFree(g->lfinal);
+  if (g->rec) (void)hipFree(g->rec);
+  if (g->rec_order) (void)hipFree(g->rec_order);
+  if (g->seg_cnt) (void)hipFree(g->seg_cnt);
+  if (g->korder) (void)hipFree(g->korder);
   if (g->screen_ctl) (void)hipFree(g->screen_ctl);
   if (g->order) (void)hipFree(g->order);
   if (g->bucket) (void)hipFree(g->bucket);
@@ -1301,60 +1400,61 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   const long n = a.n_end - a.n_begin;
   const long waves = (n + SCREEN_T * 32 - 1) / (SCREEN_T * 32);
   const unsigned blocks = (unsigned)((waves + 3) / 4);
-  const size_t slots = (size_t)blocks * 4 * SCREEN_CAP;          // survivor pair slots
-  const size_t bucket_slots = slots + 32 * (size_t)g->K;         // padded bucket slots
+  const size_t n_seg = (size_t)blocks * 4;
+  const size_t slots = n_seg * SCREEN_CAP;                  // candidate record slots
+  const size_t bucket_slots = slots + 32 * (size_t)g->K;    // padded bucket slots
+  JD_REQUIRE(bucket_slots < (size_t)1 << 31, "jd_gmm_prior_fwd_bwd: too many patches for the screened path");
   int rc;
   if ((rc = grow(&g->best, &g->best_cap, (size_t)a.n_end))) return rc;
-  if ((rc = grow(&g->pair_n, &g->pair_cap, 2 * slots))) return rc;
-  if ((rc = grow(&g->pair_order, &g->pair_order_cap, bucket_slots))) return rc;
+  if ((rc = grow(&g->lfinal, &g->lfinal_cap, (size_t)a.n_end))) return rc;
+  if ((rc = grow(&g->rec, &g->rec_cap, 3 * slots))) return rc;
+  if ((rc = grow(&g->rec_order, &g->rec_order_cap, bucket_slots))) return rc;
+  if ((rc = grow(&g->seg_cnt, &g->seg_cnt_cap, n_seg))) return rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
-  int32_t* pair_n = g->pair_n;
-  int32_t* pair_k = g->pair_n + slots;
+  int32_t* rec_n = g->rec;
+  int32_t* rec_k = g->rec + slots;
+  float* rec_ub = reinterpret_cast<float*>(g->rec + 2 * slots);
   int* flag = g->screen_ctl;
-  JD_HIP(hipMemsetAsync(g->screen_ctl, 0, (size_t)(2 * g->K + 1) * sizeof(int), s));
-  JD_HIP(hipMemsetAsync(pair_k, 0xFF, slots * sizeof(int32_t), s));
-  JD_HIP(hipMemsetAsync(g->pair_order, 0xFF, bucket_slots * sizeof(int32_t), s));
+  JD_HIP(hipMemsetAsync(g->screen_ctl, 0, (size_t)(2 * g->K + 1) * sizeof(int), s));  // flag, counts, cursor
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmScreenArgs sc{};
-  sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k;
+  sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k, sc.korder = g->korder;
   sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
-  sc.best = g->best, sc.pair_n = pair_n, sc.pair_k = pair_k, sc.flag = flag;
+  sc.best = g->best, sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
+  sc.seg_cnt = g->seg_cnt, sc.flag = flag;
   gmm_screen_kernel<<<blocks, 256, 0, s>>>(sc);
   JD_LAUNCH_CHECK();
 
-  // counting sort of the survivor slots by component (the slot index plays the role of the patch index)
+  // counting sort of the surviving records by component (the record slot plays the role of the patch index)
   GmmBucketArgs bk{};
-  bk.argmax = pair_k, bk.n_begin = 0, bk.n_end = (int)slots, bk.K = g->K;
+  bk.argmax = rec_k, bk.n_begin = 0, bk.n_end = (int)slots, bk.K = g->K;
   bk.counts = g->screen_ctl + 1, bk.cursor = g->screen_ctl + 1 + g->K, bk.offsets = g->screen_ctl + 1 + 2 * g->K;
-  bk.order = g->pair_order, bk.gpatch = nullptr;
+  bk.order = g->rec_order, bk.gpatch = nullptr;
+  bk.seg_cnt = g->seg_cnt, bk.seg_cap = SCREEN_CAP, bk.rec_n = rec_n, bk.rec_ub = rec_ub, bk.lfinal = g->lfinal;
   const unsigned chunks = (unsigned)((slots + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
   gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
   gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+  if (g->K <= KORDER_MAX_K) gmm_korder_kernel<<<1, 256, 0, s>>>(bk.counts, g->K, g->korder);
   JD_LAUNCH_CHECK();
 
   GmmExactArgs ex{};
   ex.flux = a.flux, ex.afrag = g->afrag, ex.mfrag = g->mfrag, ex.const_k = g->const_k;
-  ex.pair_n = pair_n, ex.pair_k = pair_k, ex.order = g->pair_order, ex.offsets = bk.offsets, ex.flag = flag;
+  ex.rec_n = rec_n, ex.order = g->rec_order, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag;
   ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
   ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
-  long ex_blocks = (long)(bucket_slots / 32 + 3) / 4;
-  if (ex_blocks > (long)g->n_cu * 3) ex_blocks = (long)g->n_cu * 3;
-  gmm_exact_kernel<true><<<(unsigned)ex_blocks, 256, 0, s>>>(ex);
+  gmm_exact_kernel<true><<<(unsigned)(g->n_cu * 3), 256, 0, s>>>(ex);
   JD_LAUNCH_CHECK();
 
   // fallback: the dense fp32 kernel, gated on the device flag (returns at once in the normal case)
   GmmFwdArgs dense = a;
   dense.run_flag = flag, dense.best_out = g->best, dense.argmax_out = nullptr, dense.value_patch = nullptr;
-  int dense_partials = 0;
   {
     const int tb = pick_block_tiles(n, g->n_cu);
     const unsigned dblocks = (unsigned)((n + 32L * tb - 1) / (32L * tb));
-    dense_partials = (int)dblocks;
-    (void)dense_partials;
     switch (tb) {
       case 16: rc = launch_fwd_tb<16, MODE_MAX, true>(dense, dblocks, s); break;
       case 8: rc = launch_fwd_tb<8, MODE_MAX, true>(dense, dblocks, s); break;
@@ -1369,6 +1469,19 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   gmm_best_kernel<<<best_blocks, 256, 0, s>>>(be);
   JD_LAUNCH_CHECK();
   *n_partials = (int)best_blocks;
+  if (getenv("JD_GMM_SCREEN_DEBUG")) {  // tuning only: synchronises
+    std::vector<int> ctl(3 * g->K + 2), seg(n_seg);
+    JD_HIP(hipStreamSynchronize(s));
+    JD_HIP(hipMemcpy(ctl.data(), g->screen_ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost));
+    JD_HIP(hipMemcpy(seg.data(), g->seg_cnt, seg.size() * sizeof(int), hipMemcpyDeviceToHost));
+    long survivors = 0, records = 0;
+    int seg_max = 0;
+    for (int k = 0; k < g->K; ++k) survivors += ctl[1 + k];
+    for (int v : seg) records += v, seg_max = v > seg_max ? v : seg_max;
+    fprintf(stderr, "[jd gmm screen] patches %ld records %ld (%.2f per patch, fullest wave %d of %d) survivors %ld (%.2f per "
+            "patch) fallback %d\n", n, records, (double)records / (double)n, seg_max, SCREEN_CAP, survivors,
+            (double)survivors / (double)n, ctl[0]);
+  }
   return JD_OK;
 }
 
@@ -1385,6 +1498,8 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   JD_REQUIRE(patch_row_begin >= 0 && patch_row_begin <= patch_row_end && patch_row_end <= nPy,
              "jd_gmm_prior_fwd_bwd: patch row range [%d, %d) outside [0, %d]", patch_row_begin, patch_row_end, nPy);
   hipStream_t s = as_stream(stream);
+  shift_y = ((shift_y % H) + H) % H;  // roll by any integer = roll by its residue (the kernels' wrap() relies on it)
+  shift_x = ((shift_x % W) + W) % W;
   const int n_begin = patch_row_begin * nPx, n_end = patch_row_end * nPx;
   if (n_begin == n_end) {  // empty shard: contributes nothing
     if (!accumulate_value) JD_HIP(hipMemsetAsync(value_out, 0, sizeof(float), s));
