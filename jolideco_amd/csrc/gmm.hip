@@ -415,16 +415,21 @@ __device__ __forceinline__ bool bucket_block_empty(const GmmBucketArgs& a, int b
 constexpr int BUCKET_CHUNK = 1024;  // patches per block (4 per thread)
 constexpr int BUCKET_MAX_K = 4096;  // LDS histogram capacity
 
+// Each block walks over chunks blockIdx.x, blockIdx.x + gridDim.x, ... and touches the global counters once per
+// bin: with one chunk per block the (bins x blocks) global atomics on a few hundred addresses were the cost.
 __global__ __launch_bounds__(256) void gmm_bucket_count_kernel(GmmBucketArgs a) {
   extern __shared__ int hist[];
-  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
-  if (bucket_block_empty(a, base)) return;
   for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
   __syncthreads();
+  const int n_chunks = (a.n_end - a.n_begin + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int base = a.n_begin + c * BUCKET_CHUNK;
+    if (bucket_block_empty(a, base)) continue;
 #pragma unroll
-  for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
-    const int k = bucket_key(a, base + i * 256 + threadIdx.x);
-    if (k >= 0) atomicAdd(&hist[k], 1);
+    for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
+      const int k = bucket_key(a, base + i * 256 + threadIdx.x);
+      if (k >= 0) atomicAdd(&hist[k], 1);
+    }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < a.K; k += 256)
@@ -458,32 +463,43 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
 }
 
 __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a) {
-  extern __shared__ int hist[];  // [0, K): block-local counts, then the block's base inside each bucket
-  const int base = a.n_begin + blockIdx.x * BUCKET_CHUNK;
-  if (bucket_block_empty(a, base)) return;
+  extern __shared__ int hist[];  // [0, K): the block's counts, then its next free slot inside each bucket
   for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
   __syncthreads();
-  int kk[BUCKET_CHUNK / 256], rank[BUCKET_CHUNK / 256];
+  const int n_chunks = (a.n_end - a.n_begin + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+  // pass 1: how many elements of each bin does this block hold (same walk as the count kernel)
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int base = a.n_begin + c * BUCKET_CHUNK;
+    if (bucket_block_empty(a, base)) continue;
 #pragma unroll
-  for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
-    const int n = base + i * 256 + threadIdx.x;
-    kk[i] = bucket_key(a, n);
-    if (kk[i] >= 0) {
-      rank[i] = atomicAdd(&hist[kk[i]], 1);
-    } else if (kk[i] == -1 && a.gpatch) {  // filtered patch (patches/core.py:215-216): no gradient
-      float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
-      for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
+      const int k = bucket_key(a, base + i * 256 + threadIdx.x);
+      if (k >= 0) atomicAdd(&hist[k], 1);
     }
   }
   __syncthreads();
+  // reserve the block's range of every bucket with one global atomic per bin
   for (int k = threadIdx.x; k < a.K; k += 256) {
     const int c = hist[k];
     hist[k] = c ? a.offsets[k] + atomicAdd(&a.cursor[k], c) : 0;
   }
   __syncthreads();
+  // pass 2: place the elements (the order inside a bucket does not influence any result)
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int base = a.n_begin + c * BUCKET_CHUNK;
+    if (bucket_block_empty(a, base)) continue;
 #pragma unroll
-  for (int i = 0; i < BUCKET_CHUNK / 256; ++i)
-    if (kk[i] >= 0) a.order[hist[kk[i]] + rank[i]] = base + i * 256 + threadIdx.x;
+    for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
+      const int n = base + i * 256 + threadIdx.x;
+      const int k = bucket_key(a, n);
+      if (k >= 0) {
+        a.order[atomicAdd(&hist[k], 1)] = n;
+      } else if (k == -1 && a.gpatch) {  // filtered patch (patches/core.py:215-216): no gradient
+        float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
+        for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
 }
 
 struct GmmBwdArgs {
@@ -735,9 +751,10 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
 // for a fraction of the fp32 matrix work.
 //
 //   1. SCREEN (gmm_screen_kernel): every (patch, component) log-likelihood is first evaluated APPROXIMATELY with
-//      one bf16 MFMA product, ytilde = bf16(xbar)^T bf16(P'_k) (fp32 accumulate; v_mfma_f32_32x32x16_bf16 runs at
+//      one fp16 MFMA product, ytilde = fp16(xbar / s_x)^T fp16(P'_k / s_k) (power-of-two scales, fp32 accumulate;
+//      v_mfma_f32_32x32x16_f16 runs at
 //      16x the rate of the fp32-input MFMA), together with a rigorous bound on its distance to the fp32 value:
-//        |ytilde_j - y_j| <= eps |xbar| |P'_k[:, j]|,   eps = 2^-7 + 2^-16 + accumulation  (two bf16 roundings)
+//        |ytilde_j - y_j| <= eps |xbar| |P'_k[:, j]|,   eps = 2^-10 + 2^-22 + accumulation  (two fp16 roundings)
 //        |ltilde - l|     <= B = sqrt(2 qtilde) e + e^2 / 2 (+ fp32 rounding slack),  e = eps |xbar| |P'_k|_F
 //      (Cauchy-Schwarz twice; qtilde = sum_j ytilde_j^2 / 2).  Sweep 1 over the components finds
 //      L = max_k (ltilde - B), a lower bound of the true maximum; sweep 2 keeps the components with
@@ -752,20 +769,21 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
 // device flag; the dense fp32 kernel then runs (it is always enqueued and returns at once when the flag is clear)
 // and overwrites the per-patch results.  No host synchronisation anywhere.
 // ------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int SCREEN_T = 4;        // tiles of 32 patches per wave
 constexpr int SCREEN_CAP = 4096;   // candidate records a wave can hold (128 patches: 32 per patch); multiple of BUCKET_CHUNK
 constexpr int A16_BLOCKS = 6;      // non-zero (32 coordinates x 16 pixels) blocks of an upper triangular P'
-constexpr float SCREEN_EPS = 0.0079f;
+constexpr float SCREEN_EPS = 0.001f;  // two fp16 roundings 2^-10 + 2^-22, two fp32 accumulations of 64 terms, slack
 constexpr int KORDER_MAX_K = 1024;  // the popularity order of the components is maintained up to this K
 
 struct GmmScreenArgs {
   const float* flux;
-  const uint4* afrag16;  // K * A16_BLOCKS * 64 lanes * 8 bf16
+  const uint4* afrag16;  // K * A16_BLOCKS * 64 lanes * 8 fp16 of P'_k / s_k
   const float* const_k;  // K
   const float* efro_k;   // K: SCREEN_EPS * |P'_k|_F (rounded up)
+  const float* sk2_k;    // K: s_k^2, the squared power-of-two scale of the fp16 fragments
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
   const int* korder;         // K: the order in which the components are visited (most popular first)
   unsigned long long* best;  // per patch (global index): initialised here
@@ -778,7 +796,7 @@ struct GmmScreenArgs {
 };
 
 struct ScreenFrags {
-  bf16x8 a[A16_BLOCKS];
+  f16x8 a[A16_BLOCKS];
 };
 
 __device__ __forceinline__ void load_frags16(ScreenFrags& f, const uint4* af, int k) {
@@ -786,23 +804,23 @@ __device__ __forceinline__ void load_frags16(ScreenFrags& f, const uint4* af, in
 #pragma unroll
   for (int b = 0; b < A16_BLOCKS; ++b) {
     const uint4 v = ak[b * 64];
-    f.a[b] = __builtin_bit_cast(bf16x8, v);
+    f.a[b] = __builtin_bit_cast(f16x8, v);
   }
 }
 
 // ytilde for one tile: coordinate block 0 (j < 32) needs pixel steps 0, 1; block 1 all four
-__device__ __forceinline__ void mfma_screen(f32x16 (&acc)[2], const ScreenFrags& f, const bf16x8 (&x)[4]) {
+__device__ __forceinline__ void mfma_screen(f32x16 (&acc)[2], const ScreenFrags& f, const f16x8 (&x)[4]) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], x[0], zero, 0, 0, 0);
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[2], x[0], zero, 0, 0, 0);
-  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], x[1], acc[0], 0, 0, 0);
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[3], x[1], acc[1], 0, 0, 0);
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[4], x[2], acc[1], 0, 0, 0);
-  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[5], x[3], acc[1], 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0], x[0], zero, 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[2], x[0], zero, 0, 0, 0);
+  acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[1], x[1], acc[0], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[3], x[1], acc[1], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[4], x[2], acc[1], 0, 0, 0);
+  acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[5], x[3], acc[1], 0, 0, 0);
 }
 
-// q = sum_j ytilde_j^2 of the lane's patch from the two accumulator blocks (both lane halves)
-__device__ __forceinline__ float screen_q(const f32x16 (&acc)[2]) {
+// The lane's share of q = sum_j ytilde_j^2 (the 32 coordinates of its lane half)
+__device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
   f32x2 q2 = {0.f, 0.f};
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -811,30 +829,34 @@ __device__ __forceinline__ float screen_q(const f32x16 (&acc)[2]) {
       const f32x2 v = {acc[b][r], acc[b][r + 1]};
       q2 = __builtin_elementwise_fma(v, v, q2);
     }
-  const float q = q2[0] + q2[1];
-  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(q), __float_as_uint(q), false, false);
-  return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  return q2[0] + q2[1];
 }
 
-// One (tile, component): ltilde = ck - q / 2 and the bound
-//   |l - ltilde| <= sqrt(q) e + e^2 / 2,  e = eps |xbar| |P'_k|_F
+// TWO tiles (A, B) and one component: after the MFMAs lane (h, c) holds half of q for patch c of both tiles.  One
+// v_permlane32_swap hands lanes 0-31 both halves of tile A and lanes 32-63 both halves of tile B, so the per-patch
+// arithmetic below runs once for the two tiles (per-lane state: half 0 = tile A's patch, half 1 = tile B's):
+//   ltilde = ck - q / 2,   |l - ltilde| <= sqrt(q) e + e^2 / 2,  e = eps |xbar| |P'_k|_F
 // inflated for the fp32 rounding of q, l, the hardware square root (1 ulp) and of this expression itself:
 //   B = sqrt(q) * e1 + 2e-5 q + c2,   e1 = 1.001 e,   c2 = 0.5 e1^2 + 1e-6 |ck| + 1e-30.
 // ONE sweep over the components: a component is recorded while its upper bound reaches the running lower bound L of
 // the maximum; records made before L rose are dropped later (bucket_key) against the final L.  Visiting the
 // components most-popular-first makes L rise early, so few stale records are written.
 // The issue slots beside the MFMAs are the budget (about six 4-cycle VALU instructions hide per 32-cycle MFMA).
-__device__ __forceinline__ void screen_finish(const f32x16 (&acc)[2], float ck, float ack, float hef2, float efro, float xn,
-                                              float xn2, bool ok, float& L, float& qacc, int n, int k, int lane, int seg,
-                                              int& cnt, const GmmScreenArgs& a) {
-  const float q = screen_q(acc);
+__device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], const f32x16 (&accB)[2], float ck, float ack,
+                                                   float hef2, float efro, float xn, float xn2, float s2, bool ok,
+                                                   float& L, float& qacc, int n, int k, int lane, int seg, int& cnt,
+                                                   const GmmScreenArgs& a) {
+  const float qa = screen_q_half(accA), qb = screen_q_half(accB);
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
+  // lanes 0-31: tile A, lanes 32-63: tile B; s2 = (s_x s_k)^2 undoes the power-of-two operand scales (exactly)
+  const float q = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * s2;
   qacc += q;  // a NaN / inf anywhere ends up here and raises the fallback flag
   const float e1 = efro * xn;            // efro carries eps and the factor 1.001
   const float c2 = fmaf(hef2, xn2, ack);  // hef2 = efro^2 / 2
   const float l = fmaf(-0.5f, q, ck);
   const float B = fmaf(__builtin_amdgcn_sqrtf(q), e1, fmaf(2e-5f, q, c2));
   const float ub = l + B;
-  const bool cand = ok && lane < 32 && ub >= L;
+  const bool cand = ok && ub >= L;
   L = fmaxf(L, l - B);
   const unsigned long long mask = __ballot(cand);
   if (mask) {
@@ -850,12 +872,12 @@ __device__ __forceinline__ void screen_finish(const f32x16 (&acc)[2], float ck, 
 
 __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   static_assert(SCREEN_T == 4, "the pipeline below is written for 4 tiles");
-  __shared__ uint4 xs[4][SCREEN_T * 4 * 64];  // per wave: [tile][pixel step][lane] = 8 bf16 (B fragment)
+  __shared__ uint4 xs[4][SCREEN_T * 4 * 64];  // per wave: [tile][pixel step][lane] = 8 fp16 (B fragment)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
   const int base = a.n_begin + wave_global * (SCREEN_T * 32);
   const int h = lane >> 5, c = lane & 31;  // lane (h, c): image rows 2 s + h (pixel step s) of patch c
-  float xn[SCREEN_T], xn2[SCREEN_T], L[SCREEN_T], qacc[SCREEN_T];
+  float xn[SCREEN_T], xs2[SCREEN_T];
   bool ok[SCREEN_T];
   int nidx[SCREEN_T];
 #pragma unroll
@@ -887,16 +909,22 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     const int sel_other = __shfl_xor((int)sel, 32, 64);  // unconditional: see gmm_fwd_kernel
     sel = sel && sel_other != 0;
     xn[t] = __builtin_sqrtf(n2) * 1.0001f;
-    xn2[t] = xn[t] * xn[t];
     ok[t] = valid && sel;
     nidx[t] = n;
-    L[t] = -INFINITY;
-    qacc[t] = 0.f;
+    // fp16 operand: xbar / s_x with the power of two s_x that puts max |xbar| into [2^13, 2^14) -- the scaling is
+    // exact, nothing overflows (fp16 max 65504), and whatever underflows is below 2^-27 of the largest pixel
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(x[i]));
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    int ex = 14;
+    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);
+    xs2[t] = ldexpf(1.f, 2 * (ex - 14));
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      bf16x8 v;
+      f16x8 v;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (__bf16)x[8 * s + e];
+      for (int e = 0; e < 8; ++e) v[e] = (_Float16)ldexpf(x[8 * s + e], 14 - ex);
       xs[wave][(t * 4 + s) * 64 + lane] = __builtin_bit_cast(uint4, v);
     }
     if (h == 0 && valid) a.best[n] = ok[t] ? best_key(-INFINITY, 0) : 0ull;
@@ -906,16 +934,30 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   const uint4* xs_lane = &xs[wave][lane];
   const int seg = wave_global * SCREEN_CAP;
   int cnt = 0;
+  // per-lane state of the two tile pairs: lane half 0 carries the patch of tile 2 p, half 1 that of tile 2 p + 1
+  float pxn[2], pxn2[2], pL[2], pq[2], ps2[2];
+  bool pok[2];
+  int pn[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    ps2[p] = h ? xs2[2 * p + 1] : xs2[2 * p];
+    pxn[p] = h ? xn[2 * p + 1] : xn[2 * p];
+    pxn2[p] = pxn[p] * pxn[p];
+    pok[p] = h ? ok[2 * p + 1] : ok[2 * p];
+    pn[p] = h ? nidx[2 * p + 1] : nidx[2 * p];
+    pL[p] = -INFINITY;
+    pq[p] = 0.f;
+  }
 
   ScreenFrags f0, f1;
-  bf16x8 x[4];
+  f16x8 x[4];
   f32x16 acc[SCREEN_T][2];
   auto load_x16 = [&](int t) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(bf16x8, xs_lane[(t * 4 + s) * 64]);
+    for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(f16x8, xs_lane[(t * 4 + s) * 64]);
   };
   int k_next = a.korder[0];
-  float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next];
+  float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next];
   load_frags16(f0, af, k_next);
   // prologue: tiles 0, 1 of the first component
   load_x16(0);
@@ -924,33 +966,31 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   mfma_screen(acc[1], f0, x);
   for (int kk = 0; kk < a.K; ++kk) {
     const int k = k_next;
-    const float ck = ck_next, ef = ef_next;
+    const float ck = ck_next, ef = ef_next, sk2 = sk2_next;
     const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f), hef2 = 0.5f * ef * ef;
     k_next = a.korder[kk + 1 < a.K ? kk + 1 : kk];  // scalar loads one component ahead of their use
-    ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next];
+    ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next];
     load_frags16(f1, af, k_next);  // unconditional (clamped) prefetch of the next component
     // tiles 2, 3 of k on the matrix pipe while tiles 0, 1 of k finish in its shadow
     load_x16(2);
     mfma_screen(acc[2], f0, x);
-    screen_finish(acc[0], ck, ack, hef2, ef, xn[0], xn2[0], ok[0], L[0], qacc[0], nidx[0], k, lane, seg, cnt, a);
     load_x16(3);
     mfma_screen(acc[3], f0, x);
-    screen_finish(acc[1], ck, ack, hef2, ef, xn[1], xn2[1], ok[1], L[1], qacc[1], nidx[1], k, lane, seg, cnt, a);
+    screen_finish_pair(acc[0], acc[1], ck, ack, hef2, ef, pxn[0], pxn2[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane, seg, cnt, a);
     // tiles 0, 1 of the next component while tiles 2, 3 of k finish
     load_x16(0);
     mfma_screen(acc[0], f1, x);
-    screen_finish(acc[2], ck, ack, hef2, ef, xn[2], xn2[2], ok[2], L[2], qacc[2], nidx[2], k, lane, seg, cnt, a);
     load_x16(1);
     mfma_screen(acc[1], f1, x);
-    screen_finish(acc[3], ck, ack, hef2, ef, xn[3], xn2[3], ok[3], L[3], qacc[3], nidx[3], k, lane, seg, cnt, a);
+    screen_finish_pair(acc[2], acc[3], ck, ack, hef2, ef, pxn[1], pxn2[1], ps2[1] * sk2, pok[1], pL[1], pq[1], pn[1], k, lane, seg, cnt, a);
 #pragma unroll
     for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
   }
   bool trouble = false;
 #pragma unroll
-  for (int t = 0; t < SCREEN_T; ++t) {
-    trouble = trouble || (ok[t] && !(qacc[t] < 3.0e38f));
-    if (h == 0 && nidx[t] < a.n_end) a.lfinal[nidx[t]] = L[t];
+  for (int p = 0; p < 2; ++p) {
+    trouble = trouble || (pok[p] && !(pq[p] < 3.0e38f));
+    if (pn[p] < a.n_end) a.lfinal[pn[p]] = pL[p];
   }
   if (lane == 0) a.seg_cnt[wave_global] = cnt < SCREEN_CAP ? cnt : SCREEN_CAP;
   if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
@@ -1005,16 +1045,38 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
   const int n_waves = gridDim.x * 4;
   const int n_groups = a.offsets[a.K] >> 5;
   float* st = stage[wave];
-  for (int grp = wave_global; grp < n_groups; grp += n_waves) {
-    // bucket of this group: the last k with offsets[k] <= 32 grp (buckets are padded to 32, so a group never straddles)
-    int lo = 0, hi = a.K;
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (a.offsets[mid] <= 32 * grp) lo = mid; else hi = mid;
+  // a contiguous run of groups per wave: the 40 KB of P'_k fragments are loaded once per component, not per group
+  const int per_wave = (n_groups + n_waves - 1) / n_waves;
+  const int g_begin = wave_global * per_wave, g_end = g_begin + per_wave < n_groups ? g_begin + per_wave : n_groups;
+  int k = -1;
+  float ck = 0.f;
+  float4 A[4][4], M[4];
+  for (int grp = g_begin; grp < g_end; ++grp) {
+    int kg = k;
+    if (kg < 0) {  // first group: the last k with offsets[k] <= 32 grp (buckets are padded to 32: no straddling)
+      int lo = 0, hi = a.K;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.offsets[mid] <= 32 * grp) lo = mid; else hi = mid;
+      }
+      kg = lo;
+    } else {
+      while (a.offsets[kg + 1] <= 32 * grp) ++kg;  // groups ascend, so do the buckets
     }
-    const int k = lo;
+    if (kg != k) {
+      k = kg;
+      ck = a.const_k[k];
+      const float4* ak = reinterpret_cast<const float4*>(a.afrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
+      const float4* mk = reinterpret_cast<const float4*>(a.mfrag) + (size_t)k * 16 + g;
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {
+        M[jb] = mk[jb * 4];
+#pragma unroll
+        for (int st4 = 0; st4 < 4; ++st4)
+          if (!TRI || st4 <= jb) A[jb][st4] = ak[(jb * 4 + st4) * 64];
+      }
+    }
     const int nvalid = a.counts[k] - (32 * grp - a.offsets[k]);  // >= 1
-    const float ck = a.const_k[k];
     // ---- stage: lane (q = lane / 2, hh = lane % 2) fetches columns 4 hh .. 4 hh + 3 of the 8 rows of record q
     {
       const int q = lane >> 1, hh = lane & 1;
@@ -1053,21 +1115,17 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
       for (int s4 = 0; s4 < 16; ++s4) x[nb][s4] -= mean;
     }
     f32x4 y[4][2];
-    const float4* ak = reinterpret_cast<const float4*>(a.afrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
-    const float4* mk = reinterpret_cast<const float4*>(a.mfrag) + (size_t)k * 16 + g;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
-      const float4 m = mk[jb * 4];
-      y[jb][0] = y[jb][1] = f32x4{m.x, m.y, m.z, m.w};
+      y[jb][0] = y[jb][1] = f32x4{M[jb].x, M[jb].y, M[jb].z, M[jb].w};
 #pragma unroll
       for (int st4 = 0; st4 < 4; ++st4) {
         if (TRI && st4 > jb) continue;
-        const float4 A = ak[(jb * 4 + st4) * 64];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb)
-            y[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, e), x[nb][4 * st4 + e], y[jb][nb], 0, 0, 0);
+            y[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A[jb][st4], e), x[nb][4 * st4 + e], y[jb][nb], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -1168,10 +1226,11 @@ struct jd_gmm {
   double* partials = nullptr;
   size_t partials_cap = 0;
   int n_cu = 256;
-  // screened arg-max (zero-mean, upper triangular mixtures): bf16 fragments, bound constants, work space
+  // screened arg-max (zero-mean, upper triangular mixtures): fp16 fragments, bound constants, work space
   bool screen_ok = false;
   uint4* afrag16 = nullptr;
   float* efro_k = nullptr;
+  float* sk2_k = nullptr;
   unsigned long long* best = nullptr;
   size_t best_cap = 0;
   float* lfinal = nullptr;
@@ -1241,39 +1300,62 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     for (int j = 0; j < D; ++j) mfrag[(size_t)k * 64 + j] = -mrow[j];
   }
   g->triangular = tri;
-  // screening operands: bf16(P') in 32x32x16 A-fragment order, blocks (jb, s) = (0,0) (0,1) (1,0) (1,1) (1,2) (1,3):
+  // screening operands: fp16(P' / s_k) in 32x32x16 A-fragment order, blocks (jb, s) = (0,0) (0,1) (1,0) (1,1) (1,2) (1,3):
   // lane l holds A[row l & 31][k = 8 (l >> 5) + e] = P'[pixel 16 s + 8 (l >> 5) + e][32 jb + (l & 31)]
   bool zero_means = true;
   for (size_t i = 0; i < (size_t)K * D; ++i) zero_means = zero_means && mu_prec[i] == 0.f;
   std::vector<uint16_t> a16;
-  std::vector<float> efro;
+  std::vector<float> efro, sk2;
   if (tri && zero_means) {
-    auto to_bf16 = [](float f) -> uint16_t {  // round to nearest even
+    auto to_half = [](float f) -> uint16_t {  // IEEE binary16, round to nearest even (|f| < 65504 here)
       uint32_t u;
       memcpy(&u, &f, 4);
-      if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)(u >> 16);
-      return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+      const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+      const int32_t e = (int32_t)((u >> 23) & 0xFF) - 127;
+      uint32_t m = u & 0x7FFFFFu;
+      if (e < -25) return sign;               // underflows to zero
+      if (e < -14) {                          // subnormal half
+        m |= 0x800000u;
+        const int shift = -e - 14 + 13;       // 14 .. 24
+        uint32_t h = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+      }
+      uint32_t h = ((uint32_t)(e + 15) << 10) | (m >> 13);
+      const uint32_t rem = m & 0x1FFFu;
+      if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;  // a carry into the exponent is the right answer
+      return (uint16_t)(sign | h);
     };
     static const int blk_jb[A16_BLOCKS] = {0, 0, 1, 1, 1, 1}, blk_s[A16_BLOCKS] = {0, 1, 0, 1, 2, 3};
     a16.resize((size_t)K * A16_BLOCKS * 64 * 8);
     efro.resize(K);
+    sk2.resize(K);
     for (int k = 0; k < K; ++k) {
       const float* Pk = prec_chol + (size_t)k * D * D;
-      double fro = 0.0;
+      double fro = 0.0, amax = 0.0;
       for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) {
           const float v = (float)((double)Pk[i * D + j] * sw[j]);
           fro += (double)v * v;
+          amax = std::fmax(amax, std::fabs((double)v));
         }
+      // fp16 operand P'_k / s_k with the power of two s_k that puts max |P'_k| into [2^13, 2^14)
+      int ex = 14;
+      if (amax > 0.0 && std::isfinite(amax)) (void)std::frexp(amax, &ex);
+      const double inv_s = std::ldexp(1.0, 14 - ex);
+      sk2[k] = (float)std::ldexp(1.0, 2 * (ex - 14));
       efro[k] = (float)(std::sqrt(fro) * (double)SCREEN_EPS * 1.0011);  // includes the 1.001 inflation of the bound
+      if (!std::isfinite(efro[k]) || !(sk2[k] > 0.f) || !std::isfinite(sk2[k])) zero_means = false;  // no screening
       for (int b = 0; b < A16_BLOCKS; ++b)
         for (int lane = 0; lane < 64; ++lane)
           for (int e = 0; e < 8; ++e) {
             const int pix = 16 * blk_s[b] + 8 * (lane >> 5) + e, j = 32 * blk_jb[b] + (lane & 31);
-            const float v = (float)((double)Pk[pix * D + j] * sw[j]);
-            a16[(((size_t)k * A16_BLOCKS + b) * 64 + lane) * 8 + e] = to_bf16(v);
+            const float v = (float)((double)Pk[pix * D + j] * sw[j] * inv_s);
+            a16[(((size_t)k * A16_BLOCKS + b) * 64 + lane) * 8 + e] = to_half(v);
           }
     }
+    if (!zero_means) a16.clear();
   }
   auto upload = [&](float** dst, const float* src, size_t n) -> int {
     JD_HIP(hipMalloc(dst, n * sizeof(float)));
@@ -1293,7 +1375,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
   if (!a16.empty()) {
     if (hipMalloc(&g->afrag16, a16.size() * sizeof(uint16_t)) != hipSuccess ||
         hipMemcpy(g->afrag16, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
-        (rc = upload(&g->efro_k, efro.data(), efro.size())) ||
+        (rc = upload(&g->efro_k, efro.data(), efro.size())) || (rc = upload(&g->sk2_k, sk2.data(), sk2.size())) ||
         hipMalloc(&g->screen_ctl, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess ||
         hipMalloc(&g->korder, (size_t)K * sizeof(int)) != hipSuccess) {
       jd_gmm_destroy(g);
@@ -1323,6 +1405,7 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->argmax) (void)hipFree(g->argmax);
   if (g->afrag16) (void)hipFree(g->afrag16);
   if (g->efro_k) (void)hipFree(g->efro_k);
+  if (g->sk2_k) (void)hipFree(g->sk2_k);
   if (g->best) (void)hipFree(g->best);
   if (g->lfinal) (void)hipFree(g->lfinal);
   if (g->rec) (void)hipFree(g->rec);
@@ -1394,7 +1477,7 @@ static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, in
   }
 }
 
-// Max mode through the bf16 screen (see gmm_screen_kernel): fills a.argmax_out (if any) and one fp64 partial sum per
+// Max mode through the fp16 screen (see gmm_screen_kernel): fills a.argmax_out (if any) and one fp64 partial sum per
 // 1024 patches, exactly the numbers gmm_fwd_kernel<MODE_MAX> produces.
 static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials) {
   const long n = a.n_end - a.n_begin;
@@ -1419,7 +1502,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmScreenArgs sc{};
-  sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k, sc.korder = g->korder;
+  sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k, sc.sk2_k = g->sk2_k, sc.korder = g->korder;
   sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
   sc.best = g->best, sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
@@ -1433,7 +1516,8 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   bk.counts = g->screen_ctl + 1, bk.cursor = g->screen_ctl + 1 + g->K, bk.offsets = g->screen_ctl + 1 + 2 * g->K;
   bk.order = g->rec_order, bk.gpatch = nullptr;
   bk.seg_cnt = g->seg_cnt, bk.seg_cap = SCREEN_CAP, bk.rec_n = rec_n, bk.rec_ub = rec_ub, bk.lfinal = g->lfinal;
-  const unsigned chunks = (unsigned)((slots + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+  unsigned chunks = (unsigned)((slots + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+  if (chunks > (unsigned)(4 * g->n_cu)) chunks = (unsigned)(4 * g->n_cu);  // the kernels stride over the chunks
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
   gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
@@ -1563,7 +1647,8 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   bk.order = g->order, bk.gpatch = g->gpatch;
   JD_HIP(hipMemsetAsync(g->bucket, 0, (size_t)2 * g->K * sizeof(int), s));
   JD_HIP(hipMemsetAsync(g->order, 0xFF, slots_cap * sizeof(int32_t), s));
-  const unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+  unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+  if (chunks > (unsigned)(4 * g->n_cu)) chunks = (unsigned)(4 * g->n_cu);
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   {
     ProfScope prof(JD_KERNEL_GMM_BWD, s);
