@@ -22,6 +22,7 @@
 // Backward (max mode): the patches are bucketed by arg-max component; one wave takes 32 patches that
 // share P'_k and runs y = x^T P' - m' and gamma = -P' y on the matrix cores (same block skipping);
 // the overlap-add is done race-free and in a fixed order by a gather pass.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -397,6 +398,8 @@ struct GmmBucketArgs {
   const int32_t* rec_n;
   const float* rec_ub;
   const float* lfinal;
+  // [gridDim.x][K]: per-block bin counts (count kernel), turned into the block's offset inside each bin (binscan)
+  int* blk_counts;
 };
 
 // component of element n, or -1 if it takes no part
@@ -432,8 +435,35 @@ __global__ __launch_bounds__(256) void gmm_bucket_count_kernel(GmmBucketArgs a) 
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < a.K; k += 256)
-    if (hist[k]) atomicAdd(&a.counts[k], hist[k]);
+  for (int k = threadIdx.x; k < a.K; k += 256) a.blk_counts[(size_t)blockIdx.x * a.K + k] = hist[k];
+}
+
+// Block k: exclusive prefix over the blocks of bin k's per-block counts (in place) and the bin total.  No global
+// atomics anywhere in the sort: with hundreds of blocks hammering a few hundred counters they were its whole cost.
+__global__ __launch_bounds__(256) void gmm_bucket_binscan_kernel(GmmBucketArgs a, int n_blk) {
+  __shared__ int part[2][256];
+  const int k = blockIdx.x;
+  const int per = (n_blk + 255) / 256;
+  const int b0 = threadIdx.x * per;
+  int local = 0;
+  for (int b = b0; b < b0 + per && b < n_blk; ++b) local += a.blk_counts[(size_t)b * a.K + k];
+  int cur = 0;
+  part[0][threadIdx.x] = local;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int v = part[cur][threadIdx.x];
+    if ((int)threadIdx.x >= off) v += part[cur][threadIdx.x - off];
+    part[cur ^ 1][threadIdx.x] = v;
+    cur ^= 1;
+    __syncthreads();
+  }
+  int run = part[cur][threadIdx.x] - local;
+  for (int b = b0; b < b0 + per && b < n_blk; ++b) {
+    const int v = a.blk_counts[(size_t)b * a.K + k];
+    a.blk_counts[(size_t)b * a.K + k] = run;
+    run += v;
+  }
+  if (threadIdx.x == 255) a.counts[k] = part[cur][255];
 }
 
 __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
@@ -463,26 +493,11 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
 }
 
 __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a) {
-  extern __shared__ int hist[];  // [0, K): the block's counts, then its next free slot inside each bucket
-  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
-  __syncthreads();
+  extern __shared__ int hist[];  // [0, K): the block's next free slot inside each bucket
   const int n_chunks = (a.n_end - a.n_begin + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
-  // pass 1: how many elements of each bin does this block hold (same walk as the count kernel)
-  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const int base = a.n_begin + c * BUCKET_CHUNK;
-    if (bucket_block_empty(a, base)) continue;
-#pragma unroll
-    for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
-      const int k = bucket_key(a, base + i * 256 + threadIdx.x);
-      if (k >= 0) atomicAdd(&hist[k], 1);
-    }
-  }
-  __syncthreads();
-  // reserve the block's range of every bucket with one global atomic per bin
-  for (int k = threadIdx.x; k < a.K; k += 256) {
-    const int c = hist[k];
-    hist[k] = c ? a.offsets[k] + atomicAdd(&a.cursor[k], c) : 0;
-  }
+  // the block's first slot inside every bucket: bucket offset + the counts of the blocks before it (binscan); the
+  // walk over the chunks is the count kernel's, so the numbers match
+  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = a.offsets[k] + a.blk_counts[(size_t)blockIdx.x * a.K + k];
   __syncthreads();
   // pass 2: place the elements (the order inside a bucket does not influence any result)
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -1241,6 +1256,8 @@ struct jd_gmm {
   size_t rec_order_cap = 0;
   int* seg_cnt = nullptr;
   size_t seg_cnt_cap = 0;
+  int* blk_counts = nullptr;  // per-block bin counts of the bucket sort
+  size_t blk_counts_cap = 0;
   int* korder = nullptr;      // K: visiting order of the components (most survivors in the previous call first)
   int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | cursor (K) | offsets (K + 1)
 };
@@ -1412,6 +1429,7 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->rec_order) (void)hipFree(g->rec_order);
   if (g->seg_cnt) (void)hipFree(g->seg_cnt);
   if (g->korder) (void)hipFree(g->korder);
+  if (g->blk_counts) (void)hipFree(g->blk_counts);
   if (g->screen_ctl) (void)hipFree(g->screen_ctl);
   if (g->order) (void)hipFree(g->order);
   if (g->bucket) (void)hipFree(g->bucket);
@@ -1517,9 +1535,14 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   bk.order = g->rec_order, bk.gpatch = nullptr;
   bk.seg_cnt = g->seg_cnt, bk.seg_cap = SCREEN_CAP, bk.rec_n = rec_n, bk.rec_ub = rec_ub, bk.lfinal = g->lfinal;
   unsigned chunks = (unsigned)((slots + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
-  if (chunks > (unsigned)(4 * g->n_cu)) chunks = (unsigned)(4 * g->n_cu);  // the kernels stride over the chunks
+  // the kernels stride over the chunks; many small blocks hide the latency of the dependent record loads
+  const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
+  if (chunks > max_blocks) chunks = max_blocks;
+  if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
+  bk.blk_counts = g->blk_counts;
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+  gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
   gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
   gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
   if (g->K <= KORDER_MAX_K) gmm_korder_kernel<<<1, 256, 0, s>>>(bk.counts, g->K, g->korder);
@@ -1648,11 +1671,15 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   JD_HIP(hipMemsetAsync(g->bucket, 0, (size_t)2 * g->K * sizeof(int), s));
   JD_HIP(hipMemsetAsync(g->order, 0xFF, slots_cap * sizeof(int32_t), s));
   unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
-  if (chunks > (unsigned)(4 * g->n_cu)) chunks = (unsigned)(4 * g->n_cu);
+  const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
+  if (chunks > max_blocks) chunks = max_blocks;
+  if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
+  bk.blk_counts = g->blk_counts;
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   {
     ProfScope prof(JD_KERNEL_GMM_BWD, s);
     gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+    gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
     gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
     gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
     GmmBwdArgs b{};
