@@ -45,6 +45,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
+F16_MATRIX_PEAK_TFLOPS = 2516.6  # 16 x the fp32 rate: v_mfma_f32_32x32x16_f16, dense (MI355X_MICROARCH.md: ~2.5 PF)
 PATCH, D, STRIDE = 8, 64, 4
 PROFILE_EVERY = 4  # steps of the timed region whose kernels are timed with hipEvent pairs: 0, 4, 8, ...
 
@@ -87,8 +88,11 @@ def pmc_traffic_bytes(cfg_name, kernel):
         return None
     fetch = write = None
     with open(path) as fh:
-        for row in csv.DictReader(fh):
-            if row["config"] == cfg_name and kernel in row["kernel"]:
+        rows = list(csv.DictReader(fh))
+    # "<config>s" rows: the same workload profiled on the current build (separable convolution, screened GMM)
+    for label in (cfg_name, cfg_name + "s"):
+        for row in rows:
+            if row["config"] == label and kernel in row["kernel"]:
                 if row["counter"] == "FETCH_SIZE":
                     fetch = float(row["avg_per_launch_KB"])
                 elif row["counter"] == "WRITE_SIZE":
@@ -249,17 +253,36 @@ def main():
         total, count = prof[name]
         return (total / count if count else None), count
 
-    # dominant kernel: GMM forward, fp32 matrix cores.  P_k is upper triangular, so the algorithmic
-    # work per (patch, component) is D (D + 1) multiply-adds + 4 D epilogue flop = D^2 + 5 D (the
-    # SURVEY section 8(d) figure 2 D^2 + 4 D counts the structural zeros of P_k); the kernel executes
-    # the 40 non-zero 16 x 16 x 4 MFMA blocks per 16 patches = 5120 flop + 4 D.  `achieved` uses the
-    # algorithmic count, `executed_*` what the matrix cores really did.
+    # GMM forward pass.  Algorithmic work per (patch, component): P_k is upper triangular, so D (D + 1) multiply-adds
+    # + 4 D epilogue flop = D^2 + 5 D (the SURVEY section 8(d) figure 2 D^2 + 4 D counts the structural zeros of P_k).
+    #  * dense kernel (logsumexp mode, mixtures with means, JD_GMM_SCREEN=0): fp32 matrix cores, 40 non-zero
+    #    16 x 16 x 4 MFMA blocks per 16 patches = 5120 flop + 4 D executed;
+    #  * screened arg-max (default, max mode): stage 1 `gmm_screen_kernel` evaluates every (patch, component) with ONE
+    #    fp16 MFMA product (6 blocks of 32 x 32 x 16 per 32 patches = 6144 flop) plus a rigorous error bound, stage 3
+    #    re-evaluates the few survivors in fp32 -- same bits out as the dense kernel.  The dominant kernel is then
+    #    the screen: its roofline is the fp16 matrix peak, `achieved` counts the fp16 flop it executes, and the
+    #    fp32-equivalent algorithmic rate of the whole forward pass is reported next to it.
     gmm_ms, gmm_n = avg_ms("gmm_fwd")
+    scr_ms, scr_n = avg_ms("gmm_screen")
     gmm_flop = np_local * K * (D * D + 5 * D)
     gmm_flop_executed = np_local * K * (40 * 2 * 16 * 16 * 4 // 16 + 4 * D)
     gmm_flop_dense = np_local * K * (2 * D * D + 4 * D)
     roof_gmm = None
-    if gmm_ms:
+    if scr_ms:
+        f16_flop = np_local * K * (6 * 2 * 32 * 32 * 16 // 32)
+        achieved = f16_flop / (scr_ms * 1e-3) / 1e12
+        roof_gmm = {
+            "kernel": "gmm_screen_kernel", "bound": "mfma", "achieved": achieved, "peak": F16_MATRIX_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / F16_MATRIX_PEAK_TFLOPS,
+            "traffic": pmc_traffic_bytes(args.config, "gmm_screen_kernel") if world == 1 and fake is None else None,
+            "avg_launch_ms": scr_ms, "launches": scr_n, "flop_per_launch": f16_flop, "operand_dtype": "f16 (screen only)",
+            "forward_pass_ms": gmm_ms, "stage_ms": {k: avg_ms(k)[0] for k in ("gmm_screen", "gmm_sort", "gmm_exact")},
+            "algorithmic_fp32_flop": gmm_flop,
+            "algorithmic_fp32_equivalent_tflops": gmm_flop / (gmm_ms * 1e-3) / 1e12,
+            "note": "results are bit-identical to the fp32 MFMA kernel; the fp16 product only decides which "
+                    "components can NOT be the arg-max",
+        }
+    elif gmm_ms:
         achieved = gmm_flop / (gmm_ms * 1e-3) / 1e12
         executed = gmm_flop_executed / (gmm_ms * 1e-3) / 1e12
         roof_gmm = {
@@ -284,7 +307,8 @@ def main():
             "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes,
         }
     n_profiled = len(range(0, args.steps, PROFILE_EVERY))
-    kernel_ms_per_step = {k: (v[0] / n_profiled) for k, v in prof.items() if v[1]}
+    nested = ("gmm_screen", "gmm_sort", "gmm_exact")  # stage timers inside the gmm_fwd bracket
+    kernel_ms_per_step = {k: (v[0] / n_profiled) for k, v in prof.items() if v[1] and k not in nested}
     dominant = max(kernel_ms_per_step, key=kernel_ms_per_step.get) if kernel_ms_per_step else None
     roofline = roof_poi if dominant == "poisson_fused" else roof_gmm
 
@@ -324,10 +348,15 @@ def main():
         conv_ms, conv_n = avg_ms(conv_key)
         conv_bytes = 14 * H * W
         achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
+        conv_traffic = None
+        if world == 1 and fake is None:
+            names = ("sep_conv_kernel<true, true>", "sep_conv_kernel<true, false>") if conv_key == "sep_conv" else ("direct_conv_kernel",)
+            parts = [pmc_traffic_bytes(args.config, name) for name in names]
+            conv_traffic = sum(parts) / len(parts) if all(p is not None for p in parts) else None
         out["roofline_conv"] = {
             "kernel": _hip.lib().jd_kernel_name(_hip.KERNEL_IDS[conv_key]).decode(), "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "avg_launch_ms": conv_ms, "launches": conv_n, "bytes_per_launch": conv_bytes,
+            "traffic": conv_traffic, "avg_launch_ms": conv_ms, "launches": conv_n, "bytes_per_launch": conv_bytes,
         }
     # The same fit with the PSF treated as a general (not low-rank) kernel, i.e. what an instrument PSF that is not
     # a sum of <= 3 outer products gets: MFMA Toeplitz convolution.  Reported next to the headline, never as it.

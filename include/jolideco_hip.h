@@ -220,7 +220,7 @@ int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad
  * Calling jd_profile_enable again resets the counters. */
 enum {
   JD_KERNEL_POISSON_FUSED = 0,   /* K3: clip + background + Poisson NLL + gradient */
-  JD_KERNEL_GMM_FWD = 1,         /* K4: GMM patch log-likelihood, max / logsumexp over components */
+  JD_KERNEL_GMM_FWD = 1,         /* K4: GMM patch log-likelihood, max / logsumexp over components (whole forward pass) */
   JD_KERNEL_GMM_BWD = 2,         /* K4b: per-patch gradient for the selected component(s) */
   JD_KERNEL_GMM_GATHER = 3,      /* K4c: deterministic overlap-add of the patch gradients */
   JD_KERNEL_PAD_MUL = 4,         /* K1 */
@@ -231,7 +231,10 @@ enum {
   JD_KERNEL_FFT_C2R = 9,         /* rocFFT real inverse transform (all its kernels) */
   JD_KERNEL_DIRECT_CONV = 10,    /* MFMA Toeplitz convolution / correlation (small PSFs) */
   JD_KERNEL_SEP_CONV = 11,       /* separable (low-rank PSF) convolution / correlation */
-  JD_KERNEL_COUNT = 12
+  JD_KERNEL_GMM_SCREEN = 12,     /* K4 screened arg-max, stage 1: fp16 MFMA screen with error bounds (inside GMM_FWD) */
+  JD_KERNEL_GMM_SORT = 13,       /*   stage 2: counting sort of the surviving (patch, component) records (inside GMM_FWD) */
+  JD_KERNEL_GMM_EXACT = 14,      /*   stage 3: exact fp32 MFMA evaluation of the survivors (inside GMM_FWD) */
+  JD_KERNEL_COUNT = 15
 };
 int jd_profile_enable(int capacity);
 int jd_profile_disable(void);

@@ -1525,7 +1525,10 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
   sc.best = g->best, sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
   sc.seg_cnt = g->seg_cnt, sc.flag = flag;
-  gmm_screen_kernel<<<blocks, 256, 0, s>>>(sc);
+  {
+    ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
+    gmm_screen_kernel<<<blocks, 256, 0, s>>>(sc);
+  }
   JD_LAUNCH_CHECK();
 
   // counting sort of the surviving records by component (the record slot plays the role of the patch index)
@@ -1541,11 +1544,14 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
   bk.blk_counts = g->blk_counts;
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
-  gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
-  gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
-  gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
-  gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
-  if (g->K <= KORDER_MAX_K) gmm_korder_kernel<<<1, 256, 0, s>>>(bk.counts, g->K, g->korder);
+  {
+    ProfScope stage(JD_KERNEL_GMM_SORT, s);
+    gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+    gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
+    gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
+    gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+    if (g->K <= KORDER_MAX_K) gmm_korder_kernel<<<1, 256, 0, s>>>(bk.counts, g->K, g->korder);
+  }
   JD_LAUNCH_CHECK();
 
   GmmExactArgs ex{};
@@ -1553,7 +1559,10 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   ex.rec_n = rec_n, ex.order = g->rec_order, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag;
   ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
   ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
-  gmm_exact_kernel<true><<<(unsigned)(g->n_cu * 3), 256, 0, s>>>(ex);
+  {
+    ProfScope stage(JD_KERNEL_GMM_EXACT, s);
+    gmm_exact_kernel<true><<<(unsigned)(g->n_cu * 3), 256, 0, s>>>(ex);
+  }
   JD_LAUNCH_CHECK();
 
   // fallback: the dense fp32 kernel, gated on the device flag (returns at once in the normal case)

@@ -100,6 +100,9 @@ extern "C" const char* jd_kernel_name(int kernel) {
     case JD_KERNEL_FFT_C2R: return "rocfft_c2r";
     case JD_KERNEL_DIRECT_CONV: return "direct_conv_kernel";
     case JD_KERNEL_SEP_CONV: return "sep_conv_kernel";
+    case JD_KERNEL_GMM_SCREEN: return "gmm_screen_kernel";
+    case JD_KERNEL_GMM_SORT: return "gmm_bucket_kernels";
+    case JD_KERNEL_GMM_EXACT: return "gmm_exact_kernel";
     default: return "?";
   }
 }
