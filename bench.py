@@ -294,16 +294,22 @@ def main():
             "executed_frac": executed / FP32_MATRIX_PEAK_TFLOPS,
             "dense_equivalent_achieved": gmm_flop_dense / (gmm_ms * 1e-3) / 1e12,
         }
-    # fused Poisson pass: 16 B/pixel (conv, background, counts in; g out)
+    # fused Poisson pass.  Stand-alone kernel (general PSFs, several components, up-sampling): 16 B/pixel (conv,
+    # background, counts in; g out).  With one separable component the pass is the EPILOGUE of the forward convolution
+    # (`sep_conv_kernel<.., POISSON>`): flux, exposure, background, counts in; g out = 20 B/pixel, and the convolution
+    # image (4 B/pixel written + 4 read back) never exists.
     poi_ms, poi_n = avg_ms("poisson_fused")
-    poi_bytes = 16 * H * W
+    methods = sorted({m.plan.method for m in session.total_loss.poisson_loss.npred_models_all})
+    poisson_in_conv = methods == ["separable"] and len(session.components) == 1 and not os.environ.get("JD_SEP_NO_FUSION")
+    poi_bytes = (20 if poisson_in_conv else 16) * H * W
+    poi_kernel = "sep_conv_kernel<true, true, true>" if poisson_in_conv else "poisson_fused_kernel"
     roof_poi = None
     if poi_ms:
         achieved = poi_bytes / (poi_ms * 1e-3) / 1e9
         roof_poi = {
-            "kernel": "poisson_fused_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic_bytes(args.config, "poisson_fused_kernel") if world == 1 and fake is None else None,
+            "kernel": poi_kernel + (" (forward convolution + Poisson pass)" if poisson_in_conv else ""), "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc_traffic_bytes(args.config, poi_kernel) if world == 1 and fake is None else None,
             "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes,
         }
     n_profiled = len(range(0, args.steps, PROFILE_EVERY))
@@ -339,18 +345,23 @@ def main():
         "dominant_kernel": dominant,
     }
     # which convolution the fit used: Gaussian PSFs are rank 1, so "auto" takes the separable kernel
-    methods = sorted({m.plan.method for m in session.total_loss.poisson_loss.npred_models_all})
     out["config"]["conv_method"] = "+".join(methods)
     # convolution kernel, HBM bound: forward reads flux + exposure and writes the convolution (12 B/pixel), the
     # adjoint reads g + exposure + the gradient accumulator and writes it back (16 B/pixel): 14 B/pixel on average
     conv_key = "sep_conv" if "sep_conv" in kernel_ms_per_step else "direct_conv" if "direct_conv" in kernel_ms_per_step else None
     if conv_key:
         conv_ms, conv_n = avg_ms(conv_key)
-        conv_bytes = 14 * H * W
+        # (with the Poisson pass fused into the forward launch only the adjoint carries this timer: 16 B/pixel)
+        conv_bytes = (16 if poisson_in_conv else 14) * H * W
         achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
         conv_traffic = None
         if world == 1 and fake is None:
-            names = ("sep_conv_kernel<true, true>", "sep_conv_kernel<true, false>") if conv_key == "sep_conv" else ("direct_conv_kernel",)
+            if conv_key != "sep_conv":
+                names = ("direct_conv_kernel",)
+            elif poisson_in_conv:
+                names = ("sep_conv_kernel<true, false, false>",)
+            else:
+                names = ("sep_conv_kernel<true, true, false>", "sep_conv_kernel<true, false, false>")
             parts = [pmc_traffic_bytes(args.config, name) for name in names]
             conv_traffic = sum(parts) / len(parts) if all(p is not None for p in parts) else None
         out["roofline_conv"] = {

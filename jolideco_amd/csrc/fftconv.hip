@@ -3,6 +3,7 @@
 // computed once per (dataset, component) and cached by the caller.
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -164,7 +165,7 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
     p->H = H, p->W = W, p->kh = kh, p->kw = kw, p->Hp = H, p->Wp = W;
     p->oy = (kh - 1) / 2, p->ox = (kw - 1) / 2, p->py = 0, p->px = 0;
     p->nspec = p->method == JD_CONV_SEPARABLE ? (sep_conv_operator_floats() + 1) / 2 : direct_conv_fragment_floats(kh, kw);
-    p->partials_cap = poisson_fused_max_partials(H, W);
+    p->partials_cap = std::max(poisson_fused_max_partials(H, W), sep_conv_tiles(H, W));
     int rc = JD_OK;
     if (hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
       rc = fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc of the partial sums failed");
@@ -352,6 +353,25 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   const bool calibrated = cal.shift_xy || cal.log_bkg_norm;
   if (calibrated && (rc = ensure_calibration_buffers(p, n_comp, cal.shift_xy != nullptr))) return rc;
 
+  const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
+  int n_partials = 0;
+  // one separable component, no up-sampling, no background norm: the Poisson pass is the epilogue of the convolution
+  const bool fused = p->method == JD_CONV_SEPARABLE && n_comp == 1 && upsampling == 1 && !cal.log_bkg_norm &&
+                     !getenv("JD_SEP_NO_FUSION");
+  if (fused) {
+    const float* in = flux[0];
+    if (cal.shift_xy) {
+      if ((rc = launch_shift_fwd(flux[0], p->shifted[0], p->H, p->W, cal.shift_xy, cal.shift_scale, s))) return rc;
+      in = p->shifted[0];
+    }
+    if ((rc = launch_sep_conv_poisson(in, exposure[0], khat[0], p->pad[0], p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                                      background, counts, npred_out, p->partials, eps, (float)(1.0 / n_pix),
+                                      grad_flux ? 1 : 0, &n_partials, s)))
+      return rc;
+    if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
+      return rc;
+    if (!grad_flux) return JD_OK;
+  } else {
   // forward model per component (models/npred.py:175-179), after the calibration shift (:225-232)
   for (int c = 0; c < n_comp; ++c) {
     const float* in = flux[c];
@@ -375,10 +395,8 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   a.log_bkg_norm = cal.log_bkg_norm;
   a.partials_b = (cal.log_bkg_norm && cal.grad_log_bkg_norm && grad_flux) ? p->partials_cal : nullptr;
   // the loss is the mean over the COUNTS pixels (loss.py:35-37)
-  const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   a.inv_n = (float)(1.0 / n_pix);
   a.write_grad = grad_flux ? 1 : 0;
-  int n_partials = 0;
   if ((rc = upsampling > 1 ? launch_poisson_pooled(a, &n_partials, s) : launch_poisson_fused(a, &n_partials, s)))
     return rc;
   if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
@@ -387,6 +405,7 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   if (a.partials_b &&
       (rc = launch_finalize_sum(p->partials_cal, n_partials, (double)grad_scale, 0.0, cal.grad_log_bkg_norm, 0, s)))
     return rc;
+  }
 
   // adjoint: d loss / d flux_c = [shift^T] ( E_c * corr(psf_c, g_c) )
   for (int c = 0; c < n_comp; ++c) {

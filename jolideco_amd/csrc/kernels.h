@@ -60,6 +60,11 @@ int sep_factorize(const float* psf_host, int kh, int kw, double tol, std::vector
 int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op);
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream);
+int sep_conv_tiles(int H, int W);
+int launch_sep_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh,
+                            int kw, int oy, int ox, const float* background, const float* counts, float* npred_out,
+                            double* partials, float eps, float inv_n, int write_grad, int* n_partials,
+                            hipStream_t stream);
 
 // kernel timers (profile.hip): RAII bracket around one launch
 int prof_begin(int kernel, hipStream_t s);

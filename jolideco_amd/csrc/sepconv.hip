@@ -62,13 +62,23 @@ struct SepArgs {
   int khp, kwp, oy0, ox0, rpairs, pitch, taps_off;
   float coef;
   int accumulate;
+  // fused Poisson epilogue (POISSON kernels only): `out` receives g = d loss / d conv instead of the convolution
+  const float* background;
+  const float* counts;
+  float* npred_out;   // nullable
+  double* partials;   // one per tile
+  float eps, inv_n;
+  int write_grad;
 };
 
 // LDS images:
 //   win  [rpairs][pitch][2]  the input window with two image rows interleaved per column, so that one ds_read_b128
 //                            yields the operand pairs (row 2p, row 2p+1) of two columns for v_pk_fma_f32
 //   hbuf [2 * rpairs][TX]    the row-pass result, plain row-major: the column pass packs two neighbouring x
-template <bool VEC, bool IN_SCALE>
+// POISSON: the forward model of ONE component with no up-sampling ends here -- clip, + background, Poisson NLL and
+// its gradient are computed from the convolution while it is still in registers (the arithmetic of
+// poisson_fused_kernel, statement for statement), so the convolution image is neither written nor read back.
+template <bool VEC, bool IN_SCALE, bool POISSON>
 __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   extern __shared__ float4 lds4[];
   float* win = reinterpret_cast<float*>(lds4);
@@ -164,7 +174,16 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
     const int gy = Y0 + cy + c;
     if (gy >= a.H || gx >= a.W) continue;
     const size_t off = (size_t)gy * a.W + gx;
-    if (VEC) {  // W even, bases 16-byte aligned: the pair is an aligned float2 inside the image
+    if (POISSON) {  // the two operand images of the fused epilogue ride in the same registers
+      if (VEC) {
+        oscale[c] = *reinterpret_cast<const v2f*>(a.background + off);
+        oprev[c] = *reinterpret_cast<const v2f*>(a.counts + off);
+      } else {
+        const bool two = gx + 1 < a.W;
+        oscale[c] = v2f{a.background[off], two ? a.background[off + 1] : 0.f};
+        oprev[c] = v2f{a.counts[off], two ? a.counts[off + 1] : 0.f};
+      }
+    } else if (VEC) {  // W even, bases 16-byte aligned: the pair is an aligned float2 inside the image
       if (a.out_scale) oscale[c] = *reinterpret_cast<const v2f*>(a.out_scale + off);
       if (a.accumulate) oprev[c] = *reinterpret_cast<const v2f*>(a.out + off);
     } else {
@@ -224,6 +243,47 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
     }
   }
 
+  if (POISSON) {
+    // ---- epilogue: n = max(conv, 0) + b;  loss += n - c log(n + eps);  g = (1 - c / (n + eps)) / N where conv >= 0
+    __shared__ double red[THREADS / 64];
+    double local = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int gy = Y0 + cy + c;
+      if (gy >= a.H || gx >= a.W) continue;
+      const size_t off = (size_t)gy * a.W + gx;
+      const bool two = gx + 1 < a.W;
+      float n2[2], g2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float conv = acc[c][e], b = oscale[c][e], cnt = oprev[c][e];
+        const float n = fmaxf(conv, 0.f) + b;  // clip, then the un-convolved background (npred.py:191,254-261)
+        const float ne = n + a.eps;
+        if (e == 0 || two) local += (double)(n - cnt * logf(ne));
+        const float g = (1.f - cnt / ne) * a.inv_n;
+        n2[e] = n;
+        g2[e] = conv >= 0.f ? g : 0.f;  // clamp backward: passes where conv >= 0
+      }
+      if (VEC) {
+        if (a.write_grad) *reinterpret_cast<v2f*>(a.out + off) = v2f{g2[0], g2[1]};
+        if (a.npred_out) *reinterpret_cast<v2f*>(a.npred_out + off) = v2f{n2[0], n2[1]};
+      } else {
+        if (a.write_grad) {
+          a.out[off] = g2[0];
+          if (two) a.out[off + 1] = g2[1];
+        }
+        if (a.npred_out) {
+          a.npred_out[off] = n2[0];
+          if (two) a.npred_out[off + 1] = n2[1];
+        }
+      }
+    }
+    local = wave_sum(local);
+    if ((tid & 63) == 0) red[tid >> 6] = local;
+    __syncthreads();
+    if (tid == 0) a.partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
+    return;
+  }
   // ---- epilogue: out = [out +] coef * out_scale * acc -------------------------------------------------------
   if (gx >= a.W) return;
 #pragma unroll
@@ -309,39 +369,65 @@ int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double 
   return rank;
 }
 
+namespace {
+int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool poisson, hipStream_t stream) {
+  if (!sep_conv_supported(kh, kw))
+    return fail(JD_ERR_INVALID, "separable convolution: PSF %dx%d exceeds %dx%d", kh, kw, SEP_MAX_K, SEP_MAX_K);
+  const SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
+  a.tiles_x = (a.W + TX - 1) / TX;
+  a.n_tiles = a.tiles_x * ((a.H + TY - 1) / TY);
+  a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rpairs = g.rpairs, a.pitch = g.pitch;
+  a.taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
+  const size_t lds = ((size_t)2 * g.rpairs * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
+  const int blocks = ((a.n_tiles + 7) / 8) * 8;
+  auto aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = a.W % 4 == 0 && aligned(a.in) && aligned(a.in_scale) && aligned(a.out) && aligned(a.out_scale) &&
+                   aligned(a.background) && aligned(a.counts) && aligned(a.npred_out);
+  const int variant = (poisson ? 4 : 0) + (vec ? 2 : 0) + (a.in_scale ? 1 : 0);
+  void (*const kernels[8])(SepArgs) = {
+      sep_conv_kernel<false, false, false>, sep_conv_kernel<false, true, false>, sep_conv_kernel<true, false, false>,
+      sep_conv_kernel<true, true, false>,   sep_conv_kernel<false, false, true>, sep_conv_kernel<false, true, true>,
+      sep_conv_kernel<true, false, true>,   sep_conv_kernel<true, true, true>};
+  auto kernel = kernels[variant];
+  static size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lds > 64 * 1024 && lds > lds_set[variant]) {
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set[variant] = lds;
+  }
+  ProfScope prof(poisson ? JD_KERNEL_POISSON_FUSED : JD_KERNEL_SEP_CONV, stream);  // the fused launch IS the Poisson pass
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds, stream, a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+}  // namespace
+
+int sep_conv_tiles(int H, int W) { return ((W + TX - 1) / TX) * ((H + TY - 1) / TY); }
+
 // adjoint == 0: out (+)= coef * out_scale * conv_same(in * in_scale, psf)    [crop offset (oy, ox)]
 // adjoint != 0: out (+)= coef * out_scale * corr_same(in * in_scale, psf)    (the transpose of the above)
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
                     hipStream_t stream) {
-  if (!sep_conv_supported(kh, kw))
-    return fail(JD_ERR_INVALID, "separable convolution: PSF %dx%d exceeds %dx%d", kh, kw, SEP_MAX_K, SEP_MAX_K);
-  const SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
   SepArgs a{};
   a.in = in, a.in_scale = in_scale, a.op = op, a.out = out, a.out_scale = out_scale;
-  a.H = H, a.W = W;
-  a.tiles_x = (W + TX - 1) / TX;
-  a.n_tiles = a.tiles_x * ((H + TY - 1) / TY);
-  a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rpairs = g.rpairs, a.pitch = g.pitch;
-  a.taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
-  a.coef = coef, a.accumulate = accumulate;
-  const size_t lds = ((size_t)2 * g.rpairs * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
-  const int blocks = ((a.n_tiles + 7) / 8) * 8;
-  auto aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  const bool vec = W % 4 == 0 && aligned(in) && aligned(in_scale);
-  const int variant = (vec ? 2 : 0) + (in_scale ? 1 : 0);
-  void (*const kernels[4])(SepArgs) = {sep_conv_kernel<false, false>, sep_conv_kernel<false, true>,
-                                       sep_conv_kernel<true, false>, sep_conv_kernel<true, true>};
-  auto kernel = kernels[variant];
-  static size_t lds_set[4] = {0, 0, 0, 0};
-  if (lds > 64 * 1024 && lds > lds_set[variant]) {
-    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set[variant] = lds;
-  }
-  ProfScope prof(JD_KERNEL_SEP_CONV, stream);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds, stream, a);
-  JD_LAUNCH_CHECK();
-  return JD_OK;
+  a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate;
+  return launch_sep(a, kh, kw, oy, ox, adjoint, false, stream);
+}
+
+// Forward model of one component fused with the Poisson pass: conv = conv_same(in * in_scale, psf) stays in
+// registers; g_out (if write_grad) = masked d loss / d conv, npred_out (nullable) = clip(conv) + background,
+// partials[tile] = block sums of n - c log(n + eps) (*n_partials of them).
+int launch_sep_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh,
+                            int kw, int oy, int ox, const float* background, const float* counts, float* npred_out,
+                            double* partials, float eps, float inv_n, int write_grad, int* n_partials,
+                            hipStream_t stream) {
+  SepArgs a{};
+  a.in = in, a.in_scale = in_scale, a.op = op, a.out = g_out;
+  a.H = H, a.W = W, a.coef = 1.f;
+  a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = partials;
+  a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
+  *n_partials = sep_conv_tiles(H, W);
+  return launch_sep(a, kh, kw, oy, ox, 0, true, stream);
 }
 
 }  // namespace jd

@@ -557,3 +557,42 @@ def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, monkeypat
             parts.append(float(v))
         vals[mode] = parts
     assert vals["1"] == pytest.approx(vals["0"], rel=2e-7)
+
+
+def test_poisson_epilogue_of_the_separable_convolution_matches_the_two_kernel_path(monkeypatch):
+    """One separable component without up-sampling: the Poisson pass runs as the epilogue of the forward convolution
+    (sep_conv_kernel<.., POISSON>).  Same loss, predicted counts and gradient as convolution + poisson_fused_kernel
+    (JD_SEP_NO_FUSION=1), on a ragged image and with / without the gradient."""
+    from jolideco_amd import FluxComponents, NPredModels, SpatialFluxComponent
+    from jolideco_amd.ops import stirling_mean
+
+    rs = np.random.RandomState(5)
+    shape = (97, 150)
+    g = np.exp(-0.5 * ((np.arange(17) - 8) / 2.0) ** 2)
+    data = {
+        "counts": rs.poisson(3.0, size=shape).astype(np.float32),
+        "psf": (np.outer(g, g) / np.outer(g, g).sum()).astype(np.float32),
+        "exposure": rs.uniform(0.5, 1.5, size=shape).astype(np.float32),
+        "background": rs.uniform(0.2, 1.0, size=shape).astype(np.float32),
+    }
+    flux = torch.from_numpy(rs.gamma(3.0, size=shape).astype(np.float32)).to(DEV)
+    comps = FluxComponents()
+    comps["flux"] = SpatialFluxComponent.from_numpy(flux=flux.cpu().numpy())
+    models = NPredModels.from_dataset_numpy(dataset=data, components=comps, device=DEV)
+    assert models.plan.method == "separable"
+    counts = torch.from_numpy(data["counts"]).to(DEV)
+    results = {}
+    for fusion in ("fused", "split"):
+        if fusion == "split":
+            monkeypatch.setenv("JD_SEP_NO_FUSION", "1")
+        loss, grad, npred = torch.zeros(1, device=DEV), torch.full_like(flux, 3.0), torch.empty_like(flux)
+        models.fwd_bwd([flux], counts, stirling_mean(data["counts"]), loss, grads=[grad], npred_out=npred, accumulate=True,
+                       grad_scale=0.5)
+        loss_fwd = torch.zeros(1, device=DEV)
+        models.fwd_bwd([flux], counts, stirling_mean(data["counts"]), loss_fwd)
+        torch.cuda.synchronize()
+        results[fusion] = (float(loss), float(loss_fwd), grad.cpu().numpy(), npred.cpu().numpy())
+    a, b = results["fused"], results["split"]
+    assert a[0] == pytest.approx(b[0], rel=1e-6) and a[1] == pytest.approx(b[1], rel=1e-6) and a[0] == pytest.approx(a[1], rel=1e-6)
+    assert np.array_equal(a[3], b[3])       # predicted counts: same arithmetic, same bits
+    assert rel_linf(a[2] - 3.0, b[2] - 3.0) < 1e-6  # gradient: same g, same adjoint kernel
