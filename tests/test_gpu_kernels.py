@@ -596,3 +596,70 @@ def test_poisson_epilogue_of_the_separable_convolution_matches_the_two_kernel_pa
     assert a[0] == pytest.approx(b[0], rel=1e-6) and a[1] == pytest.approx(b[1], rel=1e-6) and a[0] == pytest.approx(a[1], rel=1e-6)
     assert np.array_equal(a[3], b[3])       # predicted counts: same arithmetic, same bits
     assert rel_linf(a[2] - 3.0, b[2] - 3.0) < 1e-6  # gradient: same g, same adjoint kernel
+
+
+def _prior_both_ways(handle, flux, n_patches, monkeypatch, shifts=(1, -2)):
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("JD_GMM_SCREEN", mode)
+        value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+        argmax = torch.full((n_patches,), -7, dtype=torch.int32, device=DEV)
+        handle.prior_fwd_bwd(flux, 4, shifts, value, 1.0, grad=grad, grad_coef=1.0, argmax_out=argmax)
+        torch.cuda.synchronize()
+        out[mode] = (float(value), grad.cpu().numpy(), argmax.cpu().numpy())
+    return out["1"], out["0"]
+
+
+def test_gmm_screen_falls_back_to_the_dense_kernel(monkeypatch):
+    """The two situations in which the screen gives up (device flag -> the always-enqueued dense kernel overwrites
+    the result, no host sync): more candidates than a wave's record list holds, and non-finite screening values."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape = (160, 192)
+    n_patches = ((shape[0] - 8) // 4 + 1) * ((shape[1] - 8) // 4 + 1)
+    rs = np.random.RandomState(0)
+    # (a) 128 IDENTICAL components: every component is a candidate for every patch (128 > 32 records per patch)
+    means, covs, weights = synthetic_gmm(1, 64, seed=3)
+    K = 128
+    gmm = GaussianMixtureModel.from_numpy(
+        np.repeat(means, K, axis=0), np.repeat(covs, K, axis=0), np.full(K, 1.0 / K), meta=GaussianMixtureModelMeta(stride=4)
+    )
+    flux = torch.from_numpy(rs.gamma(20, size=shape).astype(np.float32)).to(DEV)
+    screened, dense = _prior_both_ways(gmm.handle(DEV), flux, n_patches, monkeypatch)
+    assert np.array_equal(screened[2], dense[2]) and np.all(dense[2] == 0)  # ties -> the lowest component, like torch.max
+    assert screened[0] == pytest.approx(dense[0], rel=2e-7) and np.array_equal(screened[1], dense[1])
+    # (b) an infinite pixel: the patches that contain it have no finite log-likelihood
+    means, covs, weights = synthetic_gmm(16, 64, seed=4)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+    image = rs.gamma(20, size=shape).astype(np.float32)
+    image[40, 50] = np.inf
+    flux = torch.from_numpy(image).to(DEV)
+    screened, dense = _prior_both_ways(gmm.handle(DEV), flux, n_patches, monkeypatch)
+    assert np.array_equal(screened[2], dense[2])
+    assert np.array_equal(np.isnan(screened[1]), np.isnan(dense[1]))
+    finite = np.isfinite(dense[1])
+    assert np.array_equal(screened[1][finite], dense[1][finite])
+    assert (np.isnan(screened[0]) and np.isnan(dense[0])) or screened[0] == dense[0]
+
+
+def test_gmm_screen_large_k_and_huge_dynamic_range(monkeypatch):
+    """K above the popularity-order limit (natural order is kept) and fluxes / precisions far outside the fp16 range
+    (the power-of-two operand scales keep the screen exact): still the dense kernel's bits."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape = (72, 88)
+    n_patches = ((shape[0] - 8) // 4 + 1) * ((shape[1] - 8) // 4 + 1)
+    rs = np.random.RandomState(1)
+    means, covs, weights = synthetic_gmm(1100, 64, seed=6)
+    covs = covs * np.logspace(-9, 7, covs.shape[0])[:, None, None]  # precisions from 1e-4 to 3e4: beyond fp16 without scaling
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+    handle = gmm.handle(DEV)
+    for scale in (1e-12, 1.0, 3e7):
+        flux = torch.from_numpy((scale * rs.gamma(20, size=shape)).astype(np.float32)).to(DEV)
+        for _ in range(2):  # the second call uses the component order learnt in the first
+            screened, dense = _prior_both_ways(handle, flux, n_patches, monkeypatch)
+            assert np.array_equal(screened[2], dense[2]), scale
+            assert screened[0] == pytest.approx(dense[0], rel=2e-7), scale
+            assert np.array_equal(screened[1], dense[1]), scale
