@@ -123,6 +123,21 @@ int jd_npred_poisson_fwd_bwd(jd_conv_plan* plan, int n_comp, const float* const*
                              float eps, float* loss_out, float* const* grad_flux, int accumulate,
                              float grad_scale, float* npred_out, int upsampling, void* stream);
 
+/* The joint step over SEVERAL datasets in three launches instead of four per dataset (new: the reference has no joint
+ * mode; this is the batched form of the loop `for dataset: jd_npred_poisson_fwd_bwd(..., accumulate = dataset > 0)` that
+ * jolideco_amd's fit_mode="joint" runs, jolideco/core.py:214-229 being its per-dataset counterpart).  Restrictions: one
+ * flux component, no up-sampling, no calibration, a plan with the SEPARABLE method shared by all datasets (same image
+ * and PSF shape); at most 16 datasets per call.  Same results as the loop, bit for bit (the per-dataset gradient
+ * contributions are added in dataset order).
+ *   exposure, khat, background, counts, loss_out : host arrays of n_datasets device pointers
+ *   stirling_mean                                : host array of n_datasets floats
+ *   grad_flux                                    : nullable (forward only) */
+int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* plan, int n_datasets, const float* flux, const float* const* exposure,
+                                   const float* const* khat, const float* const* background,
+                                   const float* const* counts, const float* stirling_mean, float eps,
+                                   float* const* loss_out, float* grad_flux, int accumulate, float grad_scale,
+                                   void* stream);
+
 /* The same with the per-dataset calibration of NPredCalibration (models/npred.py:298-402,225-237):
  *   shift_xy             device [2] = {shift_x, shift_y} in COUNTS pixels or NULL: every flux_c is shifted
  *                        (bilinear, zero padding = shift_image_torch, utils/torch.py:196-223) before the

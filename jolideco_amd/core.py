@@ -408,6 +408,12 @@ class FitSession:
         slot_d = {name: i for i, name in enumerate(names_all)}
         self.local_idx = [(slot_d[name], i) for i, name in enumerate(local_names)]  # (global slot, local index)
         self.step = 0
+        import os
+
+        self.batch_joint = (
+            self.joint and len(self.states) == 1 and not os.environ.get("JOLIDECO_NO_BATCH")
+            and self.total_loss.poisson_loss.batchable([li for _, li in self.local_idx])
+        )
 
     def _slot(self, i):
         return self.scalars[i : i + 1]
@@ -438,10 +444,18 @@ class FitSession:
             if dist.world_size > 1:
                 self.scalars.zero_()
             first = True
-            for gslot, li in self.local_idx:
-                self._cal_zero_grad(li)
-                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
+            if self.batch_joint:
+                # all local datasets in three launches (forward + Poisson, losses, adjoint): same numbers as the loop
+                total_loss.poisson_loss.fwd_bwd_batch(
+                    [li for _, li in self.local_idx], fluxes[0], [slot(gslot) for gslot, _ in self.local_idx],
+                    grad=grads[0], accumulate=False,
+                )
                 first = False
+            else:
+                for gslot, li in self.local_idx:
+                    self._cal_zero_grad(li)
+                    total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
+                    first = False
             if first:
                 for g in grads:
                     g.zero_()

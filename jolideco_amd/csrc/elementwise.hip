@@ -36,6 +36,34 @@ int launch_finalize_sum(const double* partials, int n, double scale, double offs
   return JD_OK;
 }
 
+struct FinalizeRowsArgs {
+  const double* partials;
+  int n;
+  double scale;
+  float offset[SEP_MAX_BATCH];
+  float* out[SEP_MAX_BATCH];
+};
+
+__global__ __launch_bounds__(BLOCK) void finalize_rows_kernel(FinalizeRowsArgs a) {
+  __shared__ double smem[BLOCK / 64];
+  const double* row = a.partials + (size_t)blockIdx.x * a.n;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < a.n; i += BLOCK) acc += row[i];
+  const double total = block_sum<BLOCK>(acc, smem);
+  if (threadIdx.x == 0) a.out[blockIdx.x][0] = (float)(a.scale * total + (double)a.offset[blockIdx.x]);
+}
+
+int launch_finalize_rows(const double* partials, int n, int n_out, double scale, const float* offset_host,
+                         float* const* out, hipStream_t stream) {
+  if (n_out < 1 || n_out > SEP_MAX_BATCH) return fail(JD_ERR_INVALID, "finalize_rows: %d outputs not in [1, %d]", n_out, SEP_MAX_BATCH);
+  FinalizeRowsArgs a{};
+  a.partials = partials, a.n = n, a.scale = scale;
+  for (int d = 0; d < n_out; ++d) a.offset[d] = offset_host[d], a.out[d] = out[d];
+  finalize_rows_kernel<<<n_out, BLOCK, 0, stream>>>(a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: padded[y][x] = image[y][x] * scale[y][x] inside (H, W), 0 in the padding
 // ------------------------------------------------------------------------------------------

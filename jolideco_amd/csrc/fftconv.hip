@@ -39,6 +39,12 @@ struct jd_conv_plan {
   float* shifted[JD_MAX_COMPONENTS] = {nullptr};
   float* gshift[JD_MAX_COMPONENTS] = {nullptr};
   double* partials_cal = nullptr;
+  // batched joint step (jd_npred_poisson_batch_fwd_bwd): one g work image per dataset, partial sums per dataset
+  float* gbatch[jd::SEP_MAX_BATCH] = {nullptr};
+  double* partials_batch = nullptr;
+  int partials_batch_cap = 0;
+  jd::SepBatchTable table_host{};          // what table_dev holds (re-uploaded only when a pointer changes)
+  jd::SepBatchTable* table_dev = nullptr;
 };
 
 namespace jd {
@@ -242,6 +248,10 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
   if (p->spec) (void)hipFree(p->spec);
   if (p->partials) (void)hipFree(p->partials);
   if (p->partials_cal) (void)hipFree(p->partials_cal);
+  if (p->partials_batch) (void)hipFree(p->partials_batch);
+  if (p->table_dev) (void)hipFree(p->table_dev);
+  for (float* g : p->gbatch)
+    if (g) (void)hipFree(g);
   for (int c = 0; c < JD_MAX_COMPONENTS; ++c) {
     if (p->pad[c]) (void)hipFree(p->pad[c]);
     if (p->conv[c]) (void)hipFree(p->conv[c]);
@@ -433,6 +443,52 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
   return npred_poisson_impl("jd_npred_poisson_fwd_bwd", p, n_comp, flux, exposure, khat, background, counts,
                             stirling_mean, eps, loss_out, grad_flux, accumulate, grad_scale, npred_out, upsampling,
                             Calibration{}, stream);
+}
+
+extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, const float* flux,
+                                              const float* const* exposure, const float* const* khat,
+                                              const float* const* background, const float* const* counts,
+                                              const float* stirling_mean, float eps, float* const* loss_out,
+                                              float* grad_flux, int accumulate, float grad_scale, void* stream) {
+  JD_REQUIRE(p && flux && exposure && khat && background && counts && stirling_mean && loss_out,
+             "jd_npred_poisson_batch_fwd_bwd: null argument");
+  JD_REQUIRE(p->method == JD_CONV_SEPARABLE,
+             "jd_npred_poisson_batch_fwd_bwd: the plan must use the separable method (one jd_npred_poisson_fwd_bwd per "
+             "dataset otherwise)");
+  JD_REQUIRE(n_datasets >= 1 && n_datasets <= SEP_MAX_BATCH, "jd_npred_poisson_batch_fwd_bwd: n_datasets = %d not in [1, %d]",
+             n_datasets, SEP_MAX_BATCH);
+  for (int d = 0; d < n_datasets; ++d)
+    JD_REQUIRE(exposure[d] && khat[d] && background[d] && counts[d] && loss_out[d],
+               "jd_npred_poisson_batch_fwd_bwd: null pointer for dataset %d", d);
+  hipStream_t s = as_stream(stream);
+  const size_t bytes = (size_t)p->H * p->W * sizeof(float);
+  for (int d = 0; d < n_datasets; ++d)
+    if (!p->gbatch[d]) JD_HIP(hipMalloc(&p->gbatch[d], bytes));
+  const int tiles = sep_conv_tiles(p->H, p->W);
+  if (p->partials_batch_cap < n_datasets * tiles) {
+    if (p->partials_batch) (void)hipFree(p->partials_batch);
+  if (p->table_dev) (void)hipFree(p->table_dev);
+    p->partials_batch = nullptr, p->partials_batch_cap = 0;
+    JD_HIP(hipMalloc(&p->partials_batch, (size_t)n_datasets * tiles * sizeof(double)));
+    p->partials_batch_cap = n_datasets * tiles;
+  }
+  SepBatchTable table{};
+  for (int d = 0; d < n_datasets; ++d)
+    table.scale[d] = exposure[d], table.op[d] = khat[d], table.bkg[d] = background[d], table.cnt[d] = counts[d],
+    table.g[d] = p->gbatch[d];
+  if (!p->table_dev) JD_HIP(hipMalloc(&p->table_dev, sizeof(SepBatchTable)));
+  if (memcmp(&table, &p->table_host, sizeof(table)) != 0) {  // a session passes the same pointers every step
+    JD_HIP(hipMemcpyAsync(p->table_dev, &table, sizeof(table), hipMemcpyHostToDevice, s));  // pageable source: staged now
+    p->table_host = table;
+  }
+  const double n_pix = (double)p->H * (double)p->W;
+  int rc = launch_sep_conv_poisson_batch(n_datasets, flux, table, p->table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                                         p->partials_batch, eps, (float)(1.0 / n_pix), grad_flux ? 1 : 0, s);
+  if (rc) return rc;
+  if ((rc = launch_finalize_rows(p->partials_batch, tiles, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s))) return rc;
+  if (!grad_flux) return JD_OK;
+  return launch_sep_conv_adjoint_batch(n_datasets, table, p->table_dev, grad_flux, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                                       grad_scale, accumulate, s);
 }
 
 extern "C" int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,

@@ -52,7 +52,7 @@ int launch_direct_conv(const float* in, const float* in_scale, const float* afra
                        hipStream_t stream);
 
 // separable (low-rank PSF) convolution (sepconv.hip)
-constexpr int SEP_MAX_K = 68, SEP_MAX_RANK = 3;
+constexpr int SEP_MAX_K = 68, SEP_MAX_RANK = 3, SEP_MAX_BATCH = 16;
 constexpr double SEP_DEFAULT_TOL = 3e-7;  // residual sum|psf - sum_r u_r v_r^T| <= tol * sum|psf|  (~5 fp32 ulps)
 bool sep_conv_supported(int kh, int kw);
 size_t sep_conv_operator_floats();
@@ -61,6 +61,23 @@ int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, do
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream);
 int sep_conv_tiles(int H, int W);
+// per-dataset pointers of a batched joint step: exposure (input scale of the forward model, output scale of the
+// adjoint), operator, background, counts, g work image
+struct SepBatchTable {
+  const float* scale[SEP_MAX_BATCH];
+  const float* op[SEP_MAX_BATCH];
+  const float* bkg[SEP_MAX_BATCH];
+  const float* cnt[SEP_MAX_BATCH];
+  float* g[SEP_MAX_BATCH];
+};
+int launch_sep_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev,
+                                  int H, int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
+                                  int write_grad, hipStream_t stream);
+int launch_sep_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H,
+                                  int W, int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream);
+// out[d][0] = scale * sum(partials[d * n .. d * n + n - 1]) + offset[d]   (one block per output, fixed order)
+int launch_finalize_rows(const double* partials, int n, int n_out, double scale, const float* offset_host,
+                         float* const* out, hipStream_t stream);
 int launch_sep_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh,
                             int kw, int oy, int ox, const float* background, const float* counts, float* npred_out,
                             double* partials, float eps, float inv_n, int write_grad, int* n_partials,

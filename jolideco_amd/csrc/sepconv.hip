@@ -69,6 +69,12 @@ struct SepArgs {
   double* partials;   // one per tile
   float eps, inv_n;
   int write_grad;
+  // batch of datasets (n_batch > 0): per-dataset exposure (in_scale of the forward model = out_scale of the adjoint),
+  // operator, background, counts, g work image (forward: output, adjoint: input)
+  // (a pointer table in DEVICE memory: indexing arrays inside the by-value kernel argument with a run-time dataset
+  // index makes hipcc copy the whole argument block to scratch, which halved the speed of every variant)
+  int n_batch;
+  const SepBatchTable* table;
 };
 
 // LDS images:
@@ -78,6 +84,11 @@ struct SepArgs {
 // POISSON: the forward model of ONE component with no up-sampling ends here -- clip, + background, Poisson NLL and
 // its gradient are computed from the convolution while it is still in registers (the arithmetic of
 // poisson_fused_kernel, statement for statement), so the convolution image is neither written nor read back.
+// Batches (a.n_batch > 0, several datasets that share the geometry and the input image layout):
+//   * POISSON: blockIdx.y selects the dataset -- one launch for all forward models of a joint step;
+//   * otherwise (the adjoint): every block walks over ALL datasets and adds their contributions in dataset order in
+//     registers, so the gradient image is read and written once instead of once per dataset (same additions in the
+//     same order as the per-dataset launches: same bits).
 template <bool VEC, bool IN_SCALE, bool POISSON>
 __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   extern __shared__ float4 lds4[];
@@ -85,7 +96,6 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   float* hbuf = win + a.rpairs * a.pitch * 2;
   float* taps = hbuf + 2 * a.rpairs * TX;  // per rank: khp row taps then kwp column taps
   const int tid = threadIdx.x;
-  const int rank = (int)a.op[0];
   const int tap_stride = a.khp + a.kwp;
   const int nrows = 2 * a.rpairs;
 
@@ -94,209 +104,233 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (tile >= a.n_tiles) return;
   const int Y0 = (tile / a.tiles_x) * TY, X0 = (tile % a.tiles_x) * TX;
-
-  for (int i = tid; i < rank * tap_stride; i += THREADS) taps[i] = a.op[a.taps_off + i];
-
-  // ---- stage the window: image * in_scale, zero outside -----------------------------------------------------
   const int gy0 = Y0 + a.oy0, gx0 = X0 + a.ox0;
-  if (VEC) {
-    // One item = 4 columns of BOTH rows of a row pair: two float4 loads (+ two of the exposure), two ds_write_b128
-    // of the interleaved (row 2p, row 2p+1) pairs.  All loads of a thread are issued before its first LDS store, so
-    // a tile exposes one memory latency; lanes outside the image load element 0 and select zero (no branches).
-    const int nv = (TX + a.kwp) / 4;  // float4 per row actually needed
-    const int total = a.rpairs * nv;
-    const int step_r = THREADS / nv, step_c = THREADS % nv;  // (row pair, float4 column) advance of i += THREADS
-    int rp = tid / nv, cv = tid - rp * nv;
-    for (int base = tid; base < total; base += STAGE_BATCH * THREADS) {
-      float4 va[STAGE_BATCH], vb[STAGE_BATCH], sa[STAGE_BATCH], sb[STAGE_BATCH];
-      int dst[STAGE_BATCH];
-      bool oka[STAGE_BATCH], okb[STAGE_BATCH];
-#pragma unroll
-      for (int b = 0; b < STAGE_BATCH; ++b) {
-        const int gy = gy0 + 2 * rp, gx = gx0 + 4 * cv;
-        const bool inx = rp < a.rpairs && gx >= 0 && gx < a.W;  // gx, W multiples of 4: never partial
-        dst[b] = rp < a.rpairs ? (rp * a.pitch + 4 * cv) * 2 : -1;
-        oka[b] = inx && gy >= 0 && gy < a.H;
-        okb[b] = inx && gy + 1 >= 0 && gy + 1 < a.H;
-        const size_t offa = oka[b] ? (size_t)gy * a.W + gx : 0, offb = okb[b] ? (size_t)(gy + 1) * a.W + gx : 0;
-        va[b] = *reinterpret_cast<const float4*>(a.in + offa);
-        vb[b] = *reinterpret_cast<const float4*>(a.in + offb);
-        if (IN_SCALE) {
-          sa[b] = *reinterpret_cast<const float4*>(a.in_scale + offa);
-          sb[b] = *reinterpret_cast<const float4*>(a.in_scale + offb);
-        }
-        rp += step_r, cv += step_c;
-        if (cv >= nv) cv -= nv, ++rp;
-      }
-#pragma unroll
-      for (int b = 0; b < STAGE_BATCH; ++b) {
-        float4 x = va[b], y = vb[b];
-        if (IN_SCALE) {
-          x.x *= sa[b].x, x.y *= sa[b].y, x.z *= sa[b].z, x.w *= sa[b].w;
-          y.x *= sb[b].x, y.y *= sb[b].y, y.z *= sb[b].z, y.w *= sb[b].w;
-        }
-        if (!oka[b]) x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!okb[b]) y = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dst[b] >= 0) {
-          float4* d = reinterpret_cast<float4*>(win + dst[b]);
-          d[0] = make_float4(x.x, y.x, x.y, y.y);
-          d[1] = make_float4(x.z, y.z, x.w, y.w);
-        }
-      }
-    }
-  } else {
-    const int nc = TX + a.kwp;
-    const int total = nrows * nc;
-    for (int i = tid; i < total; i += THREADS) {
-      const int r = i / nc, c = i - r * nc;
-      const int gy = gy0 + r, gx = gx0 + c;
-      float v = 0.f;
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        const size_t off = (size_t)gy * a.W + gx;
-        v = a.in[off];
-        if (IN_SCALE) v *= a.in_scale[off];
-      }
-      win[((r >> 1) * a.pitch + c) * 2 + (r & 1)] = v;
-    }
-  }
 
   // column-pass item of this thread: outputs (y0 .. y0+3, x and x+1)
   static_assert((TX / 2) * (TY / 4) == THREADS, "tile / block shape");
   const int cx = (tid % (TX / 2)) * 2, cy = (tid / (TX / 2)) * 4;
   const int gx = X0 + cx;
-  v2f acc[4], oscale[4], oprev[4];
-  // epilogue operands are requested now, so that their latency hides behind the two passes
+
+  const int d_begin = a.n_batch > 0 ? (POISSON ? (int)blockIdx.y : 0) : 0;
+  const int d_end = a.n_batch > 0 ? (POISSON ? d_begin + 1 : a.n_batch) : 1;
+  // a pair of pixels of an (H, W) image at `off`: aligned float2 on the VEC path
+  auto load2 = [&](const float* img, size_t off, float other) {
+    if (VEC) return *reinterpret_cast<const v2f*>(img + off);
+    return v2f{img[off], gx + 1 < a.W ? img[off + 1] : other};
+  };
+
+  v2f res[4];  // running output of the plain / adjoint epilogue: [out +] sum_d coef * out_scale_d * conv_d
+  if (!POISSON) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    acc[c] = v2f{0.f, 0.f};
-    oscale[c] = v2f{1.f, 1.f};
-    oprev[c] = v2f{0.f, 0.f};
-    const int gy = Y0 + cy + c;
-    if (gy >= a.H || gx >= a.W) continue;
-    const size_t off = (size_t)gy * a.W + gx;
-    if (POISSON) {  // the two operand images of the fused epilogue ride in the same registers
-      if (VEC) {
-        oscale[c] = *reinterpret_cast<const v2f*>(a.background + off);
-        oprev[c] = *reinterpret_cast<const v2f*>(a.counts + off);
-      } else {
-        const bool two = gx + 1 < a.W;
-        oscale[c] = v2f{a.background[off], two ? a.background[off + 1] : 0.f};
-        oprev[c] = v2f{a.counts[off], two ? a.counts[off + 1] : 0.f};
-      }
-    } else if (VEC) {  // W even, bases 16-byte aligned: the pair is an aligned float2 inside the image
-      if (a.out_scale) oscale[c] = *reinterpret_cast<const v2f*>(a.out_scale + off);
-      if (a.accumulate) oprev[c] = *reinterpret_cast<const v2f*>(a.out + off);
-    } else {
-      const bool two = gx + 1 < a.W;
-      if (a.out_scale) oscale[c] = v2f{a.out_scale[off], two ? a.out_scale[off + 1] : 1.f};
-      if (a.accumulate) oprev[c] = v2f{a.out[off], two ? a.out[off + 1] : 0.f};
+    for (int c = 0; c < 4; ++c) {
+      res[c] = v2f{0.f, 0.f};
+      const int gy = Y0 + cy + c;
+      if (a.accumulate && gy < a.H && gx < a.W) res[c] = load2(a.out, (size_t)gy * a.W + gx, 0.f);
     }
   }
 
-  for (int r = 0; r < rank; ++r) {
-    __syncthreads();  // window (r == 0) / previous column pass done with hbuf (r > 0); taps visible
-    const float* tu = taps + r * tap_stride;
-    const float* tv = tu + a.khp;
-    // ---- row pass, two rows at once: hbuf[row][x] = sum_t tv[t] * win[row][x + t] ---------------------------
-    for (int item = tid; item < a.rpairs * (TX / 8); item += THREADS) {
-      const int rp = item / (TX / 8), x0 = (item % (TX / 8)) * 8;
-      const float* w = win + (rp * a.pitch + x0) * 2;
-      v2f h[8];
+  for (int d = d_begin; d < d_end; ++d) {
+    const float* in = a.n_batch > 0 && !POISSON ? a.table->g[d] : a.in;
+    const float* in_scale = a.n_batch > 0 ? a.table->scale[d] : a.in_scale;
+    const float* op = a.n_batch > 0 ? a.table->op[d] : a.op;
+    const float* out_scale = a.n_batch > 0 ? a.table->scale[d] : a.out_scale;  // adjoint batch: the exposure of dataset d
+    const float* background = a.n_batch > 0 ? a.table->bkg[d] : a.background;
+    const float* counts = a.n_batch > 0 ? a.table->cnt[d] : a.counts;
+    const int rank = (int)op[0];
+    if (d > d_begin) __syncthreads();  // the previous dataset is done with the LDS images
+    for (int i = tid; i < rank * tap_stride; i += THREADS) taps[i] = op[a.taps_off + i];
+
+    // ---- stage the window: image * in_scale, zero outside ---------------------------------------------------
+    if (VEC) {
+      // One item = 4 columns of BOTH rows of a row pair: two float4 loads (+ two of the exposure), two
+      // ds_write_b128 of the interleaved (row 2p, row 2p+1) pairs.  All loads of a thread are issued before its
+      // first LDS store, so a tile exposes one memory latency; lanes outside the image load element 0 and select
+      // zero (no branches).
+      const int nv = (TX + a.kwp) / 4;  // float4 per row actually needed
+      const int total = a.rpairs * nv;
+      const int step_r = THREADS / nv, step_c = THREADS % nv;  // (row pair, float4 column) advance of i += THREADS
+      int rp = tid / nv, cv = tid - rp * nv;
+      for (int base = tid; base < total; base += STAGE_BATCH * THREADS) {
+        float4 va[STAGE_BATCH], vb[STAGE_BATCH], sa[STAGE_BATCH], sb[STAGE_BATCH];
+        int dst[STAGE_BATCH];
+        bool oka[STAGE_BATCH], okb[STAGE_BATCH];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) h[c] = v2f{0.f, 0.f};
-      for (int q = 0; q < a.kwp; q += 4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(tv + q);
-        const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
-        v2f ww[12];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const float4 two = *reinterpret_cast<const float4*>(w + (q + 2 * k) * 2);
-          ww[2 * k] = v2f{two.x, two.y};
-          ww[2 * k + 1] = v2f{two.z, two.w};
+        for (int b = 0; b < STAGE_BATCH; ++b) {
+          const int gy = gy0 + 2 * rp, gxs = gx0 + 4 * cv;
+          const bool inx = rp < a.rpairs && gxs >= 0 && gxs < a.W;  // gxs, W multiples of 4: never partial
+          dst[b] = rp < a.rpairs ? (rp * a.pitch + 4 * cv) * 2 : -1;
+          oka[b] = inx && gy >= 0 && gy < a.H;
+          okb[b] = inx && gy + 1 >= 0 && gy + 1 < a.H;
+          const size_t offa = oka[b] ? (size_t)gy * a.W + gxs : 0, offb = okb[b] ? (size_t)(gy + 1) * a.W + gxs : 0;
+          va[b] = *reinterpret_cast<const float4*>(in + offa);
+          vb[b] = *reinterpret_cast<const float4*>(in + offb);
+          if (IN_SCALE) {
+            sa[b] = *reinterpret_cast<const float4*>(in_scale + offa);
+            sb[b] = *reinterpret_cast<const float4*>(in_scale + offb);
+          }
+          rp += step_r, cv += step_c;
+          if (cv >= nv) cv -= nv, ++rp;
         }
+#pragma unroll
+        for (int b = 0; b < STAGE_BATCH; ++b) {
+          float4 x = va[b], y = vb[b];
+          if (IN_SCALE) {
+            x.x *= sa[b].x, x.y *= sa[b].y, x.z *= sa[b].z, x.w *= sa[b].w;
+            y.x *= sb[b].x, y.y *= sb[b].y, y.z *= sb[b].z, y.w *= sb[b].w;
+          }
+          if (!oka[b]) x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!okb[b]) y = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (dst[b] >= 0) {
+            float4* dq = reinterpret_cast<float4*>(win + dst[b]);
+            dq[0] = make_float4(x.x, y.x, x.y, y.y);
+            dq[1] = make_float4(x.z, y.z, x.w, y.w);
+          }
+        }
+      }
+    } else {
+      const int nc = TX + a.kwp;
+      const int total = nrows * nc;
+      for (int i = tid; i < total; i += THREADS) {
+        const int r = i / nc, c = i - r * nc;
+        const int gy = gy0 + r, gxs = gx0 + c;
+        float v = 0.f;
+        if (gy >= 0 && gy < a.H && gxs >= 0 && gxs < a.W) {
+          const size_t off = (size_t)gy * a.W + gxs;
+          v = in[off];
+          if (IN_SCALE) v *= in_scale[off];
+        }
+        win[((r >> 1) * a.pitch + c) * 2 + (r & 1)] = v;
+      }
+    }
+
+    // epilogue operands are requested now, so that their latency hides behind the two passes:
+    // plain / adjoint: (out_scale, -);  POISSON: (background, counts)
+    v2f acc[4], opa[4], opb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = v2f{0.f, 0.f};
+      opa[c] = v2f{1.f, 1.f};
+      opb[c] = v2f{0.f, 0.f};
+      const int gy = Y0 + cy + c;
+      if (gy >= a.H || gx >= a.W) continue;
+      const size_t off = (size_t)gy * a.W + gx;
+      if (POISSON) {
+        opa[c] = load2(background, off, 0.f);
+        opb[c] = load2(counts, off, 0.f);
+      } else if (out_scale) {
+        opa[c] = load2(out_scale, off, 1.f);
+      }
+    }
+
+    for (int r = 0; r < rank; ++r) {
+      __syncthreads();  // window (r == 0) / previous column pass done with hbuf (r > 0); taps visible
+      const float* tu = taps + r * tap_stride;
+      const float* tv = tu + a.khp;
+      // ---- row pass, two rows at once: hbuf[row][x] = sum_t tv[t] * win[row][x + t] -------------------------
+      for (int item = tid; item < a.rpairs * (TX / 8); item += THREADS) {
+        const int rp = item / (TX / 8), x0 = (item % (TX / 8)) * 8;
+        const float* w = win + (rp * a.pitch + x0) * 2;
+        v2f h[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) h[c] = v2f{0.f, 0.f};
+        for (int q = 0; q < a.kwp; q += 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(tv + q);
+          const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+          v2f ww[12];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const float4 two = *reinterpret_cast<const float4*>(w + (q + 2 * k) * 2);
+            ww[2 * k] = v2f{two.x, two.y};
+            ww[2 * k + 1] = v2f{two.z, two.w};
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const v2f t2 = v2f{tt[e], tt[e]};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) h[c] = __builtin_elementwise_fma(t2, ww[c + e], h[c]);
+          }
+        }
+        float* d0 = hbuf + (2 * rp) * TX + x0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) d0[c] = h[c].x, d0[TX + c] = h[c].y;
+      }
+      __syncthreads();
+      // ---- column pass, two columns at once: acc[y][x] += sum_t tu[t] * hbuf[y + t][x] -----------------------
+      const float* hcol = hbuf + cy * TX + cx;
+      for (int q = 0; q < a.khp; q += 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(tu + q);
+        const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+        v2f hh[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) hh[k] = *reinterpret_cast<const v2f*>(hcol + (q + k) * TX);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const v2f t2 = v2f{tt[e], tt[e]};
 #pragma unroll
-          for (int c = 0; c < 8; ++c) h[c] = __builtin_elementwise_fma(t2, ww[c + e], h[c]);
+          for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(t2, hh[c + e], acc[c]);
         }
       }
-      float* d0 = hbuf + (2 * rp) * TX + x0;
-#pragma unroll
-      for (int c = 0; c < 8; ++c) d0[c] = h[c].x, d0[TX + c] = h[c].y;
     }
-    __syncthreads();
-    // ---- column pass, two columns at once: acc[y][x] += sum_t tu[t] * hbuf[y + t][x] -------------------------
-    const float* hcol = hbuf + cy * TX + cx;
-    for (int q = 0; q < a.khp; q += 4) {
-      const float4 t4 = *reinterpret_cast<const float4*>(tu + q);
-      const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
-      v2f hh[7];
-#pragma unroll
-      for (int k = 0; k < 7; ++k) hh[k] = *reinterpret_cast<const v2f*>(hcol + (q + k) * TX);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const v2f t2 = v2f{tt[e], tt[e]};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = __builtin_elementwise_fma(t2, hh[c + e], acc[c]);
-      }
-    }
-  }
 
-  if (POISSON) {
-    // ---- epilogue: n = max(conv, 0) + b;  loss += n - c log(n + eps);  g = (1 - c / (n + eps)) / N where conv >= 0
-    __shared__ double red[THREADS / 64];
-    double local = 0.0;
+    if (POISSON) {
+      // ---- epilogue: n = max(conv, 0) + b;  loss += n - c log(n + eps);  g = (1 - c / (n + eps)) / N where conv >= 0
+      __shared__ double red[THREADS / 64];
+      float* g_out = a.n_batch > 0 ? a.table->g[d] : a.out;
+      double local = 0.0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int gy = Y0 + cy + c;
-      if (gy >= a.H || gx >= a.W) continue;
-      const size_t off = (size_t)gy * a.W + gx;
-      const bool two = gx + 1 < a.W;
-      float n2[2], g2[2];
+      for (int c = 0; c < 4; ++c) {
+        const int gy = Y0 + cy + c;
+        if (gy >= a.H || gx >= a.W) continue;
+        const size_t off = (size_t)gy * a.W + gx;
+        const bool two = gx + 1 < a.W;
+        float n2[2], g2[2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float conv = acc[c][e], b = oscale[c][e], cnt = oprev[c][e];
-        const float n = fmaxf(conv, 0.f) + b;  // clip, then the un-convolved background (npred.py:191,254-261)
-        const float ne = n + a.eps;
-        if (e == 0 || two) local += (double)(n - cnt * logf(ne));
-        const float g = (1.f - cnt / ne) * a.inv_n;
-        n2[e] = n;
-        g2[e] = conv >= 0.f ? g : 0.f;  // clamp backward: passes where conv >= 0
-      }
-      if (VEC) {
-        if (a.write_grad) *reinterpret_cast<v2f*>(a.out + off) = v2f{g2[0], g2[1]};
-        if (a.npred_out) *reinterpret_cast<v2f*>(a.npred_out + off) = v2f{n2[0], n2[1]};
-      } else {
-        if (a.write_grad) {
-          a.out[off] = g2[0];
-          if (two) a.out[off + 1] = g2[1];
+        for (int e = 0; e < 2; ++e) {
+          const float conv = acc[c][e], b = opa[c][e], cnt = opb[c][e];
+          const float n = fmaxf(conv, 0.f) + b;  // clip, then the un-convolved background (npred.py:191,254-261)
+          const float ne = n + a.eps;
+          if (e == 0 || two) local += (double)(n - cnt * logf(ne));
+          const float g = (1.f - cnt / ne) * a.inv_n;
+          n2[e] = n;
+          g2[e] = conv >= 0.f ? g : 0.f;  // clamp backward: passes where conv >= 0
         }
-        if (a.npred_out) {
-          a.npred_out[off] = n2[0];
-          if (two) a.npred_out[off + 1] = n2[1];
+        if (VEC) {
+          if (a.write_grad) *reinterpret_cast<v2f*>(g_out + off) = v2f{g2[0], g2[1]};
+          if (a.npred_out) *reinterpret_cast<v2f*>(a.npred_out + off) = v2f{n2[0], n2[1]};
+        } else {
+          if (a.write_grad) {
+            g_out[off] = g2[0];
+            if (two) g_out[off + 1] = g2[1];
+          }
+          if (a.npred_out) {
+            a.npred_out[off] = n2[0];
+            if (two) a.npred_out[off + 1] = n2[1];
+          }
         }
       }
+      local = wave_sum(local);
+      if ((tid & 63) == 0) red[tid >> 6] = local;
+      __syncthreads();
+      if (tid == 0) a.partials[(size_t)d * a.n_tiles + tile] = (red[0] + red[1]) + (red[2] + red[3]);
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) res[c] = res[c] + a.coef * acc[c] * opa[c];
     }
-    local = wave_sum(local);
-    if ((tid & 63) == 0) red[tid >> 6] = local;
-    __syncthreads();
-    if (tid == 0) a.partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
-    return;
   }
-  // ---- epilogue: out = [out +] coef * out_scale * acc -------------------------------------------------------
+  if (POISSON) return;
+
+  // ---- epilogue: out = [out +] sum_d coef * out_scale_d * conv_d ------------------------------------------------
   if (gx >= a.W) return;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int gy = Y0 + cy + c;
     if (gy >= a.H) break;
     const size_t off = (size_t)gy * a.W + gx;
-    const v2f res = oprev[c] + a.coef * acc[c] * oscale[c];
     if (VEC) {
-      *reinterpret_cast<v2f*>(a.out + off) = res;
+      *reinterpret_cast<v2f*>(a.out + off) = res[c];
     } else {
-      a.out[off] = res.x;
-      if (gx + 1 < a.W) a.out[off + 1] = res.y;
+      a.out[off] = res[c].x;
+      if (gx + 1 < a.W) a.out[off + 1] = res[c].y;
     }
   }
 }
@@ -370,7 +404,8 @@ int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double 
 }
 
 namespace {
-int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool poisson, hipStream_t stream) {
+int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool poisson, hipStream_t stream,
+               bool batch_aligned = true) {
   if (!sep_conv_supported(kh, kw))
     return fail(JD_ERR_INVALID, "separable convolution: PSF %dx%d exceeds %dx%d", kh, kw, SEP_MAX_K, SEP_MAX_K);
   const SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
@@ -381,9 +416,11 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
   const size_t lds = ((size_t)2 * g.rpairs * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
   const int blocks = ((a.n_tiles + 7) / 8) * 8;
   auto aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  const bool vec = a.W % 4 == 0 && aligned(a.in) && aligned(a.in_scale) && aligned(a.out) && aligned(a.out_scale) &&
-                   aligned(a.background) && aligned(a.counts) && aligned(a.npred_out);
-  const int variant = (poisson ? 4 : 0) + (vec ? 2 : 0) + (a.in_scale ? 1 : 0);
+  bool vec = a.W % 4 == 0 && aligned(a.in) && aligned(a.in_scale) && aligned(a.out) && aligned(a.out_scale) &&
+             aligned(a.background) && aligned(a.counts) && aligned(a.npred_out);
+  vec = vec && (a.n_batch == 0 || batch_aligned);
+  const bool in_scale = a.n_batch > 0 ? poisson : a.in_scale != nullptr;  // batches: forward scales its input, adjoint its output
+  const int variant = (poisson ? 4 : 0) + (vec ? 2 : 0) + (in_scale ? 1 : 0);
   void (*const kernels[8])(SepArgs) = {
       sep_conv_kernel<false, false, false>, sep_conv_kernel<false, true, false>, sep_conv_kernel<true, false, false>,
       sep_conv_kernel<true, true, false>,   sep_conv_kernel<false, false, true>, sep_conv_kernel<false, true, true>,
@@ -395,7 +432,7 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
     lds_set[variant] = lds;
   }
   ProfScope prof(poisson ? JD_KERNEL_POISSON_FUSED : JD_KERNEL_SEP_CONV, stream);  // the fused launch IS the Poisson pass
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(THREADS), lds, stream, a);
+  hipLaunchKernelGGL(kernel, dim3(blocks, poisson && a.n_batch > 0 ? a.n_batch : 1), dim3(THREADS), lds, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -428,6 +465,38 @@ int launch_sep_conv_poisson(const float* in, const float* in_scale, const float*
   a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
   *n_partials = sep_conv_tiles(H, W);
   return launch_sep(a, kh, kw, oy, ox, 0, true, stream);
+}
+
+static bool table_aligned(const SepBatchTable& t, int n) {
+  auto ok = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  bool all = true;
+  for (int d = 0; d < n; ++d) all = all && ok(t.scale[d]) && ok(t.bkg[d]) && ok(t.cnt[d]) && ok(t.g[d]);
+  return all;
+}
+
+// All forward models + Poisson passes of a joint step in ONE launch (grid.y = dataset): dataset d reads `flux` and
+// table.scale[d], writes g into table.g[d] (if write_grad) and its block sums into partials[d * tiles + tile].
+// `table_dev` is the device copy of `table`.
+int launch_sep_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev,
+                                  int H, int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
+                                  int write_grad, hipStream_t stream) {
+  if (n < 1 || n > SEP_MAX_BATCH) return fail(JD_ERR_INVALID, "separable batch: %d datasets not in [1, %d]", n, SEP_MAX_BATCH);
+  SepArgs a{};
+  a.in = flux, a.H = H, a.W = W, a.coef = 1.f, a.partials = partials;
+  a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_batch = n, a.table = table_dev;
+  a.op = table.op[0], a.in_scale = table.scale[0];
+  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, table_aligned(table, n));
+}
+
+// grad (+)= coef * sum_d scale[d] * corr_same(g[d], psf_d): one launch, the datasets are added in order in
+// registers (bit-identical to n accumulate launches), the gradient image is read and written once.
+int launch_sep_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H,
+                                  int W, int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream) {
+  if (n < 1 || n > SEP_MAX_BATCH) return fail(JD_ERR_INVALID, "separable batch: %d datasets not in [1, %d]", n, SEP_MAX_BATCH);
+  SepArgs a{};
+  a.out = grad, a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate, a.n_batch = n, a.table = table_dev;
+  a.in = table.g[0], a.op = table.op[0];
+  return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_aligned(table, n));
 }
 
 }  // namespace jd

@@ -80,6 +80,34 @@ class PoissonLoss:
             grad_scale=grad_scale, npred_out=npred_out,
         )
 
+    def batchable(self, indices):
+        """True if the datasets `indices` can take the batched joint step: one flux component, no up-sampling, no
+        calibration, one separable plan shared by all of them."""
+        models_all = [self.npred_models_all[i] for i in indices]
+        if len(models_all) < 2:
+            return False
+        plans = set()
+        for models in models_all:
+            if len(models) != 1 or models.calibration is not None:
+                return False
+            (model,) = models.values()
+            if (model.upsampling_factor or 1) != 1:
+                return False
+            plans.add(id(model.plan))
+        (model,) = models_all[0].values()
+        return len(plans) == 1 and model.plan.method == "separable"
+
+    def fwd_bwd_batch(self, indices, flux, loss_outs, grad=None, accumulate=False, grad_scale=1.0):
+        """Forward model + Poisson NLL (+ gradient, summed over the datasets in order) of the datasets `indices`
+        in three launches; requires `batchable(indices)`."""
+        models = [next(iter(self.npred_models_all[i].values())) for i in indices]
+        models[0].plan.npred_poisson_batch_fwd_bwd(
+            flux=flux, exposures=[m.exposure for m in models], khats=[m.khat for m in models],
+            backgrounds=[self.npred_models_all[i].background for i in indices],
+            counts=[self.counts_all[i] for i in indices], stirlings=[self.stirling_all[i] for i in indices],
+            loss_outs=loss_outs, grad=grad, accumulate=accumulate, grad_scale=grad_scale,
+        )
+
     @classmethod
     def from_datasets(cls, datasets, components, calibrations=None, device=TORCH_DEFAULT_DEVICE):
         npred_models_all, counts_all = [], []

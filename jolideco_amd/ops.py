@@ -193,6 +193,31 @@ class ConvPlan:
             )
         )
 
+    MAX_BATCH = 16  # SEP_MAX_BATCH of csrc/kernels.h
+
+    def npred_poisson_batch_fwd_bwd(self, flux, exposures, khats, backgrounds, counts, stirlings, loss_outs, grad=None,
+                                    accumulate=False, grad_scale=1.0, eps=POISSON_EPS):
+        """All datasets of a joint step at once (one flux component, separable plan shared by the datasets): one
+        launch for the forward models + Poisson passes, one for the losses, one for the adjoints
+        (jd_npred_poisson_batch_fwd_bwd).  Same numbers as the per-dataset calls with ``accumulate`` from the second
+        dataset on."""
+        n = len(exposures)
+        if not (len(khats) == len(backgrounds) == len(counts) == len(stirlings) == len(loss_outs) == n):
+            raise ValueError("all per-dataset lists must have the same length")
+        self._check_image(flux, "flux")
+        for start in range(0, n, self.MAX_BATCH):
+            sl = slice(start, min(n, start + self.MAX_BATCH))
+            m = sl.stop - sl.start
+            stirling_arr = (c_float * m)(*[float(v) for v in stirlings[sl]])
+            check(
+                _hip.lib().jd_npred_poisson_batch_fwd_bwd(
+                    self._handle, m, ptr(flux), ptr_array(exposures[sl]), ptr_array(khats[sl]),
+                    ptr_array(backgrounds[sl]), ptr_array(counts[sl]), stirling_arr, c_float(eps),
+                    ptr_array(loss_outs[sl]), ptr(grad), int(accumulate or start > 0), c_float(grad_scale),
+                    stream_ptr(flux.device),
+                )
+            )
+
 
 class GmmHandle:
     """GMM constants in MFMA fragment order on the device (jd_gmm)."""

@@ -432,3 +432,26 @@ def test_fit_writes_the_file_the_reference_writes(tmp_path):
     again = MAPDeconvolverResult.read(tmp_path / "result.fits")
     assert rel_linf(again.flux_total, result.flux_total) < 1e-6
     assert again.config["checkpoint_path"] == str(tmp_path / "ckpt")
+
+
+def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch):
+    """fit_mode="joint" with one separable component runs all datasets of a step in three launches
+    (jd_npred_poisson_batch_fwd_bwd).  Same trajectory as the per-dataset loop, bit for bit: the datasets' gradient
+    contributions are added in the same order."""
+    from jolideco_amd import MAPDeconvolver, SpatialFluxComponent, UniformPrior
+    from jolideco_amd.data import synthetic_observations
+
+    datasets, _, flux_init = synthetic_observations(shape=(96, 160), n_obs=5, seed=3)
+    results = {}
+    for mode in ("batch", "loop"):
+        if mode == "loop":
+            monkeypatch.setenv("JOLIDECO_NO_BATCH", "1")
+        comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=UniformPrior())
+        deconvolver = MAPDeconvolver(n_epochs=6, display_progress=False, device=DEV, fit_mode="joint")
+        session = deconvolver.session(datasets, components=comp)
+        assert session.batch_joint == (mode == "batch")
+        res = deconvolver.run(datasets, components=comp)
+        results[mode] = (res.flux_total, {name: np.asarray(res.trace_loss[name]) for name in res.trace_loss.colnames if name != "filename"})
+    assert np.array_equal(results["batch"][0], results["loop"][0])
+    for name, column in results["loop"][1].items():
+        np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
