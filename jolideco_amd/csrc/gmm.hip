@@ -400,22 +400,25 @@ struct GmmBucketArgs {
   const float* lfinal;
   // [gridDim.x][K]: per-block bin counts (count kernel), turned into the block's offset inside each bin (binscan)
   int* blk_counts;
+  int chunk;    // elements per chunk (multiple of 256): 1024 patches | one record segment (seg_cap)
+  int* korder;  // nullable: the scan kernel also ranks the bins by size (order of the components for the next screen)
 };
 
-// component of element n, or -1 if it takes no part
+// component of element n, or a negative number if it takes no part (-1: filtered patch)
 __device__ __forceinline__ int bucket_key(const GmmBucketArgs& a, int n) {
-  if (n >= a.n_end) return -2;
-  if (a.seg_cnt) {
-    if (n % a.seg_cap >= a.seg_cnt[n / a.seg_cap]) return -2;
-    if (!(a.rec_ub[n] >= a.lfinal[a.rec_n[n]])) return -2;
-  }
+  if (a.seg_cnt && !(a.rec_ub[n] >= a.lfinal[a.rec_n[n]])) return -2;  // stale record
   return a.argmax[n];
 }
-__device__ __forceinline__ bool bucket_block_empty(const GmmBucketArgs& a, int base) {
-  return a.seg_cnt && base < a.n_end && base % a.seg_cap >= a.seg_cnt[base / a.seg_cap];  // BUCKET_CHUNK divides seg_cap
+// number of elements of chunk c that are in use
+__device__ __forceinline__ int bucket_chunk_size(const GmmBucketArgs& a, int c) {
+  const int left = a.n_end - (a.n_begin + c * a.chunk);
+  const int full = left < a.chunk ? left : a.chunk;
+  if (!a.seg_cnt) return full;
+  const int used = a.seg_cnt[c];  // chunk == record segment
+  return used < full ? used : full;
 }
 
-constexpr int BUCKET_CHUNK = 1024;  // patches per block (4 per thread)
+constexpr int BUCKET_CHUNK = 1024;  // patches per chunk of the backward sort
 constexpr int BUCKET_MAX_K = 4096;  // LDS histogram capacity
 
 // Each block walks over chunks blockIdx.x, blockIdx.x + gridDim.x, ... and touches the global counters once per
@@ -424,13 +427,11 @@ __global__ __launch_bounds__(256) void gmm_bucket_count_kernel(GmmBucketArgs a) 
   extern __shared__ int hist[];
   for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = 0;
   __syncthreads();
-  const int n_chunks = (a.n_end - a.n_begin + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+  const int n_chunks = (a.n_end - a.n_begin + a.chunk - 1) / a.chunk;
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const int base = a.n_begin + c * BUCKET_CHUNK;
-    if (bucket_block_empty(a, base)) continue;
-#pragma unroll
-    for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
-      const int k = bucket_key(a, base + i * 256 + threadIdx.x);
+    const int base = a.n_begin + c * a.chunk, size = bucket_chunk_size(a, c);
+    for (int i = threadIdx.x; i < size; i += 256) {
+      const int k = bucket_key(a, base + i);
       if (k >= 0) atomicAdd(&hist[k], 1);
     }
   }
@@ -490,22 +491,31 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
     total += (a.counts[k] + 31) & ~31;
   }
   if (threadIdx.x == 255) a.offsets[a.K] = part[cur][255];
+  if (a.korder) {  // bins by size, largest first (ties: lowest index): the visiting order of the next screen
+    for (int k = threadIdx.x; k < a.K; k += 256) {
+      const int ck = a.counts[k];
+      int rank = 0;
+      for (int j = 0; j < a.K; ++j) {
+        const int cj = a.counts[j];
+        rank += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
+      }
+      a.korder[rank] = k;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a) {
   extern __shared__ int hist[];  // [0, K): the block's next free slot inside each bucket
-  const int n_chunks = (a.n_end - a.n_begin + BUCKET_CHUNK - 1) / BUCKET_CHUNK;
+  const int n_chunks = (a.n_end - a.n_begin + a.chunk - 1) / a.chunk;
   // the block's first slot inside every bucket: bucket offset + the counts of the blocks before it (binscan); the
   // walk over the chunks is the count kernel's, so the numbers match
   for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = a.offsets[k] + a.blk_counts[(size_t)blockIdx.x * a.K + k];
   __syncthreads();
-  // pass 2: place the elements (the order inside a bucket does not influence any result)
+  // place the elements (the order inside a bucket does not influence any result)
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const int base = a.n_begin + c * BUCKET_CHUNK;
-    if (bucket_block_empty(a, base)) continue;
-#pragma unroll
-    for (int i = 0; i < BUCKET_CHUNK / 256; ++i) {
-      const int n = base + i * 256 + threadIdx.x;
+    const int base = a.n_begin + c * a.chunk, size = bucket_chunk_size(a, c);
+    for (int i = threadIdx.x; i < size; i += 256) {
+      const int n = base + i;
       const int k = bucket_key(a, n);
       if (k >= 0) {
         a.order[atomicAdd(&hist[k], 1)] = n;
@@ -1010,19 +1020,6 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   if (lane == 0) a.seg_cnt[wave_global] = cnt < SCREEN_CAP ? cnt : SCREEN_CAP;
   if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
     if (lane == 0) atomicOr(a.flag, 1);
-  }
-}
-
-// Order of the components for the NEXT call: most survivors first (ties: lowest index), from this call's buckets.
-__global__ __launch_bounds__(256) void gmm_korder_kernel(const int* counts, int K, int* korder) {
-  for (int k = threadIdx.x; k < K; k += 256) {
-    const int ck = counts[k];
-    int rank = 0;
-    for (int j = 0; j < K; ++j) {
-      const int cj = counts[j];
-      rank += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
-    }
-    korder[rank] = k;
   }
 }
 
@@ -1537,7 +1534,9 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   bk.counts = g->screen_ctl + 1, bk.cursor = g->screen_ctl + 1 + g->K, bk.offsets = g->screen_ctl + 1 + 2 * g->K;
   bk.order = g->rec_order, bk.gpatch = nullptr;
   bk.seg_cnt = g->seg_cnt, bk.seg_cap = SCREEN_CAP, bk.rec_n = rec_n, bk.rec_ub = rec_ub, bk.lfinal = g->lfinal;
-  unsigned chunks = (unsigned)((slots + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+  bk.chunk = SCREEN_CAP;  // one record segment per chunk
+  bk.korder = g->K <= KORDER_MAX_K ? g->korder : nullptr;
+  unsigned chunks = (unsigned)n_seg;
   // the kernels stride over the chunks; many small blocks hide the latency of the dependent record loads
   const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
   if (chunks > max_blocks) chunks = max_blocks;
@@ -1550,7 +1549,6 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
     gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
     gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
-    if (g->K <= KORDER_MAX_K) gmm_korder_kernel<<<1, 256, 0, s>>>(bk.counts, g->K, g->korder);
   }
   JD_LAUNCH_CHECK();
 
@@ -1677,6 +1675,7 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   bk.argmax = arg, bk.n_begin = n_begin, bk.n_end = n_end, bk.K = g->K;
   bk.counts = g->bucket, bk.cursor = g->bucket + g->K, bk.offsets = g->bucket + 2 * g->K;
   bk.order = g->order, bk.gpatch = g->gpatch;
+  bk.chunk = BUCKET_CHUNK;
   JD_HIP(hipMemsetAsync(g->bucket, 0, (size_t)2 * g->K * sizeof(int), s));
   JD_HIP(hipMemsetAsync(g->order, 0xFF, slots_cap * sizeof(int32_t), s));
   unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
