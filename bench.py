@@ -301,7 +301,9 @@ def main():
     poi_ms, poi_n = avg_ms("poisson_fused")
     methods = sorted({m.plan.method for m in session.total_loss.poisson_loss.npred_models_all})
     poisson_in_conv = methods == ["separable"] and len(session.components) == 1 and not os.environ.get("JD_SEP_NO_FUSION")
-    poi_bytes = (20 if poisson_in_conv else 16) * H * W
+    # batched joint step: ONE launch covers all local datasets (jd_npred_poisson_batch_fwd_bwd)
+    per_launch = len(session.local_idx) if getattr(session, "batch_joint", False) else 1
+    poi_bytes = (20 if poisson_in_conv else 16) * H * W * per_launch
     poi_kernel = "sep_conv_kernel<true, true, true>" if poisson_in_conv else "poisson_fused_kernel"
     roof_poi = None
     if poi_ms:
@@ -310,7 +312,7 @@ def main():
             "kernel": poi_kernel + (" (forward convolution + Poisson pass)" if poisson_in_conv else ""), "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic_bytes(args.config, poi_kernel) if world == 1 and fake is None else None,
-            "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes,
+            "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes, "datasets_per_launch": per_launch,
         }
     n_profiled = len(range(0, args.steps, PROFILE_EVERY))
     nested = ("gmm_screen", "gmm_sort", "gmm_exact")  # stage timers inside the gmm_fwd bracket
@@ -352,7 +354,8 @@ def main():
     if conv_key:
         conv_ms, conv_n = avg_ms(conv_key)
         # (with the Poisson pass fused into the forward launch only the adjoint carries this timer: 16 B/pixel)
-        conv_bytes = (16 if poisson_in_conv else 14) * H * W
+        # a batched adjoint reads g + exposure per dataset and reads / writes the gradient once: (8 n + 8) B/pixel
+        conv_bytes = ((8 * per_launch + 8) if (poisson_in_conv and per_launch > 1) else 16 if poisson_in_conv else 14) * H * W
         achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
         conv_traffic = None
         if world == 1 and fake is None:
@@ -368,6 +371,7 @@ def main():
             "kernel": _hip.lib().jd_kernel_name(_hip.KERNEL_IDS[conv_key]).decode(), "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": conv_traffic, "avg_launch_ms": conv_ms, "launches": conv_n, "bytes_per_launch": conv_bytes,
+            "datasets_per_launch": per_launch,
         }
     # The same fit with the PSF treated as a general (not low-rank) kernel, i.e. what an instrument PSF that is not
     # a sum of <= 3 outer products gets: MFMA Toeplitz convolution.  Reported next to the headline, never as it.
