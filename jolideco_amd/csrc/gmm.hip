@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
 // cover it in a fixed order (no float atomics), un-rolls and accumulates into grad.
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
-// Screened arg-max (max mode, zero-mean mixtures): the same result as gmm_fwd_kernel<MODE_MAX>, bit for bit,
+// Screened arg-max (max mode, upper triangular precision factors): the same result as gmm_fwd_kernel<MODE_MAX>, bit for bit,
 // for a fraction of the fp32 matrix work.
 //
 //   1. SCREEN (gmm_screen_kernel): every (patch, component) log-likelihood is first evaluated APPROXIMATELY with
@@ -809,6 +809,7 @@ struct GmmScreenArgs {
   const float* const_k;  // K
   const float* efro_k;   // K: SCREEN_EPS * |P'_k|_F (rounded up)
   const float* sk2_k;    // K: s_k^2, the squared power-of-two scale of the fp16 fragments
+  const float* mnorm_k;  // K: 1.001 |m'_k| (0 for a zero-mean component)
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
   const int* korder;         // K: the order in which the components are visited (most popular first)
   unsigned long long* best;  // per patch (global index): initialised here
@@ -860,7 +861,9 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
 // TWO tiles (A, B) and one component: after the MFMAs lane (h, c) holds half of q for patch c of both tiles.  One
 // v_permlane32_swap hands lanes 0-31 both halves of tile A and lanes 32-63 both halves of tile B, so the per-patch
 // arithmetic below runs once for the two tiles (per-lane state: half 0 = tile A's patch, half 1 = tile B's):
-//   ltilde = ck - q / 2,   |l - ltilde| <= sqrt(q) e + e^2 / 2,  e = eps |xbar| |P'_k|_F
+//   ltilde = ck - q / 2,   |l - ltilde| <= sqrt(q) e + e^2 / 2,  e = eps |xbar| |P'_k|_F + |m'_k|
+// (the screen ignores the component mean m'_k: y - m' = ytilde + d with |d| <= eps |xbar| |P'_k|_F + |m'_k|, so a
+// mixture with non-zero means only gets wider bounds; the exact stage subtracts the means)
 // inflated for the fp32 rounding of q, l, the hardware square root (1 ulp) and of this expression itself:
 //   B = sqrt(q) * e1 + 2e-5 q + c2,   e1 = 1.001 e,   c2 = 0.5 e1^2 + 1e-6 |ck| + 1e-30.
 // ONE sweep over the components: a component is recorded while its upper bound reaches the running lower bound L of
@@ -868,16 +871,16 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
 // components most-popular-first makes L rise early, so few stale records are written.
 // The issue slots beside the MFMAs are the budget (about six 4-cycle VALU instructions hide per 32-cycle MFMA).
 __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], const f32x16 (&accB)[2], float ck, float ack,
-                                                   float hef2, float efro, float xn, float xn2, float s2, bool ok,
-                                                   float& L, float& qacc, int n, int k, int lane, int seg, int& cnt,
+                                                   float mnorm, float efro, float xn, float s2, bool ok, float& L,
+                                                   float& qacc, int n, int k, int lane, int seg, int& cnt,
                                                    const GmmScreenArgs& a) {
   const float qa = screen_q_half(accA), qb = screen_q_half(accB);
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
   // lanes 0-31: tile A, lanes 32-63: tile B; s2 = (s_x s_k)^2 undoes the power-of-two operand scales (exactly)
   const float q = (__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * s2;
   qacc += q;  // a NaN / inf anywhere ends up here and raises the fallback flag
-  const float e1 = efro * xn;            // efro carries eps and the factor 1.001
-  const float c2 = fmaf(hef2, xn2, ack);  // hef2 = efro^2 / 2
+  const float e1 = fmaf(efro, xn, mnorm);  // efro carries eps and the factor 1.001; mnorm = 1.001 |m'_k| (see above)
+  const float c2 = fmaf(0.5f * e1, e1, ack);
   const float l = fmaf(-0.5f, q, ck);
   const float B = fmaf(__builtin_amdgcn_sqrtf(q), e1, fmaf(2e-5f, q, c2));
   const float ub = l + B;
@@ -960,14 +963,13 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   const int seg = wave_global * SCREEN_CAP;
   int cnt = 0;
   // per-lane state of the two tile pairs: lane half 0 carries the patch of tile 2 p, half 1 that of tile 2 p + 1
-  float pxn[2], pxn2[2], pL[2], pq[2], ps2[2];
+  float pxn[2], pL[2], pq[2], ps2[2];
   bool pok[2];
   int pn[2];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     ps2[p] = h ? xs2[2 * p + 1] : xs2[2 * p];
     pxn[p] = h ? xn[2 * p + 1] : xn[2 * p];
-    pxn2[p] = pxn[p] * pxn[p];
     pok[p] = h ? ok[2 * p + 1] : ok[2 * p];
     pn[p] = h ? nidx[2 * p + 1] : nidx[2 * p];
     pL[p] = -INFINITY;
@@ -982,7 +984,7 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(f16x8, xs_lane[(t * 4 + s) * 64]);
   };
   int k_next = a.korder[0];
-  float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next];
+  float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
   load_frags16(f0, af, k_next);
   // prologue: tiles 0, 1 of the first component
   load_x16(0);
@@ -991,23 +993,23 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   mfma_screen(acc[1], f0, x);
   for (int kk = 0; kk < a.K; ++kk) {
     const int k = k_next;
-    const float ck = ck_next, ef = ef_next, sk2 = sk2_next;
-    const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f), hef2 = 0.5f * ef * ef;
+    const float ck = ck_next, ef = ef_next, sk2 = sk2_next, mn = mn_next;
+    const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f);
     k_next = a.korder[kk + 1 < a.K ? kk + 1 : kk];  // scalar loads one component ahead of their use
-    ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next];
+    ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
     load_frags16(f1, af, k_next);  // unconditional (clamped) prefetch of the next component
     // tiles 2, 3 of k on the matrix pipe while tiles 0, 1 of k finish in its shadow
     load_x16(2);
     mfma_screen(acc[2], f0, x);
     load_x16(3);
     mfma_screen(acc[3], f0, x);
-    screen_finish_pair(acc[0], acc[1], ck, ack, hef2, ef, pxn[0], pxn2[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane, seg, cnt, a);
+    screen_finish_pair(acc[0], acc[1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane, seg, cnt, a);
     // tiles 0, 1 of the next component while tiles 2, 3 of k finish
     load_x16(0);
     mfma_screen(acc[0], f1, x);
     load_x16(1);
     mfma_screen(acc[1], f1, x);
-    screen_finish_pair(acc[2], acc[3], ck, ack, hef2, ef, pxn[1], pxn2[1], ps2[1] * sk2, pok[1], pL[1], pq[1], pn[1], k, lane, seg, cnt, a);
+    screen_finish_pair(acc[2], acc[3], ck, ack, mn, ef, pxn[1], ps2[1] * sk2, pok[1], pL[1], pq[1], pn[1], k, lane, seg, cnt, a);
 #pragma unroll
     for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
   }
@@ -1238,11 +1240,12 @@ struct jd_gmm {
   double* partials = nullptr;
   size_t partials_cap = 0;
   int n_cu = 256;
-  // screened arg-max (zero-mean, upper triangular mixtures): fp16 fragments, bound constants, work space
+  // screened arg-max (upper triangular mixtures): fp16 fragments, bound constants, work space
   bool screen_ok = false;
   uint4* afrag16 = nullptr;
   float* efro_k = nullptr;
   float* sk2_k = nullptr;
+  float* mnorm_k = nullptr;
   unsigned long long* best = nullptr;
   size_t best_cap = 0;
   float* lfinal = nullptr;
@@ -1316,11 +1319,10 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
   g->triangular = tri;
   // screening operands: fp16(P' / s_k) in 32x32x16 A-fragment order, blocks (jb, s) = (0,0) (0,1) (1,0) (1,1) (1,2) (1,3):
   // lane l holds A[row l & 31][k = 8 (l >> 5) + e] = P'[pixel 16 s + 8 (l >> 5) + e][32 jb + (l & 31)]
-  bool zero_means = true;
-  for (size_t i = 0; i < (size_t)K * D; ++i) zero_means = zero_means && mu_prec[i] == 0.f;
+  bool screenable = true;
   std::vector<uint16_t> a16;
-  std::vector<float> efro, sk2;
-  if (tri && zero_means) {
+  std::vector<float> efro, sk2, mnorm;
+  if (tri) {
     auto to_half = [](float f) -> uint16_t {  // IEEE binary16, round to nearest even (|f| < 65504 here)
       uint32_t u;
       memcpy(&u, &f, 4);
@@ -1345,6 +1347,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     a16.resize((size_t)K * A16_BLOCKS * 64 * 8);
     efro.resize(K);
     sk2.resize(K);
+    mnorm.resize(K);
     for (int k = 0; k < K; ++k) {
       const float* Pk = prec_chol + (size_t)k * D * D;
       double fro = 0.0, amax = 0.0;
@@ -1360,7 +1363,13 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
       const double inv_s = std::ldexp(1.0, 14 - ex);
       sk2[k] = (float)std::ldexp(1.0, 2 * (ex - 14));
       efro[k] = (float)(std::sqrt(fro) * (double)SCREEN_EPS * 1.0011);  // includes the 1.001 inflation of the bound
-      if (!std::isfinite(efro[k]) || !(sk2[k] > 0.f) || !std::isfinite(sk2[k])) zero_means = false;  // no screening
+      double m2 = 0.0;
+      for (int j = 0; j < D; ++j) {
+        const double m = (double)mu_prec[(size_t)k * D + j] * sw[j];
+        m2 += m * m;
+      }
+      mnorm[k] = (float)(std::sqrt(m2) * 1.0011);
+      if (!std::isfinite(efro[k]) || !std::isfinite(mnorm[k]) || !(sk2[k] > 0.f) || !std::isfinite(sk2[k])) screenable = false;
       for (int b = 0; b < A16_BLOCKS; ++b)
         for (int lane = 0; lane < 64; ++lane)
           for (int e = 0; e < 8; ++e) {
@@ -1369,7 +1378,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
             a16[(((size_t)k * A16_BLOCKS + b) * 64 + lane) * 8 + e] = to_half(v);
           }
     }
-    if (!zero_means) a16.clear();
+    if (!screenable) a16.clear();
   }
   auto upload = [&](float** dst, const float* src, size_t n) -> int {
     JD_HIP(hipMalloc(dst, n * sizeof(float)));
@@ -1390,6 +1399,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     if (hipMalloc(&g->afrag16, a16.size() * sizeof(uint16_t)) != hipSuccess ||
         hipMemcpy(g->afrag16, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
         (rc = upload(&g->efro_k, efro.data(), efro.size())) || (rc = upload(&g->sk2_k, sk2.data(), sk2.size())) ||
+        (rc = upload(&g->mnorm_k, mnorm.data(), mnorm.size())) ||
         hipMalloc(&g->screen_ctl, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess ||
         hipMalloc(&g->korder, (size_t)K * sizeof(int)) != hipSuccess) {
       jd_gmm_destroy(g);
@@ -1420,6 +1430,7 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->afrag16) (void)hipFree(g->afrag16);
   if (g->efro_k) (void)hipFree(g->efro_k);
   if (g->sk2_k) (void)hipFree(g->sk2_k);
+  if (g->mnorm_k) (void)hipFree(g->mnorm_k);
   if (g->best) (void)hipFree(g->best);
   if (g->lfinal) (void)hipFree(g->lfinal);
   if (g->rec) (void)hipFree(g->rec);
@@ -1517,7 +1528,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmScreenArgs sc{};
-  sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k, sc.sk2_k = g->sk2_k, sc.korder = g->korder;
+  sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k, sc.sk2_k = g->sk2_k, sc.mnorm_k = g->mnorm_k, sc.korder = g->korder;
   sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
   sc.best = g->best, sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;

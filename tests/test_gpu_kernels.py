@@ -508,16 +508,22 @@ def test_marginalized_prior_fit_matches_oracle():
     np.testing.assert_allclose(res.trace_loss[-1]["total"], trace[-1]["total"], rtol=2e-5)
 
 
-@pytest.mark.parametrize("shape,K,seed", [((96, 128), 8, 0), ((257, 131), 37, 1), ((512, 512), 128, 2), ((64, 64), 1, 3)])
-def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, monkeypatch):
+@pytest.mark.parametrize(
+    "shape,K,seed,mean_scale",
+    [((96, 128), 8, 0, 0.0), ((257, 131), 37, 1, 0.0), ((512, 512), 128, 2, 0.0), ((64, 64), 1, 3, 0.0),
+     ((200, 168), 64, 4, 0.02), ((120, 136), 16, 5, 1.0)],
+)
+def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, mean_scale, monkeypatch):
     """Max mode through the bf16 screen + exact fp32 re-evaluation of the survivors (csrc/gmm.hip, gmm_screen_kernel)
     returns exactly the dense fp32 kernel's numbers: same arg-max for every patch, same value bits, same gradient
-    bits -- on noise, on smooth structure with bright points, with filtered patches and with cycle-spin shifts."""
+    bits -- on noise, on smooth structure with bright points, with filtered patches and with cycle-spin shifts; also
+    for mixtures with small (trained-GMM like) and large component means, which only widen the screen's bounds."""
     from jolideco_amd.data import synthetic_gmm
     from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
 
     rs = np.random.RandomState(seed)
     means, covs, weights = synthetic_gmm(K, 64, seed=seed)
+    means = means + mean_scale * rs.normal(size=means.shape)
     gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
     y, x = np.mgrid[0 : shape[0], 0 : shape[1]]
     smooth = 1.0 + 20 * np.exp(-0.5 * (((y - shape[0] / 3) / 9.0) ** 2 + ((x - shape[1] / 2) / 14.0) ** 2))
