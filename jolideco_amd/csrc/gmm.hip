@@ -872,8 +872,8 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
 // The issue slots beside the MFMAs are the budget (about six 4-cycle VALU instructions hide per 32-cycle MFMA).
 __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], const f32x16 (&accB)[2], float ck, float ack,
                                                    float mnorm, float efro, float xn, float s2, bool ok, float& L,
-                                                   float& qacc, int n, int k, int lane, int seg, int& cnt,
-                                                   const GmmScreenArgs& a) {
+                                                   float& qacc, int n, int k, int lane, int& cnt, int32_t* rec_n,
+                                                   int32_t* rec_k, float* rec_ub) {
   const float qa = screen_q_half(accA), qb = screen_q_half(accB);
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
   // lanes 0-31: tile A, lanes 32-63: tile B; s2 = (s_x s_k)^2 undoes the power-of-two operand scales (exactly)
@@ -889,10 +889,10 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   const unsigned long long mask = __ballot(cand);
   if (mask) {
     const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-    if (cand && pos < SCREEN_CAP) {
-      a.rec_n[seg + pos] = n;
-      a.rec_k[seg + pos] = k;
-      a.rec_ub[seg + pos] = ub;
+    if (cand && pos < SCREEN_CAP) {  // (the wave's segment: uniform base pointers, one 32-bit offset)
+      rec_n[pos] = n;
+      rec_k[pos] = k;
+      rec_ub[pos] = ub;
     }
     cnt += __popcll(mask);
   }
@@ -960,7 +960,10 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   // (wave-private LDS: written and read by the same wave, program order suffices)
   const uint4* af = a.afrag16 + lane;
   const uint4* xs_lane = &xs[wave][lane];
-  const int seg = wave_global * SCREEN_CAP;
+  const int seg = __builtin_amdgcn_readfirstlane(wave_global * SCREEN_CAP);
+  int32_t* seg_n = a.rec_n + seg;
+  int32_t* seg_k = a.rec_k + seg;
+  float* seg_ub = a.rec_ub + seg;
   int cnt = 0;
   // per-lane state of the two tile pairs: lane half 0 carries the patch of tile 2 p, half 1 that of tile 2 p + 1
   float pxn[2], pL[2], pq[2], ps2[2];
@@ -1003,13 +1006,13 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     mfma_screen(acc[2], f0, x);
     load_x16(3);
     mfma_screen(acc[3], f0, x);
-    screen_finish_pair(acc[0], acc[1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane, seg, cnt, a);
+    screen_finish_pair(acc[0], acc[1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane, cnt, seg_n, seg_k, seg_ub);
     // tiles 0, 1 of the next component while tiles 2, 3 of k finish
     load_x16(0);
     mfma_screen(acc[0], f1, x);
     load_x16(1);
     mfma_screen(acc[1], f1, x);
-    screen_finish_pair(acc[2], acc[3], ck, ack, mn, ef, pxn[1], ps2[1] * sk2, pok[1], pL[1], pq[1], pn[1], k, lane, seg, cnt, a);
+    screen_finish_pair(acc[2], acc[3], ck, ack, mn, ef, pxn[1], ps2[1] * sk2, pok[1], pL[1], pq[1], pn[1], k, lane, cnt, seg_n, seg_k, seg_ub);
 #pragma unroll
     for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
   }
