@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int SCREEN_T = 4;        // tiles of 32 patches per wave
+constexpr int SCREEN_T = 4;        // tiles of 32 patches per wave (2 for small inputs: more waves)
 constexpr int SCREEN_CAP = 4096;   // candidate records a wave can hold (128 patches: 32 per patch); multiple of BUCKET_CHUNK
 constexpr int A16_BLOCKS = 6;      // non-zero (32 coordinates x 16 pixels) blocks of an upper triangular P'
 constexpr float SCREEN_EPS = 0.001f;  // two fp16 roundings 2^-10 + 2^-22, two fp32 accumulations of 64 terms, slack
@@ -898,18 +898,21 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   }
 }
 
+// NP = tile pairs per wave: 2 (128 patches per wave) for large inputs; 1 (64 patches) when that is what it takes to give
+// every CU a block (a rank's share of a sharded prior).
+template <int NP>
 __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
-  static_assert(SCREEN_T == 4, "the pipeline below is written for 4 tiles");
-  __shared__ uint4 xs[4][SCREEN_T * 4 * 64];  // per wave: [tile][pixel step][lane] = 8 fp16 (B fragment)
+  constexpr int NT = 2 * NP;
+  __shared__ uint4 xs[4][NT * 4 * 64];  // per wave: [tile][pixel step][lane] = 8 fp16 (B fragment)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
-  const int base = a.n_begin + wave_global * (SCREEN_T * 32);
+  const int base = a.n_begin + wave_global * (NT * 32);
   const int h = lane >> 5, c = lane & 31;  // lane (h, c): image rows 2 s + h (pixel step s) of patch c
-  float xn[SCREEN_T], xs2[SCREEN_T];
-  bool ok[SCREEN_T];
-  int nidx[SCREEN_T];
+  float xn[NT], xs2[NT];
+  bool ok[NT];
+  int nidx[NT];
 #pragma unroll
-  for (int t = 0; t < SCREEN_T; ++t) {
+  for (int t = 0; t < NT; ++t) {
     const int n = base + 32 * t + c;
     const bool valid = n < a.n_end;
     const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
@@ -966,11 +969,11 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   float* seg_ub = a.rec_ub + seg;
   int cnt = 0;
   // per-lane state of the two tile pairs: lane half 0 carries the patch of tile 2 p, half 1 that of tile 2 p + 1
-  float pxn[2], pL[2], pq[2], ps2[2];
-  bool pok[2];
-  int pn[2];
+  float pxn[NP], pL[NP], pq[NP], ps2[NP];
+  bool pok[NP];
+  int pn[NP];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < NP; ++p) {
     ps2[p] = h ? xs2[2 * p + 1] : xs2[2 * p];
     pxn[p] = h ? xn[2 * p + 1] : xn[2 * p];
     pok[p] = h ? ok[2 * p + 1] : ok[2 * p];
@@ -981,19 +984,19 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
 
   ScreenFrags f0, f1;
   f16x8 x[4];
-  f32x16 acc[SCREEN_T][2];
-  auto load_x16 = [&](int t) {
+  f32x16 acc[2][2][2];  // [buffer][tile of the pair][coordinate block]: one pair on the matrix pipe, one in the epilogue
+  auto issue_pair = [&](f32x16 (&buf)[2][2], const ScreenFrags& f, int p) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(f16x8, xs_lane[(t * 4 + s) * 64]);
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(f16x8, xs_lane[((2 * p + u) * 4 + s) * 64]);
+      mfma_screen(buf[u], f, x);
+    }
   };
   int k_next = a.korder[0];
   float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
   load_frags16(f0, af, k_next);
-  // prologue: tiles 0, 1 of the first component
-  load_x16(0);
-  mfma_screen(acc[0], f0, x);
-  load_x16(1);
-  mfma_screen(acc[1], f0, x);
+  issue_pair(acc[0], f0, 0);  // prologue: pair 0 of the first component
   for (int kk = 0; kk < a.K; ++kk) {
     const int k = k_next;
     const float ck = ck_next, ef = ef_next, sk2 = sk2_next, mn = mn_next;
@@ -1001,24 +1004,33 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     k_next = a.korder[kk + 1 < a.K ? kk + 1 : kk];  // scalar loads one component ahead of their use
     ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
     load_frags16(f1, af, k_next);  // unconditional (clamped) prefetch of the next component
-    // tiles 2, 3 of k on the matrix pipe while tiles 0, 1 of k finish in its shadow
-    load_x16(2);
-    mfma_screen(acc[2], f0, x);
-    load_x16(3);
-    mfma_screen(acc[3], f0, x);
-    screen_finish_pair(acc[0], acc[1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane, cnt, seg_n, seg_k, seg_ub);
-    // tiles 0, 1 of the next component while tiles 2, 3 of k finish
-    load_x16(0);
-    mfma_screen(acc[0], f1, x);
-    load_x16(1);
-    mfma_screen(acc[1], f1, x);
-    screen_finish_pair(acc[2], acc[3], ck, ack, mn, ef, pxn[1], ps2[1] * sk2, pok[1], pL[1], pq[1], pn[1], k, lane, cnt, seg_n, seg_k, seg_ub);
+    if (NP == 2) {
+      // pair 1 of k on the matrix pipe while pair 0 of k finishes in its shadow, then pair 0 of k + 1 | pair 1 of k
+      issue_pair(acc[1], f0, 1);
+      screen_finish_pair(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
+                         cnt, seg_n, seg_k, seg_ub);
+      issue_pair(acc[0], f1, 0);
+      screen_finish_pair(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[NP - 1], ps2[NP - 1] * sk2, pok[NP - 1], pL[NP - 1],
+                         pq[NP - 1], pn[NP - 1], k, lane, cnt, seg_n, seg_k, seg_ub);
+    } else {
+      // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the buffers alternate
+      const int cur = kk & 1;
+      if (cur == 0) {
+        issue_pair(acc[1], f1, 0);
+        screen_finish_pair(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
+                           cnt, seg_n, seg_k, seg_ub);
+      } else {
+        issue_pair(acc[0], f1, 0);
+        screen_finish_pair(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
+                           cnt, seg_n, seg_k, seg_ub);
+      }
+    }
 #pragma unroll
     for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
   }
   bool trouble = false;
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < NP; ++p) {
     trouble = trouble || (pok[p] && !(pq[p] < 3.0e38f));
     if (pn[p] < a.n_end) a.lfinal[pn[p]] = pL[p];
   }
@@ -1510,7 +1522,9 @@ static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, in
 // 1024 patches, exactly the numbers gmm_fwd_kernel<MODE_MAX> produces.
 static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials) {
   const long n = a.n_end - a.n_begin;
-  const long waves = (n + SCREEN_T * 32 - 1) / (SCREEN_T * 32);
+  // 4 tiles per wave (fragments amortised over 128 patches) unless that leaves CUs without a block: then 2
+  const int tiles_per_wave = (n + SCREEN_T * 32 * 4 - 1) / (SCREEN_T * 32 * 4) >= g->n_cu ? SCREEN_T : 2;
+  const long waves = (n + tiles_per_wave * 32 - 1) / (tiles_per_wave * 32);
   const unsigned blocks = (unsigned)((waves + 3) / 4);
   const size_t n_seg = (size_t)blocks * 4;
   const size_t slots = n_seg * SCREEN_CAP;                  // candidate record slots
@@ -1538,7 +1552,10 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   sc.seg_cnt = g->seg_cnt, sc.flag = flag;
   {
     ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
-    gmm_screen_kernel<<<blocks, 256, 0, s>>>(sc);
+    if (tiles_per_wave == 4)
+      gmm_screen_kernel<2><<<blocks, 256, 0, s>>>(sc);
+    else
+      gmm_screen_kernel<1><<<blocks, 256, 0, s>>>(sc);
   }
   JD_LAUNCH_CHECK();
 
