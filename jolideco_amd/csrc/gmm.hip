@@ -898,21 +898,30 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   }
 }
 
-// NP = tile pairs per wave: 2 (128 patches per wave) for large inputs; 1 (64 patches) when that is what it takes to give
-// every CU a block (a rank's share of a sharded prior).
-template <int NP>
+// NP = tile pairs (of 2 x 32 patches) a wave works on.  Two decompositions:
+//   KSPLIT = false  every wave owns its NP pairs and walks over ALL components (fragments amortised over 128 patches,
+//                   no synchronisation at all): large inputs;
+//   KSPLIT = true   the four waves of a block share NP pairs and each takes every fourth component of the visiting
+//                   order: a wave's sweep is four times shorter, so a small input (a rank's share of a sharded prior)
+//                   still occupies every CU for a short time instead of a few CUs for the full sweep.  Every wave
+//                   keeps its own running bound L_w (a valid lower bound of the maximum), the final bound is their
+//                   maximum.
+template <int NP, bool KSPLIT>
 __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   constexpr int NT = 2 * NP;
-  __shared__ uint4 xs[4][NT * 4 * 64];  // per wave: [tile][pixel step][lane] = 8 fp16 (B fragment)
+  __shared__ uint4 xs[KSPLIT ? 1 : 4][NT * 4 * 64];  // [tile][pixel step][lane] = 8 fp16 (B fragment); per wave | shared
+  __shared__ float st_xn[KSPLIT ? NT * 32 : 1], st_s2[KSPLIT ? NT * 32 : 1], st_L[KSPLIT ? 4 * NT * 32 : 1];
+  __shared__ int st_ok[KSPLIT ? NT * 32 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
-  const int base = a.n_begin + wave_global * (NT * 32);
+  const int base = a.n_begin + (KSPLIT ? (int)blockIdx.x : wave_global) * (NT * 32);
   const int h = lane >> 5, c = lane & 31;  // lane (h, c): image rows 2 s + h (pixel step s) of patch c
   float xn[NT], xs2[NT];
   bool ok[NT];
   int nidx[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
+    if (KSPLIT && (t & 3) != wave) continue;  // the block's tiles are staged by one wave each
     const int n = base + 32 * t + c;
     const bool valid = n < a.n_end;
     const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
@@ -956,13 +965,20 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
       f16x8 v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (_Float16)ldexpf(x[8 * s + e], 14 - ex);
-      xs[wave][(t * 4 + s) * 64 + lane] = __builtin_bit_cast(uint4, v);
+      xs[KSPLIT ? 0 : wave][(t * 4 + s) * 64 + lane] = __builtin_bit_cast(uint4, v);
     }
     if (h == 0 && valid) a.best[n] = ok[t] ? best_key(-INFINITY, 0) : 0ull;
+    if (KSPLIT && h == 0) st_xn[t * 32 + c] = xn[t], st_s2[t * 32 + c] = xs2[t], st_ok[t * 32 + c] = ok[t] ? 1 : 0;
   }
-  // (wave-private LDS: written and read by the same wave, program order suffices)
+  if (KSPLIT) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      xn[t] = st_xn[t * 32 + c], xs2[t] = st_s2[t * 32 + c], ok[t] = st_ok[t * 32 + c] != 0, nidx[t] = base + 32 * t + c;
+  }
+  // (KSPLIT = false: wave-private LDS, written and read by the same wave, program order suffices)
   const uint4* af = a.afrag16 + lane;
-  const uint4* xs_lane = &xs[wave][lane];
+  const uint4* xs_lane = &xs[KSPLIT ? 0 : wave][lane];
   const int seg = __builtin_amdgcn_readfirstlane(wave_global * SCREEN_CAP);
   int32_t* seg_n = a.rec_n + seg;
   int32_t* seg_k = a.rec_k + seg;
@@ -993,15 +1009,18 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
       mfma_screen(buf[u], f, x);
     }
   };
-  int k_next = a.korder[0];
+  constexpr int KSTEP = KSPLIT ? 4 : 1;
+  const int kk0 = KSPLIT ? wave : 0;  // position in the visiting order: wave w takes w, w + 4, ...
+  int k_next = a.korder[kk0 < a.K ? kk0 : 0];
   float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
   load_frags16(f0, af, k_next);
-  issue_pair(acc[0], f0, 0);  // prologue: pair 0 of the first component
-  for (int kk = 0; kk < a.K; ++kk) {
+  if (kk0 < a.K) issue_pair(acc[0], f0, 0);  // prologue: pair 0 of the first component
+  int it = 0;
+  for (int kk = kk0; kk < a.K; kk += KSTEP, ++it) {
     const int k = k_next;
     const float ck = ck_next, ef = ef_next, sk2 = sk2_next, mn = mn_next;
     const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f);
-    k_next = a.korder[kk + 1 < a.K ? kk + 1 : kk];  // scalar loads one component ahead of their use
+    k_next = a.korder[kk + KSTEP < a.K ? kk + KSTEP : kk];  // scalar loads one component ahead of their use
     ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
     load_frags16(f1, af, k_next);  // unconditional (clamped) prefetch of the next component
     if (NP == 2) {
@@ -1014,7 +1033,7 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
                          pq[NP - 1], pn[NP - 1], k, lane, cnt, seg_n, seg_k, seg_ub);
     } else {
       // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the buffers alternate
-      const int cur = kk & 1;
+      const int cur = it & 1;
       if (cur == 0) {
         issue_pair(acc[1], f1, 0);
         screen_finish_pair(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
@@ -1032,7 +1051,16 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     trouble = trouble || (pok[p] && !(pq[p] < 3.0e38f));
-    if (pn[p] < a.n_end) a.lfinal[pn[p]] = pL[p];
+    if (KSPLIT)
+      st_L[wave * (NT * 32) + (2 * p + h) * 32 + c] = pL[p];
+    else if (pn[p] < a.n_end)
+      a.lfinal[pn[p]] = pL[p];
+  }
+  if (KSPLIT) {  // the final lower bound of a patch is the best of the four waves' bounds
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT * 32; i += 256)
+      if (base + i < a.n_end)
+        a.lfinal[base + i] = fmaxf(fmaxf(st_L[i], st_L[NT * 32 + i]), fmaxf(st_L[2 * NT * 32 + i], st_L[3 * NT * 32 + i]));
   }
   if (lane == 0) a.seg_cnt[wave_global] = cnt < SCREEN_CAP ? cnt : SCREEN_CAP;
   if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
@@ -1522,10 +1550,10 @@ static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, in
 // 1024 patches, exactly the numbers gmm_fwd_kernel<MODE_MAX> produces.
 static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials) {
   const long n = a.n_end - a.n_begin;
-  // 4 tiles per wave (fragments amortised over 128 patches) unless that leaves CUs without a block: then 2
-  const int tiles_per_wave = (n + SCREEN_T * 32 * 4 - 1) / (SCREEN_T * 32 * 4) >= g->n_cu ? SCREEN_T : 2;
-  const long waves = (n + tiles_per_wave * 32 - 1) / (tiles_per_wave * 32);
-  const unsigned blocks = (unsigned)((waves + 3) / 4);
+  // every wave its own 128 patches and all components, unless that leaves CUs without a block: then the four waves of
+  // a block share 128 patches and split the components (see gmm_screen_kernel)
+  const bool ksplit = (n + SCREEN_T * 32 * 4 - 1) / (SCREEN_T * 32 * 4) < g->n_cu;
+  const unsigned blocks = (unsigned)(ksplit ? (n + SCREEN_T * 32 - 1) / (SCREEN_T * 32) : ((n + SCREEN_T * 32 - 1) / (SCREEN_T * 32) + 3) / 4);
   const size_t n_seg = (size_t)blocks * 4;
   const size_t slots = n_seg * SCREEN_CAP;                  // candidate record slots
   const size_t bucket_slots = slots + 32 * (size_t)g->K;    // padded bucket slots
@@ -1552,10 +1580,10 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   sc.seg_cnt = g->seg_cnt, sc.flag = flag;
   {
     ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
-    if (tiles_per_wave == 4)
-      gmm_screen_kernel<2><<<blocks, 256, 0, s>>>(sc);
+    if (ksplit)
+      gmm_screen_kernel<2, true><<<blocks, 256, 0, s>>>(sc);
     else
-      gmm_screen_kernel<1><<<blocks, 256, 0, s>>>(sc);
+      gmm_screen_kernel<2, false><<<blocks, 256, 0, s>>>(sc);
   }
   JD_LAUNCH_CHECK();
 
