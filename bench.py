@@ -399,6 +399,27 @@ def main():
                 os.environ.pop("JOLIDECO_CONV_METHOD", None)
             else:
                 os.environ["JOLIDECO_CONV_METHOD"] = previous
+    # The same fit with the GMM arg-max evaluated by the dense fp32 MFMA kernel for every (patch, component) pair
+    # (JD_GMM_SCREEN=0; bit-identical results): reported next to the headline for whoever wants the number without the
+    # fp16 screen.
+    if world == 1 and fake is None and roof_gmm and roof_gmm["kernel"] == "gmm_screen_kernel" and not args.no_general_psf:
+        log("dense-GMM run (JD_GMM_SCREEN=0)")
+        os.environ["JD_GMM_SCREEN"] = "0"
+        try:
+            for _ in range(args.warmup):
+                session.epoch()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                session.epoch()
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            out["dense_fp32_gmm"] = {
+                "value": args.steps / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / args.steps,
+                "note": "same workload, GMM arg-max by the dense fp32 MFMA kernel (JD_GMM_SCREEN=0)",
+            }
+        finally:
+            os.environ.pop("JD_GMM_SCREEN", None)
     log("gpu result: " + json.dumps(out))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)
