@@ -477,8 +477,11 @@ extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, c
     table.scale[d] = exposure[d], table.op[d] = khat[d], table.bkg[d] = background[d], table.cnt[d] = counts[d],
     table.g[d] = p->gbatch[d];
   if (!p->table_dev) JD_HIP(hipMalloc(&p->table_dev, sizeof(SepBatchTable)));
-  if (memcmp(&table, &p->table_host, sizeof(table)) != 0) {  // a session passes the same pointers every step
-    JD_HIP(hipMemcpyAsync(p->table_dev, &table, sizeof(table), hipMemcpyHostToDevice, s));  // pageable source: staged now
+  if (memcmp(&table, &p->table_host, sizeof(table)) != 0) {
+    // a session passes the same pointers every step, so this happens once: wait for launches that may still read the
+    // old table, then copy synchronously (the source is a stack variable)
+    JD_HIP(hipStreamSynchronize(s));
+    JD_HIP(hipMemcpy(p->table_dev, &table, sizeof(table), hipMemcpyHostToDevice));
     p->table_host = table;
   }
   const double n_pix = (double)p->H * (double)p->W;
