@@ -384,15 +384,31 @@ def main():
             for _ in range(args.warmup):
                 general.epoch()
             torch.cuda.synchronize(device)
+            _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for i in range(args.steps):
+                _hip.profile_pause(i % PROFILE_EVERY != 0)
                 general.epoch()
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
+            prof_general = _hip.profile_read()
             out["general_psf"] = {
                 "value": args.steps / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / args.steps,
                 "conv_method": "direct", "note": "same workload with the PSFs convolved as general 17x17 kernels",
             }
+            # this path runs the STAND-ALONE fused Poisson pass (conv, background, counts in; g out = 16 B/pixel):
+            # the kernel BASELINE.json's "HBM GB/s on fused Poisson pass" was defined on
+            total_p, count_p = prof_general.get("poisson_fused", (0.0, 0))
+            if count_p:
+                ms = total_p / count_p
+                achieved = 16 * H * W / (ms * 1e-3) / 1e9
+                out["roofline_poisson_standalone"] = {
+                    "kernel": "poisson_fused_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic_bytes(args.config, "poisson_fused_kernel<4, 1>"),
+                    "avg_launch_ms": ms, "launches": count_p, "bytes_per_launch": 16 * H * W,
+                    "note": "hipEvent pairs add ~2 us to this ~13 us kernel; rocprofv3: profiles/README.md",
+                }
             del general
         finally:
             if previous is None:
