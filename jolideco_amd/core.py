@@ -97,7 +97,7 @@ class MAPDeconvolver:
     learning_rate : float
         Learning rate
     compute_error : bool
-        Whether to compute flux error (not implemented)
+        Whether to compute flux errors after the fit (`TotalLoss.fluxes_error`)
     stop_early : bool
         Stop once the validation loss stops improving (average over the last n epochs).
     stop_early_n_average : int
@@ -137,9 +137,7 @@ class MAPDeconvolver:
         self.n_epochs = n_epochs
         self.beta = beta
         self.learning_rate = learning_rate
-        if compute_error:
-            raise NotImplementedError("compute_error (Hessian diagonal) is not implemented in jolideco_amd")
-        self.compute_error = False
+        self.compute_error = compute_error
         self.stop_early = stop_early
         self.stop_early_n_average = stop_early_n_average
         self.display_progress = display_progress
@@ -310,6 +308,12 @@ class MAPDeconvolver:
         values = trace_dev[:n_epochs_run].cpu().numpy()
         for epoch in range(n_epochs_run):
             trace.add_row(self._row(total_loss, values[epoch], n_d, n_c, n_val, filenames[epoch]))
+
+        if self.compute_error:
+            # on the fluxes of the last step, like the reference (core.py:269-271)
+            stale = [st.flux_prev if session.joint else st.flux_trace for st in session.states]
+            flux_errors = total_loss.fluxes_error(fluxes=[f.reshape((1, 1) + tuple(f.shape)) for f in stale])
+            session.components.set_flux_errors(flux_errors=flux_errors)
 
         return MAPDeconvolverResult(
             config=self.to_dict(),

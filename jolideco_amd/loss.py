@@ -203,6 +203,21 @@ class TotalLoss:
         loss_priors = self.prior_loss.evaluate(fluxes=fluxes)
         return sum(loss_datasets) - self.beta * sum(loss_priors)
 
+    def hessian_diagonals(self, fluxes):
+        """What the reference's `hessian_diagonals` returns (jolideco/loss.py:263-279): the Hessian-vector product of
+        the total loss with vectors of ones.  There the dataset losses pass through `torch.tensor(...)`
+        (loss.py:71) and carry no graph, so ONLY the prior terms contribute: -beta * H_prior x ones per component."""
+        # "+ 0.0" turns the -0.0 of a curvature-free prior into the +0.0 autograd fills in there (error = +inf)
+        return tuple(
+            -self.beta * prior.hessian_ones(flux) + 0.0 for flux, prior in zip(fluxes, self.prior_loss.priors.values())
+        )
+
+    def fluxes_error(self, fluxes):
+        """Flux errors sqrt(1 / hessian) per component name (jolideco/loss.py:281-300): inf where the prior has no
+        curvature, nan where the curvature is negative -- as in the reference."""
+        hessians = self.hessian_diagonals(fluxes=fluxes)
+        return {name: torch.sqrt(1 / hessian) for name, hessian in zip(self.prior_loss.priors, hessians)}
+
     @classmethod
     def from_datasets_and_components(
         cls, datasets, components, datasets_validation=None, beta=1, calibrations=None, device=TORCH_DEFAULT_DEVICE

@@ -155,6 +155,11 @@ class SpatialFluxComponent(nn.Module):
         return self._flux_upsampled_error
 
     @property
+    def flux_upsampled_error_numpy(self):
+        """Flux error on the up-sampled grid as a numpy array (models/core.py:626-630)."""
+        return self.flux_upsampled_error.detach().cpu().numpy()[0, 0]
+
+    @property
     def flux_numpy(self):
         return self.flux.detach().cpu().numpy()[0, 0]
 
@@ -171,6 +176,8 @@ class SpatialFluxComponent(nn.Module):
         }
         if include_data == "numpy":
             data["flux_upsampled"] = self.flux_upsampled_numpy
+            if self.flux_upsampled_error is not None:
+                data["flux_upsampled_error"] = self.flux_upsampled_error_numpy
             if self.mask is not None:
                 data["mask"] = self.mask.cpu().numpy()
         return data

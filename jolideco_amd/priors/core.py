@@ -47,6 +47,11 @@ class Prior(nn.Module):
                 return {"type": name}
         return {}
 
+    def hessian_ones(self, flux):
+        """Hessian of the log-prior times a vector of ones (what `torch.autograd.functional.vhp(..., v=ones)`
+        of jolideco/loss.py:263-279 yields for this prior's term).  Zero unless the prior has curvature."""
+        return torch.zeros_like(flux)
+
     @classmethod
     def from_dict(cls, data):
         from . import PRIOR_REGISTRY
@@ -142,6 +147,11 @@ class InverseGammaPrior(_ElementwisePrior):
 
     def _params(self):
         return self.alpha, self.beta, self.log_constant_term
+
+    def hessian_ones(self, flux):
+        """The prior is a mean of element-wise terms, so its Hessian is diagonal:
+        d2/dx2 (-beta/x - (alpha+1) log x) / n = (-2 beta / x^3 + (alpha+1) / x^2) / n."""
+        return (-2.0 * self.beta / flux**3 + (self.alpha + 1.0) / flux**2) / flux.numel()
 
     def to_dict(self):
         data = super().to_dict()

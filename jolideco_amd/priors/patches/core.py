@@ -105,6 +105,13 @@ class GMMPatchPrior(Prior):
             marginalize=self.marginalize, patch_rows=patch_rows or (0, -1),
         )
 
+    def hessian_ones(self, flux):
+        """Every patch has its mean subtracted before the mixture sees it, so a constant vector is in the null
+        space of each patch's quadratic form: Hessian x ones is exactly zero (the reference's double backward
+        returns rounding noise there).  One pair of shifts is drawn, as the reference's evaluation does."""
+        self.draw_shifts()
+        return torch.zeros_like(flux)
+
     def n_patch_rows(self, shape):
         return (shape[-2] - self.patch_shape[0]) // self.stride + 1
 

@@ -118,6 +118,39 @@ def test_reference_known_answers(golden):
     assert rel_linf(res.flux_total, r["exponential/flux_final"]) < 1e-4
 
 
+def test_compute_error_matches_the_reference(golden):
+    """compute_error=True (jolideco/tests/test_core.py:249-272): flux error sqrt(1 / (H x ones)) after the fit.  In the
+    reference only the prior terms reach the Hessian, so a uniform prior gives inf and the inverse-Gamma prior
+    gives nan where its curvature is negative."""
+    from jolideco_amd import FluxComponents, InverseGammaPrior, MAPDeconvolver, SpatialFluxComponent, UniformPrior
+
+    c = golden("compute_error")
+    disk = unpack_datasets(c, "disk/data/")
+    comps = FluxComponents()
+    comps["flux-1"] = SpatialFluxComponent.from_numpy(
+        flux=c["flux_init"], upsampling_factor=1, prior=InverseGammaPrior(alpha=0.1)
+    )
+    deco = MAPDeconvolver(n_epochs=100, learning_rate=0.1, display_progress=False, device=DEV, compute_error=True)
+    res = deco.run(disk, components=comps)
+    assert res.config["compute_error"] is True
+    err = res.components["flux-1"].flux_upsampled_error_numpy
+    ref = c["inverse_gamma/flux_error"]
+    assert err.shape == ref.shape == (32, 32)
+    np.testing.assert_allclose(err[3, 3], 24.106102, rtol=1e-3)  # the reference's known answer
+    assert rel_linf(res.flux_total, c["inverse_gamma/flux_final"]) < 1e-4
+    assert np.array_equal(np.isnan(err), np.isnan(ref)) and np.isnan(ref).sum() == 7
+    ok = np.isfinite(ref)
+    rel = np.abs(err[ok] - ref[ok]) / np.abs(ref[ok])
+    print("flux error: median rel", np.median(rel), "max rel", rel.max())
+    assert np.median(rel) < 1e-5 and rel.max() < 1e-3
+    assert "flux_upsampled_error" in res.components["flux-1"].to_dict(include_data="numpy")
+
+    comps = FluxComponents()
+    comps["flux-1"] = SpatialFluxComponent.from_numpy(flux=c["flux_init"], prior=UniformPrior())
+    res = MAPDeconvolver(n_epochs=3, display_progress=False, device=DEV, compute_error=True).run(disk, components=comps)
+    assert np.all(np.isinf(res.components["flux-1"].flux_upsampled_error_numpy))
+
+
 def test_joint_mode_matches_reference_harness(golden):
     """fit_mode='joint': one Adam step per epoch on sum_d L_d - beta*logprior."""
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent

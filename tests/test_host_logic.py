@@ -199,3 +199,34 @@ def test_result_write_read_roundtrip(tmp_path):
     np.testing.assert_allclose(back.trace_loss["total"], [1.5, 1.25])
     d = back.calibrations["x"].to_dict()
     assert d["shift_x"] == 0.25 and d["shift_y"] == -0.5 and abs(d["background_norm"] - 1.5) < 1e-6 and d["frozen"]
+
+
+def test_prior_hessian_times_ones_matches_autograd():
+    """`Prior.hessian_ones` (the prior's share of jolideco/loss.py:263-279) against torch's double backward of
+    the same log-prior written with torch ops."""
+    import torch
+
+    from jolideco_amd.loss import PriorLoss, TotalLoss
+    from jolideco_amd.priors import ExponentialPrior, InverseGammaPrior, Priors, UniformPrior
+
+    flux = torch.tensor(np.random.RandomState(3).gamma(2.0, size=(1, 1, 6, 7)).astype(np.float32))
+    prior = InverseGammaPrior(alpha=0.1)
+
+    def log_prior(x):
+        return torch.sum(-prior.beta / x + (-prior.alpha - 1) * torch.log(x)) / x.numel() + prior.log_constant_term
+
+    expected = torch.autograd.functional.vhp(log_prior, flux, v=torch.ones_like(flux))[1]
+    np.testing.assert_allclose(prior.hessian_ones(flux).numpy(), expected.numpy(), rtol=2e-6, atol=1e-9)
+    assert torch.all(ExponentialPrior(alpha=2).hessian_ones(flux) == 0)
+    assert torch.all(UniformPrior().hessian_ones(flux) == 0)
+
+    priors = Priors({"a": prior, "b": UniformPrior()})
+    total = TotalLoss(poisson_loss=None, prior_loss=PriorLoss(priors), beta=2.0)
+    errors = total.fluxes_error(fluxes=(flux, flux))
+    assert list(errors) == ["a", "b"]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = np.sqrt(1.0 / (-2.0 * expected.numpy().astype(np.float64)))
+    got = errors["a"].numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    np.testing.assert_allclose(got[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=1e-5)
+    assert torch.all(torch.isinf(errors["b"]))
