@@ -385,10 +385,9 @@ __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
 struct GmmBucketArgs {
   const int32_t* argmax;  // global patch index -> component or -1
   int n_begin, n_end, K;
-  int* counts;    // K      (zeroed by the caller)
-  int* cursor;    // K      (zeroed by the caller)
+  int* counts;    // K      bin totals (written by the binscan kernel)
   int* offsets;   // K + 1  exclusive scan of the padded counts; offsets[K] = total slots
-  int32_t* order; // slot -> global patch index, -1 for padding (pre-filled with -1 by the caller)
+  int32_t* order; // slot -> global patch index; the slots offsets[k] + counts[k] .. offsets[k + 1] are padding (undefined)
   float* gpatch;  // rows of filtered patches (argmax < 0) are zeroed here (nullable)
   // screened forward pass only (seg_cnt != nullptr): the elements are candidate records in per-wave segments of
   // seg_cap slots of which the first seg_cnt[segment] are used; a record counts only if its upper bound still
@@ -535,6 +534,7 @@ struct GmmBwdArgs {
   const int32_t* argmax;
   const int32_t* order;
   const int* offsets;  // offsets[K] = total slots
+  const int* counts;   // elements of bucket k: the slots behind them up to offsets[k + 1] are padding
   float* gpatch;       // (n_end - n_begin) * 64
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
 };
@@ -549,14 +549,16 @@ __global__ __launch_bounds__(256) void gmm_bwd_max_kernel(GmmBwdArgs a) {
   for (int grp = wave_global; grp < n_groups; grp += n_waves) {
     // slot 0 of a group is always occupied (padding sits at the end of a bucket)
     const int k = __builtin_amdgcn_readfirstlane(a.argmax[__builtin_amdgcn_readfirstlane(a.order[32 * grp])]);
+    const int slot_end = __builtin_amdgcn_readfirstlane(a.offsets[k] + a.counts[k]);
     int n[2];
     bool valid[2];
     // ---- B operand: x[nb][st] = pixel 4 st + g of patch 16 nb + n16, mean subtracted ------------
     float x[2][16];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      n[nb] = a.order[32 * grp + 16 * nb + n16];
-      valid[nb] = n[nb] >= 0;
+      const int slot = 32 * grp + 16 * nb + n16;
+      valid[nb] = slot < slot_end;
+      n[nb] = valid[nb] ? a.order[slot] : -1;
       const int py = valid[nb] ? n[nb] / a.nPx : 0, px = valid[nb] ? n[nb] % a.nPx : 0;
 #pragma unroll
       for (int st = 0; st < 16; ++st) {
@@ -1270,7 +1272,7 @@ struct jd_gmm {
   float* mfrag = nullptr;
   float* const_k = nullptr;
   float* gfrag = nullptr;
-  int* bucket = nullptr;  // counts (K) | cursor (K) | offsets (K + 1)
+  int* bucket = nullptr;  // counts (K) | unused (K) | offsets (K + 1)
   // workspaces (grown on demand)
   int32_t* argmax = nullptr;
   size_t argmax_cap = 0;
@@ -1302,7 +1304,7 @@ struct jd_gmm {
   int* blk_counts = nullptr;  // per-block bin counts of the bucket sort
   size_t blk_counts_cap = 0;
   int* korder = nullptr;      // K: visiting order of the components (most survivors in the previous call first)
-  int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | cursor (K) | offsets (K + 1)
+  int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | unused (K) | offsets (K + 1)
 };
 
 using namespace jd;
@@ -1434,7 +1436,8 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     jd_gmm_destroy(g);
     return rc;
   }
-  if (hipMalloc(&g->bucket, (size_t)(3 * K + 1) * sizeof(int)) != hipSuccess) {
+  if (hipMalloc(&g->bucket, (size_t)(3 * K + 1) * sizeof(int)) != hipSuccess ||
+      hipMemset(g->bucket, 0, (size_t)(3 * K + 1) * sizeof(int)) != hipSuccess) {
     jd_gmm_destroy(g);
     return fail(JD_ERR_ALLOC, "jd_gmm_create: hipMalloc of the bucket counters failed");
   }
@@ -1444,6 +1447,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
         (rc = upload(&g->efro_k, efro.data(), efro.size())) || (rc = upload(&g->sk2_k, sk2.data(), sk2.size())) ||
         (rc = upload(&g->mnorm_k, mnorm.data(), mnorm.size())) ||
         hipMalloc(&g->screen_ctl, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess ||
+        hipMemset(g->screen_ctl, 0, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess ||
         hipMalloc(&g->korder, (size_t)K * sizeof(int)) != hipSuccess) {
       jd_gmm_destroy(g);
       return fail(JD_ERR_ALLOC, "jd_gmm_create: allocation of the screening operands failed");
@@ -1569,7 +1573,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   int32_t* rec_k = g->rec + slots;
   float* rec_ub = reinterpret_cast<float*>(g->rec + 2 * slots);
   int* flag = g->screen_ctl;
-  JD_HIP(hipMemsetAsync(g->screen_ctl, 0, (size_t)(2 * g->K + 1) * sizeof(int), s));  // flag, counts, cursor
+  JD_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmScreenArgs sc{};
@@ -1590,7 +1594,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   // counting sort of the surviving records by component (the record slot plays the role of the patch index)
   GmmBucketArgs bk{};
   bk.argmax = rec_k, bk.n_begin = 0, bk.n_end = (int)slots, bk.K = g->K;
-  bk.counts = g->screen_ctl + 1, bk.cursor = g->screen_ctl + 1 + g->K, bk.offsets = g->screen_ctl + 1 + 2 * g->K;
+  bk.counts = g->screen_ctl + 1, bk.offsets = g->screen_ctl + 1 + 2 * g->K;
   bk.order = g->rec_order, bk.gpatch = nullptr;
   bk.seg_cnt = g->seg_cnt, bk.seg_cap = SCREEN_CAP, bk.rec_n = rec_n, bk.rec_ub = rec_ub, bk.lfinal = g->lfinal;
   bk.chunk = SCREEN_CAP;  // one record segment per chunk
@@ -1732,11 +1736,9 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   // ---- bucket the patches by arg-max component -------------------------------------------------
   GmmBucketArgs bk{};
   bk.argmax = arg, bk.n_begin = n_begin, bk.n_end = n_end, bk.K = g->K;
-  bk.counts = g->bucket, bk.cursor = g->bucket + g->K, bk.offsets = g->bucket + 2 * g->K;
+  bk.counts = g->bucket, bk.offsets = g->bucket + 2 * g->K;
   bk.order = g->order, bk.gpatch = g->gpatch;
   bk.chunk = BUCKET_CHUNK;
-  JD_HIP(hipMemsetAsync(g->bucket, 0, (size_t)2 * g->K * sizeof(int), s));
-  JD_HIP(hipMemsetAsync(g->order, 0xFF, slots_cap * sizeof(int32_t), s));
   unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
   const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
   if (chunks > max_blocks) chunks = max_blocks;
@@ -1751,7 +1753,7 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
     gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
     GmmBwdArgs b{};
     b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
-    b.offsets = bk.offsets, b.gpatch = g->gpatch, b.K = g->K;
+    b.offsets = bk.offsets, b.counts = bk.counts, b.gpatch = g->gpatch, b.K = g->K;
     b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
     b.n_begin = n_begin, b.n_end = n_end;
     long bwd_blocks = ((long)(slots_cap / 32) + 3) / 4;
