@@ -1200,6 +1200,8 @@ struct GmmBestArgs {
   int n_begin, n_end;
   int32_t* argmax_out;  // nullable
   double* partials;     // one per block
+  int* flag;            // the fallback flag of this pass: copied to flag_seen and cleared for the next pass (the last
+  int* flag_seen;       // reader on the stream is the dense kernel before this one), which saves a memset per pass
 };
 
 constexpr int BEST_CHUNK = 1024;
@@ -1222,6 +1224,10 @@ __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
   if (threadIdx.x == 0) a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *a.flag_seen = *a.flag;
+    *a.flag = 0;
+  }
 }
 
 struct GmmGatherArgs {
@@ -1304,7 +1310,7 @@ struct jd_gmm {
   int* blk_counts = nullptr;  // per-block bin counts of the bucket sort
   size_t blk_counts_cap = 0;
   int* korder = nullptr;      // K: visiting order of the components (most survivors in the previous call first)
-  int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | unused (K) | offsets (K + 1)
+  int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | [0] flag of the last pass, rest unused (K) | offsets (K + 1)
 };
 
 using namespace jd;
@@ -1572,8 +1578,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   int32_t* rec_n = g->rec;
   int32_t* rec_k = g->rec + slots;
   float* rec_ub = reinterpret_cast<float*>(g->rec + 2 * slots);
-  int* flag = g->screen_ctl;
-  JD_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+  int* flag = g->screen_ctl;  // zero at creation, cleared again by gmm_best_kernel at the end of every pass
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmScreenArgs sc{};
@@ -1642,6 +1647,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   GmmBestArgs be{};
   be.best = g->best, be.n_begin = a.n_begin, be.n_end = a.n_end, be.argmax_out = a.argmax_out, be.partials = g->partials;
+  be.flag = flag, be.flag_seen = g->screen_ctl + 1 + g->K;
   const unsigned best_blocks = (unsigned)((n + BEST_CHUNK - 1) / BEST_CHUNK);
   gmm_best_kernel<<<best_blocks, 256, 0, s>>>(be);
   JD_LAUNCH_CHECK();
@@ -1657,7 +1663,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     for (int v : seg) records += v, seg_max = v > seg_max ? v : seg_max;
     fprintf(stderr, "[jd gmm screen] patches %ld records %ld (%.2f per patch, fullest wave %d of %d) survivors %ld (%.2f per "
             "patch) fallback %d\n", n, records, (double)records / (double)n, seg_max, SCREEN_CAP, survivors,
-            (double)survivors / (double)n, ctl[0]);
+            (double)survivors / (double)n, ctl[1 + g->K]);
   }
   return JD_OK;
 }
