@@ -68,7 +68,8 @@ struct GmmFwdArgs {
   int32_t* argmax_out;   // nullable (MODE_MAX)
   float* value_patch;    // nullable: per patch v | MODE_DENSE: (n, K) out
   double* partials;      // one per block
-  const int* run_flag;   // nullable: the kernel returns at once while *run_flag == 0 (fallback of the screened path)
+  const int* run_flag;   // nullable: the kernel returns at once unless *run_flag == run_gen (fallback of the
+  int run_gen;           //           screened path, see GmmScreenArgs::flag)
   unsigned long long* best_out;  // nullable (MODE_MAX): per patch (max, arg-max) key, 0 for a filtered patch
 };
 
@@ -258,7 +259,7 @@ __device__ __forceinline__ int xs_index(int t, int c, int p) {
 
 template <int TB, int MODE, bool TRI>
 __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
-  if (a.run_flag && *a.run_flag == 0) return;
+  if (a.run_flag && *a.run_flag != a.run_gen) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                                          // TB * 2048 floats
   float* state = lds + TB * 2048;                           // [4 waves][TB][2][32 patches]
@@ -400,6 +401,9 @@ struct GmmBucketArgs {
   // [gridDim.x][K]: per-block bin counts (count kernel), turned into the block's offset inside each bin (binscan)
   int* blk_counts;
   int chunk;    // elements per chunk (multiple of 256): 1024 patches | one record segment (seg_cap)
+  int* flag;    // nullable: the scan kernel stores `gen` here (fallback, see GmmScreenArgs) when the padded buckets
+  int gen;      //           need more than slot_cap slots
+  int slot_cap;
   int* korder;  // nullable: the scan kernel also ranks the bins by size (order of the components for the next screen)
 };
 
@@ -489,7 +493,10 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
     a.offsets[k] = total;
     total += (a.counts[k] + 31) & ~31;
   }
-  if (threadIdx.x == 255) a.offsets[a.K] = part[cur][255];
+  if (threadIdx.x == 255) {
+    a.offsets[a.K] = part[cur][255];
+    if (a.flag && part[cur][255] > a.slot_cap) __hip_atomic_store(a.flag, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (a.korder) {  // bins by size, largest first (ties: lowest index): the visiting order of the next screen
     for (int k = threadIdx.x; k < a.K; k += 256) {
       const int ck = a.counts[k];
@@ -522,6 +529,70 @@ __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a
         float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
         for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+    }
+  }
+}
+
+// First half of the arg-max backward pass: Y^T = P'^T_k Xbar^T - m'_k for the 2 x 16 patch columns of a wave
+// (x[nb][st] = pixel 4 st + g of patch 16 nb + n16, mean subtracted), fragments streamed from L2.
+template <bool TRI>
+__device__ __forceinline__ void whiten_columns(f32x4 (&y)[4][2], const float (&x)[2][16], const float* afrag,
+                                               const float* mfrag, int k, int lane) {
+  const float4* ak = reinterpret_cast<const float4*>(afrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
+  const float4* mk = reinterpret_cast<const float4*>(mfrag) + (size_t)k * 16 + (lane >> 4);
+#pragma unroll
+  for (int jb = 0; jb < 4; ++jb) {
+    const float4 m = mk[jb * 4];
+    y[jb][0] = y[jb][1] = f32x4{m.x, m.y, m.z, m.w};
+#pragma unroll
+    for (int st4 = 0; st4 < 4; ++st4) {
+      if (TRI && st4 > jb) continue;
+      const float4 A = ak[(jb * 4 + st4) * 64];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          y[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, e), x[nb][4 * st4 + e], y[jb][nb], 0, 0, 0);
+    }
+  }
+}
+
+// Second half of the arg-max backward pass, shared by the bucketed kernel, the fused exact kernel and the fallback:
+// G^T = P'_k Y^T (k-step (jb, r) feeds lane group g the value y[jb][nb][r]), gamma = -G, minus its mean over the 64
+// pixels (adjoint of the mean subtraction); lane (g, n16) writes pixels 16 ib + 4 g + (0..3) of patch (nb, n16) to
+// rows[nb] where valid[nb].  The columns (patches) of the MFMA are independent: zero columns change nothing.
+template <bool TRI>
+__device__ __forceinline__ void patch_gradient_rows(const f32x4 (&y)[4][2], const float* gfrag, int k, int lane,
+                                                    const bool (&valid)[2], float* const (&rows)[2]) {
+  const int g = lane >> 4;
+  f32x4 gacc[4][2];
+  const float4* gk = reinterpret_cast<const float4*>(gfrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
+#pragma unroll
+  for (int ib = 0; ib < 4; ++ib) {
+    gacc[ib][0] = gacc[ib][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+      if (TRI && jb < ib) continue;
+      const float4 A = gk[(ib * 4 + jb) * 64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          gacc[ib][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, r), y[jb][nb][r], gacc[ib][nb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    float sum = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib) sum += (gacc[ib][nb][0] + gacc[ib][nb][1]) + (gacc[ib][nb][2] + gacc[ib][nb][3]);
+    const float mean = sum_lane_groups(sum) * (1.f / 64.f);
+    if (valid[nb]) {
+      float4* out = reinterpret_cast<float4*>(rows[nb]);
+#pragma unroll
+      for (int ib = 0; ib < 4; ++ib)
+        out[4 * ib + g] = make_float4(mean - gacc[ib][nb][0], mean - gacc[ib][nb][1], mean - gacc[ib][nb][2],
+                                      mean - gacc[ib][nb][3]);
     }
   }
 }
@@ -572,63 +643,84 @@ __global__ __launch_bounds__(256) void gmm_bwd_max_kernel(GmmBwdArgs a) {
       for (int st = 0; st < 16; ++st) x[nb][st] -= mean;
     }
 
-    // ---- Y^T = P'^T Xbar^T - m' ------------------------------------------------------------------
     f32x4 y[4][2];
-    {
-      const float4* ak = reinterpret_cast<const float4*>(a.afrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
-      const float4* mk = reinterpret_cast<const float4*>(a.mfrag) + (size_t)k * 16 + g;
-#pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        const float4 m = mk[jb * 4];
-        y[jb][0] = y[jb][1] = f32x4{m.x, m.y, m.z, m.w};
-#pragma unroll
-        for (int st4 = 0; st4 < 4; ++st4) {
-          if (TRI && st4 > jb) continue;
-          const float4 A = ak[(jb * 4 + st4) * 64];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-              y[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, e), x[nb][4 * st4 + e], y[jb][nb], 0, 0, 0);
-        }
-      }
-    }
+    whiten_columns<TRI>(y, x, a.afrag, a.mfrag, k, lane);
+    float* rows[2] = {a.gpatch + (size_t)(valid[0] ? n[0] - a.n_begin : 0) * D, a.gpatch + (size_t)(valid[1] ? n[1] - a.n_begin : 0) * D};
+    patch_gradient_rows<TRI>(y, a.gfrag, k, lane, valid, rows);
+  }
+}
 
-    // ---- G^T = P' Y^T : k-step (jb, r) feeds lane group g the value y[jb][nb][r] --------------------
-    f32x4 gacc[4][2];
-    {
-      const float4* gk = reinterpret_cast<const float4*>(a.gfrag) + (size_t)k * (AFRAG_FLOATS / 4) + lane;
-#pragma unroll
-      for (int ib = 0; ib < 4; ++ib) {
-        gacc[ib][0] = gacc[ib][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-          if (TRI && jb < ib) continue;
-          const float4 A = gk[(ib * 4 + jb) * 64];
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-              gacc[ib][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A, r), y[jb][nb][r], gacc[ib][nb], 0, 0, 0);
-        }
-      }
-    }
+// Fallback of the fused backward pass (the screen gave up: *flag == gen, otherwise the kernel returns at once): the
+// patches in their natural order, 32 per group; the components of a group differ, so the wave serves one distinct
+// component after the other with the other patches' columns zeroed.  Per patch the arithmetic is that of
+// gmm_bwd_max_kernel (MFMA columns are independent), i.e. the same bits; slow, but so is the dense forward kernel
+// that has just run.  Filtered patches (argmax < 0) get a zero row.
+struct GmmBwdFallbackArgs {
+  const float* flux;
+  const float* afrag;
+  const float* mfrag;
+  const float* gfrag;
+  const int32_t* argmax;  // global patch index -> component or -1
+  float* gpatch;          // (n_end - n_begin) * 64
+  const int* flag;
+  int gen;
+  int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+};
 
-    // ---- gamma = -G, subtract its mean over the 64 pixels (adjoint of the mean subtraction) -------
+template <bool TRI>
+__global__ __launch_bounds__(256) void gmm_bwd_fallback_kernel(GmmBwdFallbackArgs a) {
+  if (*a.flag != a.gen) return;
+  const int lane = threadIdx.x & 63;
+  const int g = lane >> 4, n16 = lane & 15;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 4;
+  const int n_groups = (a.n_end - a.n_begin + 31) >> 5;
+  for (int grp = wave_global; grp < n_groups; grp += n_waves) {
+    int n[2], kk[2];
+    bool pending[2];
+    float x[2][16];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-      float sum = 0.f;
+      const int idx = a.n_begin + 32 * grp + 16 * nb + n16;
+      const bool in = idx < a.n_end;
+      n[nb] = in ? idx : a.n_begin;
+      kk[nb] = in ? a.argmax[idx] : -1;
+      pending[nb] = kk[nb] >= 0;
+      const int py = n[nb] / a.nPx, px = n[nb] % a.nPx;
 #pragma unroll
-      for (int ib = 0; ib < 4; ++ib) sum += (gacc[ib][nb][0] + gacc[ib][nb][1]) + (gacc[ib][nb][2] + gacc[ib][nb][3]);
-      const float mean = sum_lane_groups(sum) * (1.f / 64.f);
-      if (valid[nb]) {
-        // lane (g, n16) holds pixels 16 ib + 4 g + (0..3) of its patch in gacc[ib][nb]
-        float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(n[nb] - a.n_begin) * D);
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib)
-          out[4 * ib + g] = make_float4(mean - gacc[ib][nb][0], mean - gacc[ib][nb][1], mean - gacc[ib][nb][2],
-                                        mean - gacc[ib][nb][3]);
+      for (int st = 0; st < 16; ++st) {
+        const int p = 4 * st + g;  // pixel index: row p / 8, column p % 8
+        const int yy = wrap(py * a.stride + (p >> 3) - a.shift_y, a.H);
+        const int xx = wrap(px * a.stride + (p & 7) - a.shift_x, a.W);
+        x[nb][st] = pending[nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
       }
+      const float mean = patch_mean_groups(x[nb]);
+#pragma unroll
+      for (int st = 0; st < 16; ++st) x[nb][st] -= mean;
+      if (in && !pending[nb]) {
+        float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(idx - a.n_begin) * D);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) out[4 * ib + g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    for (;;) {
+      const unsigned long long b0 = __ballot(pending[0]), b1 = __ballot(pending[1]);
+      if ((b0 | b1) == 0ull) break;
+      const int k = __builtin_amdgcn_readfirstlane(b0 ? __shfl(kk[0], __ffsll((long long)b0) - 1) : __shfl(kk[1], __ffsll((long long)b1) - 1));
+      bool act[2];
+      float xm[2][16];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        act[nb] = pending[nb] && kk[nb] == k;
+#pragma unroll
+        for (int st = 0; st < 16; ++st) xm[nb][st] = act[nb] ? x[nb][st] : 0.f;
+      }
+      f32x4 y[4][2];
+      whiten_columns<TRI>(y, xm, a.afrag, a.mfrag, k, lane);
+      float* rows[2] = {a.gpatch + (size_t)(n[0] - a.n_begin) * D, a.gpatch + (size_t)(n[1] - a.n_begin) * D};
+      patch_gradient_rows<TRI>(y, a.gfrag, k, lane, act, rows);
+      pending[0] = pending[0] && !act[0];
+      pending[1] = pending[1] && !act[1];
     }
   }
 }
@@ -820,7 +912,10 @@ struct GmmScreenArgs {
   int32_t* rec_k;            //                     component,
   float* rec_ub;             //                     upper bound ltilde + B
   int* seg_cnt;              // [waves] records used
-  int* flag;                 // != 0: fall back to the dense kernel
+  // Fallback flag: a pass that gives up stores its generation number `gen` (> 0, different for consecutive passes
+  // of a handle) here; every later kernel of the pass compares the flag with gen.  Nothing ever has to clear it.
+  int* flag;
+  int gen;
 };
 
 struct ScreenFrags {
@@ -1066,7 +1161,7 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   }
   if (lane == 0) a.seg_cnt[wave_global] = cnt < SCREEN_CAP ? cnt : SCREEN_CAP;
   if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
-    if (lane == 0) atomicOr(a.flag, 1);
+    if (lane == 0) __hip_atomic_store(a.flag, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1080,8 +1175,14 @@ struct GmmExactArgs {
   const int* counts;      // K
   const int* offsets;     // K + 1, offsets[K] = total (padded) bucket slots
   const int* flag;
+  int gen;                // the pass has fallen back to the dense kernel when *flag == gen
   unsigned long long* best;
   int K, H, W, stride, nPx, shift_y, shift_x;
+  // fused backward pass (grec != nullptr): the gradient row of EVERY surviving record is written to grec[bucket slot]
+  // and the key carries the bucket slot instead of the component (slots ascend with the component, so ties still go
+  // to the lowest component); gmm_best_kernel turns the winning key into the row the gather kernel reads
+  const float* gfrag;
+  float* grec;
 };
 
 struct __attribute__((packed, aligned(4))) F4U {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
@@ -1096,7 +1197,7 @@ constexpr int EXACT_PITCH = 68;  // floats per staged patch (64 + pad: 16-byte a
 // backward kernel costs 4x the memory instructions) and read back in B-operand order.
 template <bool TRI>
 __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
-  if (*a.flag != 0) return;  // the dense kernel takes over
+  if (*a.flag == a.gen) return;  // the dense kernel takes over
   __shared__ __attribute__((aligned(16))) float stage[4][32 * EXACT_PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, n16 = lane & 15;
@@ -1190,7 +1291,12 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const float l = fmaf(-0.5f, sum_lane_groups(sum_squares(y, nb)), ck);  // = finish_tile of the forward kernel
-      if (g == 0 && valid[nb] && l > -INFINITY) atomicMax(a.best + n[nb], best_key(l, k));  // NaN never wins (l > b)
+      const int tie = a.grec ? 32 * grp + 16 * nb + n16 : k;
+      if (g == 0 && valid[nb] && l > -INFINITY) atomicMax(a.best + n[nb], best_key(l, tie));  // NaN never wins (l > b)
+    }
+    if (a.grec) {
+      float* rows[2] = {a.grec + (size_t)(32 * grp + n16) * D, a.grec + (size_t)(32 * grp + 16 + n16) * D};
+      patch_gradient_rows<TRI>(y, a.gfrag, k, lane, valid, rows);
     }
   }
 }
@@ -1200,8 +1306,15 @@ struct GmmBestArgs {
   int n_begin, n_end;
   int32_t* argmax_out;  // nullable
   double* partials;     // one per block
-  int* flag;            // the fallback flag of this pass: copied to flag_seen and cleared for the next pass (the last
-  int* flag_seen;       // reader on the stream is the dense kernel before this one), which saves a memset per pass
+  // fused backward pass (winner != nullptr): unless the pass fell back (*flag == gen), the low word of a key is the
+  // bucket slot of the winning record -> winner[n] (-1: no gradient); the component is looked up only if asked for.
+  // After a fallback the keys carry components (dense kernel): they go to argmax_fb for gmm_bwd_fallback_kernel.
+  const int* flag;
+  int gen;
+  int32_t* winner;
+  int32_t* argmax_fb;
+  const int32_t* rec_k;
+  const int32_t* rec_order;
 };
 
 constexpr int BEST_CHUNK = 1024;
@@ -1209,6 +1322,7 @@ constexpr int BEST_CHUNK = 1024;
 __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
   __shared__ double red[4];
   const int base = a.n_begin + blockIdx.x * BEST_CHUNK;
+  const bool slots = a.winner && *a.flag != a.gen;
   double local = 0.0;
 #pragma unroll
   for (int i = 0; i < BEST_CHUNK / 256; ++i) {
@@ -1216,18 +1330,23 @@ __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
     if (n < a.n_end) {
       const unsigned long long key = a.best[n];
       const bool ok = key != 0ull;
-      if (a.argmax_out) a.argmax_out[n] = ok ? best_component(key) : -1;
-      if (ok) local += (double)best_value(key);
+      const float v = best_value(key);
+      int k = ok ? best_component(key) : -1;
+      if (slots) {
+        const int slot = ok && v > -INFINITY ? k : -1;  // no record won: component 0 like the plain keys, no gradient
+        a.winner[n] = slot;
+        if (a.argmax_out) k = ok ? (slot >= 0 ? a.rec_k[a.rec_order[slot]] : 0) : -1;
+      } else if (a.argmax_fb) {
+        a.argmax_fb[n] = k;
+      }
+      if (a.argmax_out) a.argmax_out[n] = k;
+      if (ok) local += (double)v;
     }
   }
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
   if (threadIdx.x == 0) a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    *a.flag_seen = *a.flag;
-    *a.flag = 0;
-  }
 }
 
 struct GmmGatherArgs {
@@ -1236,6 +1355,11 @@ struct GmmGatherArgs {
   int H, W, stride, nPx, nPy, shift_y, shift_x, row_begin, row_end;  // patch-row shard
   int y_begin, y_end;                                                // rolled-frame pixel rows covered
   float coef;
+  // fused backward pass (winner != nullptr and no fallback): the row of patch n is grec[winner[n]] (none if < 0)
+  const int32_t* winner;
+  const float* grec;
+  const int* flag;
+  int gen;
 };
 
 __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
@@ -1252,14 +1376,20 @@ __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
   int px_lo = (X - (P - 1) + a.stride - 1) / a.stride;
   if (X - (P - 1) < 0) px_lo = 0;
   if (px_hi > a.nPx - 1) px_hi = a.nPx - 1;
+  const bool slots = a.winner && *a.flag != a.gen;
   float sum = 0.f;
   bool any = false;
   for (int py = py_lo; py <= py_hi; ++py) {
     const int r = Y - py * a.stride;
     for (int px = px_lo; px <= px_hi; ++px) {
       const int cc = X - px * a.stride;
-      const size_t n = (size_t)(py - a.row_begin) * a.nPx + px;
-      sum += a.gpatch[n * D + r * P + cc];
+      if (slots) {
+        const int slot = a.winner[(size_t)py * a.nPx + px];
+        if (slot >= 0) sum += a.grec[(size_t)slot * D + r * P + cc];
+      } else {
+        const size_t n = (size_t)(py - a.row_begin) * a.nPx + px;
+        sum += a.gpatch[n * D + r * P + cc];
+      }
       any = true;
     }
   }
@@ -1310,7 +1440,13 @@ struct jd_gmm {
   int* blk_counts = nullptr;  // per-block bin counts of the bucket sort
   size_t blk_counts_cap = 0;
   int* korder = nullptr;      // K: visiting order of the components (most survivors in the previous call first)
-  int* screen_ctl = nullptr;  // [0] fallback flag | counts (K) | [0] flag of the last pass, rest unused (K) | offsets (K + 1)
+  int* screen_ctl = nullptr;  // [0] fallback flag (generation stamped) | counts (K) | unused (K) | offsets (K + 1)
+  int gen = 0;                // generation of the current screened pass (1 .. 2^30, never 0)
+  // fused backward pass of the screened path
+  float* grec = nullptr;      // gradient rows of the surviving records, by bucket slot
+  size_t grec_cap = 0;
+  int32_t* winner = nullptr;  // patch -> bucket slot of its winning record
+  size_t winner_cap = 0;
 };
 
 using namespace jd;
@@ -1491,6 +1627,8 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->seg_cnt) (void)hipFree(g->seg_cnt);
   if (g->korder) (void)hipFree(g->korder);
   if (g->blk_counts) (void)hipFree(g->blk_counts);
+  if (g->grec) (void)hipFree(g->grec);
+  if (g->winner) (void)hipFree(g->winner);
   if (g->screen_ctl) (void)hipFree(g->screen_ctl);
   if (g->order) (void)hipFree(g->order);
   if (g->bucket) (void)hipFree(g->bucket);
@@ -1558,7 +1696,10 @@ static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, in
 
 // Max mode through the fp16 screen (see gmm_screen_kernel): fills a.argmax_out (if any) and one fp64 partial sum per
 // 1024 patches, exactly the numbers gmm_fwd_kernel<MODE_MAX> produces.
-static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials) {
+// fused: the exact kernel also writes the gradient row of every surviving record and gmm_best_kernel the winning row
+// of every patch (g->grec, g->winner); after a fallback the components are in fallback_argmax instead.
+static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials, bool fused,
+                            int32_t* fallback_argmax) {
   const long n = a.n_end - a.n_begin;
   // every wave its own 128 patches and all components, unless that leaves CUs without a block: then the four waves of
   // a block share 128 patches and split the components (see gmm_screen_kernel)
@@ -1578,7 +1719,15 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   int32_t* rec_n = g->rec;
   int32_t* rec_k = g->rec + slots;
   float* rec_ub = reinterpret_cast<float*>(g->rec + 2 * slots);
-  int* flag = g->screen_ctl;  // zero at creation, cleared again by gmm_best_kernel at the end of every pass
+  int* flag = g->screen_ctl;
+  g->gen = g->gen % (1 << 30) + 1;
+  // rows of the record-gradient buffer: ~1.2 records per patch survive; beyond 2 per patch (+ bucket padding) the
+  // scan kernel raises the fallback flag
+  const size_t grec_rows = fused ? (size_t)2 * (size_t)n + 32 * (size_t)g->K : 0;
+  if (fused) {
+    if ((rc = grow(&g->grec, &g->grec_cap, grec_rows * D))) return rc;
+    if ((rc = grow(&g->winner, &g->winner_cap, (size_t)a.n_end))) return rc;
+  }
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmScreenArgs sc{};
@@ -1586,7 +1735,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
   sc.best = g->best, sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
-  sc.seg_cnt = g->seg_cnt, sc.flag = flag;
+  sc.seg_cnt = g->seg_cnt, sc.flag = flag, sc.gen = g->gen;
   {
     ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
     if (ksplit)
@@ -1604,6 +1753,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   bk.seg_cnt = g->seg_cnt, bk.seg_cap = SCREEN_CAP, bk.rec_n = rec_n, bk.rec_ub = rec_ub, bk.lfinal = g->lfinal;
   bk.chunk = SCREEN_CAP;  // one record segment per chunk
   bk.korder = g->K <= KORDER_MAX_K ? g->korder : nullptr;
+  if (fused) bk.flag = flag, bk.gen = g->gen, bk.slot_cap = (int)std::min<size_t>(grec_rows, (size_t)INT32_MAX);
   unsigned chunks = (unsigned)n_seg;
   // the kernels stride over the chunks; many small blocks hide the latency of the dependent record loads
   const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
@@ -1622,7 +1772,8 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   GmmExactArgs ex{};
   ex.flux = a.flux, ex.afrag = g->afrag, ex.mfrag = g->mfrag, ex.const_k = g->const_k;
-  ex.rec_n = rec_n, ex.order = g->rec_order, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag;
+  ex.rec_n = rec_n, ex.order = g->rec_order, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag, ex.gen = g->gen;
+  ex.gfrag = g->gfrag, ex.grec = fused ? g->grec : nullptr;
   ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
   ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
   {
@@ -1633,7 +1784,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   // fallback: the dense fp32 kernel, gated on the device flag (returns at once in the normal case)
   GmmFwdArgs dense = a;
-  dense.run_flag = flag, dense.best_out = g->best, dense.argmax_out = nullptr, dense.value_patch = nullptr;
+  dense.run_flag = flag, dense.run_gen = g->gen, dense.best_out = g->best, dense.argmax_out = nullptr, dense.value_patch = nullptr;
   {
     const int tb = pick_block_tiles(n, g->n_cu);
     const unsigned dblocks = (unsigned)((n + 32L * tb - 1) / (32L * tb));
@@ -1647,7 +1798,8 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   GmmBestArgs be{};
   be.best = g->best, be.n_begin = a.n_begin, be.n_end = a.n_end, be.argmax_out = a.argmax_out, be.partials = g->partials;
-  be.flag = flag, be.flag_seen = g->screen_ctl + 1 + g->K;
+  be.flag = flag, be.gen = g->gen, be.winner = fused ? g->winner : nullptr, be.argmax_fb = fused ? fallback_argmax : nullptr;
+  be.rec_k = rec_k, be.rec_order = g->rec_order;
   const unsigned best_blocks = (unsigned)((n + BEST_CHUNK - 1) / BEST_CHUNK);
   gmm_best_kernel<<<best_blocks, 256, 0, s>>>(be);
   JD_LAUNCH_CHECK();
@@ -1663,7 +1815,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     for (int v : seg) records += v, seg_max = v > seg_max ? v : seg_max;
     fprintf(stderr, "[jd gmm screen] patches %ld records %ld (%.2f per patch, fullest wave %d of %d) survivors %ld (%.2f per "
             "patch) fallback %d\n", n, records, (double)records / (double)n, seg_max, SCREEN_CAP, survivors,
-            (double)survivors / (double)n, ctl[1 + g->K]);
+            (double)survivors / (double)n, ctl[0] == g->gen ? 1 : 0);
   }
   return JD_OK;
 }
@@ -1691,26 +1843,30 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   const long n = n_end - n_begin;
   int rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
+  const char* screen_var = getenv("JD_GMM_SCREEN");  // "0" forces the dense fp32 kernel (testing / tuning)
+  const bool screened = !marginalize && g->screen_ok && !(screen_var && atoi(screen_var) == 0) && !getenv("JD_GMM_DENSE");
+  // screened arg-max with a gradient: the exact kernel also produces the gradient rows (no second sort, no separate
+  // backward kernel); JD_GMM_FUSED_BWD=0 keeps the bucketed backward pass (testing / tuning)
+  const char* fused_var = getenv("JD_GMM_FUSED_BWD");
+  const bool fused = screened && grad_flux_accum && g->triangular && !(fused_var && atoi(fused_var) == 0);
   int32_t* arg = argmax_out;
-  if (!arg && grad_flux_accum) {
+  if (grad_flux_accum && (!arg || fused)) {  // fused: the internal buffer holds the components after a fallback
     if ((rc = grow(&g->argmax, &g->argmax_cap, (size_t)nPy * nPx))) return rc;
-    arg = g->argmax;
+    if (!arg) arg = g->argmax;
   }
   GmmFwdArgs a{};
   a.flux = flux, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
   a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x;
-  a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = arg, a.value_patch = nullptr, a.partials = g->partials;
+  a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = fused ? argmax_out : arg, a.value_patch = nullptr, a.partials = g->partials;
   if (marginalize && grad_flux_accum) {
     if ((rc = grow(&g->vpatch, &g->vpatch_cap, (size_t)nPy * nPx))) return rc;
     a.value_patch = g->vpatch;
   }
   int n_waves = 0;
-  const char* screen_var = getenv("JD_GMM_SCREEN");  // "0" forces the dense fp32 kernel (testing / tuning)
-  const bool screen_env = !(screen_var && atoi(screen_var) == 0);
   if (marginalize)
     rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
-  else if (g->screen_ok && screen_env && !getenv("JD_GMM_DENSE"))
-    rc = screened_forward(g, a, s, &n_waves);
+  else if (screened)
+    rc = screened_forward(g, a, s, &n_waves, fused, fused ? g->argmax : nullptr);
   else
     rc = launch_fwd<MODE_MAX>(a, g->triangular, g->n_cu, s, &n_waves);
   if (rc) return rc;
@@ -1734,6 +1890,20 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
         gmm_bwd_lse_kernel<true, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
       else
         gmm_bwd_lse_kernel<false, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+    }
+    JD_LAUNCH_CHECK();
+  } else if (fused) {
+    // the rows are in g->grec already; only after a fallback (device flag) this kernel has work
+    GmmBwdFallbackArgs b{};
+    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = g->argmax, b.gpatch = g->gpatch;
+    b.flag = g->screen_ctl, b.gen = g->gen, b.K = g->K;
+    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
+    b.n_begin = n_begin, b.n_end = n_end;
+    long blocks = ((n + 31) / 32 + 3) / 4;
+    if (blocks > (long)g->n_cu * 2) blocks = (long)g->n_cu * 2;
+    {
+      ProfScope prof(JD_KERNEL_GMM_BWD, s);
+      gmm_bwd_fallback_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(b);
     }
     JD_LAUNCH_CHECK();
   } else {
@@ -1779,6 +1949,7 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   ga.y_begin = patch_row_begin * stride;
   ga.y_end = (patch_row_end - 1) * stride + P;
   ga.coef = grad_coef;
+  if (fused) ga.winner = g->winner, ga.grec = g->grec, ga.flag = g->screen_ctl, ga.gen = g->gen;
   dim3 grid((W + 255) / 256, ga.y_end - ga.y_begin);
   {
     ProfScope prof(JD_KERNEL_GMM_GATHER, s);

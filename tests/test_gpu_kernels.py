@@ -649,6 +649,61 @@ def test_gmm_screen_falls_back_to_the_dense_kernel(monkeypatch):
     assert (np.isnan(screened[0]) and np.isnan(dense[0])) or screened[0] == dense[0]
 
 
+def test_gmm_fused_backward_equals_the_bucketed_backward(monkeypatch):
+    """Screened arg-max with a gradient: by default the exact kernel also writes the gradient row of every surviving
+    record and the gather kernel reads the winner's row (no second sort, no backward kernel); JD_GMM_FUSED_BWD=0 keeps
+    the bucketed backward pass.  Same bits -- whole image, a patch-row shard, with and without the arg-max asked for,
+    and when the record-gradient buffer would overflow (4 identical components: 4 records per patch > 2) or a pixel is
+    infinite (both fall back on the device: dense forward kernel + unsorted backward kernel)."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape = (136, 172)
+    n_py, n_px = (shape[0] - 8) // 4 + 1, (shape[1] - 8) // 4 + 1
+    rs = np.random.RandomState(5)
+
+    def run(handle, flux, fused, rows=(0, -1), want_argmax=True):
+        monkeypatch.setenv("JD_GMM_FUSED_BWD", "1" if fused else "0")
+        value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+        argmax = torch.full((n_py * n_px,), -7, dtype=torch.int32, device=DEV) if want_argmax else None
+        handle.prior_fwd_bwd(flux, 4, (3, -5), value, 0.25, grad=grad, grad_coef=-0.7, patch_rows=rows, argmax_out=argmax)
+        torch.cuda.synchronize()
+        return float(value), grad.cpu().numpy(), None if argmax is None else argmax.cpu().numpy()
+
+    means, covs, weights = synthetic_gmm(24, 64, seed=9)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+    image = rs.gamma(20, size=shape).astype(np.float32)
+    image[60:64, 80:90] = -2e5  # filtered patches (patches/core.py:215-216): no gradient
+    flux = torch.from_numpy(image).to(DEV)
+    handle = gmm.handle(DEV)
+    for rows in ((0, -1), (5, 19)):
+        a, b = run(handle, flux, True, rows), run(handle, flux, False, rows)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        assert np.abs(a[1]).max() > 0 and (a[2] == -1).sum() > 0
+        c = run(handle, flux, True, rows, want_argmax=False)
+        assert c[0] == a[0] and np.array_equal(c[1], a[1])
+
+    # fallbacks: the record-gradient buffer holds 2 rows per patch; an infinite pixel
+    means, covs, weights = synthetic_gmm(1, 64, seed=3)
+    gmm4 = GaussianMixtureModel.from_numpy(
+        np.repeat(means, 4, axis=0), np.repeat(covs, 4, axis=0), np.full(4, 0.25), meta=GaussianMixtureModelMeta(stride=4)
+    )
+    a, b = run(gmm4.handle(DEV), flux, True), run(gmm4.handle(DEV), flux, False)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert set(np.unique(a[2])) == {-1, 0}  # ties -> the lowest component
+    image[20, 30] = np.inf
+    flux = torch.from_numpy(image).to(DEV)
+    a, b = run(handle, flux, True), run(handle, flux, False)
+    assert np.array_equal(a[2], b[2]) and np.array_equal(np.isnan(a[1]), np.isnan(b[1]))
+    finite = np.isfinite(b[1])
+    assert np.array_equal(a[1][finite], b[1][finite])
+    # ... and the next pass on the same handle is back on the fast path (generation-stamped flag, nothing to clear)
+    image[20, 30] = 1.0
+    flux = torch.from_numpy(image).to(DEV)
+    a, b = run(handle, flux, True), run(handle, flux, False)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.isfinite(a[0])
+
+
 def test_gmm_screen_large_k_and_huge_dynamic_range(monkeypatch):
     """K above the popularity-order limit (natural order is kept) and fluxes / precisions far outside the fp16 range
     (the power-of-two operand scales keep the screen exact): still the dense kernel's bits."""
