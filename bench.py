@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 F16_MATRIX_PEAK_TFLOPS = 2516.6  # 16 x the fp32 rate: v_mfma_f32_32x32x16_f16, dense (MI355X_MICROARCH.md: ~2.5 PF)
 PATCH, D, STRIDE = 8, 64, 4
-PROFILE_EVERY = 4  # steps of the timed region whose kernels are timed with hipEvent pairs: 0, 4, 8, ...
+PROFILE_EVERY = 10  # steps of the timed region whose kernels are timed with hipEvent pairs: 0, 10, 20, ...
 
 
 def build_session(cfg_name, device, seed=0, dist=None):
@@ -171,8 +171,8 @@ def cpu_baseline(cfg_name, sample_edge=1024, max_steps=10, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-psf", action="store_true",
@@ -280,7 +280,8 @@ def main():
             "algorithmic_fp32_flop": gmm_flop,
             "algorithmic_fp32_equivalent_tflops": gmm_flop / (gmm_ms * 1e-3) / 1e12,
             "note": "results are bit-identical to the fp32 MFMA kernel; the fp16 product only decides which "
-                    "components can NOT be the arg-max",
+                    "components can NOT be the arg-max; gmm_exact also writes the gradient rows of the survivors "
+                    "(the backward pass of the arg-max prior has no kernel of its own)",
         }
     elif gmm_ms:
         achieved = gmm_flop / (gmm_ms * 1e-3) / 1e12
