@@ -398,7 +398,8 @@ struct GmmBucketArgs {
   const int32_t* rec_n;
   const float* rec_ub;
   const float* lfinal;
-  // [gridDim.x][K]: per-block bin counts (count kernel), turned into the block's offset inside each bin (binscan)
+  // [K][gridDim.x] (bin major: the binscan kernel walks along a bin): per-block bin counts (count kernel), turned
+  // into the block's offset inside each bin (binscan)
   int* blk_counts;
   int chunk;    // elements per chunk (multiple of 256): 1024 patches | one record segment (seg_cap)
   int* flag;    // nullable: the scan kernel stores `gen` here (fallback, see GmmScreenArgs) when the padded buckets
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256) void gmm_bucket_count_kernel(GmmBucketArgs a) 
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < a.K; k += 256) a.blk_counts[(size_t)blockIdx.x * a.K + k] = hist[k];
+  for (int k = threadIdx.x; k < a.K; k += 256) a.blk_counts[(size_t)k * gridDim.x + blockIdx.x] = hist[k];
 }
 
 // Block k: exclusive prefix over the blocks of bin k's per-block counts (in place) and the bin total.  No global
@@ -450,7 +451,8 @@ __global__ __launch_bounds__(256) void gmm_bucket_binscan_kernel(GmmBucketArgs a
   const int per = (n_blk + 255) / 256;
   const int b0 = threadIdx.x * per;
   int local = 0;
-  for (int b = b0; b < b0 + per && b < n_blk; ++b) local += a.blk_counts[(size_t)b * a.K + k];
+  int* bin = a.blk_counts + (size_t)k * n_blk;
+  for (int b = b0; b < b0 + per && b < n_blk; ++b) local += bin[b];
   int cur = 0;
   part[0][threadIdx.x] = local;
   __syncthreads();
@@ -463,8 +465,8 @@ __global__ __launch_bounds__(256) void gmm_bucket_binscan_kernel(GmmBucketArgs a
   }
   int run = part[cur][threadIdx.x] - local;
   for (int b = b0; b < b0 + per && b < n_blk; ++b) {
-    const int v = a.blk_counts[(size_t)b * a.K + k];
-    a.blk_counts[(size_t)b * a.K + k] = run;
+    const int v = bin[b];
+    bin[b] = run;
     run += v;
   }
   if (threadIdx.x == 255) a.counts[k] = part[cur][255];
@@ -474,10 +476,13 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
   // exclusive scan of the padded bucket sizes: thread t owns a contiguous segment of bins,
   // the 256 segment sums are scanned in LDS (Hillis-Steele)
   __shared__ int part[2][256];
+  __shared__ int cnt[BUCKET_MAX_K];  // the ranking below reads every total K times
+  for (int k = threadIdx.x; k < a.K; k += 256) cnt[k] = a.counts[k];
+  __syncthreads();
   const int seg = (a.K + 255) / 256;
   const int k0 = threadIdx.x * seg;
   int local = 0;
-  for (int k = k0; k < k0 + seg && k < a.K; ++k) local += (a.counts[k] + 31) & ~31;
+  for (int k = k0; k < k0 + seg && k < a.K; ++k) local += (cnt[k] + 31) & ~31;
   int cur = 0;
   part[0][threadIdx.x] = local;
   __syncthreads();
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
   int total = part[cur][threadIdx.x] - local;  // exclusive prefix of this thread's segment
   for (int k = k0; k < k0 + seg && k < a.K; ++k) {
     a.offsets[k] = total;
-    total += (a.counts[k] + 31) & ~31;
+    total += (cnt[k] + 31) & ~31;
   }
   if (threadIdx.x == 255) {
     a.offsets[a.K] = part[cur][255];
@@ -499,10 +504,10 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
   }
   if (a.korder) {  // bins by size, largest first (ties: lowest index): the visiting order of the next screen
     for (int k = threadIdx.x; k < a.K; k += 256) {
-      const int ck = a.counts[k];
+      const int ck = cnt[k];
       int rank = 0;
       for (int j = 0; j < a.K; ++j) {
-        const int cj = a.counts[j];
+        const int cj = cnt[j];
         rank += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
       }
       a.korder[rank] = k;
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a
   const int n_chunks = (a.n_end - a.n_begin + a.chunk - 1) / a.chunk;
   // the block's first slot inside every bucket: bucket offset + the counts of the blocks before it (binscan); the
   // walk over the chunks is the count kernel's, so the numbers match
-  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = a.offsets[k] + a.blk_counts[(size_t)blockIdx.x * a.K + k];
+  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = a.offsets[k] + a.blk_counts[(size_t)k * gridDim.x + blockIdx.x];
   __syncthreads();
   // place the elements (the order inside a bucket does not influence any result)
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
