@@ -89,8 +89,9 @@ def pmc_traffic_bytes(cfg_name, kernel):
     fetch = write = None
     with open(path) as fh:
         rows = list(csv.DictReader(fh))
-    # "<config>s" rows: the same workload profiled on the current build (separable convolution, screened GMM)
-    for label in (cfg_name, cfg_name + "s"):
+    # "<config>s" / "<config>f" rows: the same workload profiled on later builds (separable convolution + screened
+    # GMM; backward pass fused into the exact kernel) -- the last one found wins
+    for label in (cfg_name, cfg_name + "s", cfg_name + "f"):
         for row in rows:
             if row["config"] == label and kernel in row["kernel"]:
                 if row["counter"] == "FETCH_SIZE":
