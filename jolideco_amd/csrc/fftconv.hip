@@ -466,8 +466,8 @@ extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, c
     if (!p->gbatch[d]) JD_HIP(hipMalloc(&p->gbatch[d], bytes));
   const int tiles = sep_conv_tiles(p->H, p->W);
   if (p->partials_batch_cap < n_datasets * tiles) {
+    // (launches of an earlier call may still read the old buffer: hipFree waits for the device)
     if (p->partials_batch) (void)hipFree(p->partials_batch);
-  if (p->table_dev) (void)hipFree(p->table_dev);
     p->partials_batch = nullptr, p->partials_batch_cap = 0;
     JD_HIP(hipMalloc(&p->partials_batch, (size_t)n_datasets * tiles * sizeof(double)));
     p->partials_batch_cap = n_datasets * tiles;
