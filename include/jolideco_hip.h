@@ -138,6 +138,19 @@ int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* plan, int n_datasets, const flo
                                    float* const* loss_out, float* grad_flux, int accumulate, float grad_scale,
                                    void* stream);
 
+/* The batched joint step for SEVERAL flux components (NPredModels.evaluate sums the per-component models after their
+ * clip, models/npred.py:210-261; per-component PSF / exposure as in npred.py:281-295): dataset d convolves flux[c] with
+ * khat[d * n_components + c] after scaling by exposure[d * n_components + c]; one forward launch (grid.y = dataset, the
+ * components walked inside the block), one loss launch and one adjoint launch per component.  Restrictions as above;
+ * at most 4 components.  Same results as the per-dataset loop, bit for bit.
+ *   flux, grad_flux     : host arrays of n_components device pointers (grad_flux nullable: forward only)
+ *   exposure, khat      : host arrays of n_datasets * n_components device pointers, dataset major */
+int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* plan, int n_datasets, int n_components, const float* const* flux,
+                                         const float* const* exposure, const float* const* khat,
+                                         const float* const* background, const float* const* counts,
+                                         const float* stirling_mean, float eps, float* const* loss_out,
+                                         float* const* grad_flux, int accumulate, float grad_scale, void* stream);
+
 /* The same with the per-dataset calibration of NPredCalibration (models/npred.py:298-402,225-237):
  *   shift_xy             device [2] = {shift_x, shift_y} in COUNTS pixels or NULL: every flux_c is shifted
  *                        (bilinear, zero padding = shift_image_torch, utils/torch.py:196-223) before the

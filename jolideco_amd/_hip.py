@@ -53,6 +53,10 @@ EXPORTS = {
         c_int,
         [c_void_p, c_int, c_void_p, fpp, fpp, fpp, fpp, fp, c_float, fpp, c_void_p, c_int, c_float, c_void_p],
     ),
+    "jd_npred_poisson_batch_multi_fwd_bwd": (
+        c_int,
+        [c_void_p, c_int, c_int, fpp, fpp, fpp, fpp, fpp, fp, c_float, fpp, fpp, c_int, c_float, c_void_p],
+    ),
     "jd_poisson_nll": (c_int, [c_void_p, c_void_p, c_size_t, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "jd_gmm_create": (c_int, [c_int, c_int, fp, fp, fp, fp, POINTER(c_void_p)]),
     "jd_gmm_destroy": (c_int, [c_void_p]),

@@ -415,7 +415,7 @@ class FitSession:
         import os
 
         self.batch_joint = (
-            self.joint and len(self.states) == 1 and not os.environ.get("JOLIDECO_NO_BATCH")
+            self.joint and not os.environ.get("JOLIDECO_NO_BATCH")
             and self.total_loss.poisson_loss.batchable([li for _, li in self.local_idx])
         )
 
@@ -451,8 +451,8 @@ class FitSession:
             if self.batch_joint:
                 # all local datasets in three launches (forward + Poisson, losses, adjoint): same numbers as the loop
                 total_loss.poisson_loss.fwd_bwd_batch(
-                    [li for _, li in self.local_idx], fluxes[0], [slot(gslot) for gslot, _ in self.local_idx],
-                    grad=grads[0], accumulate=False,
+                    [li for _, li in self.local_idx], fluxes if n_c > 1 else fluxes[0],
+                    [slot(gslot) for gslot, _ in self.local_idx], grad=grads if n_c > 1 else grads[0], accumulate=False,
                 )
                 first = False
             else:

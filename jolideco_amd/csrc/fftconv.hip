@@ -40,7 +40,7 @@ struct jd_conv_plan {
   float* gshift[JD_MAX_COMPONENTS] = {nullptr};
   double* partials_cal = nullptr;
   // batched joint step (jd_npred_poisson_batch_fwd_bwd): one g work image per dataset, partial sums per dataset
-  float* gbatch[jd::SEP_MAX_BATCH] = {nullptr};
+  float* gbatch[jd::SEP_MAX_BATCH * jd::SEP_BATCH_MAX_COMP] = {nullptr};
   double* partials_batch = nullptr;
   int partials_batch_cap = 0;
   jd::SepBatchTable table_host{};          // what table_dev holds (re-uploaded only when a pointer changes)
@@ -445,25 +445,33 @@ extern "C" int jd_npred_poisson_fwd_bwd(jd_conv_plan* p, int n_comp, const float
                             Calibration{}, stream);
 }
 
-extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, const float* flux,
-                                              const float* const* exposure, const float* const* khat,
-                                              const float* const* background, const float* const* counts,
-                                              const float* stirling_mean, float eps, float* const* loss_out,
-                                              float* grad_flux, int accumulate, float grad_scale, void* stream) {
-  JD_REQUIRE(p && flux && exposure && khat && background && counts && stirling_mean && loss_out,
-             "jd_npred_poisson_batch_fwd_bwd: null argument");
+extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datasets, int n_comp, const float* const* flux,
+                                                    const float* const* exposure, const float* const* khat,
+                                                    const float* const* background, const float* const* counts,
+                                                    const float* stirling_mean, float eps, float* const* loss_out,
+                                                    float* const* grad_flux, int accumulate, float grad_scale,
+                                                    void* stream) {
+  const char* who = "jd_npred_poisson_batch_multi_fwd_bwd";
+  JD_REQUIRE(p && flux && exposure && khat && background && counts && stirling_mean && loss_out, "%s: null argument", who);
   JD_REQUIRE(p->method == JD_CONV_SEPARABLE,
-             "jd_npred_poisson_batch_fwd_bwd: the plan must use the separable method (one jd_npred_poisson_fwd_bwd per "
-             "dataset otherwise)");
-  JD_REQUIRE(n_datasets >= 1 && n_datasets <= SEP_MAX_BATCH, "jd_npred_poisson_batch_fwd_bwd: n_datasets = %d not in [1, %d]",
-             n_datasets, SEP_MAX_BATCH);
-  for (int d = 0; d < n_datasets; ++d)
-    JD_REQUIRE(exposure[d] && khat[d] && background[d] && counts[d] && loss_out[d],
-               "jd_npred_poisson_batch_fwd_bwd: null pointer for dataset %d", d);
+             "%s: the plan must use the separable method (one jd_npred_poisson_fwd_bwd per dataset otherwise)", who);
+  JD_REQUIRE(n_datasets >= 1 && n_datasets <= SEP_MAX_BATCH, "%s: n_datasets = %d not in [1, %d]", who, n_datasets,
+             SEP_MAX_BATCH);
+  JD_REQUIRE(n_comp >= 1 && n_comp <= SEP_BATCH_MAX_COMP, "%s: n_comp = %d not in [1, %d]", who, n_comp, SEP_BATCH_MAX_COMP);
+  for (int c = 0; c < n_comp; ++c) {
+    JD_REQUIRE(flux[c], "%s: flux[%d] is null", who, c);
+    if (grad_flux) JD_REQUIRE(grad_flux[c], "%s: grad_flux[%d] is null", who, c);
+  }
+  for (int d = 0; d < n_datasets; ++d) {
+    JD_REQUIRE(background[d] && counts[d] && loss_out[d], "%s: null pointer for dataset %d", who, d);
+    for (int c = 0; c < n_comp; ++c)
+      JD_REQUIRE(exposure[d * n_comp + c] && khat[d * n_comp + c], "%s: null exposure or operator for dataset %d, component %d",
+                 who, d, c);
+  }
   hipStream_t s = as_stream(stream);
   const size_t bytes = (size_t)p->H * p->W * sizeof(float);
-  for (int d = 0; d < n_datasets; ++d)
-    if (!p->gbatch[d]) JD_HIP(hipMalloc(&p->gbatch[d], bytes));
+  for (int i = 0; i < n_datasets * n_comp; ++i)
+    if (!p->gbatch[i]) JD_HIP(hipMalloc(&p->gbatch[i], bytes));
   const int tiles = sep_conv_tiles(p->H, p->W);
   if (p->partials_batch_cap < n_datasets * tiles) {
     // (launches of an earlier call may still read the old buffer: hipFree waits for the device)
@@ -473,9 +481,8 @@ extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, c
     p->partials_batch_cap = n_datasets * tiles;
   }
   SepBatchTable table{};
-  for (int d = 0; d < n_datasets; ++d)
-    table.scale[d] = exposure[d], table.op[d] = khat[d], table.bkg[d] = background[d], table.cnt[d] = counts[d],
-    table.g[d] = p->gbatch[d];
+  for (int d = 0; d < n_datasets; ++d) table.bkg[d] = background[d], table.cnt[d] = counts[d];
+  for (int i = 0; i < n_datasets * n_comp; ++i) table.scale[i] = exposure[i], table.op[i] = khat[i], table.g[i] = p->gbatch[i];
   if (!p->table_dev) JD_HIP(hipMalloc(&p->table_dev, sizeof(SepBatchTable)));
   if (memcmp(&table, &p->table_host, sizeof(table)) != 0) {
     // a session passes the same pointers every step, so this happens once: wait for launches that may still read the
@@ -485,13 +492,28 @@ extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, c
     p->table_host = table;
   }
   const double n_pix = (double)p->H * (double)p->W;
-  int rc = launch_sep_conv_poisson_batch(n_datasets, flux, table, p->table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+  int rc = launch_sep_conv_poisson_batch(n_datasets, n_comp, flux, table, p->table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                                          p->partials_batch, eps, (float)(1.0 / n_pix), grad_flux ? 1 : 0, s);
   if (rc) return rc;
   if ((rc = launch_finalize_rows(p->partials_batch, tiles, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s))) return rc;
   if (!grad_flux) return JD_OK;
-  return launch_sep_conv_adjoint_batch(n_datasets, table, p->table_dev, grad_flux, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
-                                       grad_scale, accumulate, s);
+  for (int c = 0; c < n_comp; ++c)
+    if ((rc = launch_sep_conv_adjoint_batch(n_datasets, n_comp, c, table, p->table_dev, grad_flux[c], p->H, p->W, p->kh,
+                                            p->kw, p->oy, p->ox, grad_scale, accumulate, s)))
+      return rc;
+  return JD_OK;
+}
+
+extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, const float* flux,
+                                              const float* const* exposure, const float* const* khat,
+                                              const float* const* background, const float* const* counts,
+                                              const float* stirling_mean, float eps, float* const* loss_out,
+                                              float* grad_flux, int accumulate, float grad_scale, void* stream) {
+  JD_REQUIRE(flux, "jd_npred_poisson_batch_fwd_bwd: null argument");
+  const float* fluxes[1] = {flux};
+  float* grads[1] = {grad_flux};
+  return jd_npred_poisson_batch_multi_fwd_bwd(p, n_datasets, 1, fluxes, exposure, khat, background, counts, stirling_mean,
+                                              eps, loss_out, grad_flux ? grads : nullptr, accumulate, grad_scale, stream);
 }
 
 extern "C" int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,

@@ -63,18 +63,22 @@ int launch_sep_conv(const float* in, const float* in_scale, const float* op, flo
 int sep_conv_tiles(int H, int W);
 // per-dataset pointers of a batched joint step: exposure (input scale of the forward model, output scale of the
 // adjoint), operator, background, counts, g work image
+constexpr int SEP_BATCH_MAX_COMP = 4;  // flux components of a batched joint step (8 pixels x 4 clip masks = 32 bits per thread)
+// Pointer table of a batched joint step (device memory; everything that stays the same from step to step).  Per
+// (dataset d, component c) entries sit at d * n_comp + c.
 struct SepBatchTable {
-  const float* scale[SEP_MAX_BATCH];
-  const float* op[SEP_MAX_BATCH];
+  const float* scale[SEP_MAX_BATCH * SEP_BATCH_MAX_COMP];   // exposure of (d, c)
+  const float* op[SEP_MAX_BATCH * SEP_BATCH_MAX_COMP];      // factorised PSF of (d, c)
+  float* g[SEP_MAX_BATCH * SEP_BATCH_MAX_COMP];             // masked d loss / d conv_(d, c) work image
   const float* bkg[SEP_MAX_BATCH];
   const float* cnt[SEP_MAX_BATCH];
-  float* g[SEP_MAX_BATCH];
 };
-int launch_sep_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev,
-                                  int H, int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
-                                  int write_grad, hipStream_t stream);
-int launch_sep_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H,
-                                  int W, int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream);
+int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
+                                  const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
+                                  double* partials, float eps, float inv_n, int write_grad, hipStream_t stream);
+int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
+                                  float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
+                                  hipStream_t stream);
 // out[d][0] = scale * sum(partials[d * n .. d * n + n - 1]) + offset[d]   (one block per output, fixed order)
 int launch_finalize_rows(const double* partials, int n, int n_out, double scale, const float* offset_host,
                          float* const* out, hipStream_t stream);

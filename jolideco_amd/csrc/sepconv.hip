@@ -75,6 +75,15 @@ struct SepArgs {
   // index makes hipcc copy the whole argument block to scratch, which halved the speed of every variant)
   int n_batch;
   const SepBatchTable* table;
+  // batches: flux components per dataset (POISSON: summed after the per-component clip, npred.py:191,254-261) and the
+  // component whose gradient an adjoint launch produces
+  int n_comp, comp;
+  // POISSON batches: the flux images of the components.  Kernel arguments, not table entries: a fit alternates between
+  // two flux buffers, and a table that changes every step would be re-uploaded (synchronously) every step.  Read with
+  // constant indices only (see above).
+  const float* in_c1;
+  const float* in_c2;
+  const float* in_c3;
 };
 
 // LDS images:
@@ -85,11 +94,15 @@ struct SepArgs {
 // its gradient are computed from the convolution while it is still in registers (the arithmetic of
 // poisson_fused_kernel, statement for statement), so the convolution image is neither written nor read back.
 // Batches (a.n_batch > 0, several datasets that share the geometry and the input image layout):
-//   * POISSON: blockIdx.y selects the dataset -- one launch for all forward models of a joint step;
+//   * POISSON: blockIdx.y selects the dataset -- one launch for all forward models of a joint step; the block walks
+//     over the dataset's flux components (own flux image, exposure and PSF each), clips each convolution, adds them
+//     up in component order and writes one masked gradient image per component;
 //   * otherwise (the adjoint): every block walks over ALL datasets and adds their contributions in dataset order in
 //     registers, so the gradient image is read and written once instead of once per dataset (same additions in the
 //     same order as the per-dataset launches: same bits).
-template <bool VEC, bool IN_SCALE, bool POISSON>
+// MULTI (POISSON batches only): more than one flux component per dataset; a compile-time switch so that the common
+// one-component launch carries none of the component loop.
+template <bool VEC, bool IN_SCALE, bool POISSON, bool MULTI = false>
 __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   extern __shared__ float4 lds4[];
   float* win = reinterpret_cast<float*>(lds4);
@@ -111,8 +124,9 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   const int cx = (tid % (TX / 2)) * 2, cy = (tid / (TX / 2)) * 4;
   const int gx = X0 + cx;
 
-  const int d_begin = a.n_batch > 0 ? (POISSON ? (int)blockIdx.y : 0) : 0;
-  const int d_end = a.n_batch > 0 ? (POISSON ? d_begin + 1 : a.n_batch) : 1;
+  // units of work of this block: POISSON batch -- the components of dataset blockIdx.y; adjoint batch -- the datasets
+  const int n_comp = (MULTI || !POISSON) && a.n_batch > 0 ? a.n_comp : 1;
+  const int u_end = a.n_batch > 0 ? (POISSON ? n_comp : a.n_batch) : 1;
   // a pair of pixels of an (H, W) image at `off`: aligned float2 on the VEC path
   auto load2 = [&](const float* img, size_t off, float other) {
     if (VEC) return *reinterpret_cast<const v2f*>(img + off);
@@ -129,15 +143,24 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
     }
   }
 
-  for (int d = d_begin; d < d_end; ++d) {
-    const float* in = a.n_batch > 0 && !POISSON ? a.table->g[d] : a.in;
-    const float* in_scale = a.n_batch > 0 ? a.table->scale[d] : a.in_scale;
-    const float* op = a.n_batch > 0 ? a.table->op[d] : a.op;
-    const float* out_scale = a.n_batch > 0 ? a.table->scale[d] : a.out_scale;  // adjoint batch: the exposure of dataset d
+  v2f nsum[4];        // POISSON: sum over the components of clip(conv_c, 0)
+  unsigned mask = 0;  // POISSON: bit 8 c + 2 row + e = (conv_c >= 0) of this thread's pixel (row, e)
+  v2f opa[4], opb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) nsum[c] = v2f{0.f, 0.f};
+
+  for (int u = 0; u < u_end; ++u) {
+    const int d = a.n_batch > 0 ? (POISSON ? (int)blockIdx.y : u) : 0;
+    const int slot = d * n_comp + (POISSON ? u : a.comp);  // table entry of (dataset, component)
+    const float* in = a.n_batch > 0 && !POISSON ? a.table->g[slot] : a.in;
+    if (MULTI) in = u == 0 ? a.in : u == 1 ? a.in_c1 : u == 2 ? a.in_c2 : a.in_c3;
+    const float* in_scale = a.n_batch > 0 ? a.table->scale[slot] : a.in_scale;
+    const float* op = a.n_batch > 0 ? a.table->op[slot] : a.op;
+    const float* out_scale = a.n_batch > 0 ? a.table->scale[slot] : a.out_scale;  // adjoint batch: the exposure of (d, c)
     const float* background = a.n_batch > 0 ? a.table->bkg[d] : a.background;
     const float* counts = a.n_batch > 0 ? a.table->cnt[d] : a.counts;
     const int rank = (int)op[0];
-    if (d > d_begin) __syncthreads();  // the previous dataset is done with the LDS images
+    if (u > 0) __syncthreads();  // the previous unit is done with the LDS images
     for (int i = tid; i < rank * tap_stride; i += THREADS) taps[i] = op[a.taps_off + i];
 
     // ---- stage the window: image * in_scale, zero outside ---------------------------------------------------
@@ -205,10 +228,11 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
 
     // epilogue operands are requested now, so that their latency hides behind the two passes:
     // plain / adjoint: (out_scale, -);  POISSON: (background, counts)
-    v2f acc[4], opa[4], opb[4];
+    v2f acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       acc[c] = v2f{0.f, 0.f};
+      if (POISSON && u > 0) continue;  // background and counts: once per dataset
       opa[c] = v2f{1.f, 1.f};
       opb[c] = v2f{0.f, 0.f};
       const int gy = Y0 + cy + c;
@@ -273,38 +297,58 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
     }
 
     if (POISSON) {
-      // ---- epilogue: n = max(conv, 0) + b;  loss += n - c log(n + eps);  g = (1 - c / (n + eps)) / N where conv >= 0
+      // clip per component, sum in component order (0 + clip(conv_0) + clip(conv_1) + ...), remember where conv_c >= 0
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          nsum[c][e] += fmaxf(acc[c][e], 0.f);
+          mask |= (acc[c][e] >= 0.f ? 1u : 0u) << (8 * u + 2 * c + e);
+        }
+      if (u + 1 < u_end) continue;
+      // ---- epilogue: n = sum_c max(conv_c, 0) + b;  loss += n - c log(n + eps);  g_c = (1 - c / (n + eps)) / N where
+      // conv_c >= 0
       __shared__ double red[THREADS / 64];
-      float* g_out = a.n_batch > 0 ? a.table->g[d] : a.out;
       double local = 0.0;
+      v2f n4[4], g4[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int gy = Y0 + cy + c;
+        n4[c] = g4[c] = v2f{0.f, 0.f};
         if (gy >= a.H || gx >= a.W) continue;
-        const size_t off = (size_t)gy * a.W + gx;
         const bool two = gx + 1 < a.W;
-        float n2[2], g2[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float conv = acc[c][e], b = opa[c][e], cnt = opb[c][e];
-          const float n = fmaxf(conv, 0.f) + b;  // clip, then the un-convolved background (npred.py:191,254-261)
+          const float b = opa[c][e], cnt = opb[c][e];
+          const float n = nsum[c][e] + b;  // the un-convolved background comes last (npred.py:191,254-261)
           const float ne = n + a.eps;
           if (e == 0 || two) local += (double)(n - cnt * logf(ne));
-          const float g = (1.f - cnt / ne) * a.inv_n;
-          n2[e] = n;
-          g2[e] = conv >= 0.f ? g : 0.f;  // clamp backward: passes where conv >= 0
+          n4[c][e] = n;
+          g4[c][e] = (1.f - cnt / ne) * a.inv_n;
         }
-        if (VEC) {
-          if (a.write_grad) *reinterpret_cast<v2f*>(g_out + off) = v2f{g2[0], g2[1]};
-          if (a.npred_out) *reinterpret_cast<v2f*>(a.npred_out + off) = v2f{n2[0], n2[1]};
-        } else {
-          if (a.write_grad) {
-            g_out[off] = g2[0];
-            if (two) g_out[off + 1] = g2[1];
-          }
-          if (a.npred_out) {
-            a.npred_out[off] = n2[0];
-            if (two) a.npred_out[off + 1] = n2[1];
+      }
+      for (int k = 0; k < n_comp; ++k) {
+        float* g_out = a.n_batch > 0 ? a.table->g[d * n_comp + k] : a.out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int gy = Y0 + cy + c;
+          if (gy >= a.H || gx >= a.W) continue;
+          const size_t off = (size_t)gy * a.W + gx;
+          const bool two = gx + 1 < a.W;
+          // clamp backward: the gradient passes where conv_k >= 0
+          const float g0 = (mask >> (8 * k + 2 * c)) & 1u ? g4[c][0] : 0.f, g1 = (mask >> (8 * k + 2 * c + 1)) & 1u ? g4[c][1] : 0.f;
+          if (VEC) {
+            if (a.write_grad) *reinterpret_cast<v2f*>(g_out + off) = v2f{g0, g1};
+            if (k == 0 && a.npred_out) *reinterpret_cast<v2f*>(a.npred_out + off) = n4[c];
+          } else {
+            if (a.write_grad) {
+              g_out[off] = g0;
+              if (two) g_out[off + 1] = g1;
+            }
+            if (k == 0 && a.npred_out) {
+              a.npred_out[off] = n4[c][0];
+              if (two) a.npred_out[off + 1] = n4[c][1];
+            }
           }
         }
       }
@@ -420,13 +464,16 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
              aligned(a.background) && aligned(a.counts) && aligned(a.npred_out);
   vec = vec && (a.n_batch == 0 || batch_aligned);
   const bool in_scale = a.n_batch > 0 ? poisson : a.in_scale != nullptr;  // batches: forward scales its input, adjoint its output
-  const int variant = (poisson ? 4 : 0) + (vec ? 2 : 0) + (in_scale ? 1 : 0);
-  void (*const kernels[8])(SepArgs) = {
+  const int variant1 = (poisson ? 4 : 0) + (vec ? 2 : 0) + (in_scale ? 1 : 0);
+  void (*const kernels[10])(SepArgs) = {
       sep_conv_kernel<false, false, false>, sep_conv_kernel<false, true, false>, sep_conv_kernel<true, false, false>,
       sep_conv_kernel<true, true, false>,   sep_conv_kernel<false, false, true>, sep_conv_kernel<false, true, true>,
-      sep_conv_kernel<true, false, true>,   sep_conv_kernel<true, true, true>};
+      sep_conv_kernel<true, false, true>,   sep_conv_kernel<true, true, true>,
+      sep_conv_kernel<false, true, true, true>, sep_conv_kernel<true, true, true, true>};
+  const bool multi = poisson && a.n_batch > 0 && a.n_comp > 1;  // batches scale their input: IN_SCALE is set
+  const int variant = multi ? (vec ? 9 : 8) : variant1;
   auto kernel = kernels[variant];
-  static size_t lds_set[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static size_t lds_set[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (lds > 64 * 1024 && lds > lds_set[variant]) {
     JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set[variant] = lds;
@@ -467,36 +514,53 @@ int launch_sep_conv_poisson(const float* in, const float* in_scale, const float*
   return launch_sep(a, kh, kw, oy, ox, 0, true, stream);
 }
 
-static bool table_aligned(const SepBatchTable& t, int n) {
+static bool table_aligned(const SepBatchTable& t, int n, int n_comp) {
   auto ok = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   bool all = true;
-  for (int d = 0; d < n; ++d) all = all && ok(t.scale[d]) && ok(t.bkg[d]) && ok(t.cnt[d]) && ok(t.g[d]);
+  for (int d = 0; d < n; ++d) all = all && ok(t.bkg[d]) && ok(t.cnt[d]);
+  for (int i = 0; i < n * n_comp; ++i) all = all && ok(t.scale[i]) && ok(t.g[i]);
   return all;
 }
-
-// All forward models + Poisson passes of a joint step in ONE launch (grid.y = dataset): dataset d reads `flux` and
-// table.scale[d], writes g into table.g[d] (if write_grad) and its block sums into partials[d * tiles + tile].
-// `table_dev` is the device copy of `table`.
-int launch_sep_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev,
-                                  int H, int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
-                                  int write_grad, hipStream_t stream) {
+static int check_batch(int n, int n_comp) {
   if (n < 1 || n > SEP_MAX_BATCH) return fail(JD_ERR_INVALID, "separable batch: %d datasets not in [1, %d]", n, SEP_MAX_BATCH);
-  SepArgs a{};
-  a.in = flux, a.H = H, a.W = W, a.coef = 1.f, a.partials = partials;
-  a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_batch = n, a.table = table_dev;
-  a.op = table.op[0], a.in_scale = table.scale[0];
-  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, table_aligned(table, n));
+  if (n_comp < 1 || n_comp > SEP_BATCH_MAX_COMP)
+    return fail(JD_ERR_INVALID, "separable batch: %d components not in [1, %d]", n_comp, SEP_BATCH_MAX_COMP);
+  return JD_OK;
 }
 
-// grad (+)= coef * sum_d scale[d] * corr_same(g[d], psf_d): one launch, the datasets are added in order in
-// registers (bit-identical to n accumulate launches), the gradient image is read and written once.
-int launch_sep_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H,
-                                  int W, int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream) {
-  if (n < 1 || n > SEP_MAX_BATCH) return fail(JD_ERR_INVALID, "separable batch: %d datasets not in [1, %d]", n, SEP_MAX_BATCH);
+// All forward models + Poisson passes of a joint step in ONE launch (grid.y = dataset): dataset d convolves the
+// n_comp flux images flux[c] (x table.scale[d * n_comp + c]), writes the masked g of component c into
+// table.g[d * n_comp + c] (if write_grad) and its block sums into partials[d * tiles + tile].
+// `table_dev` is the device copy of `table`.
+int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
+                                  const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
+                                  double* partials, float eps, float inv_n, int write_grad, hipStream_t stream) {
+  int rc = check_batch(n, n_comp);
+  if (rc) return rc;
+  SepArgs a{};
+  a.in = flux[0], a.in_c1 = n_comp > 1 ? flux[1] : nullptr, a.in_c2 = n_comp > 2 ? flux[2] : nullptr;
+  a.in_c3 = n_comp > 3 ? flux[3] : nullptr;
+  a.H = H, a.W = W, a.coef = 1.f, a.partials = partials;
+  a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_batch = n, a.n_comp = n_comp, a.table = table_dev;
+  a.op = table.op[0], a.in_scale = table.scale[0];
+  bool flux_aligned = true;
+  for (int c = 0; c < n_comp; ++c) flux_aligned = flux_aligned && (reinterpret_cast<uintptr_t>(flux[c]) & 15) == 0;
+  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, flux_aligned && table_aligned(table, n, n_comp));
+}
+
+// grad (+)= coef * sum_d scale[d, comp] * corr_same(g[d, comp], psf_(d, comp)): one launch per component, the datasets
+// are added in order in registers (bit-identical to n accumulate launches), the gradient image is read and written once.
+int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
+                                  float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
+                                  hipStream_t stream) {
+  int rc = check_batch(n, n_comp);
+  if (rc) return rc;
+  if (comp < 0 || comp >= n_comp) return fail(JD_ERR_INVALID, "separable batch: component %d not in [0, %d)", comp, n_comp);
   SepArgs a{};
   a.out = grad, a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate, a.n_batch = n, a.table = table_dev;
-  a.in = table.g[0], a.op = table.op[0];
-  return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_aligned(table, n));
+  a.n_comp = n_comp, a.comp = comp;
+  a.in = table.g[comp], a.op = table.op[comp];
+  return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_aligned(table, n, n_comp));
 }
 
 }  // namespace jd

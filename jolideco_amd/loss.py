@@ -81,28 +81,34 @@ class PoissonLoss:
         )
 
     def batchable(self, indices):
-        """True if the datasets `indices` can take the batched joint step: one flux component, no up-sampling, no
-        calibration, one separable plan shared by all of them."""
+        """True if the datasets `indices` can take the batched joint step: at most 4 flux components, no up-sampling,
+        no calibration, ONE separable plan shared by every (dataset, component) model."""
         models_all = [self.npred_models_all[i] for i in indices]
         if len(models_all) < 2:
             return False
-        plans = set()
+        plans, methods = set(), set()
         for models in models_all:
-            if len(models) != 1 or models.calibration is not None:
+            if not 1 <= len(models) <= 4 or models.calibration is not None:
                 return False
-            (model,) = models.values()
-            if (model.upsampling_factor or 1) != 1:
-                return False
-            plans.add(id(model.plan))
-        (model,) = models_all[0].values()
-        return len(plans) == 1 and model.plan.method == "separable"
+            for model in models.values():
+                if (model.upsampling_factor or 1) != 1:
+                    return False
+                plans.add(id(model.plan))
+                methods.add(model.plan.method)
+        return len(plans) == 1 and methods == {"separable"}
 
     def fwd_bwd_batch(self, indices, flux, loss_outs, grad=None, accumulate=False, grad_scale=1.0):
         """Forward model + Poisson NLL (+ gradient, summed over the datasets in order) of the datasets `indices`
-        in three launches; requires `batchable(indices)`."""
-        models = [next(iter(self.npred_models_all[i].values())) for i in indices]
-        models[0].plan.npred_poisson_batch_fwd_bwd(
-            flux=flux, exposures=[m.exposure for m in models], khats=[m.khat for m in models],
+        in three launches (+ one adjoint launch per further component); requires `batchable(indices)`.
+        ``flux`` / ``grad``: a tensor (one component) or lists with one tensor per component, in component order."""
+        per_dataset = [list(self.npred_models_all[i].values()) for i in indices]
+        single = torch.is_tensor(flux)
+        exposures = [[m.exposure for m in models] for models in per_dataset]
+        khats = [[m.khat for m in models] for models in per_dataset]
+        if single:
+            exposures, khats = [e[0] for e in exposures], [k[0] for k in khats]
+        per_dataset[0][0].plan.npred_poisson_batch_fwd_bwd(
+            flux=flux, exposures=exposures, khats=khats,
             backgrounds=[self.npred_models_all[i].background for i in indices],
             counts=[self.counts_all[i] for i in indices], stirlings=[self.stirling_all[i] for i in indices],
             loss_outs=loss_outs, grad=grad, accumulate=accumulate, grad_scale=grad_scale,

@@ -194,27 +194,45 @@ class ConvPlan:
         )
 
     MAX_BATCH = 16  # SEP_MAX_BATCH of csrc/kernels.h
+    MAX_BATCH_COMPONENTS = 4  # SEP_BATCH_MAX_COMP
 
     def npred_poisson_batch_fwd_bwd(self, flux, exposures, khats, backgrounds, counts, stirlings, loss_outs, grad=None,
                                     accumulate=False, grad_scale=1.0, eps=POISSON_EPS):
-        """All datasets of a joint step at once (one flux component, separable plan shared by the datasets): one
-        launch for the forward models + Poisson passes, one for the losses, one for the adjoints
-        (jd_npred_poisson_batch_fwd_bwd).  Same numbers as the per-dataset calls with ``accumulate`` from the second
-        dataset on."""
+        """All datasets of a joint step at once (separable plan shared by every dataset and component): one launch for
+        the forward models + Poisson passes, one for the losses, one adjoint launch per flux component
+        (jd_npred_poisson_batch_multi_fwd_bwd).  Same numbers as the per-dataset calls with ``accumulate`` from the
+        second dataset on.
+
+        One component: ``flux`` / ``grad`` are tensors and ``exposures`` / ``khats`` lists of per-dataset tensors.
+        Several components: ``flux`` / ``grad`` are lists of tensors and ``exposures[d]`` / ``khats[d]`` lists with one
+        tensor per component."""
         n = len(exposures)
         if not (len(khats) == len(backgrounds) == len(counts) == len(stirlings) == len(loss_outs) == n):
             raise ValueError("all per-dataset lists must have the same length")
-        self._check_image(flux, "flux")
+        single = torch.is_tensor(flux)
+        fluxes = [flux] if single else list(flux)
+        grads = None if grad is None else ([grad] if single else list(grad))
+        if single:
+            exposures, khats = [[e] for e in exposures], [[k] for k in khats]
+        n_comp = len(fluxes)
+        if not 1 <= n_comp <= self.MAX_BATCH_COMPONENTS:
+            raise ValueError(f"{n_comp} flux components: the batched joint step takes 1 to {self.MAX_BATCH_COMPONENTS}")
+        if any(len(e) != n_comp for e in exposures) or any(len(k) != n_comp for k in khats):
+            raise ValueError("every dataset needs one exposure and one operator per flux component")
+        if grads is not None and len(grads) != n_comp:
+            raise ValueError("one gradient image per flux component")
+        for f in fluxes:
+            self._check_image(f, "flux")
         for start in range(0, n, self.MAX_BATCH):
             sl = slice(start, min(n, start + self.MAX_BATCH))
             m = sl.stop - sl.start
             stirling_arr = (c_float * m)(*[float(v) for v in stirlings[sl]])
             check(
-                _hip.lib().jd_npred_poisson_batch_fwd_bwd(
-                    self._handle, m, ptr(flux), ptr_array(exposures[sl]), ptr_array(khats[sl]),
-                    ptr_array(backgrounds[sl]), ptr_array(counts[sl]), stirling_arr, c_float(eps),
-                    ptr_array(loss_outs[sl]), ptr(grad), int(accumulate or start > 0), c_float(grad_scale),
-                    stream_ptr(flux.device),
+                _hip.lib().jd_npred_poisson_batch_multi_fwd_bwd(
+                    self._handle, m, n_comp, ptr_array(fluxes), ptr_array([e for es in exposures[sl] for e in es]),
+                    ptr_array([k for ks in khats[sl] for k in ks]), ptr_array(backgrounds[sl]), ptr_array(counts[sl]),
+                    stirling_arr, c_float(eps), ptr_array(loss_outs[sl]), None if grads is None else ptr_array(grads),
+                    int(accumulate or start > 0), c_float(grad_scale), stream_ptr(fluxes[0].device),
                 )
             )
 

@@ -492,3 +492,36 @@ def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch):
     assert np.array_equal(results["batch"][0], results["loop"][0])
     for name, column in results["loop"][1].items():
         np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
+
+
+def test_batched_joint_step_with_two_components(monkeypatch):
+    """The batched joint step with several flux components (BASELINE config 5 in small: "extended" + "points", per-component
+    PSFs, jd_npred_poisson_batch_multi_fwd_bwd): every dataset's forward model walks over the components inside the
+    block, clips each, and writes one masked gradient image per component; one adjoint launch per component.  Same
+    trajectory as the per-dataset loop, bit for bit, for both components."""
+    from jolideco_amd import FluxComponents, InverseGammaPrior, MAPDeconvolver, SpatialFluxComponent, UniformPrior
+    from jolideco_amd.data import gaussian_kernel, synthetic_observations
+
+    datasets, _, flux_init = synthetic_observations(shape=(72, 136), n_obs=4, seed=11)
+    for i, d in enumerate(datasets.values()):
+        d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
+    results = {}
+    for mode in ("batch", "loop"):
+        if mode == "loop":
+            monkeypatch.setenv("JOLIDECO_NO_BATCH", "1")
+        comps = FluxComponents()
+        comps["extended"] = SpatialFluxComponent.from_numpy(flux=flux_init, prior=UniformPrior())
+        comps["points"] = SpatialFluxComponent.from_numpy(flux=0.1 * flux_init, prior=InverseGammaPrior(alpha=10))
+        deconvolver = MAPDeconvolver(n_epochs=6, display_progress=False, device=DEV, fit_mode="joint")
+        session = deconvolver.session(datasets, components=comps)
+        assert session.batch_joint == (mode == "batch")
+        res = deconvolver.run(datasets, components=comps)
+        results[mode] = (
+            {name: res.components[name].flux_upsampled_numpy for name in ("extended", "points")},
+            {name: np.asarray(res.trace_loss[name]) for name in res.trace_loss.colnames if name != "filename"},
+        )
+    for name in ("extended", "points"):
+        assert np.array_equal(results["batch"][0][name], results["loop"][0][name]), name
+        assert not np.array_equal(results["batch"][0][name], flux_init)
+    for name, column in results["loop"][1].items():
+        np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
