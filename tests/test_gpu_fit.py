@@ -494,7 +494,8 @@ def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch):
         np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
 
 
-def test_batched_joint_step_with_two_components(monkeypatch):
+@pytest.mark.parametrize("shape", [(72, 136), (40, 75)], ids=["w136_vector", "w75_scalar"])
+def test_batched_joint_step_with_two_components(monkeypatch, shape):
     """The batched joint step with several flux components (BASELINE config 5 in small: "extended" + "points", per-component
     PSFs, jd_npred_poisson_batch_multi_fwd_bwd): every dataset's forward model walks over the components inside the
     block, clips each, and writes one masked gradient image per component; one adjoint launch per component.  Same
@@ -502,7 +503,7 @@ def test_batched_joint_step_with_two_components(monkeypatch):
     from jolideco_amd import FluxComponents, InverseGammaPrior, MAPDeconvolver, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import gaussian_kernel, synthetic_observations
 
-    datasets, _, flux_init = synthetic_observations(shape=(72, 136), n_obs=4, seed=11)
+    datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=4, seed=11)
     for i, d in enumerate(datasets.values()):
         d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
     results = {}
