@@ -4,7 +4,7 @@ for d in sys.argv[1:]:
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
     for f in files:
         for row in csv.DictReader(open(f)):
-            k = row["Kernel_Name"][:40]
+            k = row["Kernel_Name"].replace("(anonymous namespace)::", "")[:64]
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             n[(k, row["Counter_Name"])] += 1
     for k, c in agg.items():
