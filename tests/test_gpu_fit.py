@@ -526,3 +526,34 @@ def test_batched_joint_step_with_two_components(monkeypatch, shape):
         assert not np.array_equal(results["batch"][0][name], flux_init)
     for name, column in results["loop"][1].items():
         np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
+
+
+def test_batched_joint_step_with_four_components(monkeypatch):
+    """Four flux components (the most the batched step takes; a fifth falls back to the per-dataset loop), one of them
+    frozen: same bits as the loop."""
+    from jolideco_amd import FluxComponents, MAPDeconvolver, SpatialFluxComponent, UniformPrior
+    from jolideco_amd.data import gaussian_kernel, synthetic_observations
+
+    datasets, _, flux_init = synthetic_observations(shape=(48, 80), n_obs=3, seed=5)
+    names = ["a", "b", "c", "d", "e"]
+    for n_comp in (4, 5):
+        for i, d in enumerate(datasets.values()):
+            d["psf"] = {name: gaussian_kernel(1.0 + 0.2 * j + 0.1 * i, (17, 17)).astype(np.float32) for j, name in enumerate(names[:n_comp])}
+        results = {}
+        for mode in ("batch", "loop"):
+            if mode == "loop":
+                monkeypatch.setenv("JOLIDECO_NO_BATCH", "1")
+            else:
+                monkeypatch.delenv("JOLIDECO_NO_BATCH", raising=False)
+            comps = FluxComponents()
+            for j, name in enumerate(names[:n_comp]):
+                comps[name] = SpatialFluxComponent.from_numpy(flux=flux_init / (j + 1.0), prior=UniformPrior(), frozen=(j == 2))
+            deconvolver = MAPDeconvolver(n_epochs=4, display_progress=False, device=DEV, fit_mode="joint")
+            session = deconvolver.session(datasets, components=comps)
+            assert session.batch_joint == (mode == "batch" and n_comp <= 4)
+            res = deconvolver.run(datasets, components=comps)
+            results[mode] = {name: res.components[name].flux_upsampled_numpy for name in names[:n_comp]}
+        for name in names[:n_comp]:
+            assert np.array_equal(results["batch"][name], results["loop"][name]), (n_comp, name)
+        assert np.allclose(results["batch"]["c"], flux_init / 3.0, rtol=1e-6)  # frozen
+        assert not np.array_equal(results["batch"]["a"], flux_init)
