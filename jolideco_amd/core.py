@@ -414,10 +414,12 @@ class FitSession:
         self.step = 0
         import os
 
-        self.batch_joint = (
-            self.joint and not os.environ.get("JOLIDECO_NO_BATCH")
-            and self.total_loss.poisson_loss.batchable([li for _, li in self.local_idx])
+        batchable = not os.environ.get("JOLIDECO_NO_BATCH") and self.total_loss.poisson_loss.batchable(
+            [li for _, li in self.local_idx]
         )
+        self.batch_joint = self.joint and batchable
+        # sequential mode: the per-epoch trace evaluates every dataset on the same stale flux -- one batched launch
+        self.batch_trace = (not self.joint) and batchable
 
     def _slot(self, i):
         return self.scalars[i : i + 1]
@@ -491,8 +493,14 @@ class FitSession:
                 self._cal_step(li)
             # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------------
             stale = [st.flux_trace for st in states]
-            for gslot, li in self.local_idx:
-                total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
+            if self.batch_trace:
+                total_loss.poisson_loss.fwd_bwd_batch(
+                    [li for _, li in self.local_idx], stale if n_c > 1 else stale[0],
+                    [slot(gslot) for gslot, _ in self.local_idx],
+                )
+            else:
+                for gslot, li in self.local_idx:
+                    total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
             for ci, (st, prior) in enumerate(zip(states, priors)):
                 prior.device_fwd_bwd(st.flux_trace, slot(n_d + ci))
         if self.n_val:
