@@ -50,7 +50,7 @@ PATCH, D, STRIDE = 8, 64, 4
 PROFILE_EVERY = 10  # steps of the timed region whose kernels are timed with hipEvent pairs: 0, 10, 20, ...
 
 
-def build_session(cfg_name, device, seed=0, dist=None):
+def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
     from jolideco_amd.data import synthetic_gmm, synthetic_observations
     from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
@@ -72,7 +72,7 @@ def build_session(cfg_name, device, seed=0, dist=None):
         for i, d in enumerate(datasets.values()):  # per-component PSFs: the point sources see a sharper core
             d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
         comp = comps
-    deconvolver = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="joint")
+    deconvolver = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode=fit_mode)
     return deconvolver.session(datasets, components=comp, dist=dist)
 
 
@@ -438,6 +438,27 @@ def main():
             }
         finally:
             os.environ.pop("JD_GMM_SCREEN", None)
+    # The reference's own loop (fit_mode="sequential", jolideco/core.py:209-247): one optimizer step per dataset, each
+    # with a full prior evaluation, then the per-epoch trace on all datasets -- SURVEY.md section 8(d) asks for both rates.
+    if world == 1 and fake is None and not args.no_general_psf:
+        log("sequential-mode run")
+        seq = build_session(args.config, device, fit_mode="sequential")
+        n_epochs = max(args.steps // 10, 2)
+        for _ in range(2):
+            seq.epoch()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n_epochs):
+            seq.epoch()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out["sequential_mode"] = {
+            "epochs_per_s": n_epochs / dt, "steps_per_s": n_epochs * n_obs / dt, "ms_per_epoch": 1e3 * dt / n_epochs,
+            "epochs": n_epochs,
+            "note": "reference-exact trajectory: one Adam step per observation (each with the full prior) + the trace "
+                    "evaluation of every observation per epoch",
+        }
+        del seq
     log("gpu result: " + json.dumps(out))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)
