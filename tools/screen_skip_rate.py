@@ -1,4 +1,5 @@
-"""How often could the screen kernel skip half of its work?  CPU estimate (uses oracle/cpu_ref.py, tuning only): the
+"""How often could the screen kernel skip half of its work?  CPU estimate (numpy / torch-CPU on the host-side GMM
+constants of jolideco_amd, tuning only): the
 last 32 whitened coordinates of a patch (y_j, j >= 32: 4 of the 6 MFMA blocks, half of the squares) already give the
 upper bound c_k - q_2 / 2 on its log-likelihood; if that is below the running lower bound L for all 64 patches of a
 tile pair, the first coordinate block (2 MFMAs + 16 squares per tile + the bound arithmetic) is not needed.
@@ -8,26 +9,26 @@ the FIRST 32 coordinates reject almost nothing (3-5 % of the groups).  See DESIG
 import sys; sys.path.insert(0, "/root/repo")
 import numpy as np, torch
 from jolideco_amd.data import synthetic_observations, synthetic_gmm
-from oracle import cpu_ref
+from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
 torch.set_num_threads(8)
 shape=(256,256)
 datasets, truth, flux_init = synthetic_observations(shape=shape, n_obs=1, seed=0)
 means, covs, weights = synthetic_gmm(128, 64, seed=0)
-gmm = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
 for label, img in (("init(gamma30)", flux_init.astype(np.float32)), ("truth", truth.astype(np.float32))):
     x = torch.from_numpy(img)[None,None]
     patches = torch.nn.functional.unfold(x, kernel_size=8, stride=4)[0].T  # (Np, 64)
     patches = patches - patches.mean(dim=1, keepdim=True)
-    P = gmm.precisions_cholesky  # (K, 64, 64)
-    mP = gmm.means_precisions_cholesky  # (K,64)
-    w = gmm.pixel_weights if hasattr(gmm,'pixel_weights') else None
+    P = torch.from_numpy(gmm.precisions_cholesky_numpy.astype(np.float32))  # (K, 64, 64)
+    mP = torch.from_numpy(gmm.means_precisions_cholesky_numpy.astype(np.float32))  # (K,64)
+    w = torch.from_numpy(gmm.pixel_weights_numpy.astype(np.float32))
     Np = patches.shape[0]
     y = torch.einsum('ni,kij->nkj', patches, P) - mP[None]
-    wv = gmm.pixel_weights.reshape(1,1,64) if w is not None else 1.0
+    wv = w.reshape(1,1,64)
     ysq = (y*y) * wv
     q = ysq.sum(-1)               # (Np,K)
     q1 = ysq[..., :32].sum(-1)
-    const = (gmm.log_det_cholesky + gmm.log_weights)[None]  # up to common constant
+    const = torch.from_numpy((gmm.log_det_cholesky_numpy + gmm.log_weights_numpy).astype(np.float32))[None]  # up to a common constant
     l = const - 0.5*q
     ub1 = const - 0.5*q1
     L = l.max(dim=1, keepdim=True).values
