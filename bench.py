@@ -8,19 +8,22 @@
 Workload (BASELINE.json `metric`, configs[2]): 2048x2048 image, 8 synthetic observations with
 varying PSF / exposure / background, one flux component with a GMM patch prior (8x8 patches, stride
 4, K = 128 components), fp32, JOINT fit: one "step" = one optimizer iteration on
-sum_d L_d - beta * logprior = for every observation the forward model (rocFFT R2C / k-space
-multiply / C2R), the fused Poisson NLL + gradient pass and the adjoint FFTs; the GMM prior value +
-gradient; (N > 1) ONE RCCL all-reduce of the flux gradient; the fused chain rule + Adam update.
+sum_d L_d - beta * logprior = the forward models of all observations (PSF convolution, clip, + background) with
+the fused Poisson NLL + gradient pass, the adjoint convolutions, the GMM prior value + gradient, (N > 1) ONE RCCL
+all-reduce of the flux gradient, the fused chain rule + Adam update.  The convolution method is "auto": the
+benchmark's Gaussian PSFs are rank 1, so the headline runs the separable kernel (forward launch = convolution +
+Poisson pass of all local observations); the same fit with the PSFs as general 17x17 kernels (MFMA direct
+convolution, `general_psf`) and through rocFFT (`fft_psf`, the path the north star names) is timed beside it.
 Total work is fixed as N grows (observations round-robin over the ranks, the prior split by patch
 rows): strong scaling.  All inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step (the GMM
-forward kernel: fp32 matrix-core roof), `roofline_poisson` the fused Poisson pass (HBM roof), both
-from hipEvent pairs recorded by the library around every launch of every 4th step of the timed region
-(bracketing every launch of every step costs ~4 % of the step).  `--config c2|c4|c5` run the other
-BASELINE configurations (parity-test cases; the default c3 is the one the metric is quoted on).
-`cpu_baseline` times oracle/cpu_ref.py (the PyTorch-CPU restatement of the reference) on a bounded
-sample on rank 0 at N = 1.
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step (the fp16 screen of the
+GMM arg-max: matrix-core roof; `roofline_section8d` prices the whole GMM forward pass by SURVEY section 8(d)'s
+dense fp32 definition), `roofline_poisson` the fused Poisson pass (HBM roof), both from hipEvent pairs recorded by
+the library around every launch of every 10th step of the timed region (bracketing every launch of every step costs
+~4 % of the step).  `--config c2|c4|c5` run the other BASELINE configurations (parity-test cases; the default c3
+is the one the metric is quoted on).  `cpu_baseline` times oracle/cpu_ref.py (the PyTorch-CPU restatement of the
+reference) on a bounded sample on rank 0 at N = 1.
 """
 import argparse
 import json
@@ -76,21 +79,47 @@ def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
     return deconvolver.session(datasets, components=comp, dist=dist)
 
 
+PMC_TRAFFIC_FILES = ("profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
+
+
+def pmc_traffic_file():
+    for rel in PMC_TRAFFIC_FILES:
+        if (REPO / rel).exists():
+            return rel
+    return None
+
+
+def pmc_traffic_source():
+    """Where `traffic` comes from: PMC counters cannot be read from inside this process, so the bench line quotes
+    the committed rocprofv3 PMC passes -- file and the commit that last touched it (stale once a kernel changes)."""
+    rel = pmc_traffic_file()
+    if rel is None:
+        return None
+    commit = "unknown"
+    try:
+        import subprocess
+
+        commit = subprocess.run(["git", "log", "-n1", "--format=%h", "--", rel], cwd=REPO, capture_output=True,
+                                text=True, timeout=10).stdout.strip() or "unknown"
+    except Exception:  # no git on the GPU box's copy: the file name alone identifies the round
+        pass
+    return f"{rel} @{commit} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, not measured by this run)"
+
+
 def pmc_traffic_bytes(cfg_name, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (profiles/r01/pmc_hbm_traffic.csv: FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per launch);
+    (FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per launch);
     gfx950 correction of MI355X_MICROARCH.md: reads = 2 x FETCH_SIZE, writes = WRITE_SIZE.  None when the
     workload was not profiled.  (PMC counters cannot be read from inside this process.)"""
     import csv
 
-    path = REPO / "profiles" / "r01" / "pmc_hbm_traffic.csv"
-    if not path.exists():
+    rel = pmc_traffic_file()
+    if rel is None:
         return None
     fetch = write = None
-    with open(path) as fh:
+    with open(REPO / rel) as fh:
         rows = list(csv.DictReader(fh))
-    # "<config>s" / "<config>f" rows: the same workload profiled on later builds (separable convolution + screened
-    # GMM; backward pass fused into the exact kernel) -- the last one found wins
+    # "<config>s" / "<config>f" rows: the same workload profiled on later builds -- the last one found wins
     for label in (cfg_name, cfg_name + "s", cfg_name + "f"):
         for row in rows:
             if row["config"] == label and kernel in row["kernel"]:
@@ -190,6 +219,13 @@ def main():
 
     dist_ctx = init_from_env()
     world = dist_ctx.world_size
+    # what the BACKEND saw (not what the flags said): a SCALE record can be checked for "RCCL saw N ranks"
+    dist_info = {"backend": None, "world_size_seen_by_backend": 1, "rank": 0}
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        dist_info = {
+            "backend": torch.distributed.get_backend(), "world_size_seen_by_backend": torch.distributed.get_world_size(),
+            "rank": torch.distributed.get_rank(),
+        }
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
@@ -280,6 +316,7 @@ def main():
             "forward_pass_ms": gmm_ms, "stage_ms": {k: avg_ms(k)[0] for k in ("gmm_screen", "gmm_sort", "gmm_exact")},
             "algorithmic_fp32_flop": gmm_flop,
             "algorithmic_fp32_equivalent_tflops": gmm_flop / (gmm_ms * 1e-3) / 1e12,
+            "traffic_source": pmc_traffic_source(),
             "note": "results are bit-identical to the fp32 MFMA kernel; the fp16 product only decides which "
                     "components can NOT be the arg-max; gmm_exact also writes the gradient rows of the survivors "
                     "(the backward pass of the arg-max prior has no kernel of its own)",
@@ -314,6 +351,7 @@ def main():
             "kernel": poi_kernel + (" (forward convolution + Poisson pass)" if poisson_in_conv else ""), "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic_bytes(args.config, poi_kernel) if world == 1 and fake is None else None,
+            "traffic_source": pmc_traffic_source(),
             "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes, "datasets_per_launch": per_launch,
         }
     n_profiled = len(range(0, args.steps, PROFILE_EVERY))
@@ -328,6 +366,7 @@ def main():
         "value": args.steps / elapsed,
         "unit": "iters/s",
         "n_gpus": world,
+        "distributed": dist_info,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
@@ -343,8 +382,21 @@ def main():
             "sharding": f"observations round-robin over {world} rank(s), prior by patch rows, 1 all-reduce/step"
             if world > 1 else "single GPU",
         },
+        # numerics of the run itself: the loss scalars of the last timed step [dataset losses | log-priors] -- the same
+        # for any number of ranks (tests/test_gpu_distributed.py compares a 2-rank run with a single process)
+        "check": {"epochs_run": args.warmup + args.steps, "scalars_last_step": [float(v) for v in scal]},
         "roofline": roofline,
         "roofline_poisson": roof_poi,
+        # SURVEY section 8(d)'s own definition for the GMM prior: Np K (2 D^2 + 4 D) fp32 flop over the duration of the
+        # whole forward pass, against the fp32 matrix / vector roof.  Above 1 on the screened path: the fp16 screen
+        # replaces the dense fp32 evaluation by a bound + ~1.2 exact evaluations per patch (same bits out).
+        "roofline_section8d": None if not gmm_ms else {
+            "kernel": "GMM prior forward pass (all stages)", "bound": "mfma", "unit": "TFLOP/s",
+            "achieved": gmm_flop_dense / (gmm_ms * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS,
+            "frac": gmm_flop_dense / (gmm_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "flop_per_launch": gmm_flop_dense, "forward_pass_ms": gmm_ms,
+            "note": "dense-equivalent fp32 flop of section 8(d); > 1 means the work was avoided, not executed",
+        },
         "kernel_ms_per_step": kernel_ms_per_step,
         "dominant_kernel": dominant,
     }
@@ -375,48 +427,61 @@ def main():
             "traffic": conv_traffic, "avg_launch_ms": conv_ms, "launches": conv_n, "bytes_per_launch": conv_bytes,
             "datasets_per_launch": per_launch,
         }
-    # The same fit with the PSF treated as a general (not low-rank) kernel, i.e. what an instrument PSF that is not
-    # a sum of <= 3 outer products gets: MFMA Toeplitz convolution.  Reported next to the headline, never as it.
-    if world == 1 and fake is None and "separable" in methods and not args.no_general_psf:
-        log("general-PSF run (JOLIDECO_CONV_METHOD=direct)")
+    # The same fit with the PSFs treated as general (not low-rank) kernels -- what an instrument PSF that is not a sum of
+    # <= 3 outer products gets: the MFMA Toeplitz convolution -- and through rocFFT (R2C, k-space multiply, C2R: the
+    # path BASELINE.json's north star names; the default for PSFs larger than 33x33).  Reported next to the headline,
+    # never as it.
+    def conv_method_run(method, note):
+        log(f"{method}-convolution run (JOLIDECO_CONV_METHOD={method})")
         previous = os.environ.get("JOLIDECO_CONV_METHOD")
-        os.environ["JOLIDECO_CONV_METHOD"] = "direct"
+        os.environ["JOLIDECO_CONV_METHOD"] = method
         try:
-            general = build_session(args.config, device)
+            other = build_session(args.config, device)
             for _ in range(args.warmup):
-                general.epoch()
+                other.epoch()
             torch.cuda.synchronize(device)
             _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
             t0 = time.perf_counter()
             for i in range(args.steps):
                 _hip.profile_pause(i % PROFILE_EVERY != 0)
-                general.epoch()
+                other.epoch()
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
-            prof_general = _hip.profile_read()
-            out["general_psf"] = {
+            prof_other = _hip.profile_read()
+            used = sorted({m.plan.method for m in other.total_loss.poisson_loss.npred_models_all})
+            result = {
                 "value": args.steps / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / args.steps,
-                "conv_method": "direct", "note": "same workload with the PSFs convolved as general 17x17 kernels",
+                "conv_method": "+".join(used), "note": note,
+                "kernel_ms_per_step": {k: v[0] / n_profiled for k, v in prof_other.items() if v[1] and k not in nested},
             }
-            # this path runs the STAND-ALONE fused Poisson pass (conv, background, counts in; g out = 16 B/pixel):
-            # the kernel BASELINE.json's "HBM GB/s on fused Poisson pass" was defined on
-            total_p, count_p = prof_general.get("poisson_fused", (0.0, 0))
-            if count_p:
-                ms = total_p / count_p
-                achieved = 16 * H * W / (ms * 1e-3) / 1e9
-                out["roofline_poisson_standalone"] = {
-                    "kernel": "poisson_fused_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic_bytes(args.config, "poisson_fused_kernel<4, 1>"),
-                    "avg_launch_ms": ms, "launches": count_p, "bytes_per_launch": 16 * H * W,
-                    "note": "hipEvent pairs add ~2 us to this ~13 us kernel; rocprofv3: profiles/README.md",
-                }
-            del general
+            del other
+            return result, prof_other
         finally:
             if previous is None:
                 os.environ.pop("JOLIDECO_CONV_METHOD", None)
             else:
                 os.environ["JOLIDECO_CONV_METHOD"] = previous
+
+    if world == 1 and fake is None and "separable" in methods and not args.no_general_psf:
+        out["general_psf"], prof_general = conv_method_run(
+            "direct", "same workload with the PSFs convolved as general 17x17 kernels (MFMA Toeplitz convolution)")
+        # this path runs the STAND-ALONE fused Poisson pass (conv, background, counts in; g out = 16 B/pixel):
+        # the kernel BASELINE.json's "HBM GB/s on fused Poisson pass" was defined on
+        total_p, count_p = prof_general.get("poisson_fused", (0.0, 0))
+        if count_p:
+            ms = total_p / count_p
+            achieved = 16 * H * W / (ms * 1e-3) / 1e9
+            out["roofline_poisson_standalone"] = {
+                "kernel": "poisson_fused_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": pmc_traffic_bytes(args.config, "poisson_fused_kernel<4, 1"),
+                "traffic_source": pmc_traffic_source(),
+                "avg_launch_ms": ms, "launches": count_p, "bytes_per_launch": 16 * H * W,
+                "note": "hipEvent pairs add ~2 us to this ~13 us kernel; rocprofv3: profiles/README.md",
+            }
+        out["fft_psf"], _ = conv_method_run(
+            "fft", "same workload through rocFFT: pad+scale, R2C, k-space multiply, C2R, stand-alone Poisson pass, "
+                   "R2C, conj multiply, C2R, adjoint epilogue per observation")
     # The same fit with the GMM arg-max evaluated by the dense fp32 MFMA kernel for every (patch, component) pair
     # (JD_GMM_SCREEN=0; bit-identical results): reported next to the headline for whoever wants the number without the
     # fp16 screen.

@@ -1708,7 +1708,8 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   const long n = a.n_end - a.n_begin;
   // every wave its own 128 patches and all components, unless that leaves CUs without a block: then the four waves of
   // a block share 128 patches and split the components (see gmm_screen_kernel)
-  const bool ksplit = (n + SCREEN_T * 32 * 4 - 1) / (SCREEN_T * 32 * 4) < g->n_cu;
+  bool ksplit = (n + SCREEN_T * 32 * 4 - 1) / (SCREEN_T * 32 * 4) < g->n_cu;
+  if (const char* env = getenv("JD_GMM_KSPLIT")) ksplit = atoi(env) != 0;  // testing: force either decomposition
   const unsigned blocks = (unsigned)(ksplit ? (n + SCREEN_T * 32 - 1) / (SCREEN_T * 32) : ((n + SCREEN_T * 32 - 1) / (SCREEN_T * 32) + 3) / 4);
   const size_t n_seg = (size_t)blocks * 4;
   const size_t slots = n_seg * SCREEN_CAP;                  // candidate record slots

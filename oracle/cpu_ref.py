@@ -13,6 +13,7 @@ Parity pinning: checked in the build container against the imported reference
 fixtures in tests/golden/ (generated from the reference, incl. the reference's own known-answer
 numbers from jolideco/tests/test_core.py:72-79,144-153,181-188).
 """
+import contextlib
 from dataclasses import dataclass, field
 from math import log, pi
 
@@ -21,6 +22,30 @@ import torch
 import torch.nn.functional as F
 
 TORCH_DEFAULT_GENERATOR_SEED = 67280421310721  # torch.Generator("cpu").initial_seed()
+
+# Working precision.  float32 is the reference's (and the default: every cast below is then the one the reference
+# makes).  `precision(np.float64)` re-runs the SAME restatement in double precision: the tests use it to measure how far
+# the two fp32 paths (this oracle, the HIP kernels) are from exact arithmetic where their difference exceeds 1e-5.
+_NP_DTYPE = np.float32
+
+
+@contextlib.contextmanager
+def precision(np_dtype):
+    """Context manager: run the oracle in `np_dtype` (np.float32 | np.float64)."""
+    global _NP_DTYPE
+    previous_np, previous_torch = _NP_DTYPE, torch.get_default_dtype()
+    _NP_DTYPE = np_dtype
+    torch.set_default_dtype(torch.float64 if np_dtype == np.float64 else torch.float32)
+    try:
+        yield
+    finally:
+        _NP_DTYPE = previous_np
+        torch.set_default_dtype(previous_torch)
+
+
+def _tensor(array):
+    """numpy -> tensor in the working precision (a no-op cast for float32 input at the default precision)."""
+    return torch.from_numpy(np.ascontiguousarray(array, dtype=_NP_DTYPE))
 
 
 # --------------------------------------------------------------------------------------
@@ -210,16 +235,16 @@ class GMM:
             w = np.ones((p, p))
         else:
             w = pixel_weights((p, p), self.stride)
-        self.pixel_weights = torch.from_numpy(w.reshape((1, -1)).astype(np.float32))
+        self.pixel_weights = _tensor(w.reshape((1, -1)))
 
     @classmethod
     def from_numpy(cls, means, covariances, weights, stride=None):
         """gmm.py:119-149: float64 scipy Cholesky, then cast to fp32."""
         pc = precision_cholesky(covariances)
         return cls(
-            means=torch.from_numpy(means.astype(np.float32)),
-            precisions_cholesky=torch.from_numpy(pc.astype(np.float32)),
-            weights=torch.from_numpy(weights.astype(np.float32)),
+            means=_tensor(means),
+            precisions_cholesky=_tensor(pc),
+            weights=_tensor(weights),
             stride=stride,
         )
 
@@ -367,13 +392,13 @@ class DatasetRef:
             psf = dataset["psf"]
             if isinstance(psf, dict):
                 psf = psf[name]
-            psf_t = upsample_setup(torch.from_numpy(psf[np.newaxis, np.newaxis]), u, is_psf=True)
-            exp_t = upsample_setup(torch.from_numpy(dataset["exposure"][np.newaxis, np.newaxis]), u, is_psf=False)
+            psf_t = upsample_setup(_tensor(psf[np.newaxis, np.newaxis]), u, is_psf=True)
+            exp_t = upsample_setup(_tensor(dataset["exposure"][np.newaxis, np.newaxis]), u, is_psf=False)
             exposures.append(edge_corrected_exposure(exp_t, psf_t))
             psfs.append(psf_t)
         return cls(
-            counts=torch.from_numpy(dataset["counts"][np.newaxis, np.newaxis]),
-            background=torch.from_numpy(dataset["background"][np.newaxis, np.newaxis]),
+            counts=_tensor(dataset["counts"][np.newaxis, np.newaxis]),
+            background=_tensor(dataset["background"][np.newaxis, np.newaxis]),
             exposures=exposures,
             psfs=psfs,
             upsampling_factors=list(ups),
@@ -397,7 +422,7 @@ class DatasetRef:
 def log_flux_parameter(flux_init, upsampling_factor=None, use_log_flux=True):
     """theta = log(float32(flux)) (or the flux itself for use_log_flux=False) as a (1,1,H,W) leaf,
     bilinearly up-sampled first when the component is: jolideco/models/core.py:399-402,505-540."""
-    flux = torch.from_numpy(flux_init[np.newaxis, np.newaxis].astype(np.float32))
+    flux = _tensor(flux_init[np.newaxis, np.newaxis])
     if upsampling_factor:
         flux = F.interpolate(flux, scale_factor=upsampling_factor, mode="bilinear")
     if use_log_flux:
@@ -560,7 +585,7 @@ def map_fit_joint(datasets, flux_inits, priors, n_epochs, beta=1.0, learning_rat
 # --------------------------------------------------------------------------------------
 def poisson_loss_and_grad(theta_np, dataset, component="flux"):
     """loss, npred and dL/dtheta for one dataset / one component at theta (autograd)."""
-    theta = torch.from_numpy(theta_np[np.newaxis, np.newaxis].astype(np.float32)).requires_grad_(True)
+    theta = _tensor(theta_np[np.newaxis, np.newaxis]).requires_grad_(True)
     d = DatasetRef.from_numpy(dataset, [component])
     flux = to_flux(theta)
     npred = d.npred((flux,))
@@ -571,7 +596,7 @@ def poisson_loss_and_grad(theta_np, dataset, component="flux"):
 
 def gmm_prior_value_and_grad(flux_np, gmm, stride, shifts, marginalize=False):
     """log-prior, d logprior / d flux and the arg-max component per patch (autograd)."""
-    flux = torch.from_numpy(flux_np[np.newaxis, np.newaxis].astype(np.float32)).requires_grad_(True)
+    flux = _tensor(flux_np[np.newaxis, np.newaxis]).requires_grad_(True)
     value, arg = gmm_patch_log_prior(flux, gmm, stride, shifts, marginalize, return_argmax=True)
     value.backward()
     arg_np = None if arg is None else arg.numpy().astype(np.int32)

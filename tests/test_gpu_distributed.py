@@ -65,3 +65,39 @@ def test_two_rank_joint_fit_matches_the_single_process_reference(tmp_path, golde
     for key, ref in j.items():
         if key.startswith("joint/trace/"):
             np.testing.assert_allclose(r0[key[len("joint/"):]], ref, rtol=2e-5, atol=1e-6, err_msg=key)
+
+
+@pytest.mark.timeout(1500)
+def test_bench_two_ranks_over_gloo_reports_what_the_backend_saw(tmp_path):
+    """`bench.py --gpus 2` itself, launched the way the driver launches it (torch.distributed.run, one fresh child
+    process per rank, started before any GPU call of theirs), with JOLIDECO_DIST_BACKEND=gloo so that both ranks can
+    share this box's single GPU.  The JSON line must report the world size the BACKEND saw and the loss scalars of
+    the sharded fit must equal those of the same fit in one process."""
+    import json
+    import subprocess
+
+    import bench
+
+    steps, warmup = 3, 1
+    env = dict(os.environ, JOLIDECO_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup",
+           str(warmup), "--no-general-psf"]
+    done = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1400)
+    assert done.returncode == 0, done.stderr[-3000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]  # rank 0 prints ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["warmup"] == warmup
+    assert out["distributed"] == {"backend": "gloo", "world_size_seen_by_backend": 2, "rank": 0}
+    assert out["scaling"] == "strong" and out["value"] > 0 and "cpu_baseline" not in out
+    # the same fit in this process: identical scalars (the replicas apply the identical update after the all-reduce)
+    session = bench.build_session("c3", torch.device("cuda:0"))
+    for _ in range(warmup + steps):
+        session.epoch()
+    torch.cuda.synchronize()
+    single = session.scalars.cpu().numpy()
+    assert out["check"]["epochs_run"] == warmup + steps
+    np.testing.assert_allclose(np.array(out["check"]["scalars_last_step"]), single, rtol=1e-5)

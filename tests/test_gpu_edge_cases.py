@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_linf
+from conftest import assert_prior_grad_matches, rel_linf
 from oracle import cpu_ref
 
 pytestmark = pytest.mark.gpu
@@ -39,10 +39,8 @@ def test_gmm_prior_edge_shapes(shape, K, stride, shifts):
     np.testing.assert_allclose(float(value), value_o, rtol=5e-6)
     got = argmax.cpu().numpy()
     assert got.min() >= 0 and got.max() < K
-    if np.array_equal(got, arg_o):  # near ties may flip under another summation order
-        assert rel_linf(grad.cpu().numpy(), grad_o) < 1e-5
-    else:
-        assert (got != arg_o).mean() < 0.02
+    # always compared: pixels under a flipped near-tie patch are masked, every other pixel held to 1e-5
+    assert_prior_grad_matches(grad.cpu().numpy(), grad_o, got, arg_o, shape, stride, shifts)
     # logsumexp mode on the same input
     lse_o, glse_o, _ = cpu_ref.gmm_prior_value_and_grad(flux_np, gmm_o, stride, shifts, marginalize=True)
     v2, g2 = torch.zeros(1, device=DEV), torch.zeros_like(flux)

@@ -286,8 +286,8 @@ def test_upsampling_factor_3_gmm_prior(golden, conv_method):
 def test_calibrations_match_the_reference(golden, tag, u, n_epochs, conv_method):
     """Fits with NPredCalibrations against the live-reference fixture: sub-pixel shift (bilinear, trained),
     background norm (trained), PSF scale (fixed), a zero shift that must stay exactly zero, a frozen
-    calibration.  Tolerance 1e-4: grid_sample's own pixel-coordinate rounding (W * 2^-24 px) and the Adam
-    steps on the three scalars amplify fp32 differences beyond the 1e-5 of the pure flux path."""
+    calibration.  Flux within the north-star 1e-5 of the live reference; the float64 oracle shows both fp32 paths
+    at 1e-6 .. 7e-6 from exact arithmetic (grid_sample's own pixel-coordinate rounding, W * 2^-24 px)."""
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent
 
     c = golden("calibration")
@@ -302,8 +302,24 @@ def test_calibrations_match_the_reference(golden, tag, u, n_epochs, conv_method)
         datasets, components=comp, calibrations=cals
     )
     err = rel_linf(res.flux_upsampled_total, c[f"{tag}/flux_upsampled_final"])
-    print("calibrated fit rel Linf", tag, err)
-    assert err < 1e-4
+    # the same fit by the oracle in float64: is the HIP path further from exact arithmetic than the fp32 reference?
+    from oracle import cpu_ref
+
+    with cpu_ref.precision(np.float64):
+        gmm_64 = cpu_ref.GMM.from_numpy(c[f"{tag}/gmm_means"], c[f"{tag}/gmm_covariances"], c[f"{tag}/gmm_weights"], stride=4)
+        cals_64 = {}
+        for name in datasets:
+            sx, sy, norm, psf_scale, frozen = c[f"{tag}/cal_init/{name}"]
+            cals_64[name] = cpu_ref.CalibrationRef.create(sx, sy, norm, psf_scale, bool(frozen))
+        final_64, _ = cpu_ref.map_fit_sequential(
+            datasets, {"flux": c[f"{tag}/flux_init"]}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_64)}, n_epochs=n_epochs,
+            upsampling_factors={"flux": u}, calibrations=cals_64,
+        )
+    d_gpu = rel_linf(res.flux_upsampled_total, final_64["flux"])
+    d_ref = rel_linf(c[f"{tag}/flux_upsampled_final"], final_64["flux"])
+    print(f"calibrated fit {tag}: |gpu-ref| {err:.2e}  |gpu-f64| {d_gpu:.2e}  |ref-f64| {d_ref:.2e}")
+    assert err < 1e-5  # the north-star tolerance (measured 1.0e-6 .. 2.8e-6)
+    assert d_gpu <= 3.0 * d_ref + 1e-5  # no further from the float64 fit than the fp32 reference itself
     _trace_close(res.trace_loss, c, prefix=f"{tag}/trace/", rtol=1e-4)
     for name in datasets:
         d = res.calibrations[name].to_dict()

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_linf, unpack_datasets
+from conftest import assert_prior_grad_matches, rel_linf, unpack_datasets
 
 pytestmark = pytest.mark.gpu
 
@@ -126,11 +126,12 @@ def test_gmm_prior_max_value_grad_argmax(golden, name, gname):
         np.testing.assert_allclose(float(value), float(stages[f"{key}/value"]), rtol=3e-6)
         ref_arg, margin = stages[f"{key}/argmax"], stages[f"{key}/margin"]
         got_arg = argmax.cpu().numpy()
-        clear = margin > 1e-3 * np.maximum(1.0, np.abs(margin).max() * 0)  # ties may flip under re-ordered fp32 sums
+        clear = margin > 1e-3  # near-ties may flip under re-ordered fp32 sums
         assert np.array_equal(got_arg[clear], ref_arg[clear])
         assert (got_arg != ref_arg).sum() <= 2
-        if (got_arg == ref_arg).all():
-            assert rel_linf(grad.cpu().numpy(), stages[f"{key}/grad_flux"]) < 1e-5
+        # the gradient is ALWAYS compared: pixels under a flipped near-tie patch are masked, the rest held to 1e-5
+        assert_prior_grad_matches(grad.cpu().numpy(), stages[f"{key}/grad_flux"], got_arg, ref_arg, (H, W), 4, shifts,
+                                  margin=margin)
 
 
 @pytest.mark.parametrize("name", CASES[:3])
@@ -474,6 +475,13 @@ def test_gmm_prior_marginalized_gradient_exact_inputs():
     handle.prior_fwd_bwd(flux, 4, (-1, 2), value, scale, grad=grad, grad_coef=scale, marginalize=True)
     np.testing.assert_allclose(float(value), value_o, rtol=3e-6)
     assert rel_linf(grad.cpu().numpy(), grad_o) < 5e-5
+    # the float64 oracle arbitrates the part above 1e-5: the kernel must be as close to it as the fp32 oracle is
+    with cpu_ref.precision(np.float64):
+        gmm_64 = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+        _, grad_64, _ = cpu_ref.gmm_prior_value_and_grad(flux_np, gmm_64, 4, (-1, 2), marginalize=True)
+    d_gpu, d_o = rel_linf(grad.cpu().numpy(), grad_64), rel_linf(grad_o, grad_64)
+    print(f"lse gradient: |gpu-oracle32| {rel_linf(grad.cpu().numpy(), grad_o):.2e} |gpu-f64| {d_gpu:.2e} |oracle32-f64| {d_o:.2e}")
+    assert d_gpu <= 2.0 * d_o + 2e-6
     # patch-row shards accumulate to the same gradient
     n_rows = (70 - 8) // 4 + 1
     pv, pg = torch.zeros(1, device=DEV), torch.zeros_like(flux)
@@ -504,7 +512,15 @@ def test_marginalized_prior_fit_matches_oracle():
     final, trace = cpu_ref.map_fit_sequential(
         datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o, marginalize=True)}, n_epochs=4
     )
-    assert rel_linf(res.flux_total, final["flux"]) < 5e-5  # see the tolerance note above
+    with cpu_ref.precision(np.float64):
+        gmm_64 = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+        final_64, _ = cpu_ref.map_fit_sequential(
+            datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_64, marginalize=True)}, n_epochs=4
+        )
+    err, d_gpu, d_o = rel_linf(res.flux_total, final["flux"]), rel_linf(res.flux_total, final_64["flux"]), rel_linf(final["flux"], final_64["flux"])
+    print(f"lse fit: |gpu-oracle32| {err:.2e} |gpu-f64| {d_gpu:.2e} |oracle32-f64| {d_o:.2e}")
+    assert err < 5e-5  # see the tolerance note above
+    assert d_gpu <= 2.0 * d_o + 2e-6  # as close to the float64 fit as the fp32 oracle
     np.testing.assert_allclose(res.trace_loss[-1]["total"], trace[-1]["total"], rtol=2e-5)
 
 
