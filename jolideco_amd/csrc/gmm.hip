@@ -948,7 +948,24 @@ __device__ __forceinline__ void mfma_screen(f32x16 (&acc)[2], const ScreenFrags&
 }
 
 // The lane's share of q = sum_j ytilde_j^2 (the 32 coordinates of its lane half)
+#ifndef JD_SCREEN_SCALAR_SQ
+#define JD_SCREEN_SCALAR_SQ 1
+#endif
 __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
+#if JD_SCREEN_SCALAR_SQ
+  // two scalar fmaf chains (even / odd registers): the same additions in the same order as the packed form below, but
+  // no v_pk_fma_f32 -- beside MFMAs a packed fp32 instruction costs the wave more than the two scalar ones it replaces
+  // (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), and hipcc packs only part of them
+  float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      q0 = __builtin_fmaf(acc[b][r], acc[b][r], q0);
+      q1 = __builtin_fmaf(acc[b][r + 1], acc[b][r + 1], q1);
+    }
+  return q0 + q1;
+#else
   f32x2 q2 = {0.f, 0.f};
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -958,6 +975,7 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
       q2 = __builtin_elementwise_fma(v, v, q2);
     }
   return q2[0] + q2[1];
+#endif
 }
 
 // TWO tiles (A, B) and one component: after the MFMAs lane (h, c) holds half of q for patch c of both tiles.  One
@@ -1008,12 +1026,28 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
 //                   still occupies every CU for a short time instead of a few CUs for the full sweep.  Every wave
 //                   keeps its own running bound L_w (a valid lower bound of the maximum), the final bound is their
 //                   maximum.
-template <int NP, bool KSPLIT>
+constexpr int SCREEN_KC_MAX = 512;  // components whose per-component constants are staged in LDS in visiting order
+
+// KC_LDS: (k, c_k, eps |P'_k|_F, s_k^2, |m'_k|) of the component at every position of the visiting order are staged in
+// LDS once per block (K <= SCREEN_KC_MAX).  The kernel stores records, so hipcc may not use scalar loads for these
+// uniform values; as vector loads from global memory their latency was exposed once per component (a load of
+// korder[kk + 1] followed at once by the wait for it).  From LDS they are fetched TWO positions ahead, so that the
+// component index is in a register a whole component before the fragment prefetch needs it for its address.
+template <int NP, bool KSPLIT, bool KC_LDS>
 __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   constexpr int NT = 2 * NP;
   __shared__ uint4 xs[KSPLIT ? 1 : 4][NT * 4 * 64];  // [tile][pixel step][lane] = 8 fp16 (B fragment); per wave | shared
   __shared__ float st_xn[KSPLIT ? NT * 32 : 1], st_s2[KSPLIT ? NT * 32 : 1], st_L[KSPLIT ? 4 * NT * 32 : 1];
   __shared__ int st_ok[KSPLIT ? NT * 32 : 1];
+  __shared__ int kc_k[KC_LDS ? SCREEN_KC_MAX : 1];
+  __shared__ float4 kc_f[KC_LDS ? SCREEN_KC_MAX : 1];
+  if (KC_LDS) {
+    for (int i = threadIdx.x; i < a.K; i += 256) {
+      const int k = a.korder[i];
+      kc_k[i] = k;
+      kc_f[i] = make_float4(a.const_k[k], a.efro_k[k], a.sk2_k[k], a.mnorm_k[k]);
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
   const int base = a.n_begin + (KSPLIT ? (int)blockIdx.x : wave_global) * (NT * 32);
@@ -1072,6 +1106,7 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     if (h == 0 && valid) a.best[n] = ok[t] ? best_key(-INFINITY, 0) : 0ull;
     if (KSPLIT && h == 0) st_xn[t * 32 + c] = xn[t], st_s2[t * 32 + c] = xs2[t], st_ok[t * 32 + c] = ok[t] ? 1 : 0;
   }
+  if (KC_LDS && !KSPLIT) __syncthreads();  // the constants table (KSPLIT: the barrier below)
   if (KSPLIT) {
     __syncthreads();
 #pragma unroll
@@ -1113,18 +1148,38 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   };
   constexpr int KSTEP = KSPLIT ? 4 : 1;
   const int kk0 = KSPLIT ? wave : 0;  // position in the visiting order: wave w takes w, w + 4, ...
-  int k_next = a.korder[kk0 < a.K ? kk0 : 0];
-  float ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
-  load_frags16(f0, af, k_next);
+  // (component, constants) at a position of the visiting order
+  struct KConst {
+    int k;
+    float ck, ef, sk2, mn;
+  };
+  auto fetch_consts = [&](int pos) {
+    KConst r;
+    if (KC_LDS) {
+      r.k = kc_k[pos];
+      const float4 c4 = kc_f[pos];
+      r.ck = c4.x, r.ef = c4.y, r.sk2 = c4.z, r.mn = c4.w;
+    } else {
+      r.k = a.korder[pos];
+      r.ck = a.const_k[r.k], r.ef = a.efro_k[r.k], r.sk2 = a.sk2_k[r.k], r.mn = a.mnorm_k[r.k];
+    }
+    return r;
+  };
+  auto clamp_pos = [&](int pos) { return pos < a.K ? pos : (kk0 < a.K ? kk0 : 0); };
+  KConst cur = fetch_consts(clamp_pos(kk0));
+  KConst nxt = fetch_consts(clamp_pos(kk0 + KSTEP));  // always one component ahead of `cur` ...
+  load_frags16(f0, af, __builtin_amdgcn_readfirstlane(cur.k));
   if (kk0 < a.K) issue_pair(acc[0], f0, 0);  // prologue: pair 0 of the first component
   int it = 0;
   for (int kk = kk0; kk < a.K; kk += KSTEP, ++it) {
-    const int k = k_next;
-    const float ck = ck_next, ef = ef_next, sk2 = sk2_next, mn = mn_next;
+    const int k = __builtin_amdgcn_readfirstlane(cur.k);
+    const float ck = cur.ck, ef = cur.ef, sk2 = cur.sk2, mn = cur.mn;
     const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f);
-    k_next = a.korder[kk + KSTEP < a.K ? kk + KSTEP : kk];  // scalar loads one component ahead of their use
-    ck_next = a.const_k[k_next], ef_next = a.efro_k[k_next], sk2_next = a.sk2_k[k_next], mn_next = a.mnorm_k[k_next];
-    load_frags16(f1, af, k_next);  // unconditional (clamped) prefetch of the next component
+    // unconditional (clamped) prefetch of the next component's fragments: its index has been in a register since the
+    // previous component
+    load_frags16(f1, af, __builtin_amdgcn_readfirstlane(nxt.k));
+    cur = nxt;
+    nxt = fetch_consts(clamp_pos(kk + 2 * KSTEP));  // ... and fetched two ahead of its use
     if (NP == 2) {
       // pair 1 of k on the matrix pipe while pair 0 of k finishes in its shadow, then pair 0 of k + 1 | pair 1 of k
       issue_pair(acc[1], f0, 1);
@@ -1135,8 +1190,8 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
                          pq[NP - 1], pn[NP - 1], k, lane, cnt, seg_n, seg_k, seg_ub);
     } else {
       // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the buffers alternate
-      const int cur = it & 1;
-      if (cur == 0) {
+      const int buf = it & 1;
+      if (buf == 0) {
         issue_pair(acc[1], f1, 0);
         screen_finish_pair(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
                            cnt, seg_n, seg_k, seg_ub);
@@ -1744,10 +1799,15 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   sc.seg_cnt = g->seg_cnt, sc.flag = flag, sc.gen = g->gen;
   {
     ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
-    if (ksplit)
-      gmm_screen_kernel<2, true><<<blocks, 256, 0, s>>>(sc);
+    const bool kc_lds = g->K <= SCREEN_KC_MAX && !getenv("JD_GMM_SCREEN_NO_LDS_CONSTS");  // (testing: the global-load path)
+    if (ksplit && kc_lds)
+      gmm_screen_kernel<2, true, true><<<blocks, 256, 0, s>>>(sc);
+    else if (ksplit)
+      gmm_screen_kernel<2, true, false><<<blocks, 256, 0, s>>>(sc);
+    else if (kc_lds)
+      gmm_screen_kernel<2, false, true><<<blocks, 256, 0, s>>>(sc);
     else
-      gmm_screen_kernel<2, false><<<blocks, 256, 0, s>>>(sc);
+      gmm_screen_kernel<2, false, false><<<blocks, 256, 0, s>>>(sc);
   }
   JD_LAUNCH_CHECK();
 
