@@ -209,6 +209,22 @@ int jd_gmm_prior_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int strid
                          float value_scale, float* value_out, int accumulate_value, float grad_coef,
                          float* grad_flux_accum, int32_t* argmax_out, void* stream);
 
+/* The same evaluation for ONE RANK OF A SHARDED PRIOR (joint fit over several GPUs; the
+ * reference has no distributed code): instead of accumulating into the gradient image, the gradient of the shard's
+ * patch rows is written as a compact band of the ROLLED frame,
+ *   band_out[(Y - y_begin) * W + X] = grad_coef * d(sum_{patches in shard} v_patch)/d flux_rolled[Y, X],
+ *   Y in [y_begin, y_end) = [patch_row_begin * stride, (patch_row_end - 1) * stride + 8)   (0 where no patch covers),
+ * which the ranks exchange with ONE all-gather while the all-reduce of the likelihood gradient is in flight. */
+int jd_gmm_prior_band_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int stride, int shift_y,
+                              int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
+                              float value_scale, float* value_out, int accumulate_value, float grad_coef,
+                              float* band_out, void* stream);
+/* grad[(Y - shift_y) mod H, (X - shift_x) mod W] += sum_b bands[b * chunk_floats + (Y - y_begin[b]) * W + X] over the
+ * bands with y_begin[b] <= Y < y_end[b], added in band order (identical on every rank).  `bands` is the device buffer an
+ * all-gather of the per-rank bands produced; y_begin / y_end are HOST arrays of n_bands (<= 64) entries. */
+int jd_add_rolled_bands(float* grad, int H, int W, int shift_y, int shift_x, const float* bands, size_t chunk_floats,
+                        int n_bands, const int* y_begin, const int* y_end, void* stream);
+
 /* (Np, K) log-probabilities of explicit patches: GaussianMixtureModel.estimate_log_prob
  * (patches/gmm.py:262-281).  x: (n, 64) device, out: (n, K) device. */
 int jd_gmm_estimate_log_prob(jd_gmm* gmm, const float* x, int n, float* out, void* stream);

@@ -414,12 +414,58 @@ class FitSession:
         self.step = 0
         import os
 
+        self._setup_sharded_prior(os.environ.get("JOLIDECO_DIST_OVERLAP", "1") != "0")
         batchable = not os.environ.get("JOLIDECO_NO_BATCH") and self.total_loss.poisson_loss.batchable(
             [li for _, li in self.local_idx]
         )
         self.batch_joint = self.joint and batchable
         # sequential mode: the per-epoch trace evaluates every dataset on the same stale flux -- one batched launch
         self.batch_trace = (not self.joint) and batchable
+
+    def _setup_sharded_prior(self, overlap):
+        """Sharded joint fit: every rank evaluates the GMM prior on its band of patch rows.  With ``overlap`` (default)
+        the band of the prior gradient travels in ONE all-gather of compact pieces [bands of the shardable priors |
+        their values] while the all-reduce of the likelihood gradient is in flight; otherwise the prior gradient is
+        accumulated into the flat buffer before its (single, blocking) all-reduce."""
+        from .ops import band_rows
+
+        self.band_plan = None
+        dist = self.dist
+        if not (self.joint and dist.world_size > 1):
+            return
+        # ranks must draw identical cycle-spin shifts: identical generator states at the start
+        state = []
+        for prior in self.priors:
+            generator = getattr(prior, "generator", None)
+            if prior.shardable and generator is not None:
+                state.append(int(np.frombuffer(generator.get_state().numpy().tobytes(), dtype=np.uint8).astype(np.int64).sum()))
+                state.append(int(generator.initial_seed() % (1 << 62)))
+        dist.assert_same_on_all_ranks(state or [0], "the state of the cycle-spin generators")
+        if not overlap:
+            return
+        plan, offset = [], 0
+        for ci, (st, prior) in enumerate(zip(self.states, self.priors)):
+            if not prior.shardable or st.frozen:
+                continue
+            H, W = st.shape
+            n_rows = prior.n_patch_rows(st.shape)
+            y_ranges = []
+            for r in range(dist.world_size):
+                rows = DistContext(r, dist.world_size).shard_range(n_rows)
+                y_ranges.append(band_rows(rows, prior.stride, H))
+            size = max(y1 - y0 for y0, y1 in y_ranges) * W
+            plan.append({"ci": ci, "offset": offset, "size": size, "y_ranges": y_ranges, "rows": dist.shard_range(n_rows)})
+            offset += size
+        if not plan:
+            return
+        for i, item in enumerate(plan):
+            item["value"] = offset + i  # the shard's prior value rides behind the bands
+        chunk = -(-(offset + len(plan)) // 4) * 4  # multiple of 4 floats: 16-byte aligned pieces
+        device = self.comm.device
+        self.band_plan = plan
+        self.band_chunk = chunk
+        self.band_send = torch.zeros(chunk, dtype=torch.float32, device=device)
+        self.band_recv = torch.zeros(chunk * dist.world_size, dtype=torch.float32, device=device)
 
     def _slot(self, i):
         return self.scalars[i : i + 1]
@@ -465,14 +511,41 @@ class FitSession:
             if first:
                 for g in grads:
                     g.zero_()
+            banded = {item["ci"]: item for item in (self.band_plan or [])}
             for ci, (st, prior) in enumerate(zip(states, priors)):
+                if ci in banded:
+                    continue
                 if dist.world_size > 1 and not prior.shardable and dist.rank != 0:
                     continue  # cheap element-wise priors: rank 0 only, summed by the all-reduce
                 prior.device_fwd_bwd(
                     st.flux_cur, slot(n_d + ci), grad=st.grad, coef=-float(cfg.beta),
                     patch_rows=self._prior_rows(prior, st),
                 )
-            if dist.world_size > 1:
+            if banded:
+                # likelihood gradient (+ element-wise priors, + dataset losses) on its way while the prior is evaluated
+                from .ops import add_rolled_bands
+
+                pending = dist.all_reduce_sum_async(self.comm)
+                for ci, item in banded.items():
+                    st, prior = states[ci], priors[ci]
+                    prior.device_fwd_bwd(
+                        st.flux_cur, self.band_send[item["value"] : item["value"] + 1], coef=-float(cfg.beta),
+                        patch_rows=item["rows"], band_out=self.band_send[item["offset"] : item["offset"] + item["size"]],
+                    )
+                    item["shifts"] = prior.last_shifts
+                dist.all_gather_flat(self.band_recv, self.band_send)
+                if pending is not None:
+                    pending.wait()
+                pieces = self.band_recv.view(dist.world_size, self.band_chunk)
+                for ci, item in banded.items():
+                    add_rolled_bands(states[ci].grad, item["shifts"], self.band_recv[item["offset"] :], self.band_chunk,
+                                     item["y_ranges"])
+                    # every rank sums the shard values in rank order: identical replicas
+                    if dist.dry_run:
+                        slot(n_d + ci).copy_(pieces[dist.rank, item["value"] : item["value"] + 1])
+                    else:
+                        torch.sum(pieces[:, item["value"]], dim=0, keepdim=True, out=slot(n_d + ci))
+            elif dist.world_size > 1:
                 dist.all_reduce_sum(self.comm)
             self.step += 1
             cfg._optimizer_step(states, self.step)

@@ -218,9 +218,9 @@ __global__ __launch_bounds__(BLOCK) void poisson_fused_kernel(PoissonArgs a) {
       for (int i = 0; i < VEC; ++i) {
         const float bi = (CAL && a.log_bkg_norm) ? b[r][i] * bkg_norm : b[r][i];
         n[i] += bi;  // background added last, un-convolved (npred.py:234-261)
-        const float ne = n[i] + a.eps;
-        local += (double)(n[i] - c[r][i] * logf(ne));
-        g[i] = (1.f - c[r][i] / ne) * a.inv_n;
+        float term;
+        poisson_point(n[i], c[r][i], a.eps, a.inv_n, term, g[i]);
+        local += (double)term;
         if (CAL) local_b += (double)(g[i] * bi);
       }
       if (a.npred_out) {
@@ -319,9 +319,9 @@ __global__ __launch_bounds__(BLOCK) void poisson_pooled_kernel(PoissonArgs a) {
     const float bi = a.log_bkg_norm ? a.background[off] * expf(a.log_bkg_norm[0]) : a.background[off];
     n += bi;
     const float c = a.counts[off];
-    const float ne = n + a.eps;
-    local = (double)(n - c * logf(ne));
-    const float g = (1.f - c / ne) * a.inv_n;
+    float term, g;
+    poisson_point(n, c, a.eps, a.inv_n, term, g);
+    local = (double)term;
     local_b = (double)(g * bi);
     if (a.npred_out) a.npred_out[off] = n;
     if (a.write_grad) {
@@ -419,9 +419,10 @@ __global__ __launch_bounds__(BLOCK) void poisson_nll_kernel(const float* __restr
   const size_t stride = (size_t)gridDim.x * BLOCK;
   for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
     const float v = npred[i], c = counts[i];
-    const float ve = v + eps;
-    local += (double)(v - c * logf(ve));
-    if (grad) grad[i] = (1.f - c / ve) * inv_n;
+    float term, g;
+    poisson_point(v, c, eps, inv_n, term, g);
+    local += (double)term;
+    if (grad) grad[i] = g;
   }
   const double total = block_sum<BLOCK>(local, smem);
   if (threadIdx.x == 0) partials[blockIdx.x] = total;

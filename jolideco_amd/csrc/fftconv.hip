@@ -43,8 +43,14 @@ struct jd_conv_plan {
   float* gbatch[jd::SEP_MAX_BATCH * jd::SEP_BATCH_MAX_COMP] = {nullptr};
   double* partials_batch = nullptr;
   int partials_batch_cap = 0;
-  jd::SepBatchTable table_host{};          // what table_dev holds (re-uploaded only when a pointer changes)
-  jd::SepBatchTable* table_dev = nullptr;
+  // pointer tables of the batched joint step in device memory: a few slots keyed by content, so that sessions (or the
+  // chunks of a fit with more than SEP_MAX_BATCH datasets) that alternate between tables never re-upload -- an upload
+  // has to wait for the stream
+  static constexpr int N_TABLES = 8;
+  jd::SepBatchTable table_host[N_TABLES] = {};
+  jd::SepBatchTable* table_dev[N_TABLES] = {};
+  unsigned long long table_used[N_TABLES] = {};  // last use (call counter), 0 = empty
+  unsigned long long table_clock = 0;
 };
 
 namespace jd {
@@ -249,7 +255,8 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
   if (p->partials) (void)hipFree(p->partials);
   if (p->partials_cal) (void)hipFree(p->partials_cal);
   if (p->partials_batch) (void)hipFree(p->partials_batch);
-  if (p->table_dev) (void)hipFree(p->table_dev);
+  for (auto* t : p->table_dev)
+    if (t) (void)hipFree(t);
   for (float* g : p->gbatch)
     if (g) (void)hipFree(g);
   for (int c = 0; c < JD_MAX_COMPONENTS; ++c) {
@@ -483,22 +490,30 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
   SepBatchTable table{};
   for (int d = 0; d < n_datasets; ++d) table.bkg[d] = background[d], table.cnt[d] = counts[d];
   for (int i = 0; i < n_datasets * n_comp; ++i) table.scale[i] = exposure[i], table.op[i] = khat[i], table.g[i] = p->gbatch[i];
-  if (!p->table_dev) JD_HIP(hipMalloc(&p->table_dev, sizeof(SepBatchTable)));
-  if (memcmp(&table, &p->table_host, sizeof(table)) != 0) {
-    // a session passes the same pointers every step, so this happens once: wait for launches that may still read the
-    // old table, then copy synchronously (the source is a stack variable)
-    JD_HIP(hipStreamSynchronize(s));
-    JD_HIP(hipMemcpy(p->table_dev, &table, sizeof(table), hipMemcpyHostToDevice));
-    p->table_host = table;
+  // a session passes the same pointers every step: look the table up by content, upload only a new one
+  int slot = -1, victim = 0;
+  for (int i = 0; i < jd_conv_plan::N_TABLES; ++i) {
+    if (p->table_used[i] && memcmp(&table, &p->table_host[i], sizeof(table)) == 0) slot = i;
+    if (p->table_used[i] < p->table_used[victim]) victim = i;
   }
+  if (slot < 0) {
+    // least recently used slot: wait for launches that may still read it, then copy synchronously (stack source)
+    slot = victim;
+    if (!p->table_dev[slot]) JD_HIP(hipMalloc(&p->table_dev[slot], sizeof(SepBatchTable)));
+    if (p->table_used[slot]) JD_HIP(hipStreamSynchronize(s));
+    JD_HIP(hipMemcpy(p->table_dev[slot], &table, sizeof(table), hipMemcpyHostToDevice));
+    p->table_host[slot] = table;
+  }
+  p->table_used[slot] = ++p->table_clock;
+  SepBatchTable* const table_dev = p->table_dev[slot];
   const double n_pix = (double)p->H * (double)p->W;
-  int rc = launch_sep_conv_poisson_batch(n_datasets, n_comp, flux, table, p->table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+  int rc = launch_sep_conv_poisson_batch(n_datasets, n_comp, flux, table, table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                                          p->partials_batch, eps, (float)(1.0 / n_pix), grad_flux ? 1 : 0, s);
   if (rc) return rc;
   if ((rc = launch_finalize_rows(p->partials_batch, tiles, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s))) return rc;
   if (!grad_flux) return JD_OK;
   for (int c = 0; c < n_comp; ++c)
-    if ((rc = launch_sep_conv_adjoint_batch(n_datasets, n_comp, c, table, p->table_dev, grad_flux[c], p->H, p->W, p->kh,
+    if ((rc = launch_sep_conv_adjoint_batch(n_datasets, n_comp, c, table, table_dev, grad_flux[c], p->H, p->W, p->kh,
                                             p->kw, p->oy, p->ox, grad_scale, accumulate, s)))
       return rc;
   return JD_OK;

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "jd_common.h"
@@ -911,7 +912,10 @@ struct GmmScreenArgs {
   const float* mnorm_k;  // K: 1.001 |m'_k| (0 for a zero-mean component)
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
   const int* korder;         // K: the order in which the components are visited (most popular first)
-  unsigned long long* best;  // per patch (global index): initialised here
+  const uint4* xfrag;        // staged patches (gmm_stage_kernel): fp16 B fragments [tile][pixel step][lane],
+  const float* xn;           //   1.0001 |xbar|, s_x^2 and validity per [tile * 32 + c]
+  const float* xs2;
+  const int* ok;
   float* lfinal;             // per patch: max_k (ltilde - B), a lower bound of the true maximum
   int32_t* rec_n;            // [waves][SCREEN_CAP] candidate records: patch (global index),
   int32_t* rec_k;            //                     component,
@@ -922,6 +926,88 @@ struct GmmScreenArgs {
   int* flag;
   int gen;
 };
+
+struct __attribute__((packed, aligned(4))) F4U {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
+  float x, y, z, w;
+};
+
+// Patch staging for the screen (one wave per tile of 32 patches, any number of waves per SIMD): mean-subtracted patches
+// as fp16 B fragments in global memory, their norms, scales and validity, and the initial (max, arg-max) keys.  Inside
+// the screen kernel -- one wave per SIMD, 512 registers -- this gather was a latency-bound prologue that nothing could
+// overlap: 30 us of a 230 us launch at 2048^2.  As a kernel of its own it runs at the memory system's pace; the
+// screen then starts with 16 coalesced 16-byte loads per lane.
+struct GmmStageArgs {
+  const float* flux;
+  int H, W, stride, nPx, shift_y, shift_x, n_begin, n_end, n_tiles;
+  uint4* xfrag;              // [tile][pixel step 4][lane 64] = 8 fp16 of xbar / s_x (B fragment of the 32x32x16 MFMA)
+  float* xn;                 // [tile * 32 + c] 1.0001 |xbar|
+  float* xs2;                // s_x^2
+  int* ok;                   // patch takes part (inside the shard, passes the -1e5 filter)
+  unsigned long long* best;  // per patch (global index): initialised here
+};
+
+__global__ __launch_bounds__(256) void gmm_stage_kernel(GmmStageArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= a.n_tiles) return;
+  const int h = lane >> 5, c = lane & 31;  // lane (h, c): image rows 2 s + h (pixel step s) of patch c
+  const int n = a.n_begin + 32 * tile + c;
+  const bool valid = n < a.n_end;
+  const int py = valid ? n / a.nPx : 0, px = valid ? n - (n / a.nPx) * a.nPx : 0;
+  const int x0 = px * a.stride - a.shift_x;  // in (-W, W)
+  const int xb = x0 < 0 ? x0 + a.W : x0;     // first column of the patch in the image, in [0, W)
+  const bool straight = xb + 7 < a.W;        // the 8 columns do not wrap around
+  float x[32];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float* row = a.flux + (size_t)wrap(py * a.stride + 2 * s + h - a.shift_y, a.H) * a.W;
+    if (straight) {  // two 16-byte loads at a 4-byte aligned address
+      const F4U v0 = *reinterpret_cast<const F4U*>(row + xb), v1 = *reinterpret_cast<const F4U*>(row + xb + 4);
+      x[8 * s + 0] = v0.x, x[8 * s + 1] = v0.y, x[8 * s + 2] = v0.z, x[8 * s + 3] = v0.w;
+      x[8 * s + 4] = v1.x, x[8 * s + 5] = v1.y, x[8 * s + 6] = v1.z, x[8 * s + 7] = v1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[8 * s + e] = row[wrap(x0 + e, a.W)];
+    }
+  }
+  bool sel = true;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    x[i] = valid ? x[i] : 0.f;
+    sum += x[i];
+    sel = sel && (x[i] > -1e5f);  // patches/core.py:215
+  }
+  const float mean = (sum + __shfl_xor(sum, 32, 64)) * (1.f / 64.f);
+  float n2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) x[i] -= mean, n2 = fmaf(x[i], x[i], n2);
+  n2 += __shfl_xor(n2, 32, 64);
+  const int sel_other = __shfl_xor((int)sel, 32, 64);  // unconditional: see gmm_fwd_kernel
+  sel = sel && sel_other != 0;
+  const bool ok = valid && sel;
+  // fp16 operand: xbar / s_x with the power of two s_x that puts max |xbar| into [2^13, 2^14) -- the scaling is
+  // exact, nothing overflows (fp16 max 65504), and whatever underflows is below 2^-27 of the largest pixel
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(x[i]));
+  amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+  int ex = 14;
+  if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)ldexpf(x[8 * s + e], 14 - ex);
+    a.xfrag[((size_t)tile * 4 + s) * 64 + lane] = __builtin_bit_cast(uint4, v);
+  }
+  if (h == 0) {
+    a.xn[tile * 32 + c] = __builtin_sqrtf(n2) * 1.0001f;
+    a.xs2[tile * 32 + c] = ldexpf(1.f, 2 * (ex - 14));
+    a.ok[tile * 32 + c] = ok ? 1 : 0;
+    if (valid) a.best[n] = ok ? best_key(-INFINITY, 0) : 0ull;
+  }
+}
 
 struct ScreenFrags {
   f16x8 a[A16_BLOCKS];
@@ -993,7 +1079,7 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
 __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], const f32x16 (&accB)[2], float ck, float ack,
                                                    float mnorm, float efro, float xn, float s2, bool ok, float& L,
                                                    float& qacc, int n, int k, int lane, int& cnt, int32_t* rec_n,
-                                                   int32_t* rec_k, float* rec_ub) {
+                                                   int32_t* rec_k, float* rec_ub, int cap) {
   const float qa = screen_q_half(accA), qb = screen_q_half(accB);
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
   // lanes 0-31: tile A, lanes 32-63: tile B; s2 = (s_x s_k)^2 undoes the power-of-two operand scales (exactly)
@@ -1005,11 +1091,13 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   const float B = fmaf(__builtin_amdgcn_sqrtf(q), e1, fmaf(2e-5f, q, c2));
   const float ub = l + B;
   const bool cand = ok && ub >= L;
-  L = fmaxf(L, l - B);
+  // L = max(L, l - B) as ONE v_max_f32 (fmaxf adds a canonicalising v_max in front; a NaN operand loses either way
+  // and is caught through qacc)
+  asm("v_max_f32 %0, %1, %2" : "=v"(L) : "v"(L), "v"(l - B));
   const unsigned long long mask = __ballot(cand);
   if (mask) {
     const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-    if (cand && pos < SCREEN_CAP) {  // (the wave's segment: uniform base pointers, one 32-bit offset)
+    if (cand && pos < cap) {  // (the wave's record buffer: uniform base pointers, one 32-bit offset)
       rec_n[pos] = n;
       rec_k[pos] = k;
       rec_ub[pos] = ub;
@@ -1026,6 +1114,7 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
 //                   still occupies every CU for a short time instead of a few CUs for the full sweep.  Every wave
 //                   keeps its own running bound L_w (a valid lower bound of the maximum), the final bound is their
 //                   maximum.
+constexpr int SCREEN_RB = 512;      // records a wave buffers in LDS before it writes them out (>= 2 x 64)
 constexpr int SCREEN_KC_MAX = 512;  // components whose per-component constants are staged in LDS in visiting order
 
 // KC_LDS: (k, c_k, eps |P'_k|_F, s_k^2, |m'_k|) of the component at every position of the visiting order are staged in
@@ -1036,9 +1125,13 @@ constexpr int SCREEN_KC_MAX = 512;  // components whose per-component constants 
 template <int NP, bool KSPLIT, bool KC_LDS>
 __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   constexpr int NT = 2 * NP;
-  __shared__ uint4 xs[KSPLIT ? 1 : 4][NT * 4 * 64];  // [tile][pixel step][lane] = 8 fp16 (B fragment); per wave | shared
-  __shared__ float st_xn[KSPLIT ? NT * 32 : 1], st_s2[KSPLIT ? NT * 32 : 1], st_L[KSPLIT ? 4 * NT * 32 : 1];
-  __shared__ int st_ok[KSPLIT ? NT * 32 : 1];
+  __shared__ float st_L[KSPLIT ? 4 * NT * 32 : 1];
+  // Candidate records are collected in a wave-private LDS buffer and written to the wave's segment in global memory
+  // in bulk: a global store inside the sweep is counted by vmcnt like a load, and the compiler -- which cannot know
+  // whether the conditional stores were issued -- makes every later wait for the fragment prefetch drain them as well
+  // (the waves were parked on s_waitcnt for a fifth of their cycles).
+  __shared__ int32_t rb_n[4][SCREEN_RB], rb_k[4][SCREEN_RB];
+  __shared__ float rb_ub[4][SCREEN_RB];
   __shared__ int kc_k[KC_LDS ? SCREEN_KC_MAX : 1];
   __shared__ float4 kc_f[KC_LDS ? SCREEN_KC_MAX : 1];
   if (KC_LDS) {
@@ -1050,77 +1143,39 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = blockIdx.x * 4 + wave;
-  const int base = a.n_begin + (KSPLIT ? (int)blockIdx.x : wave_global) * (NT * 32);
+  const int tile0 = (KSPLIT ? (int)blockIdx.x : wave_global) * NT;  // first of this wave's (block's) NT tiles
+  const int base = a.n_begin + tile0 * 32;
   const int h = lane >> 5, c = lane & 31;  // lane (h, c): image rows 2 s + h (pixel step s) of patch c
   float xn[NT], xs2[NT];
   bool ok[NT];
   int nidx[NT];
+  f16x8 xf[NT][4];  // the B fragments of the wave's tiles stay in registers for the whole sweep
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (KSPLIT && (t & 3) != wave) continue;  // the block's tiles are staged by one wave each
-    const int n = base + 32 * t + c;
-    const bool valid = n < a.n_end;
-    const int py = valid ? n / a.nPx : 0, px = valid ? n % a.nPx : 0;
-    float x[32];
-    bool sel = true;
-    float sum = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int yy = wrap(py * a.stride + 2 * s + h - a.shift_y, a.H);
-      const float* row = a.flux + (size_t)yy * a.W;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int xx = wrap(px * a.stride + e - a.shift_x, a.W);
-        const float v = valid ? row[xx] : 0.f;
-        x[8 * s + e] = v;
-        sum += v;
-        sel = sel && (v > -1e5f);  // patches/core.py:215
-      }
-    }
-    const float mean = (sum + __shfl_xor(sum, 32, 64)) * (1.f / 64.f);
-    float n2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) x[i] -= mean, n2 = fmaf(x[i], x[i], n2);
-    n2 += __shfl_xor(n2, 32, 64);
-    const int sel_other = __shfl_xor((int)sel, 32, 64);  // unconditional: see gmm_fwd_kernel
-    sel = sel && sel_other != 0;
-    xn[t] = __builtin_sqrtf(n2) * 1.0001f;
-    ok[t] = valid && sel;
-    nidx[t] = n;
-    // fp16 operand: xbar / s_x with the power of two s_x that puts max |xbar| into [2^13, 2^14) -- the scaling is
-    // exact, nothing overflows (fp16 max 65504), and whatever underflows is below 2^-27 of the largest pixel
-    float amax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) amax = fmaxf(amax, fabsf(x[i]));
-    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
-    int ex = 14;
-    if (amax > 0.f && amax < 3.0e38f) (void)frexpf(amax, &ex);
-    xs2[t] = ldexpf(1.f, 2 * (ex - 14));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      f16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (_Float16)ldexpf(x[8 * s + e], 14 - ex);
-      xs[KSPLIT ? 0 : wave][(t * 4 + s) * 64 + lane] = __builtin_bit_cast(uint4, v);
-    }
-    if (h == 0 && valid) a.best[n] = ok[t] ? best_key(-INFINITY, 0) : 0ull;
-    if (KSPLIT && h == 0) st_xn[t * 32 + c] = xn[t], st_s2[t * 32 + c] = xs2[t], st_ok[t * 32 + c] = ok[t] ? 1 : 0;
+    for (int s = 0; s < 4; ++s) xf[t][s] = __builtin_bit_cast(f16x8, a.xfrag[((size_t)(tile0 + t) * 4 + s) * 64 + lane]);
+    xn[t] = a.xn[(tile0 + t) * 32 + c], xs2[t] = a.xs2[(tile0 + t) * 32 + c], ok[t] = a.ok[(tile0 + t) * 32 + c] != 0;
+    nidx[t] = base + 32 * t + c;
   }
-  if (KC_LDS && !KSPLIT) __syncthreads();  // the constants table (KSPLIT: the barrier below)
-  if (KSPLIT) {
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      xn[t] = st_xn[t * 32 + c], xs2[t] = st_s2[t * 32 + c], ok[t] = st_ok[t * 32 + c] != 0, nidx[t] = base + 32 * t + c;
-  }
-  // (KSPLIT = false: wave-private LDS, written and read by the same wave, program order suffices)
+  if (KC_LDS) __syncthreads();  // the constants table
   const uint4* af = a.afrag16 + lane;
-  const uint4* xs_lane = &xs[KSPLIT ? 0 : wave][lane];
   const int seg = __builtin_amdgcn_readfirstlane(wave_global * SCREEN_CAP);
   int32_t* seg_n = a.rec_n + seg;
   int32_t* seg_k = a.rec_k + seg;
   float* seg_ub = a.rec_ub + seg;
-  int cnt = 0;
+  int cnt = 0;    // records already written to the wave's global segment (may exceed SCREEN_CAP: overflow -> fallback)
+  int cnt_l = 0;  // records in the LDS buffer
+  int32_t* const lb_n = rb_n[wave];
+  int32_t* const lb_k = rb_k[wave];
+  float* const lb_ub = rb_ub[wave];
+  // room for one more emission of up to 64 records?  otherwise write the buffer out (wave-uniform, rare)
+  auto flush = [&](bool force) {
+    if (!force && cnt_l <= SCREEN_RB - 64) return;
+    for (int i = lane; i < cnt_l; i += 64)
+      if (cnt + i < SCREEN_CAP) seg_n[cnt + i] = lb_n[i], seg_k[cnt + i] = lb_k[i], seg_ub[cnt + i] = lb_ub[i];
+    cnt += cnt_l;
+    cnt_l = 0;
+  };
   // per-lane state of the two tile pairs: lane half 0 carries the patch of tile 2 p, half 1 that of tile 2 p + 1
   float pxn[NP], pL[NP], pq[NP], ps2[NP];
   bool pok[NP];
@@ -1136,14 +1191,11 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   }
 
   ScreenFrags f0, f1;
-  f16x8 x[4];
   f32x16 acc[2][2][2];  // [buffer][tile of the pair][coordinate block]: one pair on the matrix pipe, one in the epilogue
   auto issue_pair = [&](f32x16 (&buf)[2][2], const ScreenFrags& f, int p) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) x[s] = __builtin_bit_cast(f16x8, xs_lane[((2 * p + u) * 4 + s) * 64]);
-      mfma_screen(buf[u], f, x);
+      mfma_screen(buf[u], f, xf[2 * p + u]);
     }
   };
   constexpr int KSTEP = KSPLIT ? 4 : 1;
@@ -1166,43 +1218,48 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     return r;
   };
   auto clamp_pos = [&](int pos) { return pos < a.K ? pos : (kk0 < a.K ? kk0 : 0); };
+  auto fetch_k = [&](int pos) { return KC_LDS ? kc_k[pos] : a.korder[pos]; };
   KConst cur = fetch_consts(clamp_pos(kk0));
   KConst nxt = fetch_consts(clamp_pos(kk0 + KSTEP));  // always one component ahead of `cur` ...
   load_frags16(f0, af, __builtin_amdgcn_readfirstlane(cur.k));
+  load_frags16(f1, af, __builtin_amdgcn_readfirstlane(nxt.k));
   if (kk0 < a.K) issue_pair(acc[0], f0, 0);  // prologue: pair 0 of the first component
-  int it = 0;
-  for (int kk = kk0; kk < a.K; kk += KSTEP, ++it) {
+  // One component: `fa` holds its fragments, `fb` those of the next one (requested during the PREVIOUS component).  As
+  // soon as the last MFMA that reads `fa` has been issued, the fragments of the component after next are requested into
+  // it: 1.75 components (~3000 cycles) ahead of their first use -- with the request at the top of the component that
+  // precedes the use the waves were parked on its vmcnt for a fifth of their cycles (SQ_WAIT_ANY).  The loop alternates
+  // the two buffers, so no fragment is ever copied; PHASE = parity of the component within this wave's sweep.
+  auto component = [&](ScreenFrags& fa, const ScreenFrags& fb, int kk, auto phase) {
+    constexpr int PHASE = decltype(phase)::value;
     const int k = __builtin_amdgcn_readfirstlane(cur.k);
     const float ck = cur.ck, ef = cur.ef, sk2 = cur.sk2, mn = cur.mn;
     const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f);
-    // unconditional (clamped) prefetch of the next component's fragments: its index has been in a register since the
-    // previous component
-    load_frags16(f1, af, __builtin_amdgcn_readfirstlane(nxt.k));
+    const int k_ahead = fetch_k(clamp_pos(kk + 2 * KSTEP));  // the component after next
     cur = nxt;
     nxt = fetch_consts(clamp_pos(kk + 2 * KSTEP));  // ... and fetched two ahead of its use
     if (NP == 2) {
       // pair 1 of k on the matrix pipe while pair 0 of k finishes in its shadow, then pair 0 of k + 1 | pair 1 of k
-      issue_pair(acc[1], f0, 1);
+      issue_pair(acc[1], fa, 1);
+      load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // unconditional (clamped) prefetch
       screen_finish_pair(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
-                         cnt, seg_n, seg_k, seg_ub);
-      issue_pair(acc[0], f1, 0);
+                         cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
+      flush(false);
+      issue_pair(acc[0], fb, 0);
       screen_finish_pair(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[NP - 1], ps2[NP - 1] * sk2, pok[NP - 1], pL[NP - 1],
-                         pq[NP - 1], pn[NP - 1], k, lane, cnt, seg_n, seg_k, seg_ub);
+                         pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
+      flush(false);
     } else {
-      // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the buffers alternate
-      const int buf = it & 1;
-      if (buf == 0) {
-        issue_pair(acc[1], f1, 0);
-        screen_finish_pair(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
-                           cnt, seg_n, seg_k, seg_ub);
-      } else {
-        issue_pair(acc[0], f1, 0);
-        screen_finish_pair(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
-                           cnt, seg_n, seg_k, seg_ub);
-      }
+      // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the accumulator buffers alternate
+      load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // (fa's MFMAs were issued by the previous component)
+      issue_pair(acc[1 - PHASE], fb, 0);
+      screen_finish_pair(acc[PHASE][0], acc[PHASE][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k,
+                         lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
+      flush(false);
     }
-#pragma unroll
-    for (int b = 0; b < A16_BLOCKS; ++b) f0.a[b] = f1.a[b];
+  };
+  for (int kk = kk0; kk < a.K; kk += 2 * KSTEP) {
+    component(f0, f1, kk, std::integral_constant<int, 0>{});
+    if (kk + KSTEP < a.K) component(f1, f0, kk + KSTEP, std::integral_constant<int, 1>{});
   }
   bool trouble = false;
 #pragma unroll
@@ -1219,6 +1276,7 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
       if (base + i < a.n_end)
         a.lfinal[base + i] = fmaxf(fmaxf(st_L[i], st_L[NT * 32 + i]), fmaxf(st_L[2 * NT * 32 + i], st_L[3 * NT * 32 + i]));
   }
+  flush(true);
   if (lane == 0) a.seg_cnt[wave_global] = cnt < SCREEN_CAP ? cnt : SCREEN_CAP;
   if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
     if (lane == 0) __hip_atomic_store(a.flag, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1245,9 +1303,6 @@ struct GmmExactArgs {
   float* grec;
 };
 
-struct __attribute__((packed, aligned(4))) F4U {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
-  float x, y, z, w;
-};
 
 constexpr int EXACT_PITCH = 68;  // floats per staged patch (64 + pad: 16-byte aligned rows, 2-way bank spread)
 
@@ -1420,6 +1475,10 @@ struct GmmGatherArgs {
   const float* grec;
   const int* flag;
   int gen;
+  // band output (band != nullptr): instead of accumulating into `grad` at the un-rolled position, the rows
+  // [y_begin, y_end) of the ROLLED frame are written (assigned; 0 where no patch of the shard covers a pixel) to
+  // band[(Y - y_begin) * W + X] -- the compact piece a rank of a sharded prior exchanges (jd_add_rolled_bands)
+  float* band;
 };
 
 __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
@@ -1453,9 +1512,126 @@ __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
       any = true;
     }
   }
+  if (a.band) {
+    a.band[(size_t)(Y - a.y_begin) * a.W + X] = any ? a.coef * sum : 0.f;
+    return;
+  }
   if (!any) return;
   const int yy = wrap(Y - a.shift_y, a.H), xx = wrap(X - a.shift_x, a.W);
   a.grad[(size_t)yy * a.W + xx] += a.coef * sum;
+}
+
+// The same overlap-add, one 32 x 32 pixel tile of the rolled frame per block (stride >= 4: at most 10 x 10 patches touch a
+// tile): the gradient rows of those patches are fetched ONCE, as whole 256-byte rows, into LDS and every pixel sums its
+// contributions from there in the order of gmm_gather_kernel (patch rows ascending, then patch columns: the same bits).
+// The per-pixel kernel reads 4 bytes from each of up to four different rows per thread -- 4x the memory instructions,
+// none of them a full line; at 4096^2, where the rows no longer sit in the Infinity Cache, it took 5x the 2048^2 time.
+constexpr int GATHER_T = 32, GATHER_MAX_P = 10;
+
+__global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
+  __shared__ __attribute__((aligned(16))) float rows[GATHER_MAX_P * GATHER_MAX_P][D];
+  const int tid = threadIdx.x;
+  const int X0 = blockIdx.x * GATHER_T, Y0 = a.y_begin + blockIdx.y * GATHER_T;
+  auto ceil_div_pos = [](int v, int s) { return v <= 0 ? 0 : (v + s - 1) / s; };
+  int py0 = ceil_div_pos(Y0 - (P - 1), a.stride), py1 = (Y0 + GATHER_T - 1) / a.stride;
+  int px0 = ceil_div_pos(X0 - (P - 1), a.stride), px1 = (X0 + GATHER_T - 1) / a.stride;
+  if (py0 < a.row_begin) py0 = a.row_begin;
+  if (py1 > a.row_end - 1) py1 = a.row_end - 1;
+  if (px1 > a.nPx - 1) px1 = a.nPx - 1;
+  const int npx = px1 - px0 + 1, npy = py1 - py0 + 1;
+  if (npx <= 0 || npy <= 0) {  // no patch of the shard touches this tile
+    if (a.band) {
+      const int Y = Y0 + (tid >> 3);
+      for (int i = 0; i < 4; ++i) {
+        const int X = X0 + (tid & 7) * 4 + i;
+        if (Y < a.y_end && X < a.W) a.band[(size_t)(Y - a.y_begin) * a.W + X] = 0.f;
+      }
+    }
+    return;
+  }
+  const bool slots = a.winner && *a.flag != a.gen;
+  for (int p = tid >> 4; p < npy * npx; p += 16) {
+    const int py = py0 + p / npx, px = px0 + p % npx;
+    const float* src;
+    if (slots) {
+      const int slot = a.winner[(size_t)py * a.nPx + px];
+      src = slot >= 0 ? a.grec + (size_t)slot * D : nullptr;
+    } else {
+      src = a.gpatch + ((size_t)(py - a.row_begin) * a.nPx + px) * D;
+    }
+    const float4 v = src ? reinterpret_cast<const float4*>(src)[tid & 15] : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&rows[p][(tid & 15) * 4]) = v;
+  }
+  __syncthreads();
+  const int Y = Y0 + (tid >> 3);
+  if (Y >= a.y_end) return;
+  int py_hi = Y / a.stride, py_lo = ceil_div_pos(Y - (P - 1), a.stride);
+  if (py_lo < py0) py_lo = py0;
+  if (py_hi > py1) py_hi = py1;
+  const int yy = wrap(Y - a.shift_y, a.H);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int X = X0 + (tid & 7) * 4 + i;
+    if (X >= a.W) break;
+    int px_hi = X / a.stride, px_lo = ceil_div_pos(X - (P - 1), a.stride);
+    if (px_lo < px0) px_lo = px0;
+    if (px_hi > px1) px_hi = px1;
+    float sum = 0.f;
+    bool any = false;
+    for (int py = py_lo; py <= py_hi; ++py) {
+      const int r = Y - py * a.stride;
+      for (int px = px_lo; px <= px_hi; ++px) {
+        sum += rows[(py - py0) * npx + (px - px0)][r * P + (X - px * a.stride)];  // (a zero row where a patch has no gradient)
+        any = true;
+      }
+    }
+    if (a.band)
+      a.band[(size_t)(Y - a.y_begin) * a.W + X] = any ? a.coef * sum : 0.f;
+    else if (any)
+      a.grad[(size_t)yy * a.W + wrap(X - a.shift_x, a.W)] += a.coef * sum;
+  }
+}
+
+// grad[un-rolled (Y, X)] += sum over the bands that hold row Y, in band order: the pieces of a sharded prior gradient
+// (band b = rows [y_begin[b], y_end[b]) of the rolled frame, at bands + b * chunk) put back into the gradient image.
+// Every rank adds the same numbers in the same order: replicas stay bit-identical.
+constexpr int BANDS_MAX = 64;
+struct AddBandsArgs {
+  float* grad;
+  const float* bands;
+  size_t chunk;
+  int H, W, shift_y, shift_x, n_bands, y_lo, y_hi;
+  int y_begin[BANDS_MAX], y_end[BANDS_MAX];
+};
+
+__global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
+  const int Y = a.y_lo + blockIdx.y;
+  const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (X >= a.W || Y >= a.y_hi) return;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool any = false;
+  const bool vec = (a.W & 3) == 0 && (a.chunk & 3) == 0;
+  for (int b = 0; b < a.n_bands; ++b) {  // (constant indices would need an unrolled loop: n_bands is small)
+    const int yb = a.y_begin[b], ye = a.y_end[b];
+    if (Y < yb || Y >= ye) continue;
+    const float* row = a.bands + (size_t)b * a.chunk + (size_t)(Y - yb) * a.W + X;
+    if (vec) {
+      const float4 v = *reinterpret_cast<const float4*>(row);
+      sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
+    } else {
+      sum.x += row[0];
+      if (X + 1 < a.W) sum.y += row[1];
+      if (X + 2 < a.W) sum.z += row[2];
+      if (X + 3 < a.W) sum.w += row[3];
+    }
+    any = true;
+  }
+  if (!any) return;
+  float* out = a.grad + (size_t)wrap(Y - a.shift_y, a.H) * a.W;
+  const float v[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (X + i < a.W) out[wrap(X + i - a.shift_x, a.W)] += v[i];
 }
 
 }  // namespace jd
@@ -1491,6 +1667,12 @@ struct jd_gmm {
   size_t best_cap = 0;
   float* lfinal = nullptr;
   size_t lfinal_cap = 0;
+  uint4* xfrag = nullptr;     // staged patches of the screen: fp16 fragments, norms | scales (floats), validity
+  size_t xfrag_cap = 0;
+  float* xstat = nullptr;
+  size_t xstat_cap = 0;
+  int* xok = nullptr;
+  size_t xok_cap = 0;
   int32_t* rec = nullptr;  // candidate records: patch | component | upper bound (as float), `slots` each
   size_t rec_cap = 0;
   int32_t* rec_order = nullptr;
@@ -1682,6 +1864,9 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->mnorm_k) (void)hipFree(g->mnorm_k);
   if (g->best) (void)hipFree(g->best);
   if (g->lfinal) (void)hipFree(g->lfinal);
+  if (g->xfrag) (void)hipFree(g->xfrag);
+  if (g->xstat) (void)hipFree(g->xstat);
+  if (g->xok) (void)hipFree(g->xok);
   if (g->rec) (void)hipFree(g->rec);
   if (g->rec_order) (void)hipFree(g->rec_order);
   if (g->seg_cnt) (void)hipFree(g->seg_cnt);
@@ -1790,15 +1975,26 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     if ((rc = grow(&g->winner, &g->winner_cap, (size_t)a.n_end))) return rc;
   }
 
+  const size_t n_tiles = (size_t)blocks * (ksplit ? SCREEN_T : 4 * SCREEN_T);  // tiles the screen's waves touch
+  if ((rc = grow(&g->xfrag, &g->xfrag_cap, n_tiles * 4 * 64))) return rc;
+  if ((rc = grow(&g->xstat, &g->xstat_cap, 2 * n_tiles * 32))) return rc;
+  if ((rc = grow(&g->xok, &g->xok_cap, n_tiles * 32))) return rc;
+
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
+  GmmStageArgs stg{};
+  stg.flux = a.flux, stg.H = a.H, stg.W = a.W, stg.stride = a.stride, stg.nPx = a.nPx, stg.shift_y = a.shift_y, stg.shift_x = a.shift_x;
+  stg.n_begin = a.n_begin, stg.n_end = a.n_end, stg.n_tiles = (int)n_tiles;
+  stg.xfrag = g->xfrag, stg.xn = g->xstat, stg.xs2 = g->xstat + n_tiles * 32, stg.ok = g->xok, stg.best = g->best;
   GmmScreenArgs sc{};
+  sc.xfrag = g->xfrag, sc.xn = stg.xn, sc.xs2 = stg.xs2, sc.ok = g->xok;
   sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k, sc.sk2_k = g->sk2_k, sc.mnorm_k = g->mnorm_k, sc.korder = g->korder;
   sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
-  sc.best = g->best, sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
+  sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
   sc.seg_cnt = g->seg_cnt, sc.flag = flag, sc.gen = g->gen;
   {
     ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
+    gmm_stage_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, s>>>(stg);
     const bool kc_lds = g->K <= SCREEN_KC_MAX && !getenv("JD_GMM_SCREEN_NO_LDS_CONSTS");  // (testing: the global-load path)
     if (ksplit && kc_lds)
       gmm_screen_kernel<2, true, true><<<blocks, 256, 0, s>>>(sc);
@@ -1886,10 +2082,10 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   return JD_OK;
 }
 
-extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
-                                    int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
-                                    float value_scale, float* value_out, int accumulate_value, float grad_coef,
-                                    float* grad_flux_accum, int32_t* argmax_out, void* stream) {
+static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
+                          int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
+                          float value_scale, float* value_out, int accumulate_value, float grad_coef,
+                          float* grad_flux_accum, int32_t* argmax_out, float* band_out, void* stream) {
   JD_REQUIRE(g && flux && value_out, "jd_gmm_prior_fwd_bwd: null argument");
   JD_REQUIRE(H >= P && W >= P, "jd_gmm_prior_fwd_bwd: image (%d, %d) smaller than a patch", H, W);
   JD_REQUIRE(stride >= 1 && stride <= P, "jd_gmm_prior_fwd_bwd: stride = %d not in [1, 8]", stride);
@@ -1902,10 +2098,11 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   shift_y = ((shift_y % H) + H) % H;  // roll by any integer = roll by its residue (the kernels' wrap() relies on it)
   shift_x = ((shift_x % W) + W) % W;
   const int n_begin = patch_row_begin * nPx, n_end = patch_row_end * nPx;
-  if (n_begin == n_end) {  // empty shard: contributes nothing
+  if (n_begin == n_end) {  // empty shard: contributes nothing (an empty band has no rows)
     if (!accumulate_value) JD_HIP(hipMemsetAsync(value_out, 0, sizeof(float), s));
     return JD_OK;
   }
+  if (band_out) grad_flux_accum = band_out;  // "a gradient is wanted"; the gather writes the band instead
   const long n = n_end - n_begin;
   int rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
@@ -2015,12 +2212,57 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
   ga.y_begin = patch_row_begin * stride;
   ga.y_end = (patch_row_end - 1) * stride + P;
   ga.coef = grad_coef;
+  ga.band = band_out;
   if (fused) ga.winner = g->winner, ga.grec = g->grec, ga.flag = g->screen_ctl, ga.gen = g->gen;
-  dim3 grid((W + 255) / 256, ga.y_end - ga.y_begin);
   {
     ProfScope prof(JD_KERNEL_GMM_GATHER, s);
-    gmm_gather_kernel<<<grid, 256, 0, s>>>(ga);
+    const char* tiled_var = getenv("JD_GMM_GATHER_TILED");  // "0": the per-pixel kernel (testing)
+    if (stride >= 4 && !(tiled_var && atoi(tiled_var) == 0)) {
+      dim3 grid((W + GATHER_T - 1) / GATHER_T, (ga.y_end - ga.y_begin + GATHER_T - 1) / GATHER_T);
+      gmm_gather_tile_kernel<<<grid, 256, 0, s>>>(ga);
+    } else {
+      dim3 grid((W + 255) / 256, ga.y_end - ga.y_begin);
+      gmm_gather_kernel<<<grid, 256, 0, s>>>(ga);
+    }
   }
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
+                                    int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
+                                    float value_scale, float* value_out, int accumulate_value, float grad_coef,
+                                    float* grad_flux_accum, int32_t* argmax_out, void* stream) {
+  return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, patch_row_begin, patch_row_end, marginalize, value_scale,
+                        value_out, accumulate_value, grad_coef, grad_flux_accum, argmax_out, nullptr, stream);
+}
+
+extern "C" int jd_gmm_prior_band_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
+                                         int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
+                                         float value_scale, float* value_out, int accumulate_value, float grad_coef,
+                                         float* band_out, void* stream) {
+  JD_REQUIRE(band_out, "jd_gmm_prior_band_fwd_bwd: null band");
+  return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, patch_row_begin, patch_row_end, marginalize, value_scale,
+                        value_out, accumulate_value, grad_coef, nullptr, nullptr, band_out, stream);
+}
+
+extern "C" int jd_add_rolled_bands(float* grad, int H, int W, int shift_y, int shift_x, const float* bands,
+                                   size_t chunk_floats, int n_bands, const int* y_begin, const int* y_end, void* stream) {
+  JD_REQUIRE(grad && bands && y_begin && y_end, "jd_add_rolled_bands: null argument");
+  JD_REQUIRE(n_bands >= 1 && n_bands <= BANDS_MAX, "jd_add_rolled_bands: %d bands not in [1, %d]", n_bands, BANDS_MAX);
+  AddBandsArgs a{};
+  a.grad = grad, a.bands = bands, a.chunk = chunk_floats, a.H = H, a.W = W, a.n_bands = n_bands;
+  a.shift_y = ((shift_y % H) + H) % H, a.shift_x = ((shift_x % W) + W) % W;
+  a.y_lo = H, a.y_hi = 0;
+  for (int b = 0; b < n_bands; ++b) {
+    JD_REQUIRE(y_begin[b] >= 0 && y_begin[b] <= y_end[b] && y_end[b] <= H && (size_t)(y_end[b] - y_begin[b]) * W <= chunk_floats,
+               "jd_add_rolled_bands: band %d rows [%d, %d) do not fit", b, y_begin[b], y_end[b]);
+    a.y_begin[b] = y_begin[b], a.y_end[b] = y_end[b];
+    if (y_begin[b] < y_end[b]) a.y_lo = std::min(a.y_lo, y_begin[b]), a.y_hi = std::max(a.y_hi, y_end[b]);
+  }
+  if (a.y_lo >= a.y_hi) return JD_OK;
+  dim3 grid((W + 1023) / 1024, a.y_hi - a.y_lo);
+  add_rolled_bands_kernel<<<grid, 256, 0, as_stream(stream)>>>(a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

@@ -74,6 +74,20 @@ __device__ inline double block_sum(double v, double* smem /* BLOCK/64 doubles */
   return total;
 }
 
+// One pixel of nn.PoissonNLLLoss(log_input=False, eps, full=True) without its Stirling term (jolideco/loss.py:35-37):
+//   term = n - c log(n + eps),   g = d term / d n / N = (1 - c / (n + eps)) / N
+// with the hardware reciprocal plus one Newton step (<= 1 ulp) and v_log_f32 (log2, ~1 ulp) in place of the IEEE
+// division and the accurate logf: ~10 instead of ~25 VALU instructions per pixel in kernels that are issue bound.
+// EVERY Poisson pass of the library goes through this function, so all paths (fused into the separable
+// convolution, stand-alone, pooled, calibrated) produce the same bits for the same n, c.
+__device__ __forceinline__ void poisson_point(float n, float c, float eps, float inv_n, float& term, float& g) {
+  const float ne = n + eps;
+  float r = __builtin_amdgcn_rcpf(ne);
+  r = fmaf(fmaf(-ne, r, 1.f), r, r);
+  term = fmaf(-c, __builtin_amdgcn_logf(ne) * 0.69314718055994531f, n);
+  g = fmaf(-c, r, 1.f) * inv_n;
+}
+
 // out = (accumulate ? out : 0) + scale * sum(partials[0..n)) + offset, summed in index order in fp64.
 int launch_finalize_sum(const double* partials, int n, double scale, double offset, float* out,
                         int accumulate, hipStream_t stream);

@@ -18,6 +18,7 @@
 // two image rows, the column pass on two neighbouring columns), so one LDS read feeds ~5 FMAs; the taps stay
 // runtime values (no template per PSF size).
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "jd_common.h"
@@ -78,6 +79,7 @@ struct SepArgs {
   // batches: flux components per dataset (POISSON: summed after the per-component clip, npred.py:191,254-261) and the
   // component whose gradient an adjoint launch produces
   int n_comp, comp;
+  int interleave;  // POISSON batches: the datasets of a tile are neighbours in the launch order (else dataset-major)
   // POISSON batches: the flux images of the components.  Kernel arguments, not table entries: a fit alternates between
   // two flux buffers, and a table that changes every step would be re-uploaded (synchronously) every step.  Read with
   // constant indices only (see above).
@@ -113,13 +115,17 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
   const int nrows = 2 * a.rpairs;
 
   // consecutive tiles on one XCD (blockIdx % 8) are neighbours in the image: their halos hit in that XCD's L2.
-  // POISSON batch: the datasets of ONE tile are neighbours in the launch order of an XCD as well -- they all convolve
-  // the same flux window, which then comes from that XCD's L2 for all but the first of them (with grid.y = dataset
-  // every dataset streamed the whole flux image from HBM again: 17 % of the launch's traffic at 8 observations)
+  // POISSON batch: dataset-major order, or (a.interleave, tuning) the datasets of one tile as neighbours
   const int per_xcd = (a.n_tiles + 7) / 8;
   const int in_xcd = blockIdx.x / 8;
-  const int dsel = POISSON && a.n_batch > 0 ? in_xcd % a.n_batch : 0;  // dataset of a POISSON batch block
-  const int tile = (blockIdx.x % 8) * per_xcd + (POISSON && a.n_batch > 0 ? in_xcd / a.n_batch : in_xcd);
+  int dsel = 0, t_in_xcd = in_xcd;  // dataset of a POISSON batch block, tile within the XCD's share
+  if (POISSON && a.n_batch > 0) {
+    if (a.interleave)
+      dsel = in_xcd % a.n_batch, t_in_xcd = in_xcd / a.n_batch;
+    else
+      dsel = in_xcd / per_xcd, t_in_xcd = in_xcd % per_xcd;  // (tuning: dataset-major order)
+  }
+  const int tile = (blockIdx.x % 8) * per_xcd + t_in_xcd;
   if (tile >= a.n_tiles) return;
   const int Y0 = (tile / a.tiles_x) * TY, X0 = (tile % a.tiles_x) * TX;
   const int gy0 = Y0 + a.oy0, gx0 = X0 + a.ox0;
@@ -316,6 +322,9 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
       __shared__ double red[THREADS / 64];
       double local = 0.0;
       v2f n4[4], g4[4];
+      // the thread's eight loss terms are summed in fp32 before they join the fp64 block sum (poisson_point: the
+      // arithmetic every Poisson pass of the library shares)
+      float local_f = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int gy = Y0 + cy + c;
@@ -324,14 +333,15 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
         const bool two = gx + 1 < a.W;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const float b = opa[c][e], cnt = opb[c][e];
-          const float n = nsum[c][e] + b;  // the un-convolved background comes last (npred.py:191,254-261)
-          const float ne = n + a.eps;
-          if (e == 0 || two) local += (double)(n - cnt * logf(ne));
+          const float n = nsum[c][e] + opa[c][e];  // the un-convolved background comes last (npred.py:191,254-261)
+          float term, g;
+          poisson_point(n, opb[c][e], a.eps, a.inv_n, term, g);
+          if (e == 0 || two) local_f += term;
           n4[c][e] = n;
-          g4[c][e] = (1.f - cnt / ne) * a.inv_n;
+          g4[c][e] = g;
         }
       }
+      local = (double)local_f;
       for (int k = 0; k < n_comp; ++k) {
         float* g_out = a.n_batch > 0 ? a.table->g[d * n_comp + k] : a.out;
 #pragma unroll
@@ -548,6 +558,10 @@ int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, c
   a.H = H, a.W = W, a.coef = 1.f, a.partials = partials;
   a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_batch = n, a.n_comp = n_comp, a.table = table_dev;
   a.op = table.op[0], a.in_scale = table.scale[0];
+  // dataset-major launch order by default; JD_SEP_INTERLEAVE=1 makes the datasets of a tile neighbours in an XCD's
+  // launch order (the flux window then comes from L2 for all but the first): measured neutral at 8 observations
+  // (152-154 us either way) -- the Infinity Cache already serves the repeated flux reads
+  a.interleave = getenv("JD_SEP_INTERLEAVE") ? 1 : 0;
   bool flux_aligned = true;
   for (int c = 0; c < n_comp; ++c) flux_aligned = flux_aligned && (reinterpret_cast<uintptr_t>(flux[c]) & 15) == 0;
   return launch_sep(a, kh, kw, oy, ox, 0, true, stream, flux_aligned && table_aligned(table, n, n_comp));

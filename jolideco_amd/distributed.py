@@ -50,6 +50,43 @@ class DistContext:
             dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=self.group)
         return buffer
 
+    def all_reduce_sum_async(self, buffer):
+        """Start the in-place sum all-reduce of one flat tensor and return a handle whose ``wait()`` orders the
+        current stream behind it (None for a single process).  RCCL runs the collective on its own stream, so kernels
+        enqueued on the current stream after this call overlap with it."""
+        if self.world_size > 1 and not self.dry_run:
+            return dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return None
+
+    def all_gather_flat(self, out, piece):
+        """out[r * n : (r + 1) * n] <- rank r's ``piece`` (n = piece.numel()) on every rank.  With gloo (tests: several
+        ranks on one GPU) device tensors are staged through the host; a dry run only places this rank's piece."""
+        n = piece.numel()
+        if out.numel() != n * self.world_size:
+            raise ValueError("all_gather_flat: out must hold world_size pieces")
+        if self.world_size == 1 or self.dry_run:
+            out[self.rank * n : (self.rank + 1) * n].copy_(piece)
+            return out
+        if dist.get_backend(self.group) == "gloo" and piece.is_cuda:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, piece.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, piece, group=self.group)
+        return out
+
+    def assert_same_on_all_ranks(self, values, what):
+        """Raise on every rank if the int64 vector ``values`` (host) differs between ranks (one synchronising
+        exchange at set-up time, e.g. the state of the cycle-spin generators that must draw identical shifts)."""
+        if self.world_size == 1 or self.dry_run:
+            return
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else "cpu"
+        mine = torch.as_tensor(values, dtype=torch.int64).to(device)
+        both = torch.stack([mine, -mine])
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self.group)  # max(v) and max(-v) = -min(v)
+        if not torch.equal(both[0], -both[1]):
+            raise RuntimeError(f"{what} differs between the ranks of the sharded fit")
+
     def barrier(self):
         if self.world_size > 1 and not self.dry_run:
             dist.barrier(group=self.group)

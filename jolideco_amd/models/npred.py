@@ -68,22 +68,30 @@ class NPredModel(nn.Module):
         With the convolution method "auto" a PSF that is a sum of at most three outer products (every sampled
         Gaussian is one) takes the separable kernel (csrc/sepconv.hip) unless ``allow_separable`` is False."""
         device = torch.device(device)
-        psf = np.asarray(psf, dtype=np.float32)
-        if kernel_shape is not None and tuple(kernel_shape) != psf.shape:
-            psf = embed_kernel(psf, kernel_shape)
+        psf = np.ascontiguousarray(psf, dtype=np.float32)
         exposure = np.ascontiguousarray(exposure, dtype=np.float32)
+        u = upsampling_factor or 1
         if upsampling_factor:
-            # setup-time bilinear up-sampling on the host, PSF divided by u^2 (models/npred.py:96-106)
+            # setup-time bilinear up-sampling on the host, PSF divided by u^2 (models/npred.py:96-106) -- of the PSF
+            # as given: F.interpolate clamps at the array edge, so a PSF embedded in zeros first would get a different
+            # up-sampled border than the reference's
             import torch.nn.functional as F
 
             up = lambda a: F.interpolate(torch.from_numpy(a)[None, None], scale_factor=upsampling_factor, mode="bilinear")[0, 0]  # noqa: E731
             exposure = up(exposure).numpy()
-            psf = (up(np.ascontiguousarray(psf)) / upsampling_factor**2).numpy()
+            psf = (up(psf) / upsampling_factor**2).numpy()
+        # the calibration's PSF scale acts on the PSF of the dataset, before it is embedded for the shared plan
+        rescaled = rescale_psf(psf, psf_scale) if psf_scale is not None else psf
+        if kernel_shape is not None:
+            target = (kernel_shape[0] * u, kernel_shape[1] * u)
+            if target != psf.shape:
+                same = rescaled is psf
+                psf = embed_kernel(psf, target)
+                rescaled = psf if same else embed_kernel(rescaled, target)
         exposure_t = _to_device_image(exposure, device)
         psf_t = _to_device_image(psf, device)
         H, W = exposure_t.shape
         kh, kw = psf_t.shape
-        rescaled = rescale_psf(psf, psf_scale) if psf_scale is not None else psf
         method = default_conv_method()
         if method == "auto" and allow_separable and max(kh, kw) <= SEPARABLE_MAX_EDGE:
             if psf_separable_rank(psf) and (rescaled is psf or psf_separable_rank(rescaled)):

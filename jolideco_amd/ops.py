@@ -24,6 +24,8 @@ __all__ = [
     "ElementwisePriorFunction",
     "stirling_mean",
     "require_hip_tensor",
+    "band_rows",
+    "add_rolled_bands",
 ]
 
 POISSON_EPS = 1e-25  # jolideco/loss.py:36
@@ -275,12 +277,28 @@ class GmmHandle:
             pass
 
     def prior_fwd_bwd(self, flux, stride, shifts, value_out, value_scale, grad=None, grad_coef=0.0,
-                      marginalize=False, patch_rows=(0, -1), accumulate_value=False, argmax_out=None):
+                      marginalize=False, patch_rows=(0, -1), accumulate_value=False, argmax_out=None, band_out=None):
+        """``band_out``: instead of accumulating into ``grad``, write the gradient of the patch rows ``patch_rows`` as the
+        band of the rolled frame they cover (jd_gmm_prior_band_fwd_bwd; `band_rows` gives its extent)."""
         flux = require_hip_tensor(flux, "flux")
         H, W = flux.shape[-2:]
         if flux.numel() != H * W:
             raise ValueError("flux must be a single (H, W) image")
         sy, sx = (0, 0) if shifts is None else shifts
+        if band_out is not None:
+            if grad is not None or argmax_out is not None:
+                raise ValueError("band_out excludes grad and argmax_out")
+            y0, y1 = band_rows(patch_rows, stride, H)
+            if band_out.numel() < (y1 - y0) * W:
+                raise ValueError(f"band_out holds {band_out.numel()} values, rows [{y0}, {y1}) x {W} need {(y1 - y0) * W}")
+            check(
+                _hip.lib().jd_gmm_prior_band_fwd_bwd(
+                    self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(patch_rows[0]), int(patch_rows[1]),
+                    int(bool(marginalize)), c_float(value_scale), ptr(value_out), int(accumulate_value),
+                    c_float(grad_coef), ptr(band_out), stream_ptr(flux.device),
+                )
+            )
+            return
         check(
             _hip.lib().jd_gmm_prior_fwd_bwd(
                 self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(patch_rows[0]), int(patch_rows[1]),
@@ -384,6 +402,32 @@ class ElementwisePriorFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_value):
         return (ctx.grad * grad_value).reshape(ctx.shape), None, None, None, None
+
+
+def band_rows(patch_rows, stride, H, patch=8):
+    """Pixel rows [y_begin, y_end) of the rolled frame that the patch rows ``patch_rows = (begin, end)`` cover
+    (``end < 0``: up to the last patch row); an empty shard covers no row."""
+    n_py = (H - patch) // stride + 1
+    begin, end = patch_rows
+    end = n_py if end < 0 else end
+    if end <= begin:
+        return begin * stride, begin * stride
+    return begin * stride, (end - 1) * stride + patch
+
+
+def add_rolled_bands(grad, shifts, bands, chunk, y_ranges):
+    """grad (un-rolled image) += the bands of the rolled frame (jd_add_rolled_bands): ``bands`` is the flat device buffer
+    of an all-gather, band b starts at ``b * chunk`` and holds the rows ``y_ranges[b] = (y_begin, y_end)``."""
+    grad = require_hip_tensor(grad, "grad")
+    bands = require_hip_tensor(bands, "bands")
+    H, W = grad.shape[-2:]
+    n = len(y_ranges)
+    if bands.numel() < (n - 1) * chunk + max((y1 - y0) * W for y0, y1 in y_ranges):
+        raise ValueError("bands buffer too small for n_bands pieces of `chunk` values")
+    sy, sx = (0, 0) if shifts is None else shifts
+    y0 = (c_int * n)(*[int(r[0]) for r in y_ranges])
+    y1 = (c_int * n)(*[int(r[1]) for r in y_ranges])
+    check(_hip.lib().jd_add_rolled_bands(ptr(grad), H, W, int(sy), int(sx), ptr(bands), int(chunk), n, y0, y1, stream_ptr(grad.device)))
 
 
 def adam_bias_terms(step, lr, beta1, beta2):

@@ -95,14 +95,15 @@ class GMMPatchPrior(Prior):
             flux, self.gmm.handle(flux.device), self.stride, shifts, self.marginalize, scale
         )
 
-    def device_fwd_bwd(self, flux, value_out, grad=None, coef=0.0, patch_rows=None, shifts="draw"):
-        """Fused path: value -> device scalar, ``grad += coef * d logprior / d flux``."""
+    def device_fwd_bwd(self, flux, value_out, grad=None, coef=0.0, patch_rows=None, shifts="draw", band_out=None):
+        """Fused path: value -> device scalar, ``grad += coef * d logprior / d flux``; with ``band_out`` the gradient of
+        the shard ``patch_rows`` goes, un-accumulated, to the band of the rolled frame it covers (sharded joint fit)."""
         if isinstance(shifts, str):
             shifts = self.draw_shifts()
         scale = self.log_like_weight / flux.numel()
         self.gmm.handle(flux.device).prior_fwd_bwd(
             flux.reshape(flux.shape[-2:]), self.stride, shifts, value_out, scale, grad=grad, grad_coef=coef * scale,
-            marginalize=self.marginalize, patch_rows=patch_rows or (0, -1),
+            marginalize=self.marginalize, patch_rows=patch_rows or (0, -1), band_out=band_out,
         )
 
     def hessian_ones(self, flux):

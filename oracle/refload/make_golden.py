@@ -282,6 +282,45 @@ def upsampling_case():
     print("upsampling_case ok", res.flux_total[12, 12], res3.trace_loss[-1]["total"])
 
 
+def upsampling_mixed_psf_case():
+    """upsampling_factor=2 with two flux components whose PSFs have DIFFERENT shapes (9x9 with non-negligible edges,
+    5x5 box-like): the reference up-samples each PSF as given (models/npred.py:96-106, F.interpolate clamps at the
+    array edge), so an implementation that first embeds the small PSF in the shape of the large one gets another border."""
+    rs = np.random.RandomState(31)
+    shape = (40, 44)
+    means, covs, weights = cpu_ref.synthetic_gmm(6, 64, seed=12)
+    datasets = {}
+    for i in range(2):
+        d = scene(shape, asym_psf((9, 9), 2.5 + 0.5 * i, 3.0), rs, bkg=0.6)
+        small = np.ones((5, 5)) + 0.3 * rs.uniform(size=(5, 5))  # strong edges: the up-sampled border matters
+        d["psf"] = {"extended": d["psf"], "points": (small / small.sum()).astype(np.float32)}
+        datasets[f"o{i}"] = d
+    init_ext = rs.gamma(30, size=shape)
+    init_pts = rs.gamma(2, size=shape) * 0.2
+    comps = FluxComponents()
+    comps["extended"] = SpatialFluxComponent.from_numpy(
+        flux=init_ext, upsampling_factor=2, prior=GMMPatchPrior(gmm=ref_gmm(means, covs, weights))
+    )
+    comps["points"] = SpatialFluxComponent.from_numpy(flux=init_pts, upsampling_factor=2, prior=InverseGammaPrior(alpha=10, beta=1.5))
+    n_epochs = 5
+    res = MAPDeconvolver(n_epochs=n_epochs, display_progress=False).run(datasets=datasets, components=comps)
+    gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
+    final, trace = cpu_ref.map_fit_sequential(
+        datasets, {"extended": init_ext, "points": init_pts},
+        {"extended": cpu_ref.GMMPatchPriorRef(gmm_o), "points": cpu_ref.InverseGammaPriorRef(10, 1.5)},
+        n_epochs=n_epochs, upsampling_factors={"extended": 2, "points": 2},
+    )
+    up = {name: comp.flux_upsampled.detach().numpy()[0, 0] for name, comp in res.components.items()}
+    assert np.array_equal(final["extended"], up["extended"]) and np.array_equal(final["points"], up["points"])
+    assert trace[-1]["total"] == res.trace_loss[-1]["total"]
+    out = {"gmm/means": means, "gmm/covariances": covs, "gmm/weights": weights, "init/extended": init_ext,
+           "init/points": init_pts, "final_upsampled/extended": up["extended"], "final_upsampled/points": up["points"]}
+    out.update(pack_datasets(datasets))
+    out.update(trace_to_arrays(res.trace_loss))
+    np.savez_compressed(OUT / "upsampling_mixed_psf.npz", **out)
+    print("upsampling_mixed_psf_case ok", res.trace_loss[-1]["total"])
+
+
 def calibration_case():
     """Fits with NPredCalibrations (jolideco/models/npred.py:298-510): trainable sub-pixel shift and
     background norm per dataset, a fixed PSF scale, one frozen calibration; upsampling_factor 1 and 2."""
@@ -593,6 +632,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "upsampling":  # add this fixture without touching the others
         upsampling_case()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "upsampling_mixed_psf":
+        upsampling_mixed_psf_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "calibration":
         calibration_case()
         sys.exit(0)
@@ -609,6 +651,7 @@ if __name__ == "__main__":
     stage_vectors()
     joint_and_multi()
     upsampling_case()
+    upsampling_mixed_psf_case()
     calibration_case()
     linear_flux_case()
     compute_error_case()

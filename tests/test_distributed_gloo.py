@@ -160,3 +160,47 @@ def test_shard_rules():
     # single process: the collective is a no-op
     buf = torch.arange(4.0)
     assert DistContext().all_reduce_sum(buf) is buf
+
+
+def _helpers_worker(rank, world_size, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
+                      LOCAL_RANK=str(rank))
+    from jolideco_amd.distributed import init_from_env
+
+    ctx = init_from_env(backend="gloo")
+    buf = torch.full((5,), float(rank + 1))
+    pending = ctx.all_reduce_sum_async(buf)  # the overlapped schedule: started, other work, then waited for
+    out = torch.zeros(3 * world_size)
+    ctx.all_gather_flat(out, torch.full((3,), float(rank)))
+    pending.wait()
+    assert torch.equal(buf, torch.full((5,), 3.0))
+    assert out.tolist() == [0.0, 0.0, 0.0, 1.0, 1.0, 1.0]
+    ctx.assert_same_on_all_ranks([1, 2, 3], "a vector that is the same")
+    with pytest.raises(RuntimeError, match="differs between the ranks"):
+        ctx.assert_same_on_all_ranks([1, 2, 3 + rank], "a vector that is not")
+    dist.destroy_process_group()
+
+
+def test_distcontext_overlap_helpers_world_size_2():
+    """all_reduce_sum_async / all_gather_flat / assert_same_on_all_ranks, the collectives of the overlapped sharded
+    step (jolideco_amd/core.py FitSession.epoch), over gloo on the CPU."""
+    mp.spawn(_helpers_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def test_band_geometry_of_the_sharded_prior():
+    """band_rows: the rows of the rolled frame a shard of patch rows covers; consecutive shards overlap by
+    patch - stride rows, an empty shard covers none, the shards of shard_range cover the whole patch grid."""
+    from jolideco_amd.distributed import DistContext
+    from jolideco_amd.ops import band_rows
+
+    H, stride = 2048, 4
+    n_rows = (H - 8) // stride + 1
+    ranges = [band_rows(DistContext(r, 8).shard_range(n_rows), stride, H) for r in range(8)]
+    assert ranges[0][0] == 0 and ranges[-1][1] == (n_rows - 1) * stride + 8 <= H
+    for (a0, a1), (b0, b1) in zip(ranges[:-1], ranges[1:]):
+        assert a1 - b0 == 8 - stride and a0 < b0
+    assert band_rows((5, 5), stride, H) == (20, 20)
+    assert band_rows((0, -1), stride, H) == (0, (n_rows - 1) * stride + 8)
+    # more ranks than patch rows: the surplus ranks get empty shards
+    small = [DistContext(r, 8).shard_range(3) for r in range(8)]
+    assert sum(hi - lo for lo, hi in small) == 3 and all(band_rows(s, 4, 20)[1] <= 20 for s in small)

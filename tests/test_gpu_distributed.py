@@ -27,9 +27,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world_size, port, out_dir):
+def _worker(rank, world_size, port, out_dir, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
-                      LOCAL_RANK=str(rank), JOLIDECO_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(rank), JOLIDECO_DIST_BACKEND="gloo", JOLIDECO_DIST_OVERLAP=overlap)
     from conftest import unpack_datasets
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
     from jolideco_amd.distributed import init_from_env
@@ -51,10 +51,13 @@ def _worker(rank, world_size, port, out_dir):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_joint_fit_matches_the_single_process_reference(tmp_path, golden):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_two_rank_joint_fit_matches_the_single_process_reference(tmp_path, golden, overlap):
+    """overlap "1" (default): all-reduce of the likelihood gradient in flight while the prior runs, the prior's bands in
+    one all-gather; "0": the prior accumulated into the flat buffer before its single all-reduce."""
     from conftest import rel_linf
 
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), overlap), nprocs=2, join=True)
     j = golden("joint_multi")
     r0, r1 = dict(np.load(tmp_path / "rank0.npz")), dict(np.load(tmp_path / "rank1.npz"))
     # replicas apply the identical update after the all-reduce: bit-identical parameters, no broadcast

@@ -282,6 +282,28 @@ def test_upsampling_factor_3_gmm_prior(golden, conv_method):
     _trace_close(res.trace_loss, u, prefix="u3/trace/")
 
 
+def test_upsampling_with_per_component_psfs_of_different_shapes(golden, conv_method):
+    """upsampling_factor=2, two components whose PSFs differ in shape (9x9 and a 5x5 with strong edges): the components
+    share one convolution plan, so the small PSF is embedded in the shape of the large one -- AFTER its up-sampling, as
+    the reference up-samples each PSF as given (models/npred.py:96-106; live-reference fixture)."""
+    from jolideco_amd import FluxComponents, GMMPatchPrior, InverseGammaPrior, MAPDeconvolver, SpatialFluxComponent
+
+    m = golden("upsampling_mixed_psf")
+    datasets = unpack_datasets(m)
+    comps = FluxComponents()
+    comps["extended"] = SpatialFluxComponent.from_numpy(
+        flux=m["init/extended"], upsampling_factor=2,
+        prior=GMMPatchPrior(gmm=_gmm(m["gmm/means"], m["gmm/covariances"], m["gmm/weights"])),
+    )
+    comps["points"] = SpatialFluxComponent.from_numpy(flux=m["init/points"], upsampling_factor=2,
+                                                      prior=InverseGammaPrior(alpha=10, beta=1.5))
+    res = MAPDeconvolver(n_epochs=5, display_progress=False, device=DEV).run(datasets, components=comps)
+    for name in ("extended", "points"):
+        err = rel_linf(res.components[name].flux_upsampled_numpy, m[f"final_upsampled/{name}"])
+        assert err < 1e-5, (name, err)
+    _trace_close(res.trace_loss, m)
+
+
 @pytest.mark.parametrize("tag,u,n_epochs", [("u1", 1, 8), ("u2", 2, 5)])
 def test_calibrations_match_the_reference(golden, tag, u, n_epochs, conv_method):
     """Fits with NPredCalibrations against the live-reference fixture: sub-pixel shift (bilinear, trained),

@@ -740,3 +740,89 @@ def test_gmm_screen_large_k_and_huge_dynamic_range(monkeypatch):
             assert np.array_equal(screened[2], dense[2]), scale
             assert screened[0] == pytest.approx(dense[0], rel=2e-7), scale
             assert np.array_equal(screened[1], dense[1]), scale
+
+
+@pytest.mark.parametrize("stride", [4, 5, 8])
+@pytest.mark.parametrize("marginalize", [False, True])
+def test_gmm_tiled_gather_equals_the_per_pixel_gather(monkeypatch, stride, marginalize):
+    """The overlap-add of the patch gradients runs tile-wise through LDS for strides >= 4 (`gmm_gather_tile_kernel`);
+    JD_GMM_GATHER_TILED=0 selects the per-pixel kernel.  Same additions in the same order: same bits -- whole image,
+    patch-row shards (tile boundaries inside the shard), filtered patches, image sizes that are no multiple of the
+    tile, all three sources of rows (record rows of the fused arg-max backward pass, bucketed backward, logsumexp)."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape = (150, 203)
+    rs = np.random.RandomState(stride)
+    means, covs, weights = synthetic_gmm(12, 64, seed=4)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+    image = rs.gamma(20, size=shape).astype(np.float32)
+    image[40:44, 100:110] = -2e5  # filtered patches: no gradient
+    flux = torch.from_numpy(image).to(DEV)
+    handle = gmm.handle(DEV)
+    n_rows = (shape[0] - 8) // stride + 1
+
+    def run(tiled, rows, fused=True):
+        monkeypatch.setenv("JD_GMM_GATHER_TILED", "1" if tiled else "0")
+        monkeypatch.setenv("JD_GMM_FUSED_BWD", "1" if fused else "0")
+        value, grad = torch.zeros(1, device=DEV), torch.full_like(flux, 0.5)  # accumulates into a non-zero image
+        handle.prior_fwd_bwd(flux, stride, (3, -5), value, 0.25, grad=grad, grad_coef=-0.7, patch_rows=rows,
+                             marginalize=marginalize)
+        torch.cuda.synchronize()
+        return grad.cpu().numpy()
+
+    for rows in ((0, -1), (3, n_rows - 2), (7, 8)):
+        for fused in ((True, False) if not marginalize else (True,)):
+            a, b = run(True, rows, fused), run(False, rows, fused)
+            assert np.array_equal(a, b), (rows, fused)
+            assert np.abs(a - 0.5).max() > 0
+
+
+@pytest.mark.parametrize("marginalize", [False, True])
+def test_prior_bands_of_a_sharded_prior_add_up_to_the_whole(marginalize):
+    """jd_gmm_prior_band_fwd_bwd + jd_add_rolled_bands (what the ranks of a sharded joint fit exchange with one
+    all-gather): the bands of three shards of patch rows -- one of them empty -- laid out like an all-gather buffer and
+    added back give the gradient of the accumulating calls (gradient image zero before), shard values sum to the whole
+    value."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.ops import add_rolled_bands, band_rows
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape, stride, shifts = (118, 164), 4, (-2, 3)
+    rs = np.random.RandomState(2)
+    means, covs, weights = synthetic_gmm(10, 64, seed=8)
+    handle = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4)).handle(DEV)
+    flux = torch.from_numpy(rs.gamma(20, size=shape).astype(np.float32)).to(DEV)
+    n_rows = (shape[0] - 8) // stride + 1
+    shards = [(0, 9), (9, 9), (9, n_rows)]
+    y_ranges = [band_rows(r, stride, shape[0]) for r in shards]
+    assert y_ranges[1][0] == y_ranges[1][1] and y_ranges[0][1] > y_ranges[2][0]  # empty shard; the bands overlap
+    chunk = max(y1 - y0 for y0, y1 in y_ranges) * shape[1] + 4
+    pieces = torch.full((len(shards) * chunk,), 7.0, device=DEV)  # garbage behind the bands must be ignored
+    ref_v, ref_g = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+    values = []
+    for i, rows in enumerate(shards):
+        handle.prior_fwd_bwd(flux, stride, shifts, ref_v, 0.25, grad=ref_g, grad_coef=-0.7, patch_rows=rows,
+                             accumulate_value=True, marginalize=marginalize)
+        v = torch.zeros(1, device=DEV)
+        handle.prior_fwd_bwd(flux, stride, shifts, v, 0.25, grad_coef=-0.7, patch_rows=rows, marginalize=marginalize,
+                             band_out=pieces[i * chunk : (i + 1) * chunk])
+        values.append(float(v))
+    grad = torch.zeros_like(flux)
+    add_rolled_bands(grad, shifts, pieces, chunk, y_ranges)
+    torch.cuda.synchronize()
+    # bit for bit outside the rows two bands share; there grad + coef * sum is one fused multiply-add in the accumulating
+    # calls and a rounded product plus an addition through the bands: equal to an ulp
+    got, ref = grad.cpu().numpy(), ref_g.cpu().numpy()
+    shared = np.zeros(shape[0], dtype=bool)
+    shared[(np.arange(y_ranges[2][0], y_ranges[0][1]) - shifts[0]) % shape[0]] = True
+    assert np.array_equal(got[~shared], ref[~shared]) and np.abs(ref).max() > 0
+    assert rel_linf(got, ref) < 1e-6
+    np.testing.assert_allclose(sum(values), float(ref_v), rtol=1e-6)
+    assert values[1] == 0.0
+    # into a non-zero gradient image: (g + a) + b vs g + (a + b) on the overlap rows -- equal to rounding
+    g1, g2 = torch.full_like(flux, 0.3), torch.full_like(flux, 0.3)
+    for rows in shards:
+        handle.prior_fwd_bwd(flux, stride, shifts, ref_v, 0.25, grad=g1, grad_coef=-0.7, patch_rows=rows, marginalize=marginalize)
+    add_rolled_bands(g2, shifts, pieces, chunk, y_ranges)
+    assert rel_linf(g2.cpu().numpy(), g1.cpu().numpy()) < 1e-6

@@ -271,3 +271,19 @@ def test_linear_flux_parameter(golden, tag):
     )
     assert rel_linf(final["flux"], g[f"{tag}/flux_final"]) < TOL
     _trace_close(trace, g, prefix=f"{tag}/trace/")
+
+
+def test_upsampling_with_per_component_psfs_of_different_shapes(golden):
+    """upsampling_factor=2, two components, a 9x9 and a 5x5 PSF with strong edges (live-reference fixture): every PSF
+    is up-sampled as given (models/npred.py:96-106)."""
+    m = golden("upsampling_mixed_psf")
+    datasets = unpack_datasets(m)
+    gmm = cpu_ref.GMM.from_numpy(m["gmm/means"], m["gmm/covariances"], m["gmm/weights"], stride=4)
+    final, trace = cpu_ref.map_fit_sequential(
+        datasets, {"extended": m["init/extended"], "points": m["init/points"]},
+        {"extended": cpu_ref.GMMPatchPriorRef(gmm), "points": cpu_ref.InverseGammaPriorRef(10, 1.5)},
+        n_epochs=5, upsampling_factors={"extended": 2, "points": 2},
+    )
+    for name in ("extended", "points"):
+        assert rel_linf(final[name], m[f"final_upsampled/{name}"]) < TOL
+    _trace_close(trace, m)

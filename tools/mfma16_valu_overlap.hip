@@ -18,7 +18,7 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 // MODE 0: fma on private registers; 1: squares of the other accumulator's registers (read-only) into 2 chains;
 // 2: v_pk_fma_f32 on private registers
 template <int NV, int MODE>
-__global__ __launch_bounds__(256, 1) void kern(float* out, long long* cyc, int iters, const _Float16* src) {
+__global__ __launch_bounds__(512, 1) void kern(float* out, long long* cyc, int iters, const _Float16* src) {
   f32x16 acc[4];
   for (int i = 0; i < 4; ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
@@ -50,24 +50,24 @@ __global__ __launch_bounds__(256, 1) void kern(float* out, long long* cyc, int i
     for (int r = 0; r < 16; ++r) s += acc[i][r];
   for (int i = 0; i < 8; ++i) s += v[i];
   for (int i = 0; i < 4; ++i) s += p[i][0] + p[i][1];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
-  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
 template <int NV, int MODE>
-void run(float* out, long long* cyc, const _Float16* src) {
+void run(float* out, long long* cyc, const _Float16* src, int threads = 256) {
   const int iters = 20000, blocks = 256;
   hipEvent_t e0, e1;
   hipEventCreate(&e0), hipEventCreate(&e1);
-  kern<NV, MODE><<<blocks, 256>>>(out, cyc, 100, src);
+  kern<NV, MODE><<<blocks, threads>>>(out, cyc, 100, src);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  kern<NV, MODE><<<blocks, 256>>>(out, cyc, iters, src);
+  kern<NV, MODE><<<blocks, threads>>>(out, cyc, iters, src);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
-  std::vector<long long> h(blocks * 4);
+  std::vector<long long> h(blocks * (threads / 64));
   hipMemcpy(h.data(), cyc, h.size() * 8, hipMemcpyDeviceToHost);
   double mean = 0;
   for (auto x : h) mean += (double)x;
@@ -75,7 +75,7 @@ void run(float* out, long long* cyc, const _Float16* src) {
   const double n_mfma = (double)iters * 12;
   const char* names[3] = {"v_fma_f32 (private regs)", "v_fma_f32 (squares of a finished accumulator)", "v_pk_fma_f32"};
   // s_memtime ticks at 100 MHz on gfx9 (constant clock); shader cycles = wall time x shader clock, unknown a priori
-  printf("%-46s NV=%2d: %8.3f ms, %6.2f ns per MFMA slot, memtime ticks per MFMA %.3f\n", names[MODE], NV, ms,
+  printf("waves/SIMD %d %-46s NV=%2d: %8.3f ms, %6.2f ns per MFMA slot, memtime ticks per MFMA %.3f\n", threads / 256, names[MODE], NV, ms,
          ms * 1e6 / n_mfma, mean / n_mfma);
 }
 
@@ -83,8 +83,8 @@ int main() {
   float* out;
   long long* cyc;
   _Float16* src;
-  hipMalloc(&out, 256 * 256 * 4);
-  hipMalloc(&cyc, 256 * 4 * 8);
+  hipMalloc(&out, 256 * 512 * 4);
+  hipMalloc(&cyc, 256 * 8 * 8);
   hipMalloc(&src, 4096 * 2);
   std::vector<_Float16> h(4096);
   unsigned s = 12345u;
@@ -102,5 +102,13 @@ int main() {
   run<8, 1>(out, cyc, src);
   run<2, 2>(out, cyc, src);
   run<4, 2>(out, cyc, src);
+  // two waves per SIMD: do the VALU instructions of one wave issue in the shadow of the other's MFMAs?
+  run<0, 0>(out, cyc, src, 512);
+  run<4, 0>(out, cyc, src, 512);
+  run<8, 0>(out, cyc, src, 512);
+  run<12, 0>(out, cyc, src, 512);
+  run<16, 0>(out, cyc, src, 512);
+  run<8, 1>(out, cyc, src, 512);
+  run<12, 1>(out, cyc, src, 512);
   return 0;
 }
