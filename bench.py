@@ -80,19 +80,13 @@ def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
 
 
 PMC_TRAFFIC_FILES = ("profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
+_TRAFFIC_USED = {}  # kernel -> file its traffic figure came from
 
 
-def pmc_traffic_file():
-    for rel in PMC_TRAFFIC_FILES:
-        if (REPO / rel).exists():
-            return rel
-    return None
-
-
-def pmc_traffic_source():
+def pmc_traffic_source(kernel=None):
     """Where `traffic` comes from: PMC counters cannot be read from inside this process, so the bench line quotes
     the committed rocprofv3 PMC passes -- file and the commit that last touched it (stale once a kernel changes)."""
-    rel = pmc_traffic_file()
+    rel = _TRAFFIC_USED.get(kernel) if kernel else next((r for r in PMC_TRAFFIC_FILES if (REPO / r).exists()), None)
     if rel is None:
         return None
     commit = "unknown"
@@ -107,29 +101,30 @@ def pmc_traffic_source():
 
 
 def pmc_traffic_bytes(cfg_name, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per launch);
-    gfx950 correction of MI355X_MICROARCH.md: reads = 2 x FETCH_SIZE, writes = WRITE_SIZE.  None when the
-    workload was not profiled.  (PMC counters cannot be read from inside this process.)"""
+    """HBM bytes per launch of `kernel` (a prefix of its rocprofv3 name) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate passes, KB per launch); the newest round's file that holds the
+    kernel wins.  gfx950 correction of MI355X_MICROARCH.md: reads = 2 x FETCH_SIZE, writes = WRITE_SIZE.  None when
+    the workload was not profiled.  (PMC counters cannot be read from inside this process.)"""
     import csv
 
-    rel = pmc_traffic_file()
-    if rel is None:
-        return None
-    fetch = write = None
-    with open(REPO / rel) as fh:
-        rows = list(csv.DictReader(fh))
-    # "<config>s" / "<config>f" rows: the same workload profiled on later builds -- the last one found wins
-    for label in (cfg_name, cfg_name + "s", cfg_name + "f"):
-        for row in rows:
-            if row["config"] == label and kernel in row["kernel"]:
-                if row["counter"] == "FETCH_SIZE":
-                    fetch = float(row["avg_per_launch_KB"])
-                elif row["counter"] == "WRITE_SIZE":
-                    write = float(row["avg_per_launch_KB"])
-    if fetch is None or write is None:
-        return None
-    return (2.0 * fetch + write) * 1024.0
+    for rel in PMC_TRAFFIC_FILES:
+        if not (REPO / rel).exists():
+            continue
+        fetch = write = None
+        with open(REPO / rel) as fh:
+            rows = list(csv.DictReader(fh))
+        # "<config>s" / "<config>f" rows: the same workload profiled on later builds -- the last one found wins
+        for label in (cfg_name, cfg_name + "s", cfg_name + "f"):
+            for row in rows:
+                if row["config"] == label and kernel in row["kernel"]:
+                    if row["counter"] == "FETCH_SIZE":
+                        fetch = float(row["avg_per_launch_KB"])
+                    elif row["counter"] == "WRITE_SIZE":
+                        write = float(row["avg_per_launch_KB"])
+        if fetch is not None and write is not None:
+            _TRAFFIC_USED[kernel] = rel
+            return (2.0 * fetch + write) * 1024.0
+    return None
 
 
 def host_cores(cap=16):
@@ -313,10 +308,10 @@ def main():
             "unit": "TFLOP/s", "frac": achieved / F16_MATRIX_PEAK_TFLOPS,
             "traffic": pmc_traffic_bytes(args.config, "gmm_screen_kernel") if world == 1 and fake is None else None,
             "avg_launch_ms": scr_ms, "launches": scr_n, "flop_per_launch": f16_flop, "operand_dtype": "f16 (screen only)",
-            "forward_pass_ms": gmm_ms, "stage_ms": {k: avg_ms(k)[0] for k in ("gmm_screen", "gmm_sort", "gmm_exact")},
+            "forward_pass_ms": gmm_ms, "stage_ms": {k: avg_ms(k)[0] for k in ("gmm_stage", "gmm_screen", "gmm_sort", "gmm_exact")},
             "algorithmic_fp32_flop": gmm_flop,
             "algorithmic_fp32_equivalent_tflops": gmm_flop / (gmm_ms * 1e-3) / 1e12,
-            "traffic_source": pmc_traffic_source(),
+            "traffic_source": pmc_traffic_source("gmm_screen_kernel"),
             "note": "results are bit-identical to the fp32 MFMA kernel; the fp16 product only decides which "
                     "components can NOT be the arg-max; gmm_exact also writes the gradient rows of the survivors "
                     "(the backward pass of the arg-max prior has no kernel of its own)",
@@ -343,19 +338,20 @@ def main():
     # batched joint step: ONE launch covers all local datasets (jd_npred_poisson_batch_fwd_bwd)
     per_launch = len(session.local_idx) if getattr(session, "batch_joint", False) else 1
     poi_bytes = (20 if poisson_in_conv else 16) * H * W * per_launch
-    poi_kernel = "sep_conv_kernel<true, true, true>" if poisson_in_conv else "poisson_fused_kernel"
+    # (prefixes of the rocprofv3 kernel names: the template argument lists have grown trailing defaults)
+    poi_kernel = "sep_conv_kernel<true, true, true" if poisson_in_conv else "poisson_fused_kernel"
     roof_poi = None
     if poi_ms:
         achieved = poi_bytes / (poi_ms * 1e-3) / 1e9
         roof_poi = {
-            "kernel": poi_kernel + (" (forward convolution + Poisson pass)" if poisson_in_conv else ""), "bound": "hbm",
+            "kernel": poi_kernel + ("> (forward convolution + Poisson pass)" if poisson_in_conv else ""), "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic_bytes(args.config, poi_kernel) if world == 1 and fake is None else None,
-            "traffic_source": pmc_traffic_source(),
+            "traffic_source": pmc_traffic_source(poi_kernel),
             "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes, "datasets_per_launch": per_launch,
         }
     n_profiled = len(range(0, args.steps, PROFILE_EVERY))
-    nested = ("gmm_screen", "gmm_sort", "gmm_exact")  # stage timers inside the gmm_fwd bracket
+    nested = ("gmm_stage", "gmm_screen", "gmm_sort", "gmm_exact")  # stage timers inside the gmm_fwd bracket
     kernel_ms_per_step = {k: (v[0] / n_profiled) for k, v in prof.items() if v[1] and k not in nested}
     dominant = max(kernel_ms_per_step, key=kernel_ms_per_step.get) if kernel_ms_per_step else None
     roofline = roof_poi if dominant == "poisson_fused" else roof_gmm
@@ -416,9 +412,9 @@ def main():
             if conv_key != "sep_conv":
                 names = ("direct_conv_kernel",)
             elif poisson_in_conv:
-                names = ("sep_conv_kernel<true, false, false>",)
+                names = ("sep_conv_kernel<true, false, false",)
             else:
-                names = ("sep_conv_kernel<true, true, false>", "sep_conv_kernel<true, false, false>")
+                names = ("sep_conv_kernel<true, true, false", "sep_conv_kernel<true, false, false")
             parts = [pmc_traffic_bytes(args.config, name) for name in names]
             conv_traffic = sum(parts) / len(parts) if all(p is not None for p in parts) else None
         out["roofline_conv"] = {
@@ -475,7 +471,7 @@ def main():
                 "kernel": "poisson_fused_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes(args.config, "poisson_fused_kernel<4, 1"),
-                "traffic_source": pmc_traffic_source(),
+                "traffic_source": pmc_traffic_source("poisson_fused_kernel<4, 1"),
                 "avg_launch_ms": ms, "launches": count_p, "bytes_per_launch": 16 * H * W,
                 "note": "hipEvent pairs add ~2 us to this ~13 us kernel; rocprofv3: profiles/README.md",
             }

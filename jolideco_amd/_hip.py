@@ -96,7 +96,7 @@ EXPORTS = {
 KERNEL_IDS = {
     "poisson_fused": 0, "gmm_fwd": 1, "gmm_bwd": 2, "gmm_gather": 3, "pad_mul": 4, "cmul": 5,
     "adjoint_epilogue": 6, "adam": 7, "fft_r2c": 8, "fft_c2r": 9, "direct_conv": 10, "sep_conv": 11,
-    "gmm_screen": 12, "gmm_sort": 13, "gmm_exact": 14,
+    "gmm_screen": 12, "gmm_sort": 13, "gmm_exact": 14, "gmm_stage": 15,
 }
 
 _lib = None

@@ -1276,6 +1276,9 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
       if (base + i < a.n_end)
         a.lfinal[base + i] = fmaxf(fmaxf(st_L[i], st_L[NT * 32 + i]), fmaxf(st_L[2 * NT * 32 + i], st_L[3 * NT * 32 + i]));
   }
+  // (the counting pass of the record sort was tried here, on the wave's own records against the bound it has just
+  // computed: the count kernel went away, -7 us, but at one wave per SIMD the re-read of the records is pure latency
+  // and the screen grew by 22 us)
   flush(true);
   if (lane == 0) a.seg_cnt[wave_global] = cnt < SCREEN_CAP ? cnt : SCREEN_CAP;
   if (__ballot(trouble) != 0ull || cnt > SCREEN_CAP) {
@@ -1980,6 +1983,13 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   if ((rc = grow(&g->xstat, &g->xstat_cap, 2 * n_tiles * 32))) return rc;
   if ((rc = grow(&g->xok, &g->xok_cap, n_tiles * 32))) return rc;
 
+  // chunks of the record sort: one record segment per block unless there are too many (the kernels stride then)
+  unsigned chunks = (unsigned)n_seg;
+  const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
+  if (chunks > max_blocks) chunks = max_blocks;
+  if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
+  const bool kc_lds = g->K <= SCREEN_KC_MAX && !getenv("JD_GMM_SCREEN_NO_LDS_CONSTS");  // (testing: the global-load path)
+
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmStageArgs stg{};
   stg.flux = a.flux, stg.H = a.H, stg.W = a.W, stg.stride = a.stride, stg.nPx = a.nPx, stg.shift_y = a.shift_y, stg.shift_x = a.shift_x;
@@ -1993,9 +2003,12 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
   sc.seg_cnt = g->seg_cnt, sc.flag = flag, sc.gen = g->gen;
   {
-    ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
+    ProfScope stage(JD_KERNEL_GMM_STAGE, s);
     gmm_stage_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, s>>>(stg);
-    const bool kc_lds = g->K <= SCREEN_KC_MAX && !getenv("JD_GMM_SCREEN_NO_LDS_CONSTS");  // (testing: the global-load path)
+  }
+  JD_LAUNCH_CHECK();
+  {
+    ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
     if (ksplit && kc_lds)
       gmm_screen_kernel<2, true, true><<<blocks, 256, 0, s>>>(sc);
     else if (ksplit)
@@ -2016,11 +2029,6 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   bk.chunk = SCREEN_CAP;  // one record segment per chunk
   bk.korder = g->K <= KORDER_MAX_K ? g->korder : nullptr;
   if (fused) bk.flag = flag, bk.gen = g->gen, bk.slot_cap = (int)std::min<size_t>(grec_rows, (size_t)INT32_MAX);
-  unsigned chunks = (unsigned)n_seg;
-  // the kernels stride over the chunks; many small blocks hide the latency of the dependent record loads
-  const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
-  if (chunks > max_blocks) chunks = max_blocks;
-  if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
   bk.blk_counts = g->blk_counts;
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   {
