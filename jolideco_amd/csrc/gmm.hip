@@ -1123,7 +1123,7 @@ constexpr int SCREEN_KC_MAX = 512;  // components whose per-component constants 
 // korder[kk + 1] followed at once by the wait for it).  From LDS they are fetched TWO positions ahead, so that the
 // component index is in a register a whole component before the fragment prefetch needs it for its address.
 template <int NP, bool KSPLIT, bool KC_LDS>
-__global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
+__global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScreenArgs a) {
   constexpr int NT = 2 * NP;
   __shared__ float st_L[KSPLIT ? 4 * NT * 32 : 1];
   // Candidate records are collected in a wave-private LDS buffer and written to the wave's segment in global memory
@@ -1224,6 +1224,7 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
   load_frags16(f0, af, __builtin_amdgcn_readfirstlane(cur.k));
   load_frags16(f1, af, __builtin_amdgcn_readfirstlane(nxt.k));
   if (kk0 < a.K) issue_pair(acc[0], f0, 0);  // prologue: pair 0 of the first component
+  int k_ahead_next = fetch_k(clamp_pos(kk0 + 2 * KSTEP));
   // One component: `fa` holds its fragments, `fb` those of the next one (requested during the PREVIOUS component).  As
   // soon as the last MFMA that reads `fa` has been issued, the fragments of the component after next are requested into
   // it: 1.75 components (~3000 cycles) ahead of their first use -- with the request at the top of the component that
@@ -1234,7 +1235,8 @@ __global__ __launch_bounds__(256, 1) void gmm_screen_kernel(GmmScreenArgs a) {
     const int k = __builtin_amdgcn_readfirstlane(cur.k);
     const float ck = cur.ck, ef = cur.ef, sk2 = cur.sk2, mn = cur.mn;
     const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f);
-    const int k_ahead = fetch_k(clamp_pos(kk + 2 * KSTEP));  // the component after next
+    const int k_ahead = k_ahead_next;                    // the component after next: read from LDS a component ago
+    k_ahead_next = fetch_k(clamp_pos(kk + 3 * KSTEP));  // (consumed at once it would expose the LDS latency)
     cur = nxt;
     nxt = fetch_consts(clamp_pos(kk + 2 * KSTEP));  // ... and fetched two ahead of its use
     if (NP == 2) {
@@ -1953,7 +1955,10 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   // a block share 128 patches and split the components (see gmm_screen_kernel)
   bool ksplit = (n + SCREEN_T * 32 * 4 - 1) / (SCREEN_T * 32 * 4) < g->n_cu;
   if (const char* env = getenv("JD_GMM_KSPLIT")) ksplit = atoi(env) != 0;  // testing: force either decomposition
-  const unsigned blocks = (unsigned)(ksplit ? (n + SCREEN_T * 32 - 1) / (SCREEN_T * 32) : ((n + SCREEN_T * 32 - 1) / (SCREEN_T * 32) + 3) / 4);
+  // tuning: JD_GMM_SCREEN_NP=1 -- one tile pair (64 patches) per wave, two waves per SIMD (256 registers each)
+  const bool np1 = !ksplit && getenv("JD_GMM_SCREEN_NP") && atoi(getenv("JD_GMM_SCREEN_NP")) == 1 && g->K <= SCREEN_KC_MAX;
+  const int T = np1 ? 2 : SCREEN_T;
+  const unsigned blocks = (unsigned)(ksplit ? (n + T * 32 - 1) / (T * 32) : ((n + T * 32 - 1) / (T * 32) + 3) / 4);
   const size_t n_seg = (size_t)blocks * 4;
   const size_t slots = n_seg * SCREEN_CAP;                  // candidate record slots
   const size_t bucket_slots = slots + 32 * (size_t)g->K;    // padded bucket slots
@@ -1978,7 +1983,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     if ((rc = grow(&g->winner, &g->winner_cap, (size_t)a.n_end))) return rc;
   }
 
-  const size_t n_tiles = (size_t)blocks * (ksplit ? SCREEN_T : 4 * SCREEN_T);  // tiles the screen's waves touch
+  const size_t n_tiles = (size_t)blocks * (ksplit ? T : 4 * T);  // tiles the screen's waves touch
   if ((rc = grow(&g->xfrag, &g->xfrag_cap, n_tiles * 4 * 64))) return rc;
   if ((rc = grow(&g->xstat, &g->xstat_cap, 2 * n_tiles * 32))) return rc;
   if ((rc = grow(&g->xok, &g->xok_cap, n_tiles * 32))) return rc;
@@ -2009,7 +2014,9 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   JD_LAUNCH_CHECK();
   {
     ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
-    if (ksplit && kc_lds)
+    if (np1)
+      gmm_screen_kernel<1, false, true><<<blocks, 256, 0, s>>>(sc);
+    else if (ksplit && kc_lds)
       gmm_screen_kernel<2, true, true><<<blocks, 256, 0, s>>>(sc);
     else if (ksplit)
       gmm_screen_kernel<2, true, false><<<blocks, 256, 0, s>>>(sc);

@@ -472,7 +472,11 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
   a.n_tiles = a.tiles_x * ((a.H + TY - 1) / TY);
   a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rpairs = g.rpairs, a.pitch = g.pitch;
   a.taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
-  const size_t lds = ((size_t)2 * g.rpairs * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
+  size_t lds = ((size_t)2 * g.rpairs * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
+  if (const char* env = getenv(poisson ? "JD_SEP_FWD_MIN_LDS" : "JD_SEP_ADJ_MIN_LDS")) {  // tuning: caps the blocks per CU
+    const size_t want = (size_t)atol(env);
+    if (want > lds && want <= 160 * 1024) lds = want;
+  }
   const int blocks = ((a.n_tiles + 7) / 8) * 8;
   auto aligned = [](const void* p) { return p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   bool vec = a.W % 4 == 0 && aligned(a.in) && aligned(a.in_scale) && aligned(a.out) && aligned(a.out_scale) &&
