@@ -17,6 +17,7 @@
 // passes are register blocked (8 outputs x 4 taps / 4 x 4) and use packed fp32 FMAs (v_pk_fma_f32: the row pass on
 // two image rows, the column pass on two neighbouring columns), so one LDS read feeds ~5 FMAs; the taps stay
 // runtime values (no template per PSF size).
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -28,6 +29,12 @@ namespace jd {
 
 namespace {
 
+#ifndef JD_SEP_WAVES_POISSON
+#define JD_SEP_WAVES_POISSON 6  // waves per SIMD the fused forward + Poisson kernel is compiled for (80 registers)
+#endif
+#ifndef JD_SEP_WAVES_OTHER
+#define JD_SEP_WAVES_OTHER 1    // (no register cap for the other variants)
+#endif
 constexpr int TY = 32, TX = 64, THREADS = 256, STAGE_BATCH = 3;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -79,6 +86,7 @@ struct SepArgs {
   // batches: flux components per dataset (POISSON: summed after the per-component clip, npred.py:191,254-261) and the
   // component whose gradient an adjoint launch produces
   int n_comp, comp;
+  int alias;       // the row-pass image shares the window's LDS (see the kernel)
   int interleave;  // POISSON batches: the datasets of a tile are neighbours in the launch order (else dataset-major)
   // POISSON batches: the flux images of the components.  Kernel arguments, not table entries: a fit alternates between
   // two flux buffers, and a table that changes every step would be re-uploaded (synchronously) every step.  Read with
@@ -105,11 +113,14 @@ struct SepArgs {
 // MULTI (POISSON batches only): more than one flux component per dataset; a compile-time switch so that the common
 // one-component launch carries none of the component loop.
 template <bool VEC, bool IN_SCALE, bool POISSON, bool MULTI = false>
-__global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
+__global__ __launch_bounds__(THREADS, POISSON && !MULTI ? JD_SEP_WAVES_POISSON : JD_SEP_WAVES_OTHER) void sep_conv_kernel(SepArgs a) {
   extern __shared__ float4 lds4[];
   float* win = reinterpret_cast<float*>(lds4);
-  float* hbuf = win + a.rpairs * a.pitch * 2;
-  float* taps = hbuf + 2 * a.rpairs * TX;  // per rank: khp row taps then kwp column taps
+  // a.alias: the row-pass image overwrites the window (rank-1 operators, at most one row-pass item per thread): the
+  // items are computed into registers, a barrier retires the window, then they are stored -- 19 KB instead of 32 KB of
+  // LDS per block
+  float* hbuf = a.alias ? win : win + a.rpairs * a.pitch * 2;
+  float* taps = win + a.rpairs * a.pitch * 2 + (a.alias ? 0 : 2 * a.rpairs * TX);  // per rank: khp row taps then kwp column taps
   const int tid = threadIdx.x;
   const int tap_stride = a.khp + a.kwp;
   const int nrows = 2 * a.rpairs;
@@ -262,32 +273,40 @@ __global__ __launch_bounds__(THREADS) void sep_conv_kernel(SepArgs a) {
       const float* tu = taps + r * tap_stride;
       const float* tv = tu + a.khp;
       // ---- row pass, two rows at once: hbuf[row][x] = sum_t tv[t] * win[row][x + t] -------------------------
-      for (int item = tid; item < a.rpairs * (TX / 8); item += THREADS) {
+      const int n_items = a.rpairs * (TX / 8);
+      for (int item0 = 0; item0 < n_items; item0 += THREADS) {  // (alias: one trip)
+        const int item = item0 + tid;
+        const bool has = item < n_items;
         const int rp = item / (TX / 8), x0 = (item % (TX / 8)) * 8;
-        const float* w = win + (rp * a.pitch + x0) * 2;
         v2f h[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) h[c] = v2f{0.f, 0.f};
-        for (int q = 0; q < a.kwp; q += 4) {
-          const float4 t4 = *reinterpret_cast<const float4*>(tv + q);
-          const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
-          v2f ww[12];
+        if (has) {
+          const float* w = win + (rp * a.pitch + x0) * 2;
+          for (int q = 0; q < a.kwp; q += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(tv + q);
+            const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+            v2f ww[12];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            const float4 two = *reinterpret_cast<const float4*>(w + (q + 2 * k) * 2);
-            ww[2 * k] = v2f{two.x, two.y};
-            ww[2 * k + 1] = v2f{two.z, two.w};
-          }
+            for (int k = 0; k < 6; ++k) {
+              const float4 two = *reinterpret_cast<const float4*>(w + (q + 2 * k) * 2);
+              ww[2 * k] = v2f{two.x, two.y};
+              ww[2 * k + 1] = v2f{two.z, two.w};
+            }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const v2f t2 = v2f{tt[e], tt[e]};
+            for (int e = 0; e < 4; ++e) {
+              const v2f t2 = v2f{tt[e], tt[e]};
 #pragma unroll
-            for (int c = 0; c < 8; ++c) h[c] = __builtin_elementwise_fma(t2, ww[c + e], h[c]);
+              for (int c = 0; c < 8; ++c) h[c] = __builtin_elementwise_fma(t2, ww[c + e], h[c]);
+            }
           }
         }
-        float* d0 = hbuf + (2 * rp) * TX + x0;
+        if (a.alias) __syncthreads();  // every item has read its part of the window: the results may overwrite it
+        if (has) {
+          float* d0 = hbuf + (2 * rp) * TX + x0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) d0[c] = h[c].x, d0[TX + c] = h[c].y;
+          for (int c = 0; c < 8; ++c) d0[c] = h[c].x, d0[TX + c] = h[c].y;
+        }
       }
       __syncthreads();
       // ---- column pass, two columns at once: acc[y][x] += sum_t tu[t] * hbuf[y + t][x] -----------------------
@@ -441,11 +460,16 @@ int sep_factorize(const float* psf, int kh, int kw, double tol, std::vector<doub
   return 0;
 }
 
+// Largest rank among the operator buffers built so far in this process (launch_sep: LDS aliasing needs rank 1)
+static std::atomic<int> g_sep_max_rank{0};
+
 // Host image of the operator buffer for a factorised PSF (see sep_conv_operator_floats).
 int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op) {
   std::vector<double> u, v;
   const int rank = sep_factorize(psf, kh, kw, tol, &u, &v);
   if (rank == 0) return 0;
+  for (int seen = g_sep_max_rank.load(); rank > seen && !g_sep_max_rank.compare_exchange_weak(seen, rank);) {
+  }
   op->assign(sep_conv_operator_floats(), 0.f);
   (*op)[0] = (float)rank;
   const size_t half = (op->size() - 4) / 2;
@@ -472,7 +496,11 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
   a.n_tiles = a.tiles_x * ((a.H + TY - 1) / TY);
   a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rpairs = g.rpairs, a.pitch = g.pitch;
   a.taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
-  size_t lds = ((size_t)2 * g.rpairs * (g.pitch + TX) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
+  // rank-1 operators only (every operator buffer of this process comes from sep_build_operator, which keeps the maximum)
+  // and at most one row-pass item per thread: the row-pass image may share the window's LDS -> 19 KB instead of 32 KB
+  // per block, a sixth block per CU for the fused forward + Poisson launch (JD_SEP_NO_ALIAS=1: testing)
+  a.alias = g_sep_max_rank.load() <= 1 && g.rpairs * (TX / 8) <= THREADS && !getenv("JD_SEP_NO_ALIAS") ? 1 : 0;
+  size_t lds = ((size_t)2 * g.rpairs * (g.pitch + (a.alias ? 0 : TX)) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
   if (const char* env = getenv(poisson ? "JD_SEP_FWD_MIN_LDS" : "JD_SEP_ADJ_MIN_LDS")) {  // tuning: caps the blocks per CU
     const size_t want = (size_t)atol(env);
     if (want > lds && want <= 160 * 1024) lds = want;

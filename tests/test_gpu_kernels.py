@@ -826,3 +826,57 @@ def test_prior_bands_of_a_sharded_prior_add_up_to_the_whole(marginalize):
         handle.prior_fwd_bwd(flux, stride, shifts, ref_v, 0.25, grad=g1, grad_coef=-0.7, patch_rows=rows, marginalize=marginalize)
     add_rolled_bands(g2, shifts, pieces, chunk, y_ranges)
     assert rel_linf(g2.cpu().numpy(), g1.cpu().numpy()) < 1e-6
+
+
+_ALIAS_SCRIPT = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from jolideco_amd import FluxComponents, NPredModels, SpatialFluxComponent
+from jolideco_amd.data import gaussian_kernel
+from jolideco_amd.ops import stirling_mean
+
+rs = np.random.RandomState(3)
+shape = (200, 328)
+data = {"counts": rs.poisson(3.0, size=shape).astype(np.float32), "psf": gaussian_kernel(2.0, (17, 17)).astype(np.float32),
+        "exposure": rs.uniform(0.5, 1.5, size=shape).astype(np.float32),
+        "background": rs.uniform(0.2, 1.0, size=shape).astype(np.float32)}
+flux = torch.from_numpy(rs.gamma(3.0, size=shape).astype(np.float32)).cuda()
+comps = FluxComponents()
+comps["flux"] = SpatialFluxComponent.from_numpy(flux=flux.cpu().numpy())
+models = NPredModels.from_dataset_numpy(dataset=data, components=comps, device="cuda:0")
+assert models.plan.method == "separable"
+counts = torch.from_numpy(data["counts"]).cuda()
+out = {}
+for mode in ("alias", "plain"):
+    if mode == "plain":
+        os.environ["JD_SEP_NO_ALIAS"] = "1"
+    loss, grad, npred = torch.zeros(1, device="cuda"), torch.zeros_like(flux), torch.empty_like(flux)
+    models.fwd_bwd([flux], counts, stirling_mean(data["counts"]), loss, grads=[grad], npred_out=npred)
+    grad2 = torch.zeros_like(flux)
+    models.fwd_bwd([flux], counts, stirling_mean(data["counts"]), loss, grads=[grad2])  # fused epilogue, no npred
+    conv = models.plan.conv_same(flux, models["flux"].exposure[0, 0], models["flux"].khat)
+    torch.cuda.synchronize()
+    out[mode] = [t.cpu().numpy() for t in (loss, grad, npred, grad2, conv)]
+for a, b in zip(out["alias"], out["plain"]):
+    assert np.array_equal(a, b)
+assert np.abs(out["alias"][1]).max() > 0
+print("ALIAS-OK")
+"""
+
+
+def test_separable_convolution_lds_aliasing_changes_no_bit(tmp_path):
+    """With rank-1 operators only, the row-pass image of `sep_conv_kernel` shares the LDS of the input window (a sixth
+    block per CU for the fused forward + Poisson launch); JD_SEP_NO_ALIAS=1 keeps them apart.  Same arithmetic, same
+    bits: loss, gradient, predicted counts, plain convolution.  Runs in a fresh process -- the library enables the
+    aliasing only while no operator of rank > 1 has been built in the process."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    script = tmp_path / "alias_check.py"
+    script.write_text(_ALIAS_SCRIPT)
+    repo = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("JD_SEP_NO_ALIAS", "JOLIDECO_CONV_METHOD")}
+    done = subprocess.run([sys.executable, str(script), str(repo)], capture_output=True, text=True, timeout=600, env=env)
+    assert done.returncode == 0 and "ALIAS-OK" in done.stdout, done.stderr[-2000:]
