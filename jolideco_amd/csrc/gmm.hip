@@ -390,6 +390,7 @@ struct GmmBucketArgs {
   int* counts;    // K      bin totals (written by the binscan kernel)
   int* offsets;   // K + 1  exclusive scan of the padded counts; offsets[K] = total slots
   int32_t* order; // slot -> global patch index; the slots offsets[k] + counts[k] .. offsets[k + 1] are padding (undefined)
+  int32_t* order_n;  // nullable (record sort): slot -> patch of the record, so that the exact kernel needs one hop less
   float* gpatch;  // rows of filtered patches (argmax < 0) are zeroed here (nullable)
   // screened forward pass only (seg_cnt != nullptr): the elements are candidate records in per-wave segments of
   // seg_cap slots of which the first seg_cnt[segment] are used; a record counts only if its upper bound still
@@ -530,7 +531,9 @@ __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a
       const int n = base + i;
       const int k = bucket_key(a, n);
       if (k >= 0) {
-        a.order[atomicAdd(&hist[k], 1)] = n;
+        const int pos = atomicAdd(&hist[k], 1);
+        a.order[pos] = n;
+        if (a.order_n) a.order_n[pos] = a.rec_n[n];
       } else if (k == -1 && a.gpatch) {  // filtered patch (patches/core.py:215-216): no gradient
         float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
         for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1293,8 +1296,7 @@ struct GmmExactArgs {
   const float* afrag;
   const float* mfrag;
   const float* const_k;
-  const int32_t* rec_n;
-  const int32_t* order;   // bucket slot -> record slot (only the first counts[k] slots of a bucket are written)
+  const int32_t* order_n; // bucket slot -> patch of the record (only the first counts[k] slots of a bucket are written)
   const int* counts;      // K
   const int* offsets;     // K + 1, offsets[K] = total (padded) bucket slots
   const int* flag;
@@ -1361,7 +1363,7 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
     {
       const int q = lane >> 1, hh = lane & 1;
       const bool have = q < nvalid;
-      const int n = have ? a.rec_n[a.order[32 * grp + q]] : 0;
+      const int n = have ? a.order_n[32 * grp + q] : 0;
       const int py = n / a.nPx, px = n - py * a.nPx;
       const int x0 = px * a.stride + 4 * hh - a.shift_x;  // in (-W, W)
       const bool straight = x0 >= 0 && x0 + 3 < a.W;
@@ -1387,7 +1389,7 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
     for (int nb = 0; nb < 2; ++nb) {
       const int q = 16 * nb + n16;
       valid[nb] = q < nvalid;
-      n[nb] = valid[nb] ? a.rec_n[a.order[32 * grp + q]] : 0;
+      n[nb] = valid[nb] ? a.order_n[32 * grp + q] : 0;
 #pragma unroll
       for (int s4 = 0; s4 < 16; ++s4) x[nb][s4] = valid[nb] ? st[q * EXACT_PITCH + 4 * s4 + g] : 0.f;
       const float mean = patch_mean_groups(x[nb]);
@@ -1682,6 +1684,8 @@ struct jd_gmm {
   size_t rec_cap = 0;
   int32_t* rec_order = nullptr;
   size_t rec_order_cap = 0;
+  int32_t* rec_order_n = nullptr;  // bucket slot -> patch of the record
+  size_t rec_order_n_cap = 0;
   int* seg_cnt = nullptr;
   size_t seg_cnt_cap = 0;
   int* blk_counts = nullptr;  // per-block bin counts of the bucket sort
@@ -1874,6 +1878,7 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->xok) (void)hipFree(g->xok);
   if (g->rec) (void)hipFree(g->rec);
   if (g->rec_order) (void)hipFree(g->rec_order);
+  if (g->rec_order_n) (void)hipFree(g->rec_order_n);
   if (g->seg_cnt) (void)hipFree(g->seg_cnt);
   if (g->korder) (void)hipFree(g->korder);
   if (g->blk_counts) (void)hipFree(g->blk_counts);
@@ -1968,6 +1973,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   if ((rc = grow(&g->lfinal, &g->lfinal_cap, (size_t)a.n_end))) return rc;
   if ((rc = grow(&g->rec, &g->rec_cap, 3 * slots))) return rc;
   if ((rc = grow(&g->rec_order, &g->rec_order_cap, bucket_slots))) return rc;
+  if ((rc = grow(&g->rec_order_n, &g->rec_order_n_cap, bucket_slots))) return rc;
   if ((rc = grow(&g->seg_cnt, &g->seg_cnt_cap, n_seg))) return rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
   int32_t* rec_n = g->rec;
@@ -2031,7 +2037,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   GmmBucketArgs bk{};
   bk.argmax = rec_k, bk.n_begin = 0, bk.n_end = (int)slots, bk.K = g->K;
   bk.counts = g->screen_ctl + 1, bk.offsets = g->screen_ctl + 1 + 2 * g->K;
-  bk.order = g->rec_order, bk.gpatch = nullptr;
+  bk.order = g->rec_order, bk.order_n = g->rec_order_n, bk.gpatch = nullptr;
   bk.seg_cnt = g->seg_cnt, bk.seg_cap = SCREEN_CAP, bk.rec_n = rec_n, bk.rec_ub = rec_ub, bk.lfinal = g->lfinal;
   bk.chunk = SCREEN_CAP;  // one record segment per chunk
   bk.korder = g->K <= KORDER_MAX_K ? g->korder : nullptr;
@@ -2049,7 +2055,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   GmmExactArgs ex{};
   ex.flux = a.flux, ex.afrag = g->afrag, ex.mfrag = g->mfrag, ex.const_k = g->const_k;
-  ex.rec_n = rec_n, ex.order = g->rec_order, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag, ex.gen = g->gen;
+  ex.order_n = g->rec_order_n, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag, ex.gen = g->gen;
   ex.gfrag = g->gfrag, ex.grec = fused ? g->grec : nullptr;
   ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
   ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
