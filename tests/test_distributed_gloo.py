@@ -83,11 +83,49 @@ def _worker(rank, world_size, port, out_dir):
     prior_part = _prior_rows_value_and_grad(flux, gmm, 4, shifts, rows, cpu_ref) * scale
     comm[H * W + n_d] = prior_part.detach()
     objective = objective - beta * prior_part
-    (grad_flux,) = torch.autograd.grad(objective, flux)
+    (grad_flux,) = torch.autograd.grad(objective, flux, retain_graph=True)
     comm[: H * W] = grad_flux.reshape(-1)
 
-    ctx.all_reduce_sum(comm)  # the ONE collective of the step
+    # --- the overlapped schedule of FitSession.epoch (JOLIDECO_DIST_OVERLAP=1, default): the all-reduce of the likelihood
+    # part is started, the prior's gradient travels as the band of rows its patch rows cover (rolled frame) in ONE
+    # all-gather, every rank adds the bands in rank order.  Same collectives and geometry as the product path
+    # (DistContext.all_reduce_sum_async / all_gather_flat, ops.band_rows); the HIP kernels are replaced by the oracle.
+    from jolideco_amd.ops import band_rows
+
+    like = torch.zeros(H * W + n_d + 1)
+    like_obj = flux.sum() * 0.0
+    for name in local_names:
+        loss = cpu_ref.DatasetRef.from_numpy(datasets[name], ["flux"]).loss((flux,))
+        like[H * W + names.index(name)] = loss.detach()
+        like_obj = like_obj + loss
+    (g_like,) = torch.autograd.grad(like_obj, flux, allow_unused=True)
+    if g_like is not None:
+        like[: H * W] = g_like.reshape(-1)
+    pending = ctx.all_reduce_sum_async(like)
+    (g_prior,) = torch.autograd.grad(-beta * prior_part, flux, allow_unused=True)
+    g_rolled = torch.roll(torch.zeros(H, W) if g_prior is None else g_prior[0, 0], shifts=shifts, dims=(0, 1))
+    y_ranges = [band_rows(DistContext(r, world_size).shard_range(n_rows), 4, H) for r in range(world_size)]
+    y0, y1 = y_ranges[rank]
+    outside = g_rolled.clone()
+    outside[y0:y1] = 0
+    assert float(outside.abs().max()) == 0.0  # the shard's gradient is confined to its band
+    chunk = max(b - a for a, b in y_ranges) * W + 1
+    piece = torch.zeros(chunk)
+    piece[: (y1 - y0) * W] = g_rolled[y0:y1].reshape(-1)
+    piece[-1] = prior_part.detach()
+    pieces = torch.zeros(chunk * world_size)
+    ctx.all_gather_flat(pieces, piece)
+    pending.wait()
+    rolled_sum = torch.zeros(H, W)
+    for r, (a0, a1) in enumerate(y_ranges):  # rank order, identical on every rank
+        rolled_sum[a0:a1] += pieces[r * chunk : r * chunk + (a1 - a0) * W].reshape(a1 - a0, W)
+    overlapped = like.clone()
+    overlapped[: H * W] += torch.roll(rolled_sum, shifts=(-shifts[0], -shifts[1]), dims=(0, 1)).reshape(-1)
+    overlapped[H * W + n_d] = pieces.view(world_size, chunk)[:, -1].sum()
+
+    ctx.all_reduce_sum(comm)  # the ONE collective of the step (JOLIDECO_DIST_OVERLAP=0)
     ctx.barrier()
+    assert float((overlapped - comm).abs().max()) <= 2e-6 * float(comm.abs().max())  # the two schedules agree
 
     # identical Adam update on every rank (chain rule d flux / d theta = flux)
     opt = torch.optim.Adam([theta], lr=0.1)
