@@ -474,11 +474,13 @@ __global__ __launch_bounds__(256) void gmm_bucket_binscan_kernel(GmmBucketArgs a
   if (threadIdx.x == 255) a.counts[k] = part[cur][255];
 }
 
-__global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
-  // exclusive scan of the padded bucket sizes: thread t owns a contiguous segment of bins,
-  // the 256 segment sums are scanned in LDS (Hillis-Steele)
+// Exclusive scan of the padded bucket sizes, by EVERY block of the scatter kernel for itself (K bin totals: a few hundred
+// loads and one LDS scan -- cheaper than the 6.5 us a dependent single-block launch costs); block 0 also publishes the
+// offsets for the kernels that follow, raises the overflow flag and ranks the bins for the next screen.
+// off[k] (LDS, K + 1 entries) <- offsets; thread t owns a contiguous segment of bins, the 256 segment sums are scanned
+// in LDS (Hillis-Steele).
+__device__ __forceinline__ void bucket_offsets(const GmmBucketArgs& a, int* off, int* cnt) {
   __shared__ int part[2][256];
-  __shared__ int cnt[BUCKET_MAX_K];  // the ranking below reads every total K times
   for (int k = threadIdx.x; k < a.K; k += 256) cnt[k] = a.counts[k];
   __syncthreads();
   const int seg = (a.K + 255) / 256;
@@ -488,22 +490,23 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
   int cur = 0;
   part[0][threadIdx.x] = local;
   __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
+  for (int o = 1; o < 256; o <<= 1) {
     int v = part[cur][threadIdx.x];
-    if ((int)threadIdx.x >= off) v += part[cur][threadIdx.x - off];
+    if ((int)threadIdx.x >= o) v += part[cur][threadIdx.x - o];
     part[cur ^ 1][threadIdx.x] = v;
     cur ^= 1;
     __syncthreads();
   }
   int total = part[cur][threadIdx.x] - local;  // exclusive prefix of this thread's segment
   for (int k = k0; k < k0 + seg && k < a.K; ++k) {
-    a.offsets[k] = total;
+    off[k] = total;
     total += (cnt[k] + 31) & ~31;
   }
-  if (threadIdx.x == 255) {
-    a.offsets[a.K] = part[cur][255];
-    if (a.flag && part[cur][255] > a.slot_cap) __hip_atomic_store(a.flag, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 255) off[a.K] = part[cur][255];
+  __syncthreads();
+  if (blockIdx.x != 0) return;
+  for (int k = threadIdx.x; k <= a.K; k += 256) a.offsets[k] = off[k];
+  if (threadIdx.x == 0 && a.flag && off[a.K] > a.slot_cap) __hip_atomic_store(a.flag, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (a.korder) {  // bins by size, largest first (ties: lowest index): the visiting order of the next screen
     for (int k = threadIdx.x; k < a.K; k += 256) {
       const int ck = cnt[k];
@@ -518,11 +521,13 @@ __global__ __launch_bounds__(256) void gmm_bucket_scan_kernel(GmmBucketArgs a) {
 }
 
 __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a) {
-  extern __shared__ int hist[];  // [0, K): the block's next free slot inside each bucket
+  extern __shared__ int hist[];  // [0, K): the block's next free slot inside each bucket | [K, 2K + 1): offsets | [.., 3K + 1): totals
+  int* off = hist + a.K;
+  bucket_offsets(a, off, off + a.K + 1);
   const int n_chunks = (a.n_end - a.n_begin + a.chunk - 1) / a.chunk;
   // the block's first slot inside every bucket: bucket offset + the counts of the blocks before it (binscan); the
   // walk over the chunks is the count kernel's, so the numbers match
-  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = a.offsets[k] + a.blk_counts[(size_t)k * gridDim.x + blockIdx.x];
+  for (int k = threadIdx.x; k < a.K; k += 256) hist[k] = off[k] + a.blk_counts[(size_t)k * gridDim.x + blockIdx.x];
   __syncthreads();
   // place the elements (the order inside a bucket does not influence any result)
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
@@ -2048,8 +2053,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     ProfScope stage(JD_KERNEL_GMM_SORT, s);
     gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
     gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
-    gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
-    gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+    gmm_bucket_scatter_kernel<<<chunks, 256, 3 * hist_bytes + sizeof(int), s>>>(bk);
   }
   JD_LAUNCH_CHECK();
 
@@ -2209,8 +2213,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     ProfScope prof(JD_KERNEL_GMM_BWD, s);
     gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
     gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
-    gmm_bucket_scan_kernel<<<1, 256, 0, s>>>(bk);
-    gmm_bucket_scatter_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+    gmm_bucket_scatter_kernel<<<chunks, 256, 3 * hist_bytes + sizeof(int), s>>>(bk);
     GmmBwdArgs b{};
     b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
     b.offsets = bk.offsets, b.counts = bk.counts, b.gpatch = g->gpatch, b.K = g->K;
