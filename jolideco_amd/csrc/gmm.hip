@@ -1442,6 +1442,12 @@ struct GmmBestArgs {
   int32_t* argmax_fb;
   const int32_t* rec_k;
   const int32_t* rec_order;
+  // the block that finishes last turns the partial sums into the prior value (what finalize_sum_kernel would do in a
+  // launch of its own, same summation order): value_out = [value_out +] scale * sum(partials)
+  int* ticket;  // zero between launches
+  double scale;
+  float* value_out;
+  int accumulate;
 };
 
 constexpr int BEST_CHUNK = 1024;
@@ -1473,7 +1479,30 @@ __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
-  if (threadIdx.x == 0) a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  __shared__ int last;
+  if (threadIdx.x == 0) {
+    a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();  // the partial sum is visible device-wide before the ticket is drawn
+    last = atomicAdd(a.ticket, 1) == (int)gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // finalize_sum_kernel's order: thread t adds partials t, t + 256, ..., then the fixed block reduction
+  __shared__ double smem[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+    const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(a.partials + i),
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // not through this CU's L1
+    acc += __builtin_bit_cast(double, bits);
+  }
+  const double total = block_sum<256>(acc, smem);
+  if (threadIdx.x == 0) {
+    double v = a.scale * total;
+    if (a.accumulate) v += (double)a.value_out[0];
+    a.value_out[0] = (float)v;
+    *a.ticket = 0;
+  }
 }
 
 struct GmmGatherArgs {
@@ -1844,8 +1873,8 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
         hipMemcpy(g->afrag16, a16.data(), a16.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
         (rc = upload(&g->efro_k, efro.data(), efro.size())) || (rc = upload(&g->sk2_k, sk2.data(), sk2.size())) ||
         (rc = upload(&g->mnorm_k, mnorm.data(), mnorm.size())) ||
-        hipMalloc(&g->screen_ctl, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess ||
-        hipMemset(g->screen_ctl, 0, (size_t)(3 * K + 2) * sizeof(int)) != hipSuccess ||
+        hipMalloc(&g->screen_ctl, (size_t)(3 * K + 3) * sizeof(int)) != hipSuccess ||
+        hipMemset(g->screen_ctl, 0, (size_t)(3 * K + 3) * sizeof(int)) != hipSuccess ||
         hipMalloc(&g->korder, (size_t)K * sizeof(int)) != hipSuccess) {
       jd_gmm_destroy(g);
       return fail(JD_ERR_ALLOC, "jd_gmm_create: allocation of the screening operands failed");
@@ -1959,7 +1988,7 @@ static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, in
 // fused: the exact kernel also writes the gradient row of every surviving record and gmm_best_kernel the winning row
 // of every patch (g->grec, g->winner); after a fallback the components are in fallback_argmax instead.
 static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials, bool fused,
-                            int32_t* fallback_argmax) {
+                            int32_t* fallback_argmax, double value_scale, float* value_out, int accumulate_value) {
   const long n = a.n_end - a.n_begin;
   // every wave its own 128 patches and all components, unless that leaves CUs without a block: then the four waves of
   // a block share 128 patches and split the components (see gmm_screen_kernel)
@@ -2087,6 +2116,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   be.best = g->best, be.n_begin = a.n_begin, be.n_end = a.n_end, be.argmax_out = a.argmax_out, be.partials = g->partials;
   be.flag = flag, be.gen = g->gen, be.winner = fused ? g->winner : nullptr, be.argmax_fb = fused ? fallback_argmax : nullptr;
   be.rec_k = rec_k, be.rec_order = g->rec_order;
+  be.ticket = g->screen_ctl + 3 * g->K + 2, be.scale = value_scale, be.value_out = value_out, be.accumulate = accumulate_value;
   const unsigned best_blocks = (unsigned)((n + BEST_CHUNK - 1) / BEST_CHUNK);
   gmm_best_kernel<<<best_blocks, 256, 0, s>>>(be);
   JD_LAUNCH_CHECK();
@@ -2154,11 +2184,12 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   if (marginalize)
     rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
   else if (screened)
-    rc = screened_forward(g, a, s, &n_waves, fused, fused ? g->argmax : nullptr);
+    rc = screened_forward(g, a, s, &n_waves, fused, fused ? g->argmax : nullptr, (double)value_scale, value_out, accumulate_value);
   else
     rc = launch_fwd<MODE_MAX>(a, g->triangular, g->n_cu, s, &n_waves);
   if (rc) return rc;
-  if ((rc = launch_finalize_sum(g->partials, n_waves, (double)value_scale, 0.0, value_out, accumulate_value, s)))
+  // (screened path: the last block of gmm_best_kernel has written the value already)
+  if (!screened && (rc = launch_finalize_sum(g->partials, n_waves, (double)value_scale, 0.0, value_out, accumulate_value, s)))
     return rc;
   if (!grad_flux_accum) return JD_OK;
 
