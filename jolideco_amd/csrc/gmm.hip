@@ -681,15 +681,12 @@ struct GmmBwdFallbackArgs {
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
 };
 
+// the groups grp_begin, grp_begin + grp_step, ... < grp_end of 32 patches (group 0 starts at a.n_begin), one wave each
 template <bool TRI>
-__global__ __launch_bounds__(256) void gmm_bwd_fallback_kernel(GmmBwdFallbackArgs a) {
-  if (*a.flag != a.gen) return;
+__device__ __forceinline__ void bwd_fallback_groups(const GmmBwdFallbackArgs& a, int grp_begin, int grp_end, int grp_step) {
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, n16 = lane & 15;
-  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n_waves = gridDim.x * 4;
-  const int n_groups = (a.n_end - a.n_begin + 31) >> 5;
-  for (int grp = wave_global; grp < n_groups; grp += n_waves) {
+  for (int grp = grp_begin; grp < grp_end; grp += grp_step) {
     int n[2], kk[2];
     bool pending[2];
     float x[2][16];
@@ -1435,7 +1432,7 @@ struct GmmBestArgs {
   double* partials;     // one per block
   // fused backward pass (winner != nullptr): unless the pass fell back (*flag == gen), the low word of a key is the
   // bucket slot of the winning record -> winner[n] (-1: no gradient); the component is looked up only if asked for.
-  // After a fallback the keys carry components (dense kernel): they go to argmax_fb for gmm_bwd_fallback_kernel.
+  // After a fallback the keys carry components (dense kernel): they go to argmax_fb for the fallback backward pass of this kernel (fb).
   const int* flag;
   int gen;
   int32_t* winner;
@@ -1448,6 +1445,10 @@ struct GmmBestArgs {
   double scale;
   float* value_out;
   int accumulate;
+  // fused backward pass after a fallback (fb.gpatch != nullptr and *flag == gen): every block produces the gradient
+  // rows of its own 1024 patches from the components it has just decoded -- the work of a kernel of its own that in the
+  // normal case was a 4.6 us launch returning at once
+  GmmBwdFallbackArgs fb;
 };
 
 constexpr int BEST_CHUNK = 1024;
@@ -1479,6 +1480,13 @@ __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
   local = wave_sum(local);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
+  if (a.fb.gpatch && !slots && a.winner) {  // (block-uniform: the pass fell back to the dense kernel)
+    __syncthreads();                        // this block's argmax_fb entries are written
+    const int grp0 = blockIdx.x * (BEST_CHUNK / 32);
+    const int n_groups = (a.n_end - a.n_begin + 31) >> 5;
+    const int grp1 = grp0 + BEST_CHUNK / 32 < n_groups ? grp0 + BEST_CHUNK / 32 : n_groups;
+    bwd_fallback_groups<true>(a.fb, grp0 + (threadIdx.x >> 6), grp1, 4);
+  }
   __shared__ int last;
   if (threadIdx.x == 0) {
     a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -2117,6 +2125,13 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   be.flag = flag, be.gen = g->gen, be.winner = fused ? g->winner : nullptr, be.argmax_fb = fused ? fallback_argmax : nullptr;
   be.rec_k = rec_k, be.rec_order = g->rec_order;
   be.ticket = g->screen_ctl + 3 * g->K + 2, be.scale = value_scale, be.value_out = value_out, be.accumulate = accumulate_value;
+  if (fused) {
+    GmmBwdFallbackArgs& b = be.fb;
+    b.flux = a.flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = fallback_argmax, b.gpatch = g->gpatch;
+    b.flag = flag, b.gen = g->gen, b.K = g->K;
+    b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x;
+    b.n_begin = a.n_begin, b.n_end = a.n_end;
+  }
   const unsigned best_blocks = (unsigned)((n + BEST_CHUNK - 1) / BEST_CHUNK);
   gmm_best_kernel<<<best_blocks, 256, 0, s>>>(be);
   JD_LAUNCH_CHECK();
@@ -2180,6 +2195,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     if ((rc = grow(&g->vpatch, &g->vpatch_cap, (size_t)nPy * nPx))) return rc;
     a.value_patch = g->vpatch;
   }
+  if (grad_flux_accum && (rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;  // (the fused fallback writes it)
   int n_waves = 0;
   if (marginalize)
     rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
@@ -2212,19 +2228,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     }
     JD_LAUNCH_CHECK();
   } else if (fused) {
-    // the rows are in g->grec already; only after a fallback (device flag) this kernel has work
-    GmmBwdFallbackArgs b{};
-    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = g->argmax, b.gpatch = g->gpatch;
-    b.flag = g->screen_ctl, b.gen = g->gen, b.K = g->K;
-    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
-    b.n_begin = n_begin, b.n_end = n_end;
-    long blocks = ((n + 31) / 32 + 3) / 4;
-    if (blocks > (long)g->n_cu * 2) blocks = (long)g->n_cu * 2;
-    {
-      ProfScope prof(JD_KERNEL_GMM_BWD, s);
-      gmm_bwd_fallback_kernel<true><<<(unsigned)blocks, 256, 0, s>>>(b);
-    }
-    JD_LAUNCH_CHECK();
+    // the rows are in g->grec already (after a fallback: in g->gpatch, written by gmm_best_kernel's blocks)
   } else {
   const size_t slots_cap = (size_t)n + 32 * (size_t)g->K;
   if ((rc = grow(&g->order, &g->order_cap, slots_cap))) return rc;
