@@ -32,6 +32,9 @@ namespace {
 #ifndef JD_SEP_WAVES_POISSON
 #define JD_SEP_WAVES_POISSON 6  // waves per SIMD the fused forward + Poisson kernel is compiled for (80 registers)
 #endif
+#ifndef JD_SEP_WAVES_MULTI
+#define JD_SEP_WAVES_MULTI 4    // the multi-component variant: 128 registers (132 uncapped = three waves; 96 spill badly)
+#endif
 #ifndef JD_SEP_WAVES_OTHER
 #define JD_SEP_WAVES_OTHER 1    // (no register cap for the other variants)
 #endif
@@ -113,7 +116,7 @@ struct SepArgs {
 // MULTI (POISSON batches only): more than one flux component per dataset; a compile-time switch so that the common
 // one-component launch carries none of the component loop.
 template <bool VEC, bool IN_SCALE, bool POISSON, bool MULTI = false>
-__global__ __launch_bounds__(THREADS, POISSON && !MULTI ? JD_SEP_WAVES_POISSON : JD_SEP_WAVES_OTHER) void sep_conv_kernel(SepArgs a) {
+__global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD_SEP_WAVES_POISSON) : JD_SEP_WAVES_OTHER) void sep_conv_kernel(SepArgs a) {
   extern __shared__ float4 lds4[];
   float* win = reinterpret_cast<float*>(lds4);
   // a.alias: the row-pass image overwrites the window (rank-1 operators, at most one row-pass item per thread): the
