@@ -1575,7 +1575,12 @@ __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
 // contributions from there in the order of gmm_gather_kernel (patch rows ascending, then patch columns: the same bits).
 // The per-pixel kernel reads 4 bytes from each of up to four different rows per thread -- 4x the memory instructions,
 // none of them a full line; at 4096^2, where the rows no longer sit in the Infinity Cache, it took 5x the 2048^2 time.
-constexpr int GATHER_T = 32, GATHER_MAX_P = 10;
+#ifndef JD_GATHER_MAX_P
+#define JD_GATHER_MAX_P 9
+#endif
+// patches per tile and dimension: the tile origin is a multiple of 32 above y_begin = row_begin * stride, so for stride
+// 4 (and 8) it is aligned with the patch grid: 9 (4); strides 5, 6, 7 have at most floor(38 / s) + 1 = 8, 7, 6
+constexpr int GATHER_T = 32, GATHER_MAX_P = JD_GATHER_MAX_P;
 
 __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
   __shared__ __attribute__((aligned(16))) float rows[GATHER_MAX_P * GATHER_MAX_P][D];
@@ -1587,7 +1592,9 @@ __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
   if (py0 < a.row_begin) py0 = a.row_begin;
   if (py1 > a.row_end - 1) py1 = a.row_end - 1;
   if (px1 > a.nPx - 1) px1 = a.nPx - 1;
-  const int npx = px1 - px0 + 1, npy = py1 - py0 + 1;
+  int npx = px1 - px0 + 1, npy = py1 - py0 + 1;
+  if (npx > GATHER_MAX_P) npx = GATHER_MAX_P, px1 = px0 + npx - 1;  // (cannot happen, see GATHER_MAX_P: keeps LDS in bounds)
+  if (npy > GATHER_MAX_P) npy = GATHER_MAX_P, py1 = py0 + npy - 1;
   if (npx <= 0 || npy <= 0) {  // no patch of the shard touches this tile
     if (a.band) {
       const int Y = Y0 + (tid >> 3);
