@@ -10,7 +10,8 @@ varying PSF / exposure / background, one flux component with a GMM patch prior (
 4, K = 128 components), fp32, JOINT fit: one "step" = one optimizer iteration on
 sum_d L_d - beta * logprior = the forward models of all observations (PSF convolution, clip, + background) with
 the fused Poisson NLL + gradient pass, the adjoint convolutions, the GMM prior value + gradient, (N > 1) ONE RCCL
-all-reduce of the flux gradient, the fused chain rule + Adam update.  The convolution method is "auto": the
+all-reduce of the likelihood gradient (started before the prior, overlapped with it) and one all-gather of the compact
+prior bands, the fused chain rule + Adam update.  The convolution method is "auto": the
 benchmark's Gaussian PSFs are rank 1, so the headline runs the separable kernel (forward launch = convolution +
 Poisson pass of all local observations); the same fit with the PSFs as general 17x17 kernels (MFMA direct
 convolution, `general_psf`) and through rocFFT (`fft_psf`, the path the north star names) is timed beside it.
@@ -375,7 +376,10 @@ def main():
             "workload": f"{args.config}: {H}x{W}, {n_obs} observations (17x17 Gaussian PSFs, varying exposure/"
                         f"background), GMM patch prior 8x8 stride 4 K={K}, joint fit, Adam lr 0.1",
             "global_observations": n_obs,
-            "sharding": f"observations round-robin over {world} rank(s), prior by patch rows, 1 all-reduce/step"
+            "sharding": (f"observations round-robin over {world} rank(s), prior by patch rows; per step 1 all-reduce of the "
+                         "likelihood gradient started before the prior and overlapped with it + 1 all-gather of the prior "
+                         "bands" if os.environ.get("JOLIDECO_DIST_OVERLAP", "1") != "0" else
+                         f"observations round-robin over {world} rank(s), prior by patch rows, 1 all-reduce/step")
             if world > 1 else "single GPU",
         },
         # numerics of the run itself: the loss scalars of the last timed step [dataset losses | log-priors] -- the same
