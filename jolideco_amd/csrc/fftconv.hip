@@ -490,6 +490,7 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
   SepBatchTable table{};
   for (int d = 0; d < n_datasets; ++d) table.bkg[d] = background[d], table.cnt[d] = counts[d];
   for (int i = 0; i < n_datasets * n_comp; ++i) table.scale[i] = exposure[i], table.op[i] = khat[i], table.g[i] = p->gbatch[i];
+  for (int d = 0; d < n_datasets; ++d) table.loss_out[d] = loss_out[d], table.loss_offset[d] = stirling_mean[d];
   // a session passes the same pointers every step: look the table up by content, upload only a new one
   int slot = -1, victim = 0;
   for (int i = 0; i < jd_conv_plan::N_TABLES; ++i) {
@@ -510,11 +511,15 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
   int rc = launch_sep_conv_poisson_batch(n_datasets, n_comp, flux, table, table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                                          p->partials_batch, eps, (float)(1.0 / n_pix), grad_flux ? 1 : 0, s);
   if (rc) return rc;
-  if ((rc = launch_finalize_rows(p->partials_batch, tiles, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s))) return rc;
+  // with a gradient the losses are finalised by the first blocks of the first adjoint launch (one dependent launch less
+  // per step); its grid has at least 8 blocks whatever the image size
+  const bool fold = grad_flux && n_datasets <= 8;
+  if (!fold && (rc = launch_finalize_rows(p->partials_batch, tiles, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s))) return rc;
   if (!grad_flux) return JD_OK;
   for (int c = 0; c < n_comp; ++c)
     if ((rc = launch_sep_conv_adjoint_batch(n_datasets, n_comp, c, table, table_dev, grad_flux[c], p->H, p->W, p->kh,
-                                            p->kw, p->oy, p->ox, grad_scale, accumulate, s)))
+                                            p->kw, p->oy, p->ox, grad_scale, accumulate, s,
+                                            fold && c == 0 ? p->partials_batch : nullptr, 1.0 / n_pix)))
       return rc;
   return JD_OK;
 }

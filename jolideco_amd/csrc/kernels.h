@@ -72,13 +72,19 @@ struct SepBatchTable {
   float* g[SEP_MAX_BATCH * SEP_BATCH_MAX_COMP];             // masked d loss / d conv_(d, c) work image
   const float* bkg[SEP_MAX_BATCH];
   const float* cnt[SEP_MAX_BATCH];
+  // loss of dataset d = loss_scale * sum(partials of d) + loss_offset[d] -> loss_out[d]: summed by block d of the first
+  // adjoint launch of the step (the partial sums come from the forward launch before it), which saves the launch of a
+  // finalize kernel; forward-only calls use launch_finalize_rows
+  float* loss_out[SEP_MAX_BATCH];
+  float loss_offset[SEP_MAX_BATCH];
 };
 int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
                                   const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
                                   double* partials, float eps, float inv_n, int write_grad, hipStream_t stream);
+// fin_partials != nullptr: block d < n also turns the n_tiles partial sums of dataset d into its loss (see SepBatchTable)
 int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
                                   float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
-                                  hipStream_t stream);
+                                  hipStream_t stream, const double* fin_partials = nullptr, double fin_scale = 0.0);
 // out[d][0] = scale * sum(partials[d * n .. d * n + n - 1]) + offset[d]   (one block per output, fixed order)
 int launch_finalize_rows(const double* partials, int n, int n_out, double scale, const float* offset_host,
                          float* const* out, hipStream_t stream);

@@ -90,6 +90,10 @@ struct SepArgs {
   // component whose gradient an adjoint launch produces
   int n_comp, comp;
   int alias;       // the row-pass image shares the window's LDS (see the kernel)
+  // adjoint batch, first component: block d < n_batch also finalises the loss of dataset d from the forward launch's
+  // partial sums (fin_partials[d * n_tiles + tile]) -- finalize_rows_kernel's summation order, no launch of its own
+  const double* fin_partials;
+  double fin_scale;
   int interleave;  // POISSON batches: the datasets of a tile are neighbours in the launch order (else dataset-major)
   // POISSON batches: the flux images of the components.  Kernel arguments, not table entries: a fit alternates between
   // two flux buffers, and a table that changes every step would be re-uploaded (synchronously) every step.  Read with
@@ -140,6 +144,15 @@ __global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD
       dsel = in_xcd / per_xcd, t_in_xcd = in_xcd % per_xcd;  // (tuning: dataset-major order)
   }
   const int tile = (blockIdx.x % 8) * per_xcd + t_in_xcd;
+  if (!POISSON && a.fin_partials && (int)blockIdx.x < a.n_batch) {  // (block-uniform)
+    __shared__ double fin_red[THREADS / 64];
+    const double* row = a.fin_partials + (size_t)blockIdx.x * a.n_tiles;
+    double acc = 0.0;
+    for (int i = tid; i < a.n_tiles; i += THREADS) acc += row[i];
+    const double total = block_sum<THREADS>(acc, fin_red);
+    if (tid == 0) a.table->loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.table->loss_offset[blockIdx.x]);
+    __syncthreads();
+  }
   if (tile >= a.n_tiles) return;
   const int Y0 = (tile / a.tiles_x) * TY, X0 = (tile % a.tiles_x) * TX;
   const int gy0 = Y0 + a.oy0, gx0 = X0 + a.ox0;
@@ -606,13 +619,14 @@ int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, c
 // are added in order in registers (bit-identical to n accumulate launches), the gradient image is read and written once.
 int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
                                   float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, const double* fin_partials, double fin_scale) {
   int rc = check_batch(n, n_comp);
   if (rc) return rc;
   if (comp < 0 || comp >= n_comp) return fail(JD_ERR_INVALID, "separable batch: component %d not in [0, %d)", comp, n_comp);
   SepArgs a{};
   a.out = grad, a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate, a.n_batch = n, a.table = table_dev;
   a.n_comp = n_comp, a.comp = comp;
+  a.fin_partials = fin_partials, a.fin_scale = fin_scale;
   a.in = table.g[comp], a.op = table.op[comp];
   return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_aligned(table, n, n_comp));
 }
