@@ -335,12 +335,14 @@ def main():
     # image (4 B/pixel written + 4 read back) never exists.
     poi_ms, poi_n = avg_ms("poisson_fused")
     methods = sorted({m.plan.method for m in session.total_loss.poisson_loss.npred_models_all})
-    poisson_in_conv = methods == ["separable"] and len(session.components) == 1 and not os.environ.get("JD_SEP_NO_FUSION")
+    poisson_in_conv = (methods in (["separable"], ["direct"]) and len(session.components) == 1
+                       and not os.environ.get("JD_SEP_NO_FUSION"))
     # batched joint step: ONE launch covers all local datasets (jd_npred_poisson_batch_fwd_bwd)
     per_launch = len(session.local_idx) if getattr(session, "batch_joint", False) else 1
     poi_bytes = (20 if poisson_in_conv else 16) * H * W * per_launch
     # (prefixes of the rocprofv3 kernel names: the template argument lists have grown trailing defaults)
-    poi_kernel = "sep_conv_kernel<true, true, true" if poisson_in_conv else "poisson_fused_kernel"
+    poi_kernel = ("poisson_fused_kernel" if not poisson_in_conv
+                  else "sep_conv_kernel<true, true, true" if methods == ["separable"] else "direct_conv_kernel<")
     roof_poi = None
     if poi_ms:
         achieved = poi_bytes / (poi_ms * 1e-3) / 1e9

@@ -40,13 +40,23 @@ struct DirectConvArgs {
   int ox_in;  // first input column of the strip starting at x0 is x0 + ox_in  (= ox - (kw-1))
   float coef;
   int accumulate;
+  // POISSON kernels (forward model of ONE component, no up-sampling): the epilogue is the Poisson pass -- `out`
+  // receives g = d loss / d conv instead of the convolution, one fp64 loss partial per tile
+  const float* background;  // (H, W)
+  const float* counts;      // (H, W)
+  float* npred_out;         // nullable (H, W)
+  double* partials;         // n_tiles
+  float eps, inv_n;
+  int write_grad;
 };
 
 // Persistent, software pipelined: a block walks over its tiles; while the MFMAs of tile i run out of
 // LDS (image window AND Toeplitz fragments, so the matrix stream never waits on vmcnt), the loads of
 // tile i+1's window are already in flight into registers and are written to LDS after the epilogue.
 // Only the first window load and the last epilogue of a block are not overlapped with MFMA work.
-template <int KC, bool VEC>
+// POISSON: clip, + background, Poisson NLL and its gradient applied to the accumulators (models/npred.py:191,254-261;
+// loss.py:35-37) -- the convolution never goes to memory and the stand-alone Poisson launch disappears.
+template <int KC, bool VEC, bool POISSON = false>
 __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   constexpr int STEPS = KC / 4;
   constexpr int COLS = 48 + KC;    // window columns: 64 outputs + KC - 16 halo
@@ -211,7 +221,60 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
     const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
     const int x = x0 + wave * 16 + 4 * kk;
     const bool vec = (a.W % 4 == 0) && (x + 3 < a.W);
-    if (vec) {
+    __shared__ double red[4];
+    if constexpr (POISSON) {
+      // the thread's sixteen loss terms are summed in fp32 before they join the fp64 sum of the tile (poisson_point:
+      // the arithmetic every Poisson pass of the library shares)
+      float local = 0.f;
+      if (vec) {
+        float4 b4[4], c4[4];
+        bool live[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int y = y0 + 16 * b + n;
+          live[b] = y < a.H;
+          const size_t off = (size_t)(live[b] ? y : y0) * a.W + x;  // row y0 always exists
+          b4[b] = *reinterpret_cast<const float4*>(a.background + off);
+          c4[b] = *reinterpret_cast<const float4*>(a.counts + off);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          if (!live[b]) continue;
+          const size_t off = (size_t)(y0 + 16 * b + n) * a.W + x;
+          const float bg[4] = {b4[b].x, b4[b].y, b4[b].z, b4[b].w}, cn[4] = {c4[b].x, c4[b].y, c4[b].z, c4[b].w};
+          float np[4], g[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float term;
+            np[i] = fmaxf(acc[b][i], 0.f) + bg[i];
+            poisson_point(np[i], cn[i], a.eps, a.inv_n, term, g[i]);
+            local += term;
+            g[i] = acc[b][i] >= 0.f ? g[i] : 0.f;  // clamp backward: the gradient passes where conv >= 0
+          }
+          if (a.write_grad) *reinterpret_cast<float4*>(a.out + off) = make_float4(g[0], g[1], g[2], g[3]);
+          if (a.npred_out) *reinterpret_cast<float4*>(a.npred_out + off) = make_float4(np[0], np[1], np[2], np[3]);
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int y = y0 + 16 * b + n;
+          if (y >= a.H || x >= a.W) continue;
+          const size_t off = (size_t)y * a.W + x;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (x + i >= a.W) break;
+            float term, g;
+            const float np = fmaxf(acc[b][i], 0.f) + a.background[off + i];
+            poisson_point(np, a.counts[off + i], a.eps, a.inv_n, term, g);
+            local += term;
+            if (a.write_grad) a.out[off + i] = acc[b][i] >= 0.f ? g : 0.f;
+            if (a.npred_out) a.npred_out[off + i] = np;
+          }
+        }
+      }
+      const double wave_total = wave_sum((double)local);
+      if (lane == 0) red[wave] = wave_total;
+    } else if (vec) {
       // all loads of the four row groups are issued before the first one is consumed: one memory
       // round trip per tile instead of eight dependent ones
       float4 s4[4], o4[4];
@@ -248,6 +311,8 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
       }
     }
     __syncthreads();  // every wave is done reading the window before it is overwritten
+    // (the next write of `red` comes after the barrier at the top of the next tile)
+    if (POISSON && threadIdx.x == 0) a.partials[tile] = (red[0] + red[1]) + (red[2] + red[3]);
     tile = next;
   }
 }
@@ -283,16 +348,16 @@ int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_a
 
 static int g_conv_n_cu = 0;
 
-template <int KC>
+template <int KC, bool POISSON>
 static int launch_kc(const DirectConvArgs& a, hipStream_t stream) {
   constexpr int PITCH = 48 + KC + 2;
   const int rows = TILE - 1 + a.kh;
   const size_t lds = (size_t)(((rows * PITCH + 3) & ~3) + a.kh * (KC / 4) * 64) * sizeof(float);
   static int configured_bytes = 0;
   if ((int)lds > configured_bytes) {
-    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, true>),
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, true, POISSON>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, false>),
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, false, POISSON>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured_bytes = (int)lds;
   }
@@ -318,11 +383,27 @@ static int launch_kc(const DirectConvArgs& a, hipStream_t stream) {
                    (reinterpret_cast<uintptr_t>(a.in) % 16 == 0) &&
                    (!a.in_scale || reinterpret_cast<uintptr_t>(a.in_scale) % 16 == 0);
   if (vec)
-    direct_conv_kernel<KC, true><<<grid, 256, lds, stream>>>(a);
+    direct_conv_kernel<KC, true, POISSON><<<grid, 256, lds, stream>>>(a);
   else
-    direct_conv_kernel<KC, false><<<grid, 256, lds, stream>>>(a);
+    direct_conv_kernel<KC, false, POISSON><<<grid, 256, lds, stream>>>(a);
   JD_LAUNCH_CHECK();
   return JD_OK;
+}
+
+template <bool POISSON>
+static int dispatch_kc(const DirectConvArgs& a, int kw, hipStream_t stream) {
+  switch (direct_conv_kc(kw)) {
+    case 16: return launch_kc<16, POISSON>(a, stream);
+    case 20: return launch_kc<20, POISSON>(a, stream);
+    case 24: return launch_kc<24, POISSON>(a, stream);
+    case 28: return launch_kc<28, POISSON>(a, stream);
+    case 32: return launch_kc<32, POISSON>(a, stream);
+    case 36: return launch_kc<36, POISSON>(a, stream);
+    case 40: return launch_kc<40, POISSON>(a, stream);
+    case 44: return launch_kc<44, POISSON>(a, stream);
+    case 48: return launch_kc<48, POISSON>(a, stream);
+    default: return fail(JD_ERR_INVALID, "direct convolution: PSF width %d not supported", kw);
+  }
 }
 
 // adjoint == 0: out (+)= coef * out_scale * conv_same(in * in_scale, psf)    [crop offset (oy, ox)]
@@ -341,18 +422,27 @@ int launch_direct_conv(const float* in, const float* in_scale, const float* afra
     a.ox_in = ox - (kw - 1);
   }
   ProfScope prof(JD_KERNEL_DIRECT_CONV, stream);
-  switch (direct_conv_kc(kw)) {
-    case 16: return launch_kc<16>(a, stream);
-    case 20: return launch_kc<20>(a, stream);
-    case 24: return launch_kc<24>(a, stream);
-    case 28: return launch_kc<28>(a, stream);
-    case 32: return launch_kc<32>(a, stream);
-    case 36: return launch_kc<36>(a, stream);
-    case 40: return launch_kc<40>(a, stream);
-    case 44: return launch_kc<44>(a, stream);
-    case 48: return launch_kc<48>(a, stream);
-    default: return fail(JD_ERR_INVALID, "direct convolution: PSF width %d not supported", kw);
-  }
+  return dispatch_kc<false>(a, kw, stream);
+}
+
+int direct_conv_tiles(int H, int W) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
+
+// Forward model of one component with the Poisson pass as the epilogue:
+//   n = max(conv_same(in * in_scale, psf), 0) + background;  partials[tile] = sum of n - counts log(n + eps);
+//   g_out = (1 - counts / (n + eps)) * inv_n where conv >= 0, else 0   (only if write_grad);  npred_out = n (nullable)
+int launch_direct_conv_poisson(const float* in, const float* in_scale, const float* afrag, float* g_out, int H, int W,
+                               int kh, int kw, int oy, int ox, const float* background, const float* counts,
+                               float* npred_out, double* partials, float eps, float inv_n, int write_grad,
+                               int* n_partials, hipStream_t stream) {
+  DirectConvArgs a{};
+  a.in = in, a.in_scale = in_scale, a.afrag = afrag, a.out = g_out;
+  a.H = H, a.W = W, a.kh = kh, a.coef = 1.f;
+  a.oy = oy, a.ox_in = ox - (kw - 1);
+  a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = partials;
+  a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
+  *n_partials = direct_conv_tiles(H, W);
+  ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);  // the fused launch IS the Poisson pass
+  return dispatch_kc<true>(a, kw, stream);
 }
 
 }  // namespace jd

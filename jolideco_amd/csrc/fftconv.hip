@@ -177,7 +177,7 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
     p->H = H, p->W = W, p->kh = kh, p->kw = kw, p->Hp = H, p->Wp = W;
     p->oy = (kh - 1) / 2, p->ox = (kw - 1) / 2, p->py = 0, p->px = 0;
     p->nspec = p->method == JD_CONV_SEPARABLE ? (sep_conv_operator_floats() + 1) / 2 : direct_conv_fragment_floats(kh, kw);
-    p->partials_cap = std::max(poisson_fused_max_partials(H, W), sep_conv_tiles(H, W));
+    p->partials_cap = std::max(std::max(poisson_fused_max_partials(H, W), sep_conv_tiles(H, W)), direct_conv_tiles(H, W));
     int rc = JD_OK;
     if (hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
       rc = fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc of the partial sums failed");
@@ -372,19 +372,24 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
 
   const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   int n_partials = 0;
-  // one separable component, no up-sampling, no background norm: the Poisson pass is the epilogue of the convolution
-  const bool fused = p->method == JD_CONV_SEPARABLE && n_comp == 1 && upsampling == 1 && !cal.log_bkg_norm &&
-                     !getenv("JD_SEP_NO_FUSION");
+  // one component convolved on the unpadded grid (separable or MFMA direct), no up-sampling, no background norm: the
+  // Poisson pass is the epilogue of the convolution
+  const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
+                     upsampling == 1 && !cal.log_bkg_norm && !getenv("JD_SEP_NO_FUSION");
   if (fused) {
     const float* in = flux[0];
     if (cal.shift_xy) {
       if ((rc = launch_shift_fwd(flux[0], p->shifted[0], p->H, p->W, cal.shift_xy, cal.shift_scale, s))) return rc;
       in = p->shifted[0];
     }
-    if ((rc = launch_sep_conv_poisson(in, exposure[0], khat[0], p->pad[0], p->H, p->W, p->kh, p->kw, p->oy, p->ox,
-                                      background, counts, npred_out, p->partials, eps, (float)(1.0 / n_pix),
-                                      grad_flux ? 1 : 0, &n_partials, s)))
-      return rc;
+    rc = p->method == JD_CONV_SEPARABLE
+             ? launch_sep_conv_poisson(in, exposure[0], khat[0], p->pad[0], p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                                       background, counts, npred_out, p->partials, eps, (float)(1.0 / n_pix),
+                                       grad_flux ? 1 : 0, &n_partials, s)
+             : launch_direct_conv_poisson(in, exposure[0], khat[0], p->pad[0], p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                                          background, counts, npred_out, p->partials, eps, (float)(1.0 / n_pix),
+                                          grad_flux ? 1 : 0, &n_partials, s);
+    if (rc) return rc;
     if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
       return rc;
     if (!grad_flux) return JD_OK;

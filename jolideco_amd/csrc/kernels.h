@@ -50,6 +50,11 @@ int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_a
 int launch_direct_conv(const float* in, const float* in_scale, const float* afrag, float* out, const float* out_scale,
                        int H, int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
                        hipStream_t stream);
+int direct_conv_tiles(int H, int W);
+int launch_direct_conv_poisson(const float* in, const float* in_scale, const float* afrag, float* g_out, int H, int W,
+                               int kh, int kw, int oy, int ox, const float* background, const float* counts,
+                               float* npred_out, double* partials, float eps, float inv_n, int write_grad,
+                               int* n_partials, hipStream_t stream);
 
 // separable (low-rank PSF) convolution (sepconv.hip)
 constexpr int SEP_MAX_K = 68, SEP_MAX_RANK = 3, SEP_MAX_BATCH = 16;

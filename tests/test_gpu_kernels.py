@@ -581,27 +581,35 @@ def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, mean_scal
     assert vals["1"] == pytest.approx(vals["0"], rel=2e-7)
 
 
-def test_poisson_epilogue_of_the_separable_convolution_matches_the_two_kernel_path(monkeypatch):
-    """One separable component without up-sampling: the Poisson pass runs as the epilogue of the forward convolution
-    (sep_conv_kernel<.., POISSON>).  Same loss, predicted counts and gradient as convolution + poisson_fused_kernel
-    (JD_SEP_NO_FUSION=1), on a ragged image and with / without the gradient."""
+@pytest.mark.parametrize("method,shape", [("separable", (97, 150)), ("direct", (97, 150)), ("direct", (200, 192))])
+def test_poisson_epilogue_of_the_convolution_matches_the_two_kernel_path(monkeypatch, method, shape):
+    """One component without up-sampling: the Poisson pass runs as the epilogue of the forward convolution
+    (sep_conv_kernel<.., POISSON> / direct_conv_kernel<.., POISSON>).  Same loss, predicted counts and gradient as
+    convolution + poisson_fused_kernel (JD_SEP_NO_FUSION=1), on a ragged image (scalar epilogue) and on one with
+    W % 4 == 0 (float4 epilogue, partial last tile row), with / without the gradient."""
     from jolideco_amd import FluxComponents, NPredModels, SpatialFluxComponent
     from jolideco_amd.ops import stirling_mean
 
+    monkeypatch.setenv("JOLIDECO_CONV_METHOD", method)
     rs = np.random.RandomState(5)
-    shape = (97, 150)
     g = np.exp(-0.5 * ((np.arange(17) - 8) / 2.0) ** 2)
+    psf = np.outer(g, g)
+    if method == "direct":  # not separable, with negative lobes: conv < 0 somewhere, the clamp's backward pass matters
+        psf = psf * (1.0 + 0.3 * rs.uniform(-1, 1, size=psf.shape)) - 0.02
     data = {
         "counts": rs.poisson(3.0, size=shape).astype(np.float32),
-        "psf": (np.outer(g, g) / np.outer(g, g).sum()).astype(np.float32),
+        "psf": (psf / psf.sum()).astype(np.float32),
         "exposure": rs.uniform(0.5, 1.5, size=shape).astype(np.float32),
         "background": rs.uniform(0.2, 1.0, size=shape).astype(np.float32),
     }
-    flux = torch.from_numpy(rs.gamma(3.0, size=shape).astype(np.float32)).to(DEV)
+    flux_np = rs.gamma(3.0, size=shape).astype(np.float32)
+    if method == "direct":  # sparse sources: the negative lobes win between them
+        flux_np *= rs.uniform(size=shape) < 0.03
+    flux = torch.from_numpy(flux_np).to(DEV)
     comps = FluxComponents()
     comps["flux"] = SpatialFluxComponent.from_numpy(flux=flux.cpu().numpy())
     models = NPredModels.from_dataset_numpy(dataset=data, components=comps, device=DEV)
-    assert models.plan.method == "separable"
+    assert models.plan.method == method
     counts = torch.from_numpy(data["counts"]).to(DEV)
     results = {}
     for fusion in ("fused", "split"):
@@ -617,6 +625,9 @@ def test_poisson_epilogue_of_the_separable_convolution_matches_the_two_kernel_pa
     a, b = results["fused"], results["split"]
     assert a[0] == pytest.approx(b[0], rel=1e-6) and a[1] == pytest.approx(b[1], rel=1e-6) and a[0] == pytest.approx(a[1], rel=1e-6)
     assert np.array_equal(a[3], b[3])       # predicted counts: same arithmetic, same bits
+    if method == "direct":
+        clipped = a[3] == data["background"]
+        assert 0.05 < clipped.mean() < 0.95  # the clamp is active on part of the image
     assert rel_linf(a[2] - 3.0, b[2] - 3.0) < 1e-6  # gradient: same g, same adjoint kernel
 
 
