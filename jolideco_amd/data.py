@@ -127,6 +127,35 @@ def synthetic_gmm(n_components=128, n_features=64, seed=0):
     return np.zeros((n_components, n_features)), covs, weights
 
 
+def image_like_gmm(n_components=128, patch=8, seed=0, ridge=1e-4):
+    """Seeded mixture with the structure of a patch prior trained on images (the reference's trained mixtures are not
+    in its tree): component k is a stationary random field seen through a `patch` x `patch`
+    window, cov_k[i, j] = s_k * (rho(d_k(i, j)) + ridge * [i == j]) with rho(d) = exp(-d) (even k; spectrum ~ f^-3) or
+    (1 + d) exp(-d) (odd k; ~ f^-5), an anisotropic distance d_k (correlation lengths 1-8 pixels along a random axis,
+    0.5-1 x that across it), amplitudes s_k log-uniform over four decades, zero means, Dirichlet weights.  Power-law
+    spectra: condition numbers 1e2-1e4, and smooth patches are nearly orthogonal to the high-precision directions --
+    the hard case for a low-precision screen of the arg-max.
+    Returns float64 (means, covariances, weights)."""
+    rs = np.random.RandomState(seed)
+    d = patch * patch
+    yy, xx = np.mgrid[0:patch, 0:patch]
+    dy = (yy.reshape(-1, 1) - yy.reshape(1, -1)).astype(np.float64)
+    dx = (xx.reshape(-1, 1) - xx.reshape(1, -1)).astype(np.float64)
+    covs = np.empty((n_components, d, d))
+    for k in range(n_components):
+        angle = rs.uniform(0, np.pi)
+        length = rs.uniform(1.0, 8.0)
+        across = length * rs.uniform(0.5, 1.0)
+        u = (np.cos(angle) * dx + np.sin(angle) * dy) / length
+        v = (-np.sin(angle) * dx + np.cos(angle) * dy) / across
+        scale = 10.0 ** rs.uniform(-2, 2)
+        dist = np.sqrt(u * u + v * v)
+        rho = np.exp(-dist) if k % 2 == 0 else (1.0 + dist) * np.exp(-dist)
+        covs[k] = scale * (rho + ridge * np.eye(d))
+    weights = rs.dirichlet(np.ones(n_components))
+    return np.zeros((n_components, d)), covs, weights
+
+
 def synthetic_observations(shape=(2048, 2048), n_obs=8, seed=0, n_points=64, dtype=np.float32):
     """`n_obs` observations of one sky (smooth blobs + point sources) with varying PSF width,
     exposure and background (BASELINE config 3):

@@ -31,16 +31,16 @@ def _gmm_pair():
     return gmm, cpu_ref.GMM.from_numpy(means, covs, weights, stride=STRIDE)
 
 
-def oracle_prior_banded(flux_np, gmm_o, shifts, band=None):
+def oracle_prior_banded(flux_np, gmm_o, shifts, band=None, with_values=False):
     """log-prior value, d/d flux, arg-max and top-2 margin of `cpu_ref.gmm_patch_log_prior` (max mode), evaluated
     band by band over the patch rows of the rolled image so that autograd never holds more than `band` rows of
     per-component intermediates (the whole 2048^2 image at K = 128 needs ~40 GB, 4096^2 ~150 GB)."""
     H, W = flux_np.shape
-    flux = torch.from_numpy(np.ascontiguousarray(flux_np, dtype=np.float32))[None, None].requires_grad_(True)
+    flux = cpu_ref._tensor(flux_np)[None, None].requires_grad_(True)  # (the oracle's working precision: fp32 | fp64)
     image = torch.roll(flux, shifts=shifts, dims=(2, 3))  # priors/patches/core.py:199 -> utils/torch.py:119
     n_py, n_px = (H - 8) // STRIDE + 1, (W - 8) // STRIDE + 1
     band = band or max(8, 32768 // n_px)  # ~32 k patches per band: < 5 GB of autograd state at K = 128
-    total, args, margins = 0.0, [], []
+    total, args, margins, values = 0.0, [], [], []
     for r0 in range(0, n_py, band):
         r1 = min(n_py, r0 + band)
         sub = image[..., r0 * STRIDE : (r1 - 1) * STRIDE + 8, :]
@@ -52,8 +52,10 @@ def oracle_prior_banded(flux_np, gmm_o, shifts, band=None):
         total += float(part.detach())
         args.append(best.indices.numpy().astype(np.int32))
         margins.append((top2[:, 0] - top2[:, 1]).numpy())
+        values.append(top2[:, 0].numpy())
     scale = STRIDE**2 / 64 / (H * W)  # priors/patches/core.py:222-246
-    return total * scale, flux.grad.numpy()[0, 0] * scale, np.concatenate(args), np.concatenate(margins)
+    out = (total * scale, flux.grad.numpy()[0, 0] * scale, np.concatenate(args), np.concatenate(margins))
+    return out + (np.concatenate(values),) if with_values else out
 
 
 def oracle_joint_objective(datasets, flux_np, gmm_o, shifts, beta=1.0):
@@ -179,6 +181,56 @@ def test_c2_prior_value_argmax_gradient(c2_prior_oracle, variant, image, monkeyp
                                       max_flip_fraction=1e-3)
     print(f"c2 prior {variant}/{image}: value {float(value):.7f} vs {value_o:.7f}, {flips} near-tie flips of {got.size}, "
           f"{int((~clear).sum())} patches with margin <= 1e-3")
+
+
+@pytest.mark.parametrize("image", ["noisy", "smooth", "halfway"])
+def test_image_like_mixture_prior_value_argmax_gradient(image):
+    """The same check with a mixture that has the structure of a TRAINED patch prior (jolideco_amd.data.image_like_gmm:
+    stationary fields with power-law spectra, amplitudes over four decades, condition numbers up to 1.5e5) instead of
+    the seeded random covariances of SURVEY section 8(d): smooth patches are nearly orthogonal to the high-precision
+    directions of such components, the case in which an fp16 screen has the widest bounds.  768^2, K = 128."""
+    from jolideco_amd.data import image_like_gmm, synthetic_observations
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    means, covs, weights = image_like_gmm(128, 8, seed=0)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=STRIDE))
+    gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=STRIDE)
+    H = W = 768
+    _, truth, flux_init = synthetic_observations(shape=(H, W), n_obs=1, seed=0)
+    img = {"noisy": flux_init, "smooth": truth + 1.0, "halfway": 0.5 * (flux_init + truth)}[image].astype(np.float32)
+    shifts = {"noisy": (3, -1), "smooth": (-2, 2), "halfway": (0, 1)}[image]
+    value_o, grad_o, arg_o, margin, best_o = oracle_prior_banded(img, gmm_o, shifts, with_values=True)
+    flux = torch.from_numpy(img).to(DEV)
+    scale = (STRIDE**2 / 64) / (H * W)
+    value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+    argmax = torch.full((arg_o.size,), -7, dtype=torch.int32, device=DEV)
+    gmm.handle(DEV).prior_fwd_bwd(flux, STRIDE, shifts, value, scale, grad=grad, grad_coef=scale, argmax_out=argmax)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(value), value_o, rtol=3e-6)
+    got = argmax.cpu().numpy()
+    # a tie is "near" relative to what fp32 resolves at the magnitude of the log-likelihoods (up to 1e6 here): a margin
+    # below 64 ulp of the value can go either way under another summation order of the 64 + 64 x 64 terms
+    near = np.maximum(1e-3, 64 * np.finfo(np.float32).eps * np.abs(best_o))
+    assert np.array_equal(got[margin > near], arg_o[margin > near])
+    # The gradient row P'_k (P'_k^T xbar) of a component with condition number 1e5 amplifies fp32 rounding: the fp32
+    # oracle itself is ~1e-5 away from its float64 run on the smooth image.  float64 arbitrates: the HIP result must be
+    # within 1e-5 of the fp32 oracle OR no further from float64 than twice the fp32 oracle is.
+    with cpu_ref.precision(np.float64):
+        gmm_64 = cpu_ref.GMM.from_numpy(means, covs, weights, stride=STRIDE)
+        _, grad_64, arg_64, _ = oracle_prior_banded(img, gmm_64, shifts)
+    from conftest import patch_cover_mask
+
+    flipped = np.flatnonzero((got != arg_o) | (arg_64 != arg_o))
+    assert flipped.size <= 1e-3 * got.size
+    keep = ~patch_cover_mask(flipped, (H, W), STRIDE, shifts)
+    norm = np.abs(grad_64).max()
+    d_gpu_32 = np.abs(grad.cpu().numpy() - grad_o)[keep].max() / norm
+    d_gpu_64 = np.abs(grad.cpu().numpy() - grad_64)[keep].max() / norm
+    d_o_64 = np.abs(grad_o - grad_64)[keep].max() / norm
+    print(f"image-like mixture / {image}: value {float(value):.7f} vs {value_o:.7f}, {flipped.size} near-tie flips of "
+          f"{got.size}, |log-likelihood| up to {np.abs(best_o).max():.3g}; gradient rel L-inf HIP-fp32 oracle "
+          f"{d_gpu_32:.2e}, HIP-float64 {d_gpu_64:.2e}, fp32 oracle-float64 {d_o_64:.2e}")
+    assert d_gpu_32 < 1e-5 or d_gpu_64 <= 2 * d_o_64
 
 
 def test_c2_poisson_step_separable_fused(monkeypatch):
