@@ -96,8 +96,11 @@ def pmc_traffic_source(kernel=None):
 
         commit = subprocess.run(["git", "log", "-n1", "--format=%h", "--", rel], cwd=REPO, capture_output=True,
                                 text=True, timeout=10).stdout.strip() or "unknown"
-    except Exception:  # no git on the GPU box's copy: the file name alone identifies the round
+    except Exception:  # no git on the GPU box's copy: the sidecar written when the file was committed
         pass
+    sidecar = REPO / (rel + ".commit")
+    if commit == "unknown" and sidecar.exists():
+        commit = sidecar.read_text().strip() or "unknown"
     return f"{rel} @{commit} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, not measured by this run)"
 
 
