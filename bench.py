@@ -469,7 +469,8 @@ def main():
 
     if world == 1 and fake is None and "separable" in methods and not args.no_general_psf:
         out["general_psf"], prof_general = conv_method_run(
-            "direct", "same workload with the PSFs convolved as general 17x17 kernels (MFMA Toeplitz convolution)")
+            "direct", "same workload with the PSFs convolved as general 17x17 kernels (MFMA Toeplitz convolution, "
+                      "fp16 x 3 split operands; Poisson pass in the forward launch's epilogue)")
         # this path runs the STAND-ALONE fused Poisson pass (conv, background, counts in; g out = 16 B/pixel):
         # the kernel BASELINE.json's "HBM GB/s on fused Poisson pass" was defined on
         total_p, count_p = prof_general.get("poisson_fused", (0.0, 0))

@@ -17,6 +17,16 @@
 // each MFMA needs one conflict-free ds_read_b32 (row pitch == 2 mod 4).  Cost: kh * KC/4 * 4 MFMAs of
 // 32 cycles per 1024 outputs, i.e. 17 cycles/output at 17x17 (~30 us for 2048^2 on 1024 SIMDs)
 // against ~150 us for two rocFFT transforms + the k-space multiply; the FFT path stays for large PSFs.
+//
+// SPLIT (the default where it fits): the same Toeplitz product on the fp16 matrix cores with both operands split in
+// two, x = x_hi + x_lo (x_hi = fp16(x), x_lo = fp16(x - x_hi): 22 significant bits), and three products per step,
+//   D += A_hi B_hi + A_lo B_hi + A_hi B_lo          (v_mfma_f32_16x16x32_f16: K = 32 input columns per instruction)
+// with fp32 accumulation: A_lo B_lo (2^-22 of a term) is dropped, so a term is off by <= 3 x 2^-22 = 7e-7 of itself
+// and a sum of same-signed terms by no more (typically 1e-7; the reference's FFT convolution is no closer to the exact
+// sum).  The window is scaled per tile by the power of two that puts its largest |value| into [2^13, 2^14) (exact;
+// fp16 would otherwise overflow / lose the faint pixels), the PSF likewise once per table; both scales are undone
+// exactly in the epilogue.  Cost: kh * 12 MFMAs of 16 cycles per 1024 outputs instead of kh * 32 of 32 cycles --
+// 5.3 x less matrix time, so the kernel is bound by its LDS reads and the image traffic, not by the matrix cores.
 #include <cstdint>
 #include <cstdlib>
 
@@ -26,6 +36,8 @@
 namespace jd {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE = 64;  // outputs per block edge
 
@@ -33,6 +45,7 @@ struct DirectConvArgs {
   const float* in;         // (H, W)
   const float* in_scale;   // nullable, multiplied onto `in` while staging (forward: exposure)
   const float* afrag;      // kh * (KC/4) * 64 floats: Toeplitz fragments of the (possibly flipped) PSF
+                           // SPLIT: kh * (KC/32) * 2 planes * 64 lanes * 8 fp16 of psf * s_p, then 1 / s_p (a float)
   float* out;              // (H, W)
   const float* out_scale;  // nullable, multiplied onto the result (adjoint: exposure)
   int H, W, kh;
@@ -56,16 +69,25 @@ struct DirectConvArgs {
 // Only the first window load and the last epilogue of a block are not overlapped with MFMA work.
 // POISSON: clip, + background, Poisson NLL and its gradient applied to the accumulators (models/npred.py:191,254-261;
 // loss.py:35-37) -- the convolution never goes to memory and the stand-alone Poisson launch disappears.
-template <int KC, bool VEC, bool POISSON = false>
+// (SPLIT: requesting the epilogue's operands before the matrix phase costs 36 registers -- 268, one block per CU: 35 us
+// instead of 27 at 2048^2; capped at 256 with 33 spilled registers: 33 us)
+template <int KC, bool VEC, bool POISSON = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   constexpr int STEPS = KC / 4;
+  constexpr int KS = KC / 32;      // SPLIT: 32-column steps of the fp16 MFMA (KC = 32 or 64)
   constexpr int COLS = 48 + KC;    // window columns: 64 outputs + KC - 16 halo
   constexpr int PITCH = COLS + 2;  // == 2 (mod 4): the 16 rows x 2 columns of a half-wave hit 32 banks
+  constexpr int PH = COLS + 8;     // SPLIT: fp16 per row of one plane (16-byte aligned rows; 44 / 60 words: rows 0-7 of a
+                                   // ds_read_b128 group start on 8 different multiples of 4 banks)
   constexpr int NPF = (96 * COLS + 255) / 256;  // window elements per thread (kh <= 33: at most 96 rows)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int rows = TILE - 1 + a.kh;
   float* win = lds;                        // rows * PITCH
   float* afl = lds + ((rows * PITCH + 3) & ~3);  // kh * STEPS * 64 Toeplitz fragments
+  // SPLIT: two fp16 planes of the window (hi, lo), then the fragment table (uint4 per lane, plane and step)
+  _Float16* winH = reinterpret_cast<_Float16*>(lds);
+  _Float16* winL = winH + rows * PH;
+  uint4* afl16 = reinterpret_cast<uint4*>(lds + ((rows * PH + 3) & ~3));  // 2 planes x rows x PH halfs = rows * PH floats
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -74,7 +96,12 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   const int n_tiles = tiles_x * tiles_y;
 
   // Toeplitz fragments -> LDS (once per block; the table is a multiple of 256 floats)
-  {
+  float inv_sp = 1.f;
+  if constexpr (SPLIT) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.afrag);
+    for (int i = threadIdx.x; i < a.kh * KS * 128; i += 256) afl16[i] = src[i];
+    inv_sp = a.afrag[(size_t)a.kh * KS * 512];
+  } else {
     const float4* src = reinterpret_cast<const float4*>(a.afrag);
     float4* dst = reinterpret_cast<float4*>(afl);
     for (int i = threadIdx.x; i < a.kh * STEPS * 16; i += 256) dst[i] = src[i];
@@ -136,6 +163,58 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
       }
     }
   };
+  // SPLIT: window * in_scale, scaled by the power of two `s` that puts the tile's largest |value| into [2^13, 2^14),
+  // as two fp16 planes; returns 1 / s.  (One more barrier per tile for the block-wide maximum.)
+  __shared__ float red_max[4];
+  auto store_window_split = [&]() -> float {
+    float m = 0.f;
+    if constexpr (VEC) {
+#pragma unroll
+      for (int u = 0; u < NPF4; ++u) {
+        pv4[u].x *= ps4[u].x, pv4[u].y *= ps4[u].y, pv4[u].z *= ps4[u].z, pv4[u].w *= ps4[u].w;
+        if (wr[u] >= 0) m = fmaxf(fmaxf(m, fmaxf(fabsf(pv4[u].x), fabsf(pv4[u].y))), fmaxf(fabsf(pv4[u].z), fabsf(pv4[u].w)));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        pv[u] *= ps[u];
+        if (threadIdx.x + 256 * u < total) m = fmaxf(m, fabsf(pv[u]));
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) red_max[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red_max[0], red_max[1]), fmaxf(red_max[2], red_max[3]));
+    int ex = 14;  // zero, inf or NaN somewhere: no scaling (non-finite values propagate through the fp16 planes)
+    if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);
+    ex = ex < -100 ? -100 : ex;
+    const float s = ldexpf(1.f, 14 - ex);
+    auto split = [&](float x, _Float16& hi, _Float16& lo) {
+      const float xs = x * s;
+      hi = (_Float16)xs;
+      lo = (_Float16)(xs - (float)hi);
+    };
+    if constexpr (VEC) {
+#pragma unroll
+      for (int u = 0; u < NPF4; ++u) {
+        if (wr[u] >= 0) {  // 4 fp16 = 8 bytes per plane (PH and wc are multiples of 4)
+          _Float16 h[4], l[4];
+          split(pv4[u].x, h[0], l[0]), split(pv4[u].y, h[1], l[1]), split(pv4[u].z, h[2], l[2]), split(pv4[u].w, h[3], l[3]);
+          *reinterpret_cast<f16x4*>(winH + wr[u] * PH + wc[u]) = f16x4{h[0], h[1], h[2], h[3]};
+          *reinterpret_cast<f16x4*>(winL + wr[u] * PH + wc[u]) = f16x4{l[0], l[1], l[2], l[3]};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        const int r = i / COLS, c = i - r * COLS;
+        if (i < total) split(pv[u], winH[r * PH + c], winL[r * PH + c]);
+      }
+    }
+    return ldexpf(1.f, ex - 14);
+  };
   auto store_window = [&]() {
     if constexpr (VEC) {
 #pragma unroll
@@ -171,15 +250,69 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   if (tile < n_tiles) issue_window_loads(tile);
   const int n = lane & 15, kk = lane >> 4;
   while (tile < n_tiles) {
-    store_window();
+    float inv = 1.f;  // SPLIT: undoes the window's and the PSF's power-of-two scales
+    if constexpr (SPLIT)
+      inv = store_window_split() * inv_sp;
+    else
+      store_window();
     __syncthreads();
     work = next_work(work + gridDim.x);
     const int next = work < n_work ? tile_of(work) : n_tiles;
     if (next < n_tiles) issue_window_loads(next);  // in flight during the MFMA phase below
 
+    // this lane's outputs: out[y0 + 16 b + n][x0 + 16 wave + 4 kk + 0..3]
+    const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
+    const int x = x0 + wave * 16 + 4 * kk;
+    const bool vec = (a.W % 4 == 0) && (x + 3 < a.W);
     f32x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (SPLIT) {
+      // Step t = dy * KS + ks: A = the two planes of the Toeplitz fragment of PSF row dy, input columns 32 ks .. + 31;
+      // B = 8 consecutive fp16 of window row 16 b + n + (kh - 1 - dy) at column 16 wave + 32 ks + 8 kk (one ds_read_b128
+      // per plane).  The operands of step t + 1 are read while the 12 MFMAs of step t issue.
+      const _Float16* bh = winH + (n + a.kh - 1) * PH + wave * 16 + 8 * kk;
+      const _Float16* bl = winL + (n + a.kh - 1) * PH + wave * 16 + 8 * kk;
+      const uint4* ap = afl16 + lane;
+      const int n_steps = a.kh * KS;
+      struct Ops {
+        f16x8 ah, al, bh[4], bl[4];
+      };
+      Ops o0, o1;
+      auto load_step = [&](Ops& o, int t) {
+        t = t < n_steps ? t : n_steps - 1;
+        const int dy = t / KS, ks = t - dy * KS;
+        o.ah = __builtin_bit_cast(f16x8, ap[(t * 2) * 64]);
+        o.al = __builtin_bit_cast(f16x8, ap[(t * 2 + 1) * 64]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int off = (16 * b - dy) * PH + 32 * ks;
+          o.bh[b] = *reinterpret_cast<const f16x8*>(bh + off);
+          o.bl[b] = *reinterpret_cast<const f16x8*>(bl + off);
+        }
+      };
+      auto mfma_step = [&](const Ops& o) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, o.bh[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.al, o.bh[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, o.bl[b], acc[b], 0, 0, 0);
+      };
+      load_step(o0, 0);
+      for (int t = 0; t < n_steps; t += 2) {
+        load_step(o1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step(o0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_step(o0, t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < n_steps) mfma_step(o1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[b] *= inv;
+    } else {
     // window row of output row (16 b + n) for PSF row dy is 16 b + n + (kh - 1 - dy).  The operands of
     // PSF row dy + 1 are read from LDS while the MFMAs of row dy issue (register double buffer, the
     // loop is unrolled by two so no copies are needed); reads past the last row are clamped.
@@ -217,10 +350,8 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
 
+    }
     // ---- epilogue: lane holds out[y0 + 16 b + n][x0 + 16 wave + 4 kk + 0..3] ---------------------
-    const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
-    const int x = x0 + wave * 16 + 4 * kk;
-    const bool vec = (a.W % 4 == 0) && (x + 3 < a.W);
     __shared__ double red[4];
     if constexpr (POISSON) {
       // the thread's sixteen loss terms are summed in fp32 before they join the fp64 sum of the tile (poisson_point:
@@ -331,13 +462,71 @@ __global__ __launch_bounds__(256) void toeplitz_fragments_kernel(const float* __
   afrag[i] = v;
 }
 
+// SPLIT tables: afrag16[(dy * KS + ks) * 2 + plane][lane] = 8 fp16 of psf'[dy][m + kw - 1 - c] * s_p, m = lane & 15,
+// c = 32 ks + 8 (lane >> 4) + e; plane 0 = fp16(v), plane 1 = fp16(v - plane 0); s_p = the power of two that puts
+// max |psf| into [2^13, 2^14); the float after the table is 1 / s_p.  One block (a PSF has at most 33 x 33 taps).
+__global__ __launch_bounds__(256) void toeplitz_fragments16_kernel(const float* __restrict__ psf, uint4* __restrict__ afrag,
+                                                                  int kh, int kw, int ks_count, int flip) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < kh * kw; i += 256) m = fmaxf(m, fabsf(psf[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  int ex = 14;
+  if (m > 0.f && m < 3.0e38f) (void)frexpf(m, &ex);
+  ex = ex < -100 ? -100 : ex;
+  const float sp = ldexpf(1.f, 14 - ex);
+  for (int i = threadIdx.x; i < kh * ks_count * 64; i += 256) {
+    const int lane = i & 63, t = i >> 6, ks = t % ks_count, dy = t / ks_count;
+    const int mrow = lane & 15, g = lane >> 4;
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 32 * ks + 8 * g + e;
+      const int dx = mrow + kw - 1 - c;
+      float v = 0.f;
+      if (dx >= 0 && dx < kw) v = flip ? psf[(kh - 1 - dy) * kw + (kw - 1 - dx)] : psf[dy * kw + dx];
+      v *= sp;
+      hi[e] = (_Float16)v;
+      lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    afrag[(t * 2) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    afrag[(t * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+  }
+  if (threadIdx.x == 0) reinterpret_cast<float*>(afrag)[(size_t)kh * ks_count * 512] = ldexpf(1.f, ex - 14);
+}
+
 int direct_conv_kc(int kw) { return ((16 + kw - 1) + 3) / 4 * 4; }
 
 bool direct_conv_supported(int kh, int kw) { return kh >= 1 && kw >= 1 && kh <= 33 && direct_conv_kc(kw) <= 48; }
 
-size_t direct_conv_fragment_floats(int kh, int kw) { return (size_t)kh * (direct_conv_kc(kw) / 4) * 64; }
+static int direct_split_ks(int kw) { return (16 + kw - 1 + 31) / 32; }
+static size_t direct_split_lds(int kh, int kw) {
+  const int ks = direct_split_ks(kw), rows = TILE - 1 + kh, ph = 48 + 32 * ks + 8;
+  return (size_t)(((rows * ph + 3) & ~3)) * sizeof(float) + (size_t)kh * ks * 128 * sizeof(uint4);
+}
+// the split-fp16 kernel needs its two window planes and its fragment table in the 160 KB of LDS
+bool direct_conv_split_supported(int kh, int kw) {
+  return direct_conv_supported(kh, kw) && direct_split_ks(kw) <= 2 && direct_split_lds(kh, kw) <= 160 * 1024;
+}
 
-int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_adj, int kh, int kw, hipStream_t stream) {
+size_t direct_conv_fragment_floats(int kh, int kw, int split) {
+  if (split) return (size_t)kh * direct_split_ks(kw) * 512 + 4;
+  return (size_t)kh * (direct_conv_kc(kw) / 4) * 64;
+}
+
+int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_adj, int kh, int kw, int split,
+                              hipStream_t stream) {
+  if (split) {
+    const int ks = direct_split_ks(kw);
+    toeplitz_fragments16_kernel<<<1, 256, 0, stream>>>(psf, reinterpret_cast<uint4*>(afrag_fwd), kh, kw, ks, 0);
+    toeplitz_fragments16_kernel<<<1, 256, 0, stream>>>(psf, reinterpret_cast<uint4*>(afrag_adj), kh, kw, ks, 1);
+    JD_LAUNCH_CHECK();
+    return JD_OK;
+  }
   const int steps = direct_conv_kc(kw) / 4;
   const int n = kh * steps * 64;
   toeplitz_fragments_kernel<<<(n + 255) / 256, 256, 0, stream>>>(psf, afrag_fwd, kh, kw, steps, 0);
@@ -348,16 +537,17 @@ int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_a
 
 static int g_conv_n_cu = 0;
 
-template <int KC, bool POISSON>
+template <int KC, bool POISSON, bool SPLIT = false>
 static int launch_kc(const DirectConvArgs& a, hipStream_t stream) {
-  constexpr int PITCH = 48 + KC + 2;
+  constexpr int PITCH = 48 + KC + 2, PH = 48 + KC + 8;
   const int rows = TILE - 1 + a.kh;
-  const size_t lds = (size_t)(((rows * PITCH + 3) & ~3) + a.kh * (KC / 4) * 64) * sizeof(float);
+  const size_t lds = SPLIT ? (size_t)((rows * PH + 3) & ~3) * sizeof(float) + (size_t)a.kh * (KC / 32) * 128 * sizeof(uint4)
+                           : (size_t)(((rows * PITCH + 3) & ~3) + a.kh * (KC / 4) * 64) * sizeof(float);
   static int configured_bytes = 0;
   if ((int)lds > configured_bytes) {
-    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, true, POISSON>),
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, true, POISSON, SPLIT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, false, POISSON>),
+    JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&direct_conv_kernel<KC, false, POISSON, SPLIT>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured_bytes = (int)lds;
   }
@@ -383,15 +573,16 @@ static int launch_kc(const DirectConvArgs& a, hipStream_t stream) {
                    (reinterpret_cast<uintptr_t>(a.in) % 16 == 0) &&
                    (!a.in_scale || reinterpret_cast<uintptr_t>(a.in_scale) % 16 == 0);
   if (vec)
-    direct_conv_kernel<KC, true, POISSON><<<grid, 256, lds, stream>>>(a);
+    direct_conv_kernel<KC, true, POISSON, SPLIT><<<grid, 256, lds, stream>>>(a);
   else
-    direct_conv_kernel<KC, false, POISSON><<<grid, 256, lds, stream>>>(a);
+    direct_conv_kernel<KC, false, POISSON, SPLIT><<<grid, 256, lds, stream>>>(a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
 
 template <bool POISSON>
-static int dispatch_kc(const DirectConvArgs& a, int kw, hipStream_t stream) {
+static int dispatch_kc(const DirectConvArgs& a, int kw, int split, hipStream_t stream) {
+  if (split) return direct_split_ks(kw) == 1 ? launch_kc<32, POISSON, true>(a, stream) : launch_kc<64, POISSON, true>(a, stream);
   switch (direct_conv_kc(kw)) {
     case 16: return launch_kc<16, POISSON>(a, stream);
     case 20: return launch_kc<20, POISSON>(a, stream);
@@ -409,7 +600,7 @@ static int dispatch_kc(const DirectConvArgs& a, int kw, hipStream_t stream) {
 // adjoint == 0: out (+)= coef * out_scale * conv_same(in * in_scale, psf)    [crop offset (oy, ox)]
 // adjoint != 0: out (+)= coef * out_scale * corr_same(in * in_scale, psf)    (the transpose of the above)
 int launch_direct_conv(const float* in, const float* in_scale, const float* afrag, float* out, const float* out_scale,
-                       int H, int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
+                       int H, int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, int split,
                        hipStream_t stream) {
   DirectConvArgs a{};
   a.in = in, a.in_scale = in_scale, a.afrag = afrag, a.out = out, a.out_scale = out_scale;
@@ -422,7 +613,7 @@ int launch_direct_conv(const float* in, const float* in_scale, const float* afra
     a.ox_in = ox - (kw - 1);
   }
   ProfScope prof(JD_KERNEL_DIRECT_CONV, stream);
-  return dispatch_kc<false>(a, kw, stream);
+  return dispatch_kc<false>(a, kw, split, stream);
 }
 
 int direct_conv_tiles(int H, int W) { return ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE); }
@@ -433,7 +624,7 @@ int direct_conv_tiles(int H, int W) { return ((W + TILE - 1) / TILE) * ((H + TIL
 int launch_direct_conv_poisson(const float* in, const float* in_scale, const float* afrag, float* g_out, int H, int W,
                                int kh, int kw, int oy, int ox, const float* background, const float* counts,
                                float* npred_out, double* partials, float eps, float inv_n, int write_grad,
-                               int* n_partials, hipStream_t stream) {
+                               int* n_partials, int split, hipStream_t stream) {
   DirectConvArgs a{};
   a.in = in, a.in_scale = in_scale, a.afrag = afrag, a.out = g_out;
   a.H = H, a.W = W, a.kh = kh, a.coef = 1.f;
@@ -442,7 +633,7 @@ int launch_direct_conv_poisson(const float* in, const float* in_scale, const flo
   a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
   *n_partials = direct_conv_tiles(H, W);
   ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);  // the fused launch IS the Poisson pass
-  return dispatch_kc<true>(a, kw, stream);
+  return dispatch_kc<true>(a, kw, split, stream);
 }
 
 }  // namespace jd

@@ -25,6 +25,7 @@ struct jd_conv_plan {
   int method = jd::JD_CONV_FFT;
   int py = 0, px = 0;        // offset of the (H, W) image inside the conv / pad buffers (FFT: oy, ox; direct: 0)
   size_t nspec = 0;  // complex elements of one spectrum (direct: floats of one Toeplitz fragment table)
+  int split = 0;     // direct: the split-fp16 kernel (default where it fits; JD_DIRECT_FP32=1: the fp32 MFMA kernel)
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   void* work = nullptr;
@@ -110,7 +111,7 @@ static int conv_forward(jd_conv_plan* p, int c, const float* image, const float*
                         hipStream_t stream) {
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0,
-                              1.f, 0, stream);
+                              1.f, 0, p->split, stream);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0,
                            stream);
@@ -137,7 +138,7 @@ static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const f
                               int accumulate, hipStream_t stream) {
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(p->pad[c], nullptr, khat + p->nspec, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
-                              1, coef, accumulate, stream);
+                              1, coef, accumulate, p->split, stream);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(p->pad[c], nullptr, khat, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1, coef,
                            accumulate, stream);
@@ -176,7 +177,9 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
     p->method = mode == JD_CONV_MODE_SEPARABLE ? JD_CONV_SEPARABLE : JD_CONV_DIRECT;
     p->H = H, p->W = W, p->kh = kh, p->kw = kw, p->Hp = H, p->Wp = W;
     p->oy = (kh - 1) / 2, p->ox = (kw - 1) / 2, p->py = 0, p->px = 0;
-    p->nspec = p->method == JD_CONV_SEPARABLE ? (sep_conv_operator_floats() + 1) / 2 : direct_conv_fragment_floats(kh, kw);
+    p->split = p->method == JD_CONV_DIRECT && direct_conv_split_supported(kh, kw) && !getenv("JD_DIRECT_FP32") ? 1 : 0;
+    p->nspec = p->method == JD_CONV_SEPARABLE ? (sep_conv_operator_floats() + 1) / 2
+                                              : direct_conv_fragment_floats(kh, kw, p->split);
     p->partials_cap = std::max(std::max(poisson_fused_max_partials(H, W), sep_conv_tiles(H, W)), direct_conv_tiles(H, W));
     int rc = JD_OK;
     if (hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
@@ -287,7 +290,8 @@ extern "C" int jd_psf_separable_rank(const float* psf_host, int kh, int kw, floa
 extern "C" int jd_conv_psf_spectrum(jd_conv_plan* p, const float* psf, float* khat, void* stream) {
   JD_REQUIRE(p && psf && khat, "jd_conv_psf_spectrum: null argument");
   hipStream_t s = as_stream(stream);
-  if (p->method == JD_CONV_DIRECT) return launch_toeplitz_fragments(psf, khat, khat + p->nspec, p->kh, p->kw, s);
+  if (p->method == JD_CONV_DIRECT)
+    return launch_toeplitz_fragments(psf, khat, khat + p->nspec, p->kh, p->kw, p->split, s);
   if (p->method == JD_CONV_SEPARABLE) {
     // setup-time only: the factorisation runs on the host (a PSF is a few KB), so this call synchronises
     std::vector<float> host((size_t)p->kh * p->kw), op;
@@ -317,7 +321,8 @@ extern "C" int jd_conv_same(jd_conv_plan* p, const float* image, const float* sc
   JD_REQUIRE(p && image && khat && out, "jd_conv_same: null argument");
   hipStream_t s = as_stream(stream);
   if (p->method == JD_CONV_DIRECT)
-    return launch_direct_conv(image, scale_image, khat, out, nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0, s);
+    return launch_direct_conv(image, scale_image, khat, out, nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0,
+                              p->split, s);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(image, scale_image, khat, out, nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0, s);
   int rc = conv_forward(p, 0, image, scale_image, khat, s);
@@ -331,7 +336,7 @@ extern "C" int jd_conv_same_adjoint(jd_conv_plan* p, const float* grad_out, cons
   hipStream_t s = as_stream(stream);
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(grad_out, nullptr, khat + p->nspec, grad_image, scale_image, p->H, p->W, p->kh, p->kw,
-                              p->oy, p->ox, 1, 1.f, accumulate, s);
+                              p->oy, p->ox, 1, 1.f, accumulate, p->split, s);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(grad_out, nullptr, khat, grad_image, scale_image, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1,
                            1.f, accumulate, s);
@@ -388,7 +393,7 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
                                        grad_flux ? 1 : 0, &n_partials, s)
              : launch_direct_conv_poisson(in, exposure[0], khat[0], p->pad[0], p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                                           background, counts, npred_out, p->partials, eps, (float)(1.0 / n_pix),
-                                          grad_flux ? 1 : 0, &n_partials, s);
+                                          grad_flux ? 1 : 0, &n_partials, p->split, s);
     if (rc) return rc;
     if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
       return rc;

@@ -45,16 +45,19 @@ int launch_finalize_multi(const double* partials, int n_blocks, int n_out, doubl
 // direct (MFMA Toeplitz) convolution for small PSFs (directconv.hip)
 enum { JD_CONV_FFT = 0, JD_CONV_DIRECT = 1, JD_CONV_SEPARABLE = 2 };
 bool direct_conv_supported(int kh, int kw);
-size_t direct_conv_fragment_floats(int kh, int kw);
-int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_adj, int kh, int kw, hipStream_t stream);
+// split: the fp16 x 3 kernel (two-term fp16 split of both operands, 22 significant bits) instead of the fp32 MFMA one
+bool direct_conv_split_supported(int kh, int kw);
+size_t direct_conv_fragment_floats(int kh, int kw, int split);
+int launch_toeplitz_fragments(const float* psf, float* afrag_fwd, float* afrag_adj, int kh, int kw, int split,
+                              hipStream_t stream);
 int launch_direct_conv(const float* in, const float* in_scale, const float* afrag, float* out, const float* out_scale,
-                       int H, int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
+                       int H, int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, int split,
                        hipStream_t stream);
 int direct_conv_tiles(int H, int W);
 int launch_direct_conv_poisson(const float* in, const float* in_scale, const float* afrag, float* g_out, int H, int W,
                                int kh, int kw, int oy, int ox, const float* background, const float* counts,
                                float* npred_out, double* partials, float eps, float inv_n, int write_grad,
-                               int* n_partials, hipStream_t stream);
+                               int* n_partials, int split, hipStream_t stream);
 
 // separable (low-rank PSF) convolution (sepconv.hip)
 constexpr int SEP_MAX_K = 68, SEP_MAX_RANK = 3, SEP_MAX_BATCH = 16;

@@ -40,7 +40,10 @@ def test_convolution_adjoint_identity_and_linearity(edge):
         adj = plan.conv_same_adjoint(go, scale, khat)
         lhs = float((cu.double() * go.double()).sum())
         rhs = float((u.double() * adj.double()).sum())
-        assert abs(lhs - rhs) < 2e-6 * max(1.0, abs(lhs))
+        # <A u, g> is a cancelling sum (g ~ N(0, 1): |lhs| ~ 1e2 .. 1e3 from terms that add up to ~1e5 .. 1e6 in
+        # magnitude): the bound is relative to the sum of the |terms|.  The fp32 kernels are exact transposes of each
+        # other (~1e-10); the split-fp16 direct kernel rounds u and g independently (measured 2e-9).
+        assert abs(lhs - rhs) < 1e-7 * float((cu.abs().double() * go.abs().double()).sum())
         # flux conservation of a unit-sum PSF away from the edges
         ones = plan.conv_same(torch.ones_like(u), None, khat)
         assert float((ones[16:-16, 16:-16] - 1).abs().max()) < 1e-5

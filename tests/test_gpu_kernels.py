@@ -274,9 +274,13 @@ def test_product_path_fails_loudly_without_gpu_tensors():
     [((64, 64), (1, 1)), ((70, 130), (17, 17)), ((129, 67), (33, 33)), ((50, 200), (2, 31)), ((203, 61), (32, 3)),
      ((256, 256), (5, 16))],
 )
-def test_direct_conv_matches_fft_and_float64(shape, kshape):
-    """The MFMA Toeplitz kernel, rocFFT on the fast grid and rocFFT on the reference's exact grid
-    all compute the same 'same' convolution and its adjoint (ragged tiles, even / 1-pixel PSFs)."""
+@pytest.mark.parametrize("direct_kernel", ["split_fp16", "fp32"])
+def test_direct_conv_matches_fft_and_float64(shape, kshape, direct_kernel, monkeypatch):
+    """The MFMA Toeplitz kernels (split-fp16 x 3, the default where its window planes and fragment table fit in LDS --
+    not at 33 x 33 -- and the fp32 one, JD_DIRECT_FP32=1), rocFFT on the fast grid and rocFFT on the reference's exact
+    grid all compute the same 'same' convolution and its adjoint (ragged tiles, even / 1-pixel PSFs)."""
+    if direct_kernel == "fp32":
+        monkeypatch.setenv("JD_DIRECT_FP32", "1")
     from scipy.signal import convolve2d
 
     from jolideco_amd.ops import ConvPlan
