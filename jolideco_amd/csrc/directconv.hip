@@ -69,8 +69,6 @@ struct DirectConvArgs {
 // Only the first window load and the last epilogue of a block are not overlapped with MFMA work.
 // POISSON: clip, + background, Poisson NLL and its gradient applied to the accumulators (models/npred.py:191,254-261;
 // loss.py:35-37) -- the convolution never goes to memory and the stand-alone Poisson launch disappears.
-// (SPLIT: requesting the epilogue's operands before the matrix phase costs 36 registers -- 268, one block per CU: 35 us
-// instead of 27 at 2048^2; capped at 256 with 33 spilled registers: 33 us)
 template <int KC, bool VEC, bool POISSON = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
   constexpr int STEPS = KC / 4;
@@ -264,6 +262,26 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
     const int x0 = (tile % tiles_x) * TILE, y0 = (tile / tiles_x) * TILE;
     const int x = x0 + wave * 16 + 4 * kk;
     const bool vec = (a.W % 4 == 0) && (x + 3 < a.W);
+    // SPLIT: the matrix phase is short, so the operands of the epilogue -- (background, counts) or (out_scale, out) -- are
+    // requested before it instead of after it
+    float4 e0[SPLIT ? 4 : 1], e1[SPLIT ? 4 : 1];
+    if constexpr (SPLIT) {
+      if (vec) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int y = y0 + 16 * b + n;
+          const size_t off = (size_t)(y < a.H ? y : y0) * a.W + x;  // row y0 always exists
+          if constexpr (POISSON) {
+            e0[b] = *reinterpret_cast<const float4*>(a.background + off);
+            e1[b] = *reinterpret_cast<const float4*>(a.counts + off);
+          } else {
+            e0[b] = a.out_scale ? *reinterpret_cast<const float4*>(a.out_scale + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+            e1[b] = a.accumulate ? *reinterpret_cast<const float4*>(a.out + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+    }
+
     f32x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -275,39 +293,43 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
       const _Float16* bl = winL + (n + a.kh - 1) * PH + wave * 16 + 8 * kk;
       const uint4* ap = afl16 + lane;
       const int n_steps = a.kh * KS;
+      // (hi, hi) and (lo, hi) products first: their operands are double buffered; the lo plane of the window is read
+      // at the start of a step into ONE buffer and is back before the third product needs it (8 MFMAs = 128 cycles
+      // later) -- 16 registers less than double buffering it, which is what lets the epilogue's operands be
+      // requested before the matrix phase without losing the second block per CU
       struct Ops {
-        f16x8 ah, al, bh[4], bl[4];
+        f16x8 ah, al, bh[4];
       };
       Ops o0, o1;
+      f16x8 blv[4];
       auto load_step = [&](Ops& o, int t) {
         t = t < n_steps ? t : n_steps - 1;
         const int dy = t / KS, ks = t - dy * KS;
         o.ah = __builtin_bit_cast(f16x8, ap[(t * 2) * 64]);
         o.al = __builtin_bit_cast(f16x8, ap[(t * 2 + 1) * 64]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int off = (16 * b - dy) * PH + 32 * ks;
-          o.bh[b] = *reinterpret_cast<const f16x8*>(bh + off);
-          o.bl[b] = *reinterpret_cast<const f16x8*>(bl + off);
-        }
+        for (int b = 0; b < 4; ++b) o.bh[b] = *reinterpret_cast<const f16x8*>(bh + (16 * b - dy) * PH + 32 * ks);
       };
-      auto mfma_step = [&](const Ops& o) {
+      auto mfma_step = [&](const Ops& o, int t) {
+        const int dy = t / KS, ks = t - dy * KS;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) blv[b] = *reinterpret_cast<const f16x8*>(bl + (16 * b - dy) * PH + 32 * ks);
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, o.bh[b], acc[b], 0, 0, 0);
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.al, o.bh[b], acc[b], 0, 0, 0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, o.bl[b], acc[b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, blv[b], acc[b], 0, 0, 0);
       };
       load_step(o0, 0);
       for (int t = 0; t < n_steps; t += 2) {
         load_step(o1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_step(o0);
+        mfma_step(o0, t);
         __builtin_amdgcn_sched_barrier(0);
         load_step(o0, t + 2);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < n_steps) mfma_step(o1);
+        if (t + 1 < n_steps) mfma_step(o1, t + 1);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -364,9 +386,13 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
         for (int b = 0; b < 4; ++b) {
           const int y = y0 + 16 * b + n;
           live[b] = y < a.H;
-          const size_t off = (size_t)(live[b] ? y : y0) * a.W + x;  // row y0 always exists
-          b4[b] = *reinterpret_cast<const float4*>(a.background + off);
-          c4[b] = *reinterpret_cast<const float4*>(a.counts + off);
+          if constexpr (SPLIT) {
+            b4[b] = e0[b], c4[b] = e1[b];
+          } else {
+            const size_t off = (size_t)(live[b] ? y : y0) * a.W + x;  // row y0 always exists
+            b4[b] = *reinterpret_cast<const float4*>(a.background + off);
+            c4[b] = *reinterpret_cast<const float4*>(a.counts + off);
+          }
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
@@ -414,9 +440,13 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
       for (int b = 0; b < 4; ++b) {
         const int y = y0 + 16 * b + n;
         live[b] = y < a.H;
-        const size_t off = (size_t)(live[b] ? y : y0) * a.W + x;  // row y0 always exists
-        s4[b] = a.out_scale ? *reinterpret_cast<const float4*>(a.out_scale + off) : make_float4(1.f, 1.f, 1.f, 1.f);
-        o4[b] = a.accumulate ? *reinterpret_cast<const float4*>(a.out + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SPLIT) {
+          s4[b] = e0[b], o4[b] = e1[b];
+        } else {
+          const size_t off = (size_t)(live[b] ? y : y0) * a.W + x;  // row y0 always exists
+          s4[b] = a.out_scale ? *reinterpret_cast<const float4*>(a.out_scale + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+          o4[b] = a.accumulate ? *reinterpret_cast<const float4*>(a.out + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
