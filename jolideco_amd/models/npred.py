@@ -12,6 +12,7 @@ import torch.nn as nn
 from ..ops import ConvPlan, ConvSameFunction, default_conv_method, psf_separable_rank
 
 SEPARABLE_MAX_EDGE = 68  # SEP_MAX_K of csrc/kernels.h
+DIRECT_FAST_EDGE = 17    # widest PSF the split-fp16 direct kernel covers with one 32-column step per PSF row
 
 __all__ = ["NPredModel", "NPredModels", "NPredCalibration", "NPredCalibrations"]
 
@@ -94,7 +95,15 @@ class NPredModel(nn.Module):
         kh, kw = psf_t.shape
         method = default_conv_method()
         if method == "auto" and allow_separable and max(kh, kw) <= SEPARABLE_MAX_EDGE:
-            if psf_separable_rank(psf) and (rescaled is psf or psf_separable_rank(rescaled)):
+            rank = psf_separable_rank(psf)
+            if rank and rescaled is not psf:
+                rank = max(rank, psf_separable_rank(rescaled)) if psf_separable_rank(rescaled) else 0
+            # rank 1: always (18 against 27 us per 2048^2 convolution at 17 x 17, and the joint step batches it).  Rank 2
+            # and 3 cost 25 / 31 us there and switch off the LDS aliasing of every rank-1 launch of the process, against
+            # 26 us for the split-fp16 direct kernel -- which grows with the PSF area, the separable passes with its
+            # edge: beyond 17 taps (two 32-column steps per PSF row) the separable kernel wins again
+            # (tools/rank_bench.py)
+            if rank == 1 or (rank > 1 and max(kh, kw) > DIRECT_FAST_EDGE):
                 method = "separable"
         plan = ConvPlan.get(H, W, kh, kw, device, method=method)
         khat = plan.psf_spectrum(psf_t)
