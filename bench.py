@@ -27,6 +27,7 @@ is the one the metric is quoted on).  `cpu_baseline` times oracle/cpu_ref.py (th
 reference) on a bounded sample on rank 0 at N = 1.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -117,8 +118,9 @@ def pmc_traffic_bytes(cfg_name, kernel):
         fetch = write = None
         with open(REPO / rel) as fh:
             rows = list(csv.DictReader(fh))
-        # "<config>s" / "<config>f" rows: the same workload profiled on later builds -- the last one found wins
-        for label in (cfg_name, cfg_name + "s", cfg_name + "f"):
+        # "<config>s" / "<config>f" / "<config>g" rows: the same workload profiled on later builds -- the last one
+        # found wins (the .commit sidecar names the build of the newest rows)
+        for label in (cfg_name, cfg_name + "s", cfg_name + "f", cfg_name + "g"):
             for row in rows:
                 if row["config"] == label and kernel in row["kernel"]:
                     if row["counter"] == "FETCH_SIZE":
@@ -252,6 +254,11 @@ def main():
     # kernel timers: hipEvent pairs around every launch of every PROFILE_EVERY-th step of the timed
     # region (a pair costs ~2 us of stream time, ~4 % of the step if every launch is bracketed)
     _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
+    # Python's cycle collector stays out of the timed steps: when it frees the device buffers of an earlier session
+    # (set-up objects, a side run) inside the loop, every hipFree synchronises the device -- seen once as 65 ms in a
+    # 100-step side run
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         _hip.profile_pause(i % PROFILE_EVERY != 0)
@@ -260,6 +267,7 @@ def main():
     dist_ctx.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    gc.enable()
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
     prof = _hip.profile_read()
 
@@ -446,12 +454,15 @@ def main():
                 other.epoch()
             torch.cuda.synchronize(device)
             _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
+            gc.collect()
+            gc.disable()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 _hip.profile_pause(i % PROFILE_EVERY != 0)
                 other.epoch()
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
+            gc.enable()
             prof_other = _hip.profile_read()
             used = sorted({m.plan.method for m in other.total_loss.poisson_loss.npred_models_all})
             result = {
@@ -498,11 +509,14 @@ def main():
             for _ in range(args.warmup):
                 session.epoch()
             torch.cuda.synchronize(device)
+            gc.collect()
+            gc.disable()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 session.epoch()
             torch.cuda.synchronize(device)
             dt = time.perf_counter() - t0
+            gc.enable()
             out["dense_fp32_gmm"] = {
                 "value": args.steps / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / args.steps,
                 "note": "same workload, GMM arg-max by the dense fp32 MFMA kernel (JD_GMM_SCREEN=0)",
@@ -518,11 +532,14 @@ def main():
         for _ in range(2):
             seq.epoch()
         torch.cuda.synchronize(device)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         for _ in range(n_epochs):
             seq.epoch()
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
+        gc.enable()
         out["sequential_mode"] = {
             "epochs_per_s": n_epochs / dt, "steps_per_s": n_epochs * n_obs / dt, "ms_per_epoch": 1e3 * dt / n_epochs,
             "epochs": n_epochs,
