@@ -23,7 +23,9 @@ def _gmm_pair(K, seed, stride, zero_means=False):
 @pytest.mark.parametrize(
     "shape,K,stride,shifts",
     [((8, 8), 1, 4, (0, 0)), ((8, 8), 3, 4, (2, -2)), ((9, 13), 2, 4, (-1, 1)), ((31, 17), 5, 2, (1, 2)),
-     ((40, 33), 7, 3, (-2, 0)), ((16, 200), 6, 4, (0, 1)), ((130, 12), 9, 1, (2, 2)), ((64, 64), 128, 4, (-2, -2))],
+     ((40, 33), 7, 3, (-2, 0)), ((16, 200), 6, 4, (0, 1)), ((130, 12), 9, 1, (2, 2)), ((64, 64), 128, 4, (-2, -2)),
+     # component counts of the reference's trained mixtures (zoran-weiss: 200, gmm.py:358-367) and one past a power of 2
+     ((96, 120), 200, 4, (1, -3)), ((72, 72), 129, 4, (0, 2))],
 )
 def test_gmm_prior_edge_shapes(shape, K, stride, shifts):
     gmm, gmm_o = _gmm_pair(K, seed=shape[0] + K, stride=stride)
