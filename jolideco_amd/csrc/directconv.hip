@@ -19,8 +19,11 @@
 // against ~150 us for two rocFFT transforms + the k-space multiply; the FFT path stays for large PSFs.
 //
 // SPLIT (the default where it fits): the same Toeplitz product on the fp16 matrix cores with both operands split in
-// two, x = x_hi + x_lo (x_hi = fp16(x), x_lo = fp16(x - x_hi): 22 significant bits), and three products per step,
-//   D += A_hi B_hi + A_lo B_hi + A_hi B_lo          (v_mfma_f32_16x16x32_f16: K = 32 input columns per instruction)
+// two, x = x_hi + 2^-11 x_lo (x_hi = fp16(x), x_lo = fp16(2^11 (x - x_hi)): 22 significant bits; the factor 2^11 keeps
+// x_lo a NORMAL fp16 number wherever x_hi is one, so a pixel 10^8 times fainter than the brightest of its tile still
+// has all its bits), and three products per step in two accumulators,
+//   D_main += A_hi B_hi,   D_cross += A_lo B_hi + A_hi B_lo,   D = D_main + 2^-11 D_cross
+//   (v_mfma_f32_16x16x32_f16: K = 32 input columns per instruction)
 // with fp32 accumulation: A_lo B_lo (2^-22 of a term) is dropped, so a term is off by <= 3 x 2^-22 = 7e-7 of itself
 // and a sum of same-signed terms by no more (typically 1e-7; the reference's FFT convolution is no closer to the exact
 // sum).  The window is scaled per tile by the power of two that puts its largest |value| into [2^13, 2^14) (exact;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
     auto split = [&](float x, _Float16& hi, _Float16& lo) {
       const float xs = x * s;
       hi = (_Float16)xs;
-      lo = (_Float16)(xs - (float)hi);
+      lo = (_Float16)((xs - (float)hi) * 2048.f);  // |xs - hi| <= 2^-11 |hi|: the scaled remainder is as large as hi
     };
     if constexpr (VEC) {
 #pragma unroll
@@ -302,6 +305,9 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
       };
       Ops o0, o1;
       f16x8 blv[4];
+      f32x4 accx[4];  // the cross products (their lo operands carry a factor 2^11)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) accx[b] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto load_step = [&](Ops& o, int t) {
         t = t < n_steps ? t : n_steps - 1;
         const int dy = t / KS, ks = t - dy * KS;
@@ -317,9 +323,9 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, o.bh[b], acc[b], 0, 0, 0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.al, o.bh[b], acc[b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) accx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.al, o.bh[b], accx[b], 0, 0, 0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, blv[b], acc[b], 0, 0, 0);
+        for (int b = 0; b < 4; ++b) accx[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(o.ah, blv[b], accx[b], 0, 0, 0);
       };
       load_step(o0, 0);
       for (int t = 0; t < n_steps; t += 2) {
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(256) void direct_conv_kernel(DirectConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[b] *= inv;
+      for (int b = 0; b < 4; ++b) acc[b] = (acc[b] + accx[b] * (1.f / 2048.f)) * inv;
     } else {
     // window row of output row (16 b + n) for PSF row dy is 16 b + n + (kh - 1 - dy).  The operands of
     // PSF row dy + 1 are read from LDS while the MFMAs of row dy issue (register double buffer, the
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(256) void toeplitz_fragments_kernel(const float* __
 }
 
 // SPLIT tables: afrag16[(dy * KS + ks) * 2 + plane][lane] = 8 fp16 of psf'[dy][m + kw - 1 - c] * s_p, m = lane & 15,
-// c = 32 ks + 8 (lane >> 4) + e; plane 0 = fp16(v), plane 1 = fp16(v - plane 0); s_p = the power of two that puts
+// c = 32 ks + 8 (lane >> 4) + e; plane 0 = fp16(v), plane 1 = fp16(2^11 (v - plane 0)); s_p = the power of two that puts
 // max |psf| into [2^13, 2^14); the float after the table is 1 / s_p.  One block (a PSF has at most 33 x 33 taps).
 __global__ __launch_bounds__(256) void toeplitz_fragments16_kernel(const float* __restrict__ psf, uint4* __restrict__ afrag,
                                                                   int kh, int kw, int ks_count, int flip) {
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(256) void toeplitz_fragments16_kernel(const float* 
       if (dx >= 0 && dx < kw) v = flip ? psf[(kh - 1 - dy) * kw + (kw - 1 - dx)] : psf[dy * kw + dx];
       v *= sp;
       hi[e] = (_Float16)v;
-      lo[e] = (_Float16)(v - (float)hi[e]);
+      lo[e] = (_Float16)((v - (float)hi[e]) * 2048.f);
     }
     afrag[(t * 2) * 64 + lane] = __builtin_bit_cast(uint4, hi);
     afrag[(t * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);

@@ -320,6 +320,36 @@ def test_direct_conv_matches_fft_and_float64(shape, kshape, direct_kernel, monke
         assert rel_linf(results[method][1], results["direct"][1]) < 1e-5
 
 
+def test_split_direct_conv_keeps_faint_pixels_next_to_bright_sources():
+    """The split-fp16 direct kernel scales every 80 x 80 window by ONE power of two; its lo planes carry a factor
+    2^11, so a pixel keeps its 22 bits while it is more than 3.7e-9 of the brightest pixel of its window.  A sky of
+    0.01 with point sources of 1e5 (ratio 1e7, more than a deconvolved image of a bright point source on a faint
+    background shows): every output pixel -- also the faint ones between the sources, where a maximum-normalised error
+    would hide anything -- must agree with the float64 convolution RELATIVE TO ITS OWN VALUE."""
+    from scipy.signal import convolve2d
+
+    from jolideco_amd.ops import ConvPlan
+
+    rs = np.random.RandomState(12)
+    shape = (192, 256)
+    image = (0.01 * rs.uniform(0.5, 1.5, size=shape)).astype(np.float32)
+    for _ in range(12):
+        image[rs.randint(0, shape[0]), rs.randint(0, shape[1])] = 1e5 * rs.uniform(0.5, 2.0)
+    scale = rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    g = np.exp(-0.5 * ((np.arange(17) - 8) / 2.0) ** 2)
+    psf = np.outer(g, g) * (1.0 + 0.2 * rs.uniform(-1, 1, size=(17, 17)))  # not separable
+    psf = (psf / psf.sum()).astype(np.float32)
+    ref = convolve2d((image * scale).astype(np.float64), psf.astype(np.float64), mode="full")[8:-8, 8:-8]
+    plan = ConvPlan(shape[0], shape[1], 17, 17, DEV, method="direct")
+    khat = plan.psf_spectrum(torch.from_numpy(psf).to(DEV))
+    out = plan.conv_same(torch.from_numpy(image).to(DEV), torch.from_numpy(scale).to(DEV), khat).cpu().numpy()
+    plan.close()
+    local = np.abs(out - ref) / ref
+    print("split direct conv, dynamic range 1e7: worst error relative to the pixel's own value", local.max(),
+          "at a pixel of", ref.flat[local.argmax()], "; output range", ref.min(), ref.max())
+    assert local.max() < 3e-6
+
+
 def _gauss(n, sigma, offset=0.0):
     x = np.arange(n) - (n - 1) / 2 - offset
     return np.exp(-0.5 * (x / sigma) ** 2)
