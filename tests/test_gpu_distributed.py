@@ -104,3 +104,48 @@ def test_bench_two_ranks_over_gloo_reports_what_the_backend_saw(tmp_path):
     single = session.scalars.cpu().numpy()
     assert out["check"]["epochs_run"] == warmup + steps
     np.testing.assert_allclose(np.array(out["check"]["scalars_last_step"]), single, rtol=1e-5)
+
+
+@pytest.mark.parametrize("world_size", [8, 3])
+def test_every_rank_of_a_sharded_joint_step_in_one_process(world_size):
+    """The sharded joint step as EVERY rank of an N-GPU job computes it (DistContext(rank, N, dry_run=True): the
+    partition of the datasets, the band plan of the prior incl. the ragged last band, the band kernels and
+    jd_add_rolled_bands -- everything but the transport), one rank after the other in this process on the bench's
+    workload shape (8 observations, K = 128).  What the collectives would deliver, summed on the host in float64, must be
+    the single-GPU step: gradient buffer and loss scalars.  (N = 8: one observation per rank, the driver's scaling run;
+    N = 3: uneven observation counts and band heights.)"""
+    from conftest import rel_linf
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+    from jolideco_amd.data import synthetic_gmm, synthetic_observations
+    from jolideco_amd.distributed import DistContext
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape, n_obs = (328, 512), 8  # 81 patch rows: not a multiple of 8 or 3
+    datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=n_obs, seed=0)
+    means, covs, weights = synthetic_gmm(128, 64, seed=0)
+
+    def one_step(dist):
+        gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+        comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+        deco = MAPDeconvolver(n_epochs=1, display_progress=False, device="cuda:0", fit_mode="joint")
+        session = deco.session(datasets, components=comp, dist=dist)
+        session.cfg._optimizer_step = lambda states, step: None  # keep the gradient buffer, no update
+        session.epoch()
+        torch.cuda.synchronize()
+        return (session.states[0].grad.double().cpu().numpy().copy(), session.scalars.double().cpu().numpy().copy(),
+                session.priors[0].last_shifts, len(session.local_idx))
+
+    grad_1, scalars_1, shifts_1, n_local = one_step(DistContext())
+    assert n_local == n_obs
+    grad_sum, scalars_sum, owned = np.zeros_like(grad_1), np.zeros_like(scalars_1), 0
+    for rank in range(world_size):
+        grad_r, scalars_r, shifts_r, n_local = one_step(DistContext(rank=rank, world_size=world_size, dry_run=True))
+        assert shifts_r == shifts_1  # identically seeded generators: every rank rolls the image the same way
+        grad_sum += grad_r
+        scalars_sum += scalars_r
+        owned += n_local
+    assert owned == n_obs
+    err = rel_linf(grad_sum, grad_1)
+    print(f"{world_size} emulated ranks: gradient rel Linf {err:.2e}, scalars", np.abs(scalars_sum / scalars_1 - 1).max())
+    assert err < 2e-6
+    np.testing.assert_allclose(scalars_sum, scalars_1, rtol=2e-6)

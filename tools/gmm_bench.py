@@ -1,5 +1,5 @@
 """Time the GMM prior forward(+backward) at a given image size:
-    python tools/gmm_bench.py [edge=2048] [K=128] [grad=0] [gmm=synthetic|image] [image=noise|truth|mix]
+    python tools/gmm_bench.py [edge=2048] [K=128] [grad=0] [gmm=synthetic|image] [image=noise|truth|mix] [lse=0]
 (JD_GMM_SCREEN_DEBUG=1 prints the candidate records and survivors per patch of every call)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -14,6 +14,7 @@ with_grad = len(sys.argv) > 3 and sys.argv[3] == "1"
 dev = "cuda:0"
 kind = sys.argv[4] if len(sys.argv) > 4 else "synthetic"
 image = sys.argv[5] if len(sys.argv) > 5 else "noise"
+lse = len(sys.argv) > 6 and sys.argv[6] == "1"  # marginalize=True: logsumexp over the components
 means, covs, weights = synthetic_gmm(K, 64, seed=0) if kind == "synthetic" else image_like_gmm(K, 8, seed=0)
 gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
 h = gmm.handle(dev)
@@ -27,15 +28,15 @@ flux = torch.from_numpy(flux_np.astype(np.float32)).to(dev)
 v = torch.zeros(1, device=dev)
 g = torch.zeros_like(flux) if with_grad else None
 for _ in range(3):
-    h.prior_fwd_bwd(flux, 4, (1, -1), v, 1.0, grad=g, grad_coef=1.0)
+    h.prior_fwd_bwd(flux, 4, (1, -1), v, 1.0, grad=g, grad_coef=1.0, marginalize=lse)
 torch.cuda.synchronize()
 _hip.profile_enable(capacity=4096)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 10
 e0.record()
 for _ in range(n):
-    h.prior_fwd_bwd(flux, 4, (1, -1), v, 1.0, grad=g, grad_coef=1.0)
+    h.prior_fwd_bwd(flux, 4, (1, -1), v, 1.0, grad=g, grad_coef=1.0, marginalize=lse)
 e1.record(); torch.cuda.synchronize()
 prof = _hip.profile_read()
-print(f"{edge}^2 K={K} gmm={kind} image={image}: {e0.elapsed_time(e1) / n * 1e3:.1f} us per call;",
+print(f"{edge}^2 K={K} gmm={kind} image={image} lse={int(lse)}: {e0.elapsed_time(e1) / n * 1e3:.1f} us per call;",
       {k: round(t / c * 1e3, 1) for k, (t, c) in prof.items() if c}, "value", float(v))
