@@ -99,6 +99,9 @@ def init_from_env(backend=None):
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     if world_size <= 1:
         return DistContext()
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer registration fails with
+    # "hipIpcGetMemHandle: invalid argument" (read by the HSA runtime when the first GPU call initialises it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
         # JOLIDECO_DIST_BACKEND=gloo lets several ranks share ONE GPU (tests on a single-GPU box; gloo
