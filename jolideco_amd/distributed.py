@@ -3,10 +3,12 @@
 new.
 
 Partitioning: rank r owns datasets {d : d mod R = r}; the GMM prior is split by contiguous patch
-rows; theta, optimizer state and GMM constants are replicated.  The only exchange per optimizer
-step is ONE sum all-reduce of a flat buffer holding every component's flux gradient followed by
-the epoch's loss scalars (16.8 MB per component at 2048^2); every rank then applies the identical
-update, so no broadcast is needed.
+rows; theta, optimizer state and GMM constants are replicated.  Per optimizer step: ONE sum all-reduce
+of a flat buffer holding every component's likelihood gradient followed by the epoch's loss scalars
+(16.8 MB per component at 2048^2), started asynchronously, and -- while it is in flight -- the rank's
+band of the prior gradient, exchanged with ONE all-gather of the compact bands (`FitSession`,
+JOLIDECO_DIST_OVERLAP=0: the prior accumulated into the flat buffer before one blocking all-reduce).
+Every rank then applies the identical update, so no broadcast is needed.
 """
 import os
 
