@@ -209,6 +209,12 @@ int jd_gmm_prior_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int strid
                          float value_scale, float* value_out, int accumulate_value, float grad_coef,
                          float* grad_flux_accum, int32_t* argmax_out, void* stream);
 
+/* Diagnostics of the screened arg-max path, read without synchronisation from host-mapped memory the last block of a
+ * pass writes: out[0..4] = {generation of the last finished pass, it fell back to the dense fp32 kernel (0 / 1), bucket
+ * slots its surviving records used, patches it covered, gradient rows per patch the record buffer has room for now}.
+ * The library uses the same numbers to double that room (4 -> 32) after a pass that ran out of it. */
+int jd_gmm_screen_stats(const jd_gmm* gmm, int* out);
+
 /* The same evaluation for ONE RANK OF A SHARDED PRIOR (joint fit over several GPUs; the
  * reference has no distributed code): instead of accumulating into the gradient image, the gradient of the shard's
  * patch rows is written as a compact band of the ROLLED frame,

@@ -1445,6 +1445,10 @@ struct GmmBestArgs {
   double scale;
   float* value_out;
   int accumulate;
+  // what the NEXT call's host code wants to know, stored into host-mapped memory by the finishing block (no copy, no
+  // synchronisation: the host reads whatever pass has landed): {generation, fell back, bucket slots used, patches}
+  int* host_stats;          // nullable
+  const int* slots_used;    // offsets[K] of the record sort
   // fused backward pass after a fallback (fb.gpatch != nullptr and *flag == gen): every block produces the gradient
   // rows of its own 1024 patches from the components it has just decoded -- the work of a kernel of its own that in the
   // normal case was a 4.6 us launch returning at once
@@ -1510,6 +1514,13 @@ __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
     if (a.accumulate) v += (double)a.value_out[0];
     a.value_out[0] = (float)v;
     *a.ticket = 0;
+    if (a.host_stats) {
+      a.host_stats[1] = *a.flag == a.gen ? 1 : 0;
+      a.host_stats[2] = *a.slots_used;
+      a.host_stats[3] = a.n_end - a.n_begin;
+      __threadfence_system();
+      a.host_stats[0] = a.gen;  // last: marks the other three as belonging to this pass
+    }
   }
 }
 
@@ -1737,6 +1748,13 @@ struct jd_gmm {
   size_t rec_order_n_cap = 0;
   int* seg_cnt = nullptr;
   size_t seg_cnt_cap = 0;
+  // Gradient rows per patch the record buffer has room for (x 256 B x patches).  Starts at 4; a pass that fell back
+  // because it needed more, or filled more than 60 % of it, doubles it for the following passes (up to 32) -- known
+  // from the host-mapped statistics the last block of gmm_best_kernel leaves behind, read without synchronisation.
+  int rows_per_patch = 4;
+  int* host_stats = nullptr;      // hipHostMalloc (mapped): {generation, fell back, bucket slots used, patches}
+  int* host_stats_dev = nullptr;  // its device address
+  int stats_seen_gen = 0;
   int* blk_counts = nullptr;  // per-block bin counts of the bucket sort
   size_t blk_counts_cap = 0;
   int* korder = nullptr;      // K: visiting order of the components (most survivors in the previous call first)
@@ -1901,6 +1919,21 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
       return fail(JD_ERR_HIP, "jd_gmm_create: upload of the component order failed");
     }
     g->screen_ok = true;
+    // statistics of the last finished pass in host-mapped memory (optional: without it the record buffer keeps its
+    // initial capacity)
+    void* mapped = nullptr;
+    if (!getenv("JD_GMM_NO_HOST_STATS") &&
+        hipHostMalloc(reinterpret_cast<void**>(&g->host_stats), 4 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
+      memset(g->host_stats, 0, 4 * sizeof(int));
+      if (hipHostGetDevicePointer(&mapped, g->host_stats, 0) == hipSuccess) {
+        g->host_stats_dev = static_cast<int*>(mapped);
+      } else {
+        (void)hipHostFree(g->host_stats);
+        g->host_stats = nullptr;
+      }
+    } else {
+      g->host_stats = nullptr;
+    }
   }
   int dev = 0;
   hipDeviceProp_t prop;
@@ -1929,6 +1962,7 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->rec_order) (void)hipFree(g->rec_order);
   if (g->rec_order_n) (void)hipFree(g->rec_order_n);
   if (g->seg_cnt) (void)hipFree(g->seg_cnt);
+  if (g->host_stats) (void)hipHostFree(g->host_stats);
   if (g->korder) (void)hipFree(g->korder);
   if (g->blk_counts) (void)hipFree(g->blk_counts);
   if (g->grec) (void)hipFree(g->grec);
@@ -2033,7 +2067,17 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   // rows of the record-gradient buffer: 1.0-1.3 records per patch survive on the seeded mixtures of the benchmark, up
   // to 1.9 on noise under an image-like mixture (condition numbers 1e5: wider bounds); beyond 4 per patch (+ bucket
   // padding; 1 KB per patch) the scan kernel raises the fallback flag and the dense kernel takes the pass
-  const size_t grec_rows = fused ? (size_t)4 * (size_t)n + 32 * (size_t)g->K : 0;
+  if (fused && g->host_stats) {
+    volatile int* hs = g->host_stats;
+    const int seen = hs[0];
+    if (seen != g->stats_seen_gen && seen > 0) {  // a pass has finished since the last look
+      const long used = hs[2], patches = hs[3];
+      if (patches > 0 && (hs[1] != 0 || used - 32L * g->K > (long)(0.6 * g->rows_per_patch * (double)patches)) && g->rows_per_patch < 32)
+        g->rows_per_patch *= 2;
+      g->stats_seen_gen = seen;
+    }
+  }
+  const size_t grec_rows = fused ? (size_t)g->rows_per_patch * (size_t)n + 32 * (size_t)g->K : 0;
   if (fused) {
     if ((rc = grow(&g->grec, &g->grec_cap, grec_rows * D))) return rc;
     if ((rc = grow(&g->winner, &g->winner_cap, (size_t)a.n_end))) return rc;
@@ -2133,6 +2177,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   be.flag = flag, be.gen = g->gen, be.winner = fused ? g->winner : nullptr, be.argmax_fb = fused ? fallback_argmax : nullptr;
   be.rec_k = rec_k, be.rec_order = g->rec_order;
   be.ticket = g->screen_ctl + 3 * g->K + 2, be.scale = value_scale, be.value_out = value_out, be.accumulate = accumulate_value;
+  be.host_stats = fused ? g->host_stats_dev : nullptr, be.slots_used = bk.offsets + g->K;
   if (fused) {
     GmmBwdFallbackArgs& b = be.fb;
     b.flux = a.flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = fallback_argmax, b.gpatch = g->gpatch;
@@ -2302,6 +2347,16 @@ extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, 
                                     float* grad_flux_accum, int32_t* argmax_out, void* stream) {
   return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, patch_row_begin, patch_row_end, marginalize, value_scale,
                         value_out, accumulate_value, grad_coef, grad_flux_accum, argmax_out, nullptr, stream);
+}
+
+// Diagnostics of the screened arg-max path (no synchronisation: whatever pass has landed in the host-mapped block):
+// out = {generation of that pass, it fell back to the dense kernel (0 / 1), bucket slots it used, patches it covered,
+// gradient rows per patch the record buffer currently has room for}.
+extern "C" int jd_gmm_screen_stats(const jd_gmm* g, int* out) {
+  JD_REQUIRE(g && out, "jd_gmm_screen_stats: null argument");
+  for (int i = 0; i < 4; ++i) out[i] = g->host_stats ? reinterpret_cast<volatile int*>(g->host_stats)[i] : 0;
+  out[4] = g->rows_per_patch;
+  return JD_OK;
 }
 
 extern "C" int jd_gmm_prior_band_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,

@@ -307,6 +307,13 @@ class GmmHandle:
             )
         )
 
+    def screen_stats(self):
+        """(generation, fell_back, bucket_slots, patches, rows_per_patch) of the last screened pass that has finished
+        (jd_gmm_screen_stats; no synchronisation)."""
+        out = (c_int * 5)()
+        check(_hip.lib().jd_gmm_screen_stats(self._handle, out))
+        return tuple(int(v) for v in out)
+
     def estimate_log_prob(self, x):
         x = require_hip_tensor(x, "x")
         if x.ndim != 2 or x.shape[1] != self.D:

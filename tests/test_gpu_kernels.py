@@ -678,6 +678,38 @@ def _prior_both_ways(handle, flux, n_patches, monkeypatch, shifts=(1, -2)):
     return out["1"], out["0"]
 
 
+def test_gmm_record_buffer_grows_after_a_pass_that_ran_out_of_it():
+    """16 distinct components, each present 8 times: every patch has at least 8 exactly tied candidates, twice what the
+    record-gradient buffer has room for at first (4 rows per patch).  The first passes fall back to the dense kernel
+    (same bits, four times the work); the statistics the last block of a pass leaves in host-mapped memory make the
+    following passes double the room until the screened path holds: no synchronisation, no wrong number in between."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape = (160, 192)
+    n_patches = ((shape[0] - 8) // 4 + 1) * ((shape[1] - 8) // 4 + 1)
+    means, covs, weights = synthetic_gmm(16, 64, seed=5)
+    gmm = GaussianMixtureModel.from_numpy(np.tile(means, (8, 1)), np.tile(covs, (8, 1, 1)), np.tile(weights, 8) / 8,
+                                          meta=GaussianMixtureModelMeta(stride=4))
+    handle = gmm.handle(DEV)
+    flux = torch.from_numpy(np.random.RandomState(1).gamma(20, size=shape).astype(np.float32)).to(DEV)
+    results, stats = [], []
+    for _ in range(6):
+        value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+        argmax = torch.full((n_patches,), -7, dtype=torch.int32, device=DEV)
+        handle.prior_fwd_bwd(flux, 4, (2, -1), value, 1.0, grad=grad, grad_coef=1.0, argmax_out=argmax)
+        torch.cuda.synchronize()  # (the test wants to see each pass's statistics; the library never waits for them)
+        results.append((float(value), grad.cpu().numpy(), argmax.cpu().numpy()))
+        stats.append(handle.screen_stats())
+    print("screen statistics per pass (generation, fell back, slots, patches, rows per patch):", stats)
+    assert stats[0][1] == 1 and stats[0][4] == 4           # ran out of room: the dense kernel took the first pass
+    assert stats[-1][1] == 0 and stats[-1][4] >= 16         # room doubled until the screened path holds
+    assert all(s[3] == n_patches for s in stats)
+    for value, grad, argmax in results[1:]:                 # the same bits whoever computed them
+        assert value == results[0][0] and np.array_equal(grad, results[0][1]) and np.array_equal(argmax, results[0][2])
+    assert np.all(results[0][2] < 16)                       # ties go to the lowest component, like torch.max
+
+
 def test_gmm_screen_falls_back_to_the_dense_kernel(monkeypatch):
     """The two situations in which the screen gives up (device flag -> the always-enqueued dense kernel overwrites
     the result, no host sync): more candidates than a wave's record list holds, and non-finite screening values."""
