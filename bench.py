@@ -18,11 +18,18 @@ convolution, `general_psf`) and through rocFFT (`fft_psf`, the path the north st
 Total work is fixed as N grows (observations round-robin over the ranks, the prior split by patch
 rows): strong scaling.  All inputs are resident in HBM before the timed region.
 
+Timing protocol: W warm-up steps, then a settle phase of at least 0.3 s of steps (`settle`, its own field: clocks and
+caches reach their sustained state), then R = `--repeats` timed regions of EXACTLY K steps each, every one bracketed by
+barrier + synchronize and reduced by MAX over the ranks; `ms_per_step` / `value` are the MEDIAN region (min and max are
+reported beside it).  The kernel timers (hipEvent pairs recorded by the library around every launch, on the launch
+stream) run in a separate, untimed phase of >= 16 steps after the timed regions, so they neither perturb the timed
+steps nor rest on two samples.  `clock_mhz` is the shader clock the device holds under a vector-ALU load on every CU
+(jd_clock_probe): boards differ by several percent, and the line says which one it was measured on.
+
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step (the fp16 screen of the
 GMM arg-max: matrix-core roof; `roofline_section8d` prices the whole GMM forward pass by SURVEY section 8(d)'s
-dense fp32 definition), `roofline_poisson` the fused Poisson pass (HBM roof), both from hipEvent pairs recorded by
-the library around every launch of every 10th step of the timed region (bracketing every launch of every step costs
-~4 % of the step).  `--config c2|c4|c5` run the other BASELINE configurations (parity-test cases; the default c3
+dense fp32 definition), `roofline_poisson` the fused Poisson pass (HBM roof), `roofline_poisson_standalone` the
+stand-alone Poisson kernel as it runs in the rocFFT side run.  `--config c2|c4|c5` run the other BASELINE configurations (parity-test cases; the default c3
 is the one the metric is quoted on).  `cpu_baseline` times oracle/cpu_ref.py (the PyTorch-CPU restatement of the
 reference) on a bounded sample on rank 0 at N = 1.
 """
@@ -52,7 +59,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
 F16_MATRIX_PEAK_TFLOPS = 2516.6  # 16 x the fp32 rate: v_mfma_f32_32x32x16_f16, dense (MI355X_MICROARCH.md: ~2.5 PF)
 PATCH, D, STRIDE = 8, 64, 4
-PROFILE_EVERY = 10  # steps of the timed region whose kernels are timed with hipEvent pairs: 0, 10, 20, ...
+PROFILE_STEPS = 16  # steps of the untimed profile phase: every launch of every one of them is bracketed by a hipEvent pair
+SETTLE_SECONDS = 0.3
 
 
 def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
@@ -81,7 +89,7 @@ def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
     return deconvolver.session(datasets, components=comp, dist=dist)
 
 
-PMC_TRAFFIC_FILES = ("profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
+PMC_TRAFFIC_FILES = ("profiles/r03/pmc_hbm_traffic.csv", "profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
 _TRAFFIC_USED = {}  # kernel -> file its traffic figure came from
 
 
@@ -120,7 +128,7 @@ def pmc_traffic_bytes(cfg_name, kernel):
             rows = list(csv.DictReader(fh))
         # "<config>s" / "<config>f" / "<config>g" rows: the same workload profiled on later builds -- the last one
         # found wins (the .commit sidecar names the build of the newest rows)
-        for label in (cfg_name, cfg_name + "s", cfg_name + "f", cfg_name + "g"):
+        for label in (cfg_name, cfg_name + "s", cfg_name + "f", cfg_name + "g", cfg_name + "h"):
             for row in rows:
                 if row["config"] == label and kernel in row["kernel"]:
                     if row["counter"] == "FETCH_SIZE":
@@ -199,11 +207,81 @@ def cpu_baseline(cfg_name, sample_edge=1024, max_steps=10, budget_s=15.0):
     }
 
 
+def settle(session, device, dist_ctx, seconds=SETTLE_SECONDS, chunk=20):
+    """Steps for at least `seconds` before the timed regions (chunks of `chunk` steps; every rank runs the same number:
+    the ranks agree after each chunk whether all of them have had enough)."""
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(chunk):
+            session.epoch()
+        n += chunk
+        torch.cuda.synchronize(device)
+        more = time.perf_counter() - t0 < seconds
+        if dist_ctx.world_size > 1:
+            t = torch.tensor([1.0 if more else 0.0], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            more = bool(t.item() > 0)
+        if not more:
+            break
+    return {"seconds": time.perf_counter() - t0, "steps": n}
+
+
+def timed_regions(session, steps, repeats, device, dist_ctx):
+    """`repeats` regions of exactly `steps` steps, each bracketed by barrier + synchronize; per region the MAX over the
+    ranks.  Returns the list of region times in seconds."""
+    times = []
+    # Python's cycle collector stays out of the timed steps: when it frees the device buffers of an earlier session
+    # (set-up objects, a side run) inside the loop, every hipFree synchronises the device
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(repeats):
+            torch.cuda.synchronize(device)
+            dist_ctx.barrier()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                session.epoch()
+            torch.cuda.synchronize(device)
+            dist_ctx.barrier()
+            torch.cuda.synchronize(device)
+            times.append(time.perf_counter() - t0)
+    finally:
+        gc.enable()
+    if dist_ctx.world_size > 1:
+        t = torch.tensor(times, dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        times = [float(v) for v in t.cpu()]
+    return times
+
+
+def profile_phase(session, device, n_obs, steps=PROFILE_STEPS):
+    """Untimed: `steps` steps with every launch bracketed by a hipEvent pair.  {kernel: (total ms, launches)}"""
+    from jolideco_amd import _hip
+
+    _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * steps))
+    for _ in range(steps):
+        session.epoch()
+    torch.cuda.synchronize(device)
+    return _hip.profile_read()
+
+
+def region_stats(times, steps):
+    med = float(np.median(times))
+    return {"ms_per_step": 1e3 * med / steps, "ms_per_step_min": 1e3 * min(times) / steps,
+            "ms_per_step_max": 1e3 * max(times) / steps, "value": steps / med}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--settle-seconds", type=float, default=SETTLE_SECONDS,
+                    help="steps run for at least this long between the warm-up and the timed regions (0: none)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-psf", action="store_true",
@@ -247,37 +325,21 @@ def main():
     for _ in range(args.warmup):
         session.epoch()
     torch.cuda.synchronize(device)
-    dist_ctx.barrier()
+    settled = settle(session, device, dist_ctx, args.settle_seconds) if args.settle_seconds > 0 else {"seconds": 0.0, "steps": 0}
+    log(f"settled: {settled['steps']} steps in {settled['seconds']:.3f} s; timed regions")
+    times = timed_regions(session, args.steps, max(args.repeats, 1), device, dist_ctx)
+    stats = region_stats(times, args.steps)
+    elapsed = args.steps / stats["value"]  # the median region
+    log(f"timed regions done: {stats['ms_per_step']:.4f} ms/step (median of {len(times)}; "
+        f"{stats['ms_per_step_min']:.4f} .. {stats['ms_per_step_max']:.4f})")
+    clock_mhz = _hip.clock_probe(2.0, device)
+    # numerics of the run itself: the loss scalars after the last TIMED step (before the untimed profile phase)
     torch.cuda.synchronize(device)
-
-    log("timed region")
-    # kernel timers: hipEvent pairs around every launch of every PROFILE_EVERY-th step of the timed
-    # region (a pair costs ~2 us of stream time, ~4 % of the step if every launch is bracketed)
-    _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
-    # Python's cycle collector stays out of the timed steps: when it frees the device buffers of an earlier session
-    # (set-up objects, a side run) inside the loop, every hipFree synchronises the device -- seen once as 65 ms in a
-    # 100-step side run
-    gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        _hip.profile_pause(i % PROFILE_EVERY != 0)
-        session.epoch()
-    torch.cuda.synchronize(device)
-    dist_ctx.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
-    prof = _hip.profile_read()
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    scal = session.scalars.detach().cpu().numpy()
+    epochs_run = args.warmup + settled["steps"] + args.steps * len(times)
+    prof = profile_phase(session, device, n_obs)
 
     # sanity: the fit must have produced finite numbers
-    scal = session.scalars.detach().cpu().numpy()
     if not np.all(np.isfinite(scal)):
         raise SystemExit(f"non-finite losses after the timed region: {scal}")
 
@@ -345,26 +407,47 @@ def main():
     # (`sep_conv_kernel<.., POISSON>`): flux, exposure, background, counts in; g out = 20 B/pixel, and the convolution
     # image (4 B/pixel written + 4 read back) never exists.
     poi_ms, poi_n = avg_ms("poisson_fused")
-    methods = sorted({m.plan.method for m in session.total_loss.poisson_loss.npred_models_all})
-    poisson_in_conv = (methods in (["separable"], ["direct"]) and len(session.components) == 1
-                       and not os.environ.get("JD_SEP_NO_FUSION"))
-    # batched joint step: ONE launch covers all local datasets (jd_npred_poisson_batch_fwd_bwd)
-    per_launch = len(session.local_idx) if getattr(session, "batch_joint", False) else 1
-    poi_bytes = (20 if poisson_in_conv else 16) * H * W * per_launch
-    # (prefixes of the rocprofv3 kernel names: the template argument lists have grown trailing defaults)
-    poi_kernel = ("poisson_fused_kernel" if not poisson_in_conv
-                  else "sep_conv_kernel<true, true, true" if methods == ["separable"] else "direct_conv_kernel<")
+    models_all = session.total_loss.poisson_loss.npred_models_all
+    methods = sorted({m.plan.method for m in models_all})
+    n_comp = len(session.components)
+    # batched joint step: ONE launch covers all local datasets (jd_npred_poisson_batch_[multi_]fwd_bwd)
+    batched = bool(getattr(session, "batch_joint", False))
+    per_launch = len(session.local_idx) if batched else 1
+    # where the Poisson pass runs, which kernel that is (prefix of its rocprofv3 name) and its algorithmic bytes per
+    # (pixel, dataset) -- decided from what the library says it launches, never from the timer's name alone:
+    #  * one separable / direct component: EPILOGUE of the forward convolution: flux, exposure, background, counts in,
+    #    g out = 20 B; the convolution image (4 B written + 4 read back) never exists;
+    #  * several separable components in a batched step (config 5): epilogue of the MULTI tile kernel: per component
+    #    flux + exposure in and g out (12 B each), background + counts once (8 B): 12 C + 8;
+    #  * otherwise the stand-alone kernel: conv_c, background, counts in, g_c out: 8 C + 8 (16 B at C = 1).
+    fused_one = methods in (["separable"], ["direct"]) and n_comp == 1 and _hip.get_option("JD_SEP_NO_FUSION") is None
+    fused_multi = methods == ["separable"] and n_comp > 1 and batched
+    walk = methods == ["separable"] and n_comp == 1 and models_all[0].plan.takes_walk(per_launch)
+    if fused_one:
+        poi_px_bytes = 20
+        poi_kernel = ("direct_conv_kernel<" if methods == ["direct"] else
+                      "walk_kernel<4, 2, true, true, 0>" if walk else "sep_conv_kernel<true, true, true, false>")
+        poi_what = "forward convolution + Poisson pass"
+    elif fused_multi:
+        poi_px_bytes = 12 * n_comp + 8
+        poi_kernel, poi_what = "sep_conv_kernel<true, true, true, true>", f"forward convolutions of {n_comp} components + Poisson pass"
+    else:
+        poi_px_bytes = 8 * n_comp + 8
+        poi_kernel, poi_what = "poisson_fused_kernel", "stand-alone Poisson pass"
+    poi_bytes = poi_px_bytes * H * W * per_launch
     roof_poi = None
     if poi_ms:
         achieved = poi_bytes / (poi_ms * 1e-3) / 1e9
         roof_poi = {
-            "kernel": poi_kernel + ("> (forward convolution + Poisson pass)" if poisson_in_conv else ""), "bound": "hbm",
+            "kernel": f"{poi_kernel} ({poi_what})", "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic_bytes(args.config, poi_kernel) if world == 1 and fake is None else None,
             "traffic_source": pmc_traffic_source(poi_kernel),
             "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes, "datasets_per_launch": per_launch,
+            "bytes_per_pixel_and_dataset": poi_px_bytes,
         }
-    n_profiled = len(range(0, args.steps, PROFILE_EVERY))
+    poisson_in_conv = fused_one
+    n_profiled = PROFILE_STEPS
     nested = ("gmm_stage", "gmm_screen", "gmm_sort", "gmm_exact")  # stage timers inside the gmm_fwd bracket
     kernel_ms_per_step = {k: (v[0] / n_profiled) for k, v in prof.items() if v[1] and k not in nested}
     dominant = max(kernel_ms_per_step, key=kernel_ms_per_step.get) if kernel_ms_per_step else None
@@ -380,6 +463,11 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_min": stats["ms_per_step_min"], "ms_per_step_max": stats["ms_per_step_max"],
+        "repeats": len(times), "timing": "median of `repeats` regions of `steps` steps, each bracketed by barrier + synchronize",
+        "settle": settled,
+        "clock_mhz": clock_mhz,
+        "kernel_profile_steps": PROFILE_STEPS,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -397,7 +485,7 @@ def main():
         },
         # numerics of the run itself: the loss scalars of the last timed step [dataset losses | log-priors] -- the same
         # for any number of ranks (tests/test_gpu_distributed.py compares a 2-rank run with a single process)
-        "check": {"epochs_run": args.warmup + args.steps, "scalars_last_step": [float(v) for v in scal]},
+        "check": {"epochs_run": epochs_run, "scalars_last_step": [float(v) for v in scal]},
         "roofline": roofline,
         "roofline_poisson": roof_poi,
         # SURVEY section 8(d)'s own definition for the GMM prior: Np K (2 D^2 + 4 D) fp32 flop over the duration of the
@@ -422,12 +510,14 @@ def main():
         conv_ms, conv_n = avg_ms(conv_key)
         # (with the Poisson pass fused into the forward launch only the adjoint carries this timer: 16 B/pixel)
         # a batched adjoint reads g + exposure per dataset and reads / writes the gradient once: (8 n + 8) B/pixel
-        conv_bytes = ((8 * per_launch + 8) if (poisson_in_conv and per_launch > 1) else 16 if poisson_in_conv else 14) * H * W
+        conv_bytes = ((8 * per_launch + 8) if ((poisson_in_conv or fused_multi) and per_launch > 1) else 16 if poisson_in_conv else 14) * H * W
         achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
         conv_traffic = None
         if world == 1 and fake is None:
             if conv_key != "sep_conv":
                 names = ("direct_conv_kernel",)
+            elif poisson_in_conv and walk:
+                names = ("walk_kernel<2, 2, false, false, 6>",) if per_launch >= 6 else ("walk_kernel<4, 2, false, false, 0>",)
             elif poisson_in_conv:
                 names = ("sep_conv_kernel<true, false, false",)
             else:
@@ -435,7 +525,8 @@ def main():
             parts = [pmc_traffic_bytes(args.config, name) for name in names]
             conv_traffic = sum(parts) / len(parts) if all(p is not None for p in parts) else None
         out["roofline_conv"] = {
-            "kernel": _hip.lib().jd_kernel_name(_hip.KERNEL_IDS[conv_key]).decode(), "bound": "hbm",
+            "kernel": ("walk_kernel (adjoint)" if conv_key == "sep_conv" and walk else
+                       _hip.lib().jd_kernel_name(_hip.KERNEL_IDS[conv_key]).decode()), "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": conv_traffic, "avg_launch_ms": conv_ms, "launches": conv_n, "bytes_per_launch": conv_bytes,
             "datasets_per_launch": per_launch,
@@ -444,6 +535,8 @@ def main():
     # <= 3 outer products gets: the MFMA Toeplitz convolution -- and through rocFFT (R2C, k-space multiply, C2R: the
     # path BASELINE.json's north star names; the default for PSFs larger than 33x33).  Reported next to the headline,
     # never as it.
+    side_repeats = min(max(args.repeats, 1), 3)
+
     def conv_method_run(method, note):
         log(f"{method}-convolution run (JOLIDECO_CONV_METHOD={method})")
         previous = os.environ.get("JOLIDECO_CONV_METHOD")
@@ -453,20 +546,11 @@ def main():
             for _ in range(args.warmup):
                 other.epoch()
             torch.cuda.synchronize(device)
-            _hip.profile_enable(capacity=min(1 << 16, 64 * (n_obs + 2) * max(args.steps, 1)))
-            gc.collect()
-            gc.disable()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                _hip.profile_pause(i % PROFILE_EVERY != 0)
-                other.epoch()
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
-            gc.enable()
-            prof_other = _hip.profile_read()
+            side = region_stats(timed_regions(other, args.steps, side_repeats, device, dist_ctx), args.steps)
+            prof_other = profile_phase(other, device, n_obs)
             used = sorted({m.plan.method for m in other.total_loss.poisson_loss.npred_models_all})
             result = {
-                "value": args.steps / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / args.steps,
+                "value": side["value"], "unit": "iters/s", "ms_per_step": side["ms_per_step"],
                 "conv_method": "+".join(used), "note": note,
                 "kernel_ms_per_step": {k: v[0] / n_profiled for k, v in prof_other.items() if v[1] and k not in nested},
             }
@@ -479,50 +563,42 @@ def main():
                 os.environ["JOLIDECO_CONV_METHOD"] = previous
 
     if world == 1 and fake is None and "separable" in methods and not args.no_general_psf:
-        out["general_psf"], prof_general = conv_method_run(
+        out["general_psf"], _ = conv_method_run(
             "direct", "same workload with the PSFs convolved as general 17x17 kernels (MFMA Toeplitz convolution, "
                       "fp16 x 3 split operands; Poisson pass in the forward launch's epilogue)")
-        # this path runs the STAND-ALONE fused Poisson pass (conv, background, counts in; g out = 16 B/pixel):
-        # the kernel BASELINE.json's "HBM GB/s on fused Poisson pass" was defined on
-        total_p, count_p = prof_general.get("poisson_fused", (0.0, 0))
-        if count_p:
+        out["fft_psf"], prof_fft = conv_method_run(
+            "fft", "same workload through rocFFT: pad+scale, R2C, k-space multiply, C2R, stand-alone Poisson pass, "
+                   "R2C, conj multiply, C2R, adjoint epilogue per observation")
+        # the rocFFT run is the one that executes the STAND-ALONE fused Poisson kernel (conv, background, counts in; g out
+        # = 16 B/pixel at one component): the kernel BASELINE.json's "HBM GB/s on fused Poisson pass" was defined on
+        total_p, count_p = prof_fft.get("poisson_fused", (0.0, 0))
+        if count_p and out["fft_psf"]["conv_method"] == "fft":
             ms = total_p / count_p
-            achieved = 16 * H * W / (ms * 1e-3) / 1e9
+            px_bytes = 8 * n_comp + 8
+            achieved = px_bytes * H * W / (ms * 1e-3) / 1e9
             out["roofline_poisson_standalone"] = {
-                "kernel": "poisson_fused_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "kernel": "poisson_fused_kernel (stand-alone pass of the rocFFT side run)", "bound": "hbm",
+                "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic_bytes(args.config, "poisson_fused_kernel<4, 1"),
                 "traffic_source": pmc_traffic_source("poisson_fused_kernel<4, 1"),
-                "avg_launch_ms": ms, "launches": count_p, "bytes_per_launch": 16 * H * W,
+                "avg_launch_ms": ms, "launches": count_p, "bytes_per_launch": px_bytes * H * W,
                 "note": "hipEvent pairs add ~2 us to this ~13 us kernel; rocprofv3: profiles/README.md",
             }
-        out["fft_psf"], _ = conv_method_run(
-            "fft", "same workload through rocFFT: pad+scale, R2C, k-space multiply, C2R, stand-alone Poisson pass, "
-                   "R2C, conj multiply, C2R, adjoint epilogue per observation")
     # The same fit with the GMM arg-max evaluated by the dense fp32 MFMA kernel for every (patch, component) pair
     # (JD_GMM_SCREEN=0; bit-identical results): reported next to the headline for whoever wants the number without the
     # fp16 screen.
     if world == 1 and fake is None and roof_gmm and roof_gmm["kernel"] == "gmm_screen_kernel" and not args.no_general_psf:
-        log("dense-GMM run (JD_GMM_SCREEN=0)")
-        os.environ["JD_GMM_SCREEN"] = "0"
-        try:
+        log("dense-GMM run (option JD_GMM_SCREEN=0)")
+        with _hip.options(JD_GMM_SCREEN=0):
             for _ in range(args.warmup):
                 session.epoch()
             torch.cuda.synchronize(device)
-            gc.collect()
-            gc.disable()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                session.epoch()
-            torch.cuda.synchronize(device)
-            dt = time.perf_counter() - t0
-            gc.enable()
+            side = region_stats(timed_regions(session, args.steps, side_repeats, device, dist_ctx), args.steps)
             out["dense_fp32_gmm"] = {
-                "value": args.steps / dt, "unit": "iters/s", "ms_per_step": 1e3 * dt / args.steps,
-                "note": "same workload, GMM arg-max by the dense fp32 MFMA kernel (JD_GMM_SCREEN=0)",
+                "value": side["value"], "unit": "iters/s", "ms_per_step": side["ms_per_step"],
+                "note": "same workload, GMM arg-max by the dense fp32 MFMA kernel (option JD_GMM_SCREEN=0)",
             }
-        finally:
-            os.environ.pop("JD_GMM_SCREEN", None)
     # The reference's own loop (fit_mode="sequential", jolideco/core.py:209-247): one optimizer step per dataset, each
     # with a full prior evaluation, then the per-epoch trace on all datasets -- SURVEY.md section 8(d) asks for both rates.
     if world == 1 and fake is None and not args.no_general_psf:
@@ -532,14 +608,7 @@ def main():
         for _ in range(2):
             seq.epoch()
         torch.cuda.synchronize(device)
-        gc.collect()
-        gc.disable()
-        t0 = time.perf_counter()
-        for _ in range(n_epochs):
-            seq.epoch()
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
-        gc.enable()
+        dt = float(np.median(timed_regions(seq, n_epochs, side_repeats, device, dist_ctx)))
         out["sequential_mode"] = {
             "epochs_per_s": n_epochs / dt, "steps_per_s": n_epochs * n_obs / dt, "ms_per_epoch": 1e3 * dt / n_epochs,
             "epochs": n_epochs,

@@ -46,6 +46,14 @@ const char* jd_last_error(void);
 /* number of HIP devices visible / name of the compiled target ("gfx950") */
 const char* jd_target_arch(void);
 
+/* Tuning / test switches (new; the reference has none).  Every switch has the name of the environment variable that
+ * sets its initial value when the library is loaded (JD_GMM_SCREEN, JD_SEP_WALK, JD_SEP_NO_ALIAS, ...; the full list is
+ * the table in csrc/options.hip); after loading, the environment is never read again by a launch path -- a test or an
+ * A/B tool that wants another variant calls jd_set_option(key, "value"), or (key, NULL) to return to the default.
+ * Unknown keys are an error.  jd_get_option: *is_set / *value of the switch as the library sees it now. */
+int jd_set_option(const char* key, const char* value);
+int jd_get_option(const char* key, int* is_set, int* value);
+
 /* Convolution plan --------------------------------------------------------------------------
  * Replaces the per-call shape logic of jolideco/utils/torch.py:363-370 (`convolve_fft_torch`):
  * linear "same" convolution of an (H, W) image with a (kh, kw) kernel, zero outside the image; the
@@ -80,6 +88,11 @@ int jd_conv_plan_destroy(jd_conv_plan* plan);
 int jd_conv_plan_shape(const jd_conv_plan* plan, int* shape6);
 /* 0 = FFT, 1 = DIRECT, 2 = SEPARABLE */
 int jd_conv_plan_method(const jd_conv_plan* plan);
+/* 1 when a SEPARABLE plan runs a launch over `n_datasets` datasets (1 = the per-dataset calls) on the strip-walk kernels
+ * of csrc/walkconv.hip instead of the tile kernel of csrc/sepconv.hip, given rank-1 operators (PSFs up to 17 x 17, image
+ * width a multiple of 4, enough pixels x datasets to fill the chip; option JD_SEP_WALK = 0 / 1 forces either).  Both
+ * compute the same function; a benchmark uses this to name the kernel it timed. */
+int jd_conv_plan_takes_walk(const jd_conv_plan* plan, int n_datasets);
 /* HALF the number of floats of one per-(dataset, component) kernel operator buffer `khat`:
  * FFT: complex64 elements of the kernel spectrum, Hp * (Wp/2 + 1); DIRECT: floats of one Toeplitz
  * fragment table (the buffer holds the forward and the adjoint table); SEPARABLE: the rank and the row /
@@ -293,6 +306,11 @@ int jd_profile_disable(void);
 int jd_profile_pause(int paused);
 int jd_profile_read(int kernel, double* total_ms, long long* launches);
 const char* jd_kernel_name(int kernel);
+/* Sustained shader clock of the current device under a vector-ALU load on every CU, in MHz (new; a measurement aid:
+ * MI355X boards hold different clocks under load, so a benchmark line should say which clock its times were taken at).
+ * Runs a dependent-FMA kernel for about `milliseconds` on `stream`, stamped with s_memtime / s_memrealtime, and
+ * SYNCHRONISES the stream. */
+int jd_clock_probe(double milliseconds, double* mhz_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,11 +30,14 @@ EXPORTS = {
     "jd_version": (c_int, []),
     "jd_last_error": (c_char_p, []),
     "jd_target_arch": (c_char_p, []),
+    "jd_set_option": (c_int, [c_char_p, c_char_p]),
+    "jd_get_option": (c_int, [c_char_p, POINTER(c_int), POINTER(c_int)]),
     "jd_conv_plan_create": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
     "jd_conv_plan_destroy": (c_int, [c_void_p]),
     "jd_conv_plan_shape": (c_int, [c_void_p, POINTER(c_int)]),
     "jd_conv_plan_spectrum_size": (c_size_t, [c_void_p]),
     "jd_conv_plan_method": (c_int, [c_void_p]),
+    "jd_conv_plan_takes_walk": (c_int, [c_void_p, c_int]),
     "jd_psf_separable_rank": (c_int, [c_void_p, c_int, c_int, c_float]),
     "jd_conv_psf_spectrum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jd_conv_same": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -92,6 +95,7 @@ EXPORTS = {
     "jd_profile_pause": (c_int, [c_int]),
     "jd_profile_read": (c_int, [c_int, POINTER(c_double), POINTER(c_longlong)]),
     "jd_kernel_name": (c_char_p, [c_int]),
+    "jd_clock_probe": (c_int, [c_double, POINTER(c_double), c_void_p]),
 }
 
 KERNEL_IDS = {
@@ -120,6 +124,45 @@ def lib():
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+def set_option(key, value=None):
+    """Set a tuning / test switch of the library (`JD_*`, csrc/options.hip); None returns it to its default.  The library
+    reads the environment only once, when it is loaded."""
+    check(lib().jd_set_option(key.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(key):
+    """Value of a switch (int) or None when it is unset."""
+    is_set, value = c_int(0), c_int(0)
+    check(lib().jd_get_option(key.encode(), ctypes.byref(is_set), ctypes.byref(value)))
+    return value.value if is_set.value else None
+
+
+class options:
+    """Context manager: `with _hip.options(JD_GMM_SCREEN=0): ...` sets switches and restores the previous values."""
+
+    def __init__(self, **switches):
+        self.switches = switches
+        self.previous = {}
+
+    def __enter__(self):
+        for key, value in self.switches.items():
+            self.previous[key] = get_option(key)
+            set_option(key, value)
+        return self
+
+    def __exit__(self, *exc):
+        for key, value in self.previous.items():
+            set_option(key, value)
+        return False
+
+
+def clock_probe(milliseconds=2.0, device=None):
+    """Shader clock (MHz) the device holds under a vector-ALU load on every CU (jd_clock_probe; synchronises)."""
+    mhz = c_double(0.0)
+    check(lib().jd_clock_probe(float(milliseconds), ctypes.byref(mhz), stream_ptr(device)))
+    return mhz.value
 
 
 def profile_enable(capacity=8192):

@@ -599,8 +599,8 @@ static int launch_kc(const DirectConvArgs& a, hipStream_t stream) {
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 2) per_cu = 2;
   if (per_cu < 1) per_cu = 1;
-  if (const char* env = getenv("JD_CONV_BLOCKS_PER_CU")) {  // tuning override
-    const int v = atoi(env);
+  {  // tuning override
+    const int v = opt_value(OPT_CONV_BLOCKS_PER_CU, 0);
     if (v >= 1 && v <= 8) per_cu = v;
   }
   int grid = g_conv_n_cu * per_cu;

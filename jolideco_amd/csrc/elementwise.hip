@@ -263,8 +263,8 @@ int launch_poisson_fused(const PoissonArgs& a, int* n_partials, hipStream_t stre
   const int span = a.write_grad ? a.Wp : a.W;
   const int rows = a.write_grad ? a.Hp : a.H;
   int rows_per_block = 1;  // measured on MI355X at 2048^2: 1 row 14.6 us, 2 rows 15.8 us, 4 rows 17.3 us
-  if (const char* env = getenv("JD_POISSON_ROWS")) {  // tuning override
-    const int v = atoi(env);
+  {  // tuning override
+    const int v = opt_value(OPT_POISSON_ROWS, 0);
     if (vec && (v == 1 || v == 2 || v == 4)) rows_per_block = v;
   }
   dim3 grid((span + per_block - 1) / per_block, (rows + rows_per_block - 1) / rows_per_block);

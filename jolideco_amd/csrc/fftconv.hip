@@ -26,6 +26,7 @@ struct jd_conv_plan {
   int py = 0, px = 0;        // offset of the (H, W) image inside the conv / pad buffers (FFT: oy, ox; direct: 0)
   size_t nspec = 0;  // complex elements of one spectrum (direct: floats of one Toeplitz fragment table)
   int split = 0;     // direct: the split-fp16 kernel (default where it fits; JD_DIRECT_FP32=1: the fp32 MFMA kernel)
+  bool allow_walk = true;  // separable: the strip-walk kernel may take plain launches (false inside multi-component models)
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   void* work = nullptr;
@@ -114,7 +115,7 @@ static int conv_forward(jd_conv_plan* p, int c, const float* image, const float*
                               1.f, 0, p->split, stream);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0,
-                           stream);
+                           stream, p->allow_walk);
   int rc = launch_pad_mul(image, scale, p->pad[c], p->H, p->W, p->Hp, p->Wp, stream);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream))) return rc;
@@ -141,7 +142,7 @@ static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const f
                               1, coef, accumulate, p->split, stream);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(p->pad[c], nullptr, khat, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1, coef,
-                           accumulate, stream);
+                           accumulate, stream, p->allow_walk);
   int rc = corr_backward(p, c, khat, stream);
   if (rc) return rc;
   return launch_adjoint_epilogue(p->conv[c], scale, grad, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox, coef, accumulate,
@@ -177,7 +178,7 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
     p->method = mode == JD_CONV_MODE_SEPARABLE ? JD_CONV_SEPARABLE : JD_CONV_DIRECT;
     p->H = H, p->W = W, p->kh = kh, p->kw = kw, p->Hp = H, p->Wp = W;
     p->oy = (kh - 1) / 2, p->ox = (kw - 1) / 2, p->py = 0, p->px = 0;
-    p->split = p->method == JD_CONV_DIRECT && direct_conv_split_supported(kh, kw) && !getenv("JD_DIRECT_FP32") ? 1 : 0;
+    p->split = p->method == JD_CONV_DIRECT && direct_conv_split_supported(kh, kw) && !opt_is_set(OPT_DIRECT_FP32) ? 1 : 0;
     p->nspec = p->method == JD_CONV_SEPARABLE ? (sep_conv_operator_floats() + 1) / 2
                                               : direct_conv_fragment_floats(kh, kw, p->split);
     p->partials_cap = std::max(std::max(poisson_fused_max_partials(H, W), sep_conv_tiles(H, W)), direct_conv_tiles(H, W));
@@ -282,6 +283,11 @@ extern "C" size_t jd_conv_plan_spectrum_size(const jd_conv_plan* p) { return p ?
 
 extern "C" int jd_conv_plan_method(const jd_conv_plan* p) { return p ? p->method : -1; }
 
+extern "C" int jd_conv_plan_takes_walk(const jd_conv_plan* p, int n_datasets) {
+  if (!p || p->method != JD_CONV_SEPARABLE || n_datasets < 1) return 0;
+  return walk_takes_launch(p->H, p->W, n_datasets, p->kh, p->kw, p->oy, p->ox) ? 1 : 0;
+}
+
 extern "C" int jd_psf_separable_rank(const float* psf_host, int kh, int kw, float tol) {
   if (!psf_host || !sep_conv_supported(kh, kw)) return 0;
   return sep_factorize(psf_host, kh, kw, tol > 0.f ? (double)tol : SEP_DEFAULT_TOL, nullptr, nullptr);
@@ -302,6 +308,7 @@ extern "C" int jd_conv_psf_spectrum(jd_conv_plan* p, const float* psf, float* kh
                "(ask jd_psf_separable_rank() first); use JD_CONV_MODE_AUTO", p->kh, p->kw, SEP_MAX_RANK, SEP_DEFAULT_TOL);
     JD_HIP(hipMemcpyAsync(khat, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
     JD_HIP(hipStreamSynchronize(s));
+    sep_register_operator(khat, rank);
     return JD_OK;
   }
   int rc = launch_pad_mul(psf, nullptr, p->pad[0], p->kh, p->kw, p->Hp, p->Wp, s);
@@ -380,7 +387,8 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   // one component convolved on the unpadded grid (separable or MFMA direct), no up-sampling, no background norm: the
   // Poisson pass is the epilogue of the convolution
   const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
-                     upsampling == 1 && !cal.log_bkg_norm && !getenv("JD_SEP_NO_FUSION");
+                     upsampling == 1 && !cal.log_bkg_norm && !opt_is_set(OPT_SEP_NO_FUSION);
+  p->allow_walk = n_comp == 1;  // (a multi-component batch runs the tile kernel: its per-dataset form must round alike)
   if (fused) {
     const float* in = flux[0];
     if (cal.shift_xy) {
@@ -486,6 +494,22 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
                  who, d, c);
   }
   hipStream_t s = as_stream(stream);
+  {
+    // a batch whose datasets would not all take the same kernel family (some PSFs rank 1 and small: strip-walk kernels,
+    // others not) runs the per-dataset calls it stands for -- same results by definition
+    SepBatchTable probe{};
+    for (int d = 0; d < n_datasets; ++d) probe.bkg[d] = background[d], probe.cnt[d] = counts[d];
+    for (int i = 0; i < n_datasets * n_comp; ++i) probe.scale[i] = exposure[i], probe.op[i] = khat[i], probe.g[i] = nullptr;
+    if (sep_batch_is_mixed(n_datasets, n_comp, probe, p->H, p->W, p->kh, p->kw, p->oy, p->ox)) {
+      for (int d = 0; d < n_datasets; ++d) {
+        int rc = npred_poisson_impl(who, p, n_comp, flux, exposure + d * n_comp, khat + d * n_comp, background[d], counts[d],
+                                    stirling_mean[d], eps, loss_out[d], grad_flux, accumulate || d > 0, grad_scale, nullptr,
+                                    1, Calibration{}, stream);
+        if (rc) return rc;
+      }
+      return JD_OK;
+    }
+  }
   const size_t bytes = (size_t)p->H * p->W * sizeof(float);
   for (int i = 0; i < n_datasets * n_comp; ++i)
     if (!p->gbatch[i]) JD_HIP(hipMalloc(&p->gbatch[i], bytes));
@@ -518,19 +542,24 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
   p->table_used[slot] = ++p->table_clock;
   SepBatchTable* const table_dev = p->table_dev[slot];
   const double n_pix = (double)p->H * (double)p->W;
+  int n_part = 0;  // partial sums per dataset the forward launch wrote (<= tiles)
   int rc = launch_sep_conv_poisson_batch(n_datasets, n_comp, flux, table, table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
-                                         p->partials_batch, eps, (float)(1.0 / n_pix), grad_flux ? 1 : 0, s);
+                                         p->partials_batch, eps, (float)(1.0 / n_pix), grad_flux ? 1 : 0, &n_part, s);
   if (rc) return rc;
-  // with a gradient the losses are finalised by the first blocks of the first adjoint launch (one dependent launch less
-  // per step); its grid has at least 8 blocks whatever the image size
-  const bool fold = grad_flux && n_datasets <= 8;
-  if (!fold && (rc = launch_finalize_rows(p->partials_batch, tiles, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s))) return rc;
-  if (!grad_flux) return JD_OK;
-  for (int c = 0; c < n_comp; ++c)
+  // with a gradient the losses are finalised by the first blocks of the first adjoint launch where it can (one dependent
+  // launch less per step)
+  if (!grad_flux) return launch_finalize_rows(p->partials_batch, n_part, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s);
+  int folded = 0;
+  for (int c = 0; c < n_comp; ++c) {
+    int done = 0;
     if ((rc = launch_sep_conv_adjoint_batch(n_datasets, n_comp, c, table, table_dev, grad_flux[c], p->H, p->W, p->kh,
                                             p->kw, p->oy, p->ox, grad_scale, accumulate, s,
-                                            fold && c == 0 ? p->partials_batch : nullptr, 1.0 / n_pix)))
+                                            c == 0 && n_datasets <= 8 ? p->partials_batch : nullptr, 1.0 / n_pix, n_part,
+                                            &done)))
       return rc;
+    folded |= done;
+  }
+  if (!folded) return launch_finalize_rows(p->partials_batch, n_part, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s);
   return JD_OK;
 }
 

@@ -1922,7 +1922,7 @@ extern "C" int jd_gmm_create(int K, int Dn, const float* prec_chol, const float*
     // statistics of the last finished pass in host-mapped memory (optional: without it the record buffer keeps its
     // initial capacity)
     void* mapped = nullptr;
-    if (!getenv("JD_GMM_NO_HOST_STATS") &&
+    if (!opt_is_set(OPT_GMM_NO_HOST_STATS) &&
         hipHostMalloc(reinterpret_cast<void**>(&g->host_stats), 4 * sizeof(int), hipHostMallocMapped) == hipSuccess) {
       memset(g->host_stats, 0, 4 * sizeof(int));
       if (hipHostGetDevicePointer(&mapped, g->host_stats, 0) == hipSuccess) {
@@ -1980,8 +1980,8 @@ extern "C" int jd_gmm_is_triangular(const jd_gmm* g) { return g ? (g->triangular
 // Tiles per block: the choice that minimises (rounds over the CUs) x (tiles per block); ties go to
 // the larger block (fewer fragment re-reads).
 static int pick_block_tiles(long n_patches, int n_cu) {
-  if (const char* env = getenv("JD_GMM_BLOCK_TILES")) {  // tuning override
-    const int t = atoi(env);
+  {  // tuning override
+    const int t = opt_value(OPT_GMM_BLOCK_TILES, 0);
     if (t == 4 || t == 8 || t == 16) return t;
   }
   const long nt = (n_patches + 31) / 32;
@@ -2013,7 +2013,7 @@ static int launch_fwd_tb(const GmmFwdArgs& a, unsigned blocks, hipStream_t s) {
 template <int MODE>
 static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, int* n_partials) {
   const long n = a.n_end - a.n_begin;
-  if (getenv("JD_GMM_DENSE")) tri = false;  // tuning / testing: force the dense variant
+  if (opt_is_set(OPT_GMM_DENSE)) tri = false;  // tuning / testing: force the dense variant
   const int tb = pick_block_tiles(n, n_cu);
   const unsigned blocks = (unsigned)((n + 32L * tb - 1) / (32L * tb));
   *n_partials = (int)blocks;
@@ -2042,9 +2042,9 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   // every wave its own 128 patches and all components, unless that leaves CUs without a block: then the four waves of
   // a block share 128 patches and split the components (see gmm_screen_kernel)
   bool ksplit = (n + SCREEN_T * 32 * 4 - 1) / (SCREEN_T * 32 * 4) < g->n_cu;
-  if (const char* env = getenv("JD_GMM_KSPLIT")) ksplit = atoi(env) != 0;  // testing: force either decomposition
+  if (opt_is_set(OPT_GMM_KSPLIT)) ksplit = opt_value(OPT_GMM_KSPLIT, 0) != 0;  // testing: force either decomposition
   // tuning: JD_GMM_SCREEN_NP=1 -- one tile pair (64 patches) per wave, two waves per SIMD (256 registers each)
-  const bool np1 = !ksplit && getenv("JD_GMM_SCREEN_NP") && atoi(getenv("JD_GMM_SCREEN_NP")) == 1 && g->K <= SCREEN_KC_MAX;
+  const bool np1 = !ksplit && opt_value(OPT_GMM_SCREEN_NP, 0) == 1 && g->K <= SCREEN_KC_MAX;
   const int T = np1 ? 2 : SCREEN_T;
   const unsigned blocks = (unsigned)(ksplit ? (n + T * 32 - 1) / (T * 32) : ((n + T * 32 - 1) / (T * 32) + 3) / 4);
   const size_t n_seg = (size_t)blocks * 4;
@@ -2093,7 +2093,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
   if (chunks > max_blocks) chunks = max_blocks;
   if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
-  const bool kc_lds = g->K <= SCREEN_KC_MAX && !getenv("JD_GMM_SCREEN_NO_LDS_CONSTS");  // (testing: the global-load path)
+  const bool kc_lds = g->K <= SCREEN_KC_MAX && !opt_is_set(OPT_GMM_SCREEN_NO_LDS_CONSTS);  // (testing: the global-load path)
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmStageArgs stg{};
@@ -2189,7 +2189,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   gmm_best_kernel<<<best_blocks, 256, 0, s>>>(be);
   JD_LAUNCH_CHECK();
   *n_partials = (int)best_blocks;
-  if (getenv("JD_GMM_SCREEN_DEBUG")) {  // tuning only: synchronises
+  if (opt_is_set(OPT_GMM_SCREEN_DEBUG)) {  // tuning only: synchronises
     std::vector<int> ctl(3 * g->K + 2), seg(n_seg);
     JD_HIP(hipStreamSynchronize(s));
     JD_HIP(hipMemcpy(ctl.data(), g->screen_ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -2229,12 +2229,11 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   const long n = n_end - n_begin;
   int rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
-  const char* screen_var = getenv("JD_GMM_SCREEN");  // "0" forces the dense fp32 kernel (testing / tuning)
-  const bool screened = !marginalize && g->screen_ok && !(screen_var && atoi(screen_var) == 0) && !getenv("JD_GMM_DENSE");
+  // option JD_GMM_SCREEN = 0 forces the dense fp32 kernel (testing / tuning)
+  const bool screened = !marginalize && g->screen_ok && opt_value(OPT_GMM_SCREEN, 1) != 0 && !opt_is_set(OPT_GMM_DENSE);
   // screened arg-max with a gradient: the exact kernel also produces the gradient rows (no second sort, no separate
   // backward kernel); JD_GMM_FUSED_BWD=0 keeps the bucketed backward pass (testing / tuning)
-  const char* fused_var = getenv("JD_GMM_FUSED_BWD");
-  const bool fused = screened && grad_flux_accum && g->triangular && !(fused_var && atoi(fused_var) == 0);
+  const bool fused = screened && grad_flux_accum && g->triangular && opt_value(OPT_GMM_FUSED_BWD, 1) != 0;
   int32_t* arg = argmax_out;
   if (grad_flux_accum && (!arg || fused)) {  // fused: the internal buffer holds the components after a fallback
     if ((rc = grow(&g->argmax, &g->argmax_cap, (size_t)nPy * nPx))) return rc;
@@ -2274,7 +2273,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     if (blocks > g->n_cu) blocks = g->n_cu;       // one block per CU (one wave per SIMD), grid-stride over the rest
     {
       ProfScope prof(JD_KERNEL_GMM_BWD, s);
-      if (g->triangular && !getenv("JD_GMM_DENSE"))
+      if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
         gmm_bwd_lse_kernel<true, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
       else
         gmm_bwd_lse_kernel<false, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
@@ -2310,7 +2309,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     long bwd_blocks = ((long)(slots_cap / 32) + 3) / 4;
     const long cap = (long)g->n_cu * 3;  // 3 blocks of 4 waves per CU: one wave per SIMD x 3
     if (bwd_blocks > cap) bwd_blocks = cap;
-    if (g->triangular && !getenv("JD_GMM_DENSE"))
+    if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
       gmm_bwd_max_kernel<true><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
     else
       gmm_bwd_max_kernel<false><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
@@ -2328,8 +2327,8 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   if (fused) ga.winner = g->winner, ga.grec = g->grec, ga.flag = g->screen_ctl, ga.gen = g->gen;
   {
     ProfScope prof(JD_KERNEL_GMM_GATHER, s);
-    const char* tiled_var = getenv("JD_GMM_GATHER_TILED");  // "0": the per-pixel kernel (testing)
-    if (stride >= 4 && !(tiled_var && atoi(tiled_var) == 0)) {
+    // option JD_GMM_GATHER_TILED = 0: the per-pixel kernel (testing)
+    if (stride >= 4 && opt_value(OPT_GMM_GATHER_TILED, 1) != 0) {
       dim3 grid((W + GATHER_T - 1) / GATHER_T, (ga.y_end - ga.y_begin + GATHER_T - 1) / GATHER_T);
       gmm_gather_tile_kernel<<<grid, 256, 0, s>>>(ga);
     } else {

@@ -59,15 +59,42 @@ int launch_direct_conv_poisson(const float* in, const float* in_scale, const flo
                                float* npred_out, double* partials, float eps, float inv_n, int write_grad,
                                int* n_partials, int split, hipStream_t stream);
 
+// tuning / test switches (options.hip): read from the environment once at load time, changed by jd_set_option()
+enum JdOption {
+  OPT_SEP_NO_ALIAS, OPT_SEP_FWD_MIN_LDS, OPT_SEP_ADJ_MIN_LDS, OPT_SEP_INTERLEAVE, OPT_SEP_NO_FUSION, OPT_SEP_WALK,
+  OPT_SEP_WALK_COLS, OPT_SEP_WALK_ROWS, OPT_SEP_WALK_ADJ_COLS, OPT_SEP_WALK_ADJ_ROWS, OPT_DIRECT_FP32,
+  OPT_CONV_BLOCKS_PER_CU, OPT_POISSON_ROWS, OPT_GMM_NO_HOST_STATS, OPT_GMM_BLOCK_TILES, OPT_GMM_DENSE, OPT_GMM_KSPLIT,
+  OPT_GMM_SCREEN_NP, OPT_GMM_SCREEN_NO_LDS_CONSTS, OPT_GMM_SCREEN_DEBUG, OPT_GMM_SCREEN, OPT_GMM_FUSED_BWD,
+  OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_COUNT
+};
+bool opt_is_set(int id);
+int opt_value(int id, int unset_value);
+
 // separable (low-rank PSF) convolution (sepconv.hip)
 constexpr int SEP_MAX_K = 68, SEP_MAX_RANK = 3, SEP_MAX_BATCH = 16;
+struct SepGeom {
+  int khp, kwp;    // padded tap counts (multiples of 4): rows / columns
+  int oy0, ox0;    // image offset of window (row 0, col 0) relative to the tile origin
+  int shiftx;      // zero taps prepended to the column taps so that ox0 is a multiple of 4
+  int rpairs;      // window row PAIRS of the tile kernel: ceil((TY + khp - 1) / 2)
+  int pitch;       // window columns per row (>= TX + kwp), pitch % 4 == 2 (bank spread of the row-pair reads)
+};
+SepGeom sep_geom(int kh, int kw, int oy, int ox, bool adjoint);
+// rank of the operator buffers this process has built (jd_conv_psf_spectrum registers them by device address); 0 = a
+// buffer the library has not seen (a copy made by the caller): such a buffer never takes a path that assumes its rank
+void sep_register_operator(const void* op_dev, int rank);
+int sep_operator_rank(const void* op_dev);
 constexpr double SEP_DEFAULT_TOL = 3e-7;  // residual sum|psf - sum_r u_r v_r^T| <= tol * sum|psf|  (~5 fp32 ulps)
 bool sep_conv_supported(int kh, int kw);
 size_t sep_conv_operator_floats();
 int sep_factorize(const float* psf_host, int kh, int kw, double tol, std::vector<double>* u, std::vector<double>* v);
 int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op);
+// allow_walk: the strip-walk kernel may take the launch (not inside a multi-component model, whose batched form runs
+// the tile kernel: both forms must round alike)
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
-                    int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream);
+                    int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream,
+                    bool allow_walk = true);
+int sep_guard_check(int** guard_dev);
 int sep_conv_tiles(int H, int W);
 // per-dataset pointers of a batched joint step: exposure (input scale of the forward model, output scale of the
 // adjoint), operator, background, counts, g work image
@@ -86,13 +113,37 @@ struct SepBatchTable {
   float* loss_out[SEP_MAX_BATCH];
   float loss_offset[SEP_MAX_BATCH];
 };
+// *n_partials <- partial sums written per dataset: partials[d * *n_partials + i]
 int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
                                   const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
-                                  double* partials, float eps, float inv_n, int write_grad, hipStream_t stream);
-// fin_partials != nullptr: block d < n also turns the n_tiles partial sums of dataset d into its loss (see SepBatchTable)
+                                  double* partials, float eps, float inv_n, int write_grad, int* n_partials,
+                                  hipStream_t stream);
+// fin_partials != nullptr: block d < n also turns the fin_count partial sums of dataset d into its loss (see
+// SepBatchTable); *fin_done <- whether the launch did (a launch that cannot leaves the losses to launch_finalize_rows)
 int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
                                   float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
-                                  hipStream_t stream, const double* fin_partials = nullptr, double fin_scale = 0.0);
+                                  hipStream_t stream, const double* fin_partials = nullptr, double fin_scale = 0.0,
+                                  int fin_count = 0, int* fin_done = nullptr);
+// true when the walk kernels take some but not all operators of a batch: the caller then runs the per-dataset calls
+// (the batched and the per-dataset step must choose the same kernel for every dataset to stay bit-identical)
+bool sep_batch_is_mixed(int n, int n_comp, const SepBatchTable& table, int H, int W, int kh, int kw, int oy, int ox);
+
+// strip-walk form of the separable convolution (walkconv.hip; rank-1 PSFs up to 17 x 17): same contracts as the
+// launch_sep_* functions above; JD_WALK_NOT_TAKEN when the case is not theirs (nothing was launched)
+constexpr int JD_WALK_NOT_TAKEN = 1;
+// geometry, size and option JD_SEP_WALK only (rank-1 operators and aligned images assumed): forward and adjoint
+bool walk_takes_launch(int H, int W, int n_datasets, int kh, int kw, int oy, int ox);
+int walk_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H, int W,
+              int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream);
+int walk_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh, int kw,
+                      int oy, int ox, const float* background, const float* counts, float* npred_out, double* partials,
+                      float eps, float inv_n, int write_grad, int* n_partials, hipStream_t stream);
+int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev, int H,
+                            int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
+                            int write_grad, int* n_partials, hipStream_t stream);
+int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H, int W,
+                            int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream,
+                            const double* fin_partials, double fin_scale, int fin_count, int* fin_done);
 // out[d][0] = scale * sum(partials[d * n .. d * n + n - 1]) + offset[d]   (one block per output, fixed order)
 int launch_finalize_rows(const double* partials, int n, int n_out, double scale, const float* offset_host,
                          float* const* out, hipStream_t stream);

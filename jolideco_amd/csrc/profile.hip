@@ -2,6 +2,7 @@
 // KERNEL IS LAUNCHED ON, so a benchmark can report the average launch duration of a kernel inside
 // its timed region without a profiler attached (bench.py `roofline`).  Disabled by default: the
 // record calls cost nothing unless jd_profile_enable() was called.
+#include <algorithm>
 #include <vector>
 
 #include "jd_common.h"
@@ -83,6 +84,57 @@ extern "C" int jd_profile_read(int kernel, double* total_ms, long long* launches
   }
   *total_ms = total;
   *launches = n;
+  return JD_OK;
+}
+
+namespace jd {
+// Sustained shader clock: every CU runs a dependent fp32 FMA chain for `iters` rounds; one lane per block stamps the shader
+// clock (s_memtime: one tick per shader cycle) and the constant 100 MHz reference clock (s_memrealtime) around it
+// (MI355X_MICROARCH.md, DVFS give-back item 6): MHz = 100 * d(memtime) / d(memrealtime).
+__global__ __launch_bounds__(256) void clock_probe_kernel(unsigned long long* stamps, float* sink, int iters) {
+  float a = 1.0f + 1e-7f * threadIdx.x, b = 0.5f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 64; ++k) b = fmaf(a, b, 1e-9f);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    stamps[2 * blockIdx.x] = t1 - t0;
+    stamps[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (b == 123.456f) sink[0] = b;  // keeps the chain alive
+}
+}  // namespace jd
+
+extern "C" int jd_clock_probe(double milliseconds, double* mhz_out, void* stream) {
+  JD_REQUIRE(mhz_out && milliseconds > 0.0 && milliseconds <= 100.0, "jd_clock_probe: bad argument");
+  hipStream_t s = as_stream(stream);
+  int dev = 0;
+  hipDeviceProp_t prop;
+  JD_HIP(hipGetDevice(&dev));
+  JD_HIP(hipGetDeviceProperties(&prop, dev));
+  const int blocks = prop.multiProcessorCount * 4;  // four blocks of four waves per CU: every SIMD has four waves
+  unsigned long long* stamps = nullptr;
+  float* sink = nullptr;
+  JD_HIP(hipMalloc(&stamps, (size_t)blocks * 2 * sizeof(unsigned long long)));
+  JD_HIP(hipMalloc(&sink, sizeof(float)));
+  // 64 dependent FMAs per round at 4 waves per SIMD: ~8 cycles per FMA and wave -> ~0.25 us per round at 2 GHz
+  const int iters = (int)(milliseconds * 1e3 / 0.25);
+  clock_probe_kernel<<<blocks, 256, 0, s>>>(stamps, sink, iters > 1 ? iters : 1);
+  hipError_t e = hipGetLastError();
+  std::vector<unsigned long long> host((size_t)blocks * 2);
+  if (e == hipSuccess) e = hipMemcpyAsync(host.data(), stamps, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(stamps);
+  (void)hipFree(sink);
+  if (e != hipSuccess) return fail(JD_ERR_HIP, "jd_clock_probe: %s", hipGetErrorString(e));
+  std::vector<double> mhz;
+  for (int b = 0; b < blocks; ++b)
+    if (host[2 * b + 1]) mhz.push_back(100.0 * (double)host[2 * b] / (double)host[2 * b + 1]);
+  JD_REQUIRE(!mhz.empty(), "jd_clock_probe: no stamps");
+  std::sort(mhz.begin(), mhz.end());
+  *mhz_out = mhz[mhz.size() / 2];  // median over the blocks
   return JD_OK;
 }
 

@@ -17,9 +17,10 @@
 // passes are register blocked (8 outputs x 4 taps / 4 x 4) and use packed fp32 FMAs (v_pk_fma_f32: the row pass on
 // two image rows, the column pass on two neighbouring columns), so one LDS read feeds ~5 FMAs; the taps stay
 // runtime values (no template per PSF size).
-#include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "jd_common.h"
@@ -40,28 +41,6 @@ namespace {
 #endif
 constexpr int TY = 32, TX = 64, THREADS = 256, STAGE_BATCH = 3;
 typedef float v2f __attribute__((ext_vector_type(2)));
-
-struct SepGeom {
-  int khp, kwp;    // padded tap counts (multiples of 4): rows / columns
-  int oy0, ox0;    // image offset of window (row 0, col 0) relative to the tile origin
-  int shiftx;      // zero taps prepended to the column taps so that ox0 is a multiple of 4
-  int rpairs;      // window row PAIRS: ceil((TY + khp - 1) / 2)
-  int pitch;       // window columns per row (>= TX + kwp), pitch % 4 == 2 (bank spread of the row-pair reads)
-};
-
-inline SepGeom sep_geom(int kh, int kw, int oy, int ox, bool adjoint) {
-  SepGeom g{};
-  // forward: out[y] = sum_t u[kh-1-t] in[y + oy - (kh-1) + t];  adjoint: out[y] = sum_t u[t] in[y - oy + t]
-  g.oy0 = adjoint ? -oy : oy - (kh - 1);
-  const int ox0 = adjoint ? -ox : ox - (kw - 1);
-  g.shiftx = ((ox0 % 4) + 4) % 4;
-  g.ox0 = ox0 - g.shiftx;
-  g.khp = (kh + 3) / 4 * 4;
-  g.kwp = (kw + g.shiftx + 3) / 4 * 4;
-  g.rpairs = (TY + g.khp) / 2;  // khp is a multiple of 4: (TY + khp - 1 + 1) / 2
-  g.pitch = TX + g.kwp + 2;
-  return g;
-}
 
 struct SepArgs {
   const float* in;
@@ -101,6 +80,7 @@ struct SepArgs {
   const float* in_c1;
   const float* in_c2;
   const float* in_c3;
+  int* guard;  // host-mapped flag: an operator contradicted the rank the host launched it for
 };
 
 // LDS images:
@@ -198,6 +178,7 @@ __global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD
     const float* background = a.n_batch > 0 ? a.table->bkg[d] : a.background;
     const float* counts = a.n_batch > 0 ? a.table->cnt[d] : a.counts;
     const int rank = (int)op[0];
+    if (a.alias && rank != 1 && tid == 0) *a.guard = 1;  // launched for rank 1 (host registry): reported at the next call
     if (u > 0) __syncthreads();  // the previous unit is done with the LDS images
     for (int i = tid; i < rank * tap_stride; i += THREADS) taps[i] = op[a.taps_off + i];
 
@@ -431,6 +412,20 @@ __global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD
 
 }  // namespace
 
+SepGeom sep_geom(int kh, int kw, int oy, int ox, bool adjoint) {
+  SepGeom g{};
+  // forward: out[y] = sum_t u[kh-1-t] in[y + oy - (kh-1) + t];  adjoint: out[y] = sum_t u[t] in[y - oy + t]
+  g.oy0 = adjoint ? -oy : oy - (kh - 1);
+  const int ox0 = adjoint ? -ox : ox - (kw - 1);
+  g.shiftx = ((ox0 % 4) + 4) % 4;
+  g.ox0 = ox0 - g.shiftx;
+  g.khp = (kh + 3) / 4 * 4;
+  g.kwp = (kw + g.shiftx + 3) / 4 * 4;
+  g.rpairs = (TY + g.khp) / 2;  // khp is a multiple of 4: (TY + khp - 1 + 1) / 2
+  g.pitch = TX + g.kwp + 2;
+  return g;
+}
+
 bool sep_conv_supported(int kh, int kw) { return kh >= 1 && kw >= 1 && kh <= SEP_MAX_K && kw <= SEP_MAX_K; }
 
 size_t sep_conv_operator_floats() {
@@ -476,16 +471,48 @@ int sep_factorize(const float* psf, int kh, int kw, double tol, std::vector<doub
   return 0;
 }
 
-// Largest rank among the operator buffers built so far in this process (launch_sep: LDS aliasing needs rank 1)
-static std::atomic<int> g_sep_max_rank{0};
+// Rank of every operator buffer this process has built, by device address (jd_conv_psf_spectrum registers it after the
+// upload).  The kernels that assume rank 1 (LDS aliasing of the tile kernel, the walk kernels) are only launched for
+// buffers found here with rank 1 and still check op[0] on the device: a mismatch (the buffer was overwritten behind the
+// library's back) raises a host-mapped flag that the next launch reports as an error.
+static std::mutex g_rank_mutex;
+static std::unordered_map<const void*, int> g_op_rank;
+static int* g_guard_host = nullptr;
+static int* g_guard_dev = nullptr;
+
+void sep_register_operator(const void* op_dev, int rank) {
+  std::lock_guard<std::mutex> lock(g_rank_mutex);
+  g_op_rank[op_dev] = rank;
+}
+
+int sep_operator_rank(const void* op_dev) {
+  std::lock_guard<std::mutex> lock(g_rank_mutex);
+  auto it = g_op_rank.find(op_dev);
+  return it == g_op_rank.end() ? 0 : it->second;
+}
+
+int sep_guard_check(int** guard_dev) {
+  if (!g_guard_host) {
+    JD_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_guard_host), sizeof(int), hipHostMallocMapped));
+    *g_guard_host = 0;
+    void* mapped = nullptr;
+    JD_HIP(hipHostGetDevicePointer(&mapped, g_guard_host, 0));
+    g_guard_dev = static_cast<int*>(mapped);
+  }
+  *guard_dev = g_guard_dev;
+  if (*g_guard_host) {
+    *g_guard_host = 0;
+    return fail(JD_ERR_INVALID, "separable convolution: an operator buffer registered as rank 1 held another rank on the "
+                "device (was it overwritten after jd_conv_psf_spectrum?)");
+  }
+  return JD_OK;
+}
 
 // Host image of the operator buffer for a factorised PSF (see sep_conv_operator_floats).
 int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op) {
   std::vector<double> u, v;
   const int rank = sep_factorize(psf, kh, kw, tol, &u, &v);
   if (rank == 0) return 0;
-  for (int seen = g_sep_max_rank.load(); rank > seen && !g_sep_max_rank.compare_exchange_weak(seen, rank);) {
-  }
   op->assign(sep_conv_operator_floats(), 0.f);
   (*op)[0] = (float)rank;
   const size_t half = (op->size() - 4) / 2;
@@ -503,7 +530,8 @@ int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double 
 }
 
 namespace {
-int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool poisson, hipStream_t stream,
+// rank1: every operator of the launch is registered with rank 1 (sep_operator_rank)
+int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool poisson, hipStream_t stream, bool rank1,
                bool batch_aligned = true) {
   if (!sep_conv_supported(kh, kw))
     return fail(JD_ERR_INVALID, "separable convolution: PSF %dx%d exceeds %dx%d", kh, kw, SEP_MAX_K, SEP_MAX_K);
@@ -512,13 +540,15 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
   a.n_tiles = a.tiles_x * ((a.H + TY - 1) / TY);
   a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rpairs = g.rpairs, a.pitch = g.pitch;
   a.taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
-  // rank-1 operators only (every operator buffer of this process comes from sep_build_operator, which keeps the maximum)
-  // and at most one row-pass item per thread: the row-pass image may share the window's LDS -> 19 KB instead of 32 KB
-  // per block, a sixth block per CU for the fused forward + Poisson launch (JD_SEP_NO_ALIAS=1: testing)
-  a.alias = g_sep_max_rank.load() <= 1 && g.rpairs * (TX / 8) <= THREADS && !getenv("JD_SEP_NO_ALIAS") ? 1 : 0;
+  // rank-1 operators only and at most one row-pass item per thread: the row-pass image may share the window's LDS ->
+  // 19 KB instead of 32 KB per block, a sixth block per CU for the fused forward + Poisson launch (option
+  // JD_SEP_NO_ALIAS: testing)
+  int rc = sep_guard_check(&a.guard);
+  if (rc) return rc;
+  a.alias = rank1 && g.rpairs * (TX / 8) <= THREADS && !opt_is_set(OPT_SEP_NO_ALIAS) ? 1 : 0;
   size_t lds = ((size_t)2 * g.rpairs * (g.pitch + (a.alias ? 0 : TX)) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
-  if (const char* env = getenv(poisson ? "JD_SEP_FWD_MIN_LDS" : "JD_SEP_ADJ_MIN_LDS")) {  // tuning: caps the blocks per CU
-    const size_t want = (size_t)atol(env);
+  {  // tuning: caps the blocks per CU
+    const size_t want = (size_t)opt_value(poisson ? OPT_SEP_FWD_MIN_LDS : OPT_SEP_ADJ_MIN_LDS, 0);
     if (want > lds && want <= 160 * 1024) lds = want;
   }
   const int blocks = ((a.n_tiles + 7) / 8) * 8;
@@ -554,11 +584,15 @@ int sep_conv_tiles(int H, int W) { return ((W + TX - 1) / TX) * ((H + TY - 1) / 
 // adjoint != 0: out (+)= coef * out_scale * corr_same(in * in_scale, psf)    (the transpose of the above)
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
-                    hipStream_t stream) {
+                    hipStream_t stream, bool allow_walk) {
+  if (allow_walk) {
+    const int rc = walk_conv(in, in_scale, op, out, out_scale, H, W, kh, kw, oy, ox, adjoint, coef, accumulate, stream);
+    if (rc != JD_WALK_NOT_TAKEN) return rc;
+  }
   SepArgs a{};
   a.in = in, a.in_scale = in_scale, a.op = op, a.out = out, a.out_scale = out_scale;
   a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate;
-  return launch_sep(a, kh, kw, oy, ox, adjoint, false, stream);
+  return launch_sep(a, kh, kw, oy, ox, adjoint, false, stream, sep_operator_rank(op) == 1);
 }
 
 // Forward model of one component fused with the Poisson pass: conv = conv_same(in * in_scale, psf) stays in
@@ -568,13 +602,18 @@ int launch_sep_conv_poisson(const float* in, const float* in_scale, const float*
                             int kw, int oy, int ox, const float* background, const float* counts, float* npred_out,
                             double* partials, float eps, float inv_n, int write_grad, int* n_partials,
                             hipStream_t stream) {
+  {
+    const int rc = walk_conv_poisson(in, in_scale, op, g_out, H, W, kh, kw, oy, ox, background, counts, npred_out, partials,
+                                     eps, inv_n, write_grad, n_partials, stream);
+    if (rc != JD_WALK_NOT_TAKEN) return rc;
+  }
   SepArgs a{};
   a.in = in, a.in_scale = in_scale, a.op = op, a.out = g_out;
   a.H = H, a.W = W, a.coef = 1.f;
   a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = partials;
   a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
   *n_partials = sep_conv_tiles(H, W);
-  return launch_sep(a, kh, kw, oy, ox, 0, true, stream);
+  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, sep_operator_rank(op) == 1);
 }
 
 static bool table_aligned(const SepBatchTable& t, int n, int n_comp) {
@@ -583,6 +622,11 @@ static bool table_aligned(const SepBatchTable& t, int n, int n_comp) {
   for (int d = 0; d < n; ++d) all = all && ok(t.bkg[d]) && ok(t.cnt[d]);
   for (int i = 0; i < n * n_comp; ++i) all = all && ok(t.scale[i]) && ok(t.g[i]);
   return all;
+}
+static bool table_rank1(const SepBatchTable& t, int entries) {
+  for (int i = 0; i < entries; ++i)
+    if (sep_operator_rank(t.op[i]) != 1) return false;
+  return true;
 }
 static int check_batch(int n, int n_comp) {
   if (n < 1 || n > SEP_MAX_BATCH) return fail(JD_ERR_INVALID, "separable batch: %d datasets not in [1, %d]", n, SEP_MAX_BATCH);
@@ -597,9 +641,16 @@ static int check_batch(int n, int n_comp) {
 // `table_dev` is the device copy of `table`.
 int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
                                   const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
-                                  double* partials, float eps, float inv_n, int write_grad, hipStream_t stream) {
+                                  double* partials, float eps, float inv_n, int write_grad, int* n_partials,
+                                  hipStream_t stream) {
   int rc = check_batch(n, n_comp);
   if (rc) return rc;
+  if (n_comp == 1) {
+    rc = walk_conv_poisson_batch(n, flux[0], table, table_dev, H, W, kh, kw, oy, ox, partials, eps, inv_n, write_grad,
+                                 n_partials, stream);
+    if (rc != JD_WALK_NOT_TAKEN) return rc;
+  }
+  *n_partials = sep_conv_tiles(H, W);
   SepArgs a{};
   a.in = flux[0], a.in_c1 = n_comp > 1 ? flux[1] : nullptr, a.in_c2 = n_comp > 2 ? flux[2] : nullptr;
   a.in_c3 = n_comp > 3 ? flux[3] : nullptr;
@@ -609,26 +660,42 @@ int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, c
   // dataset-major launch order by default; JD_SEP_INTERLEAVE=1 makes the datasets of a tile neighbours in an XCD's
   // launch order (the flux window then comes from L2 for all but the first): measured neutral at 8 observations
   // (152-154 us either way) -- the Infinity Cache already serves the repeated flux reads
-  a.interleave = getenv("JD_SEP_INTERLEAVE") ? 1 : 0;
+  a.interleave = opt_is_set(OPT_SEP_INTERLEAVE) ? 1 : 0;
   bool flux_aligned = true;
   for (int c = 0; c < n_comp; ++c) flux_aligned = flux_aligned && (reinterpret_cast<uintptr_t>(flux[c]) & 15) == 0;
-  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, flux_aligned && table_aligned(table, n, n_comp));
+  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, table_rank1(table, n * n_comp),
+                    flux_aligned && table_aligned(table, n, n_comp));
 }
 
 // grad (+)= coef * sum_d scale[d, comp] * corr_same(g[d, comp], psf_(d, comp)): one launch per component, the datasets
 // are added in order in registers (bit-identical to n accumulate launches), the gradient image is read and written once.
 int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
                                   float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
-                                  hipStream_t stream, const double* fin_partials, double fin_scale) {
+                                  hipStream_t stream, const double* fin_partials, double fin_scale, int fin_count,
+                                  int* fin_done) {
   int rc = check_batch(n, n_comp);
   if (rc) return rc;
   if (comp < 0 || comp >= n_comp) return fail(JD_ERR_INVALID, "separable batch: component %d not in [0, %d)", comp, n_comp);
+  if (fin_done) *fin_done = 0;
+  if (n_comp == 1) {
+    int folded = 0;
+    rc = walk_conv_adjoint_batch(n, table, table_dev, grad, H, W, kh, kw, oy, ox, coef, accumulate, stream, fin_partials,
+                                 fin_scale, fin_count, &folded);
+    if (rc != JD_WALK_NOT_TAKEN) {
+      if (fin_done) *fin_done = folded;
+      return rc;
+    }
+  }
   SepArgs a{};
   a.out = grad, a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate, a.n_batch = n, a.table = table_dev;
   a.n_comp = n_comp, a.comp = comp;
-  a.fin_partials = fin_partials, a.fin_scale = fin_scale;
+  // (the fold of the tile kernel sums a.n_tiles partial sums per dataset: only when the forward launch was its own)
+  if (fin_partials && fin_count == sep_conv_tiles(H, W)) {
+    a.fin_partials = fin_partials, a.fin_scale = fin_scale;
+    if (fin_done) *fin_done = 1;
+  }
   a.in = table.g[comp], a.op = table.op[comp];
-  return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_aligned(table, n, n_comp));
+  return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_rank1(table, n * n_comp), table_aligned(table, n, n_comp));
 }
 
 }  // namespace jd

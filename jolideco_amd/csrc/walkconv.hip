@@ -1,0 +1,553 @@
+// Strip-walk form of the separable 'same' convolution (rank-1 PSFs up to 17 x 17: every sampled Gaussian).
+//
+// The tile kernel of sepconv.hip stages a (32 + halo) x (64 + halo) window in LDS, runs the row pass over ALL window
+// rows (1.63 x the output rows) into a second LDS image, then the column pass: ~1000 vector instructions and ~200 KB of
+// LDS traffic per 2048-pixel tile make it issue / LDS bound at 55-60 % of the HBM rate.  Here ONE WAVE owns a strip of
+// 64 C columns (C = 2 or 4 per lane) and walks down R rows of it:
+//   * per image row: the lanes multiply flux x exposure for their C columns, exchange the products through a
+//     (64 C + 16)-float LDS row (one store, (16 + C) / 4 reads per lane), and run the 17-tap row pass on registers;
+//   * the column pass is in SCATTER form: the finished row-pass value h[r] is added into the 17 outputs r - 8 .. r + 8
+//     it contributes to, which live in 17 C rotating accumulator registers per lane (the loop is unrolled over the 17
+//     rotation states so that every register index is static); output row r - 8 is complete after row r and leaves the
+//     wave through the epilogue (Poisson pass, or scale + accumulate for the adjoint).
+// No second LDS image, no block barriers, no halo rows recomputed inside a tile: 34 FMAs, 1 + (16 + C) / C LDS floats
+// and one set of streaming loads per pixel; the only overhead is the 16 warm-up rows of a tile (R = 64: 25 % more row
+// passes).  Loads of row r + P are issued P steps ahead (registers), taps live in SGPRs.
+//
+// Batched adjoint (the gradient of a joint step, sum over the datasets of E_d x corr(g_d, psf_d)): a block is one wave
+// PER DATASET walking the same strip; finished rows go to an LDS exchange buffer in groups of 4, and the waves add them
+// in dataset order -- the additions of the per-dataset launches, bit for bit -- into the gradient image, which is read
+// and written once.
+#include "jd_common.h"
+#include "kernels.h"
+
+namespace jd {
+
+namespace {
+
+constexpr int WK = 17;  // taps per direction of the walk's frame: out[y] = sum_t tu[t] h[y - 8 + t]
+constexpr int WH = 8;
+constexpr int WS = 18;  // accumulator slots (rotation period of the unrolled walk)
+constexpr int XG_MAX = 6;  // rows per exchange group of the batched adjoint: 2, 3 or 6 (a divisor of WS, <= waves)
+constexpr int XW = 8;   // waves (= datasets) per block of the batched adjoint
+#ifndef JD_WALK_PREFETCH
+#define JD_WALK_PREFETCH 2
+#endif
+constexpr int WALK_PREFETCH = JD_WALK_PREFETCH;  // rows the streaming loads run ahead of the arithmetic
+// Launches below this many (pixel, dataset) pairs stay with the tile kernel, which has four times the waves for the
+// same image: measured on MI355X (tools/walk_check.py) forward + adjoint of one 2048^2 dataset 38.9 us (tile) against
+// 51.8 (walk), of two 65 / 77, of four 129 / 112, of eight 282 / 199, of one 4096^2 dataset 138 / 118
+constexpr size_t WALK_MIN_PIXELS = (size_t)1 << 24;
+
+template <int C> struct Vec;
+template <> struct Vec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct Vec<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+struct WalkArgs {
+  const float* in;         // forward: flux; plain / adjoint: the image to convolve
+  const float* in_scale;   // forward: exposure
+  const float* op;         // operator buffer of sepconv.hip
+  float* out;              // POISSON: g = d loss / d conv; plain: the result (+= when accumulate)
+  const float* out_scale;  // plain: nullable
+  const float* background;
+  const float* counts;
+  float* npred_out;  // nullable
+  double* partials;  // POISSON: one per (dataset, tile)
+  int H, W, strips, tiles_y, rows;
+  int taps_u, taps_v;          // op offsets of the first row tap / first column tap of this direction
+  int kh, kw, offy, offx;      // PSF size, position of its first tap in the 17-tap frame
+  float coef;
+  int accumulate;
+  float eps, inv_n;
+  int write_grad;
+  int n_batch;                 // > 0: per-dataset pointers come from `table`
+  const SepBatchTable* table;
+  int d_base;                  // batched adjoint: first dataset of this launch (wave w = dataset d_base + w)
+  const double* fin_partials;  // batched adjoint: blocks < fin_n finalise the losses of the forward launch
+  double fin_scale;
+  int fin_count, fin_n;
+  int* guard;                  // host-mapped: set when an operator is not rank 1
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only keeps the COMPILER from moving them across
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// XG > 0: the batched adjoint (one wave per dataset, rows exchanged in groups of XG, wave w < XG adds up row w of a group)
+template <int C, int P, bool POISSON, bool IN_SCALE, int XG>
+__global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
+#pragma clang fp contract(off)  // every fused multiply-add below is an explicit fmaf: batched and per-dataset paths round alike
+  constexpr bool XCHG = XG > 0;
+  static_assert(!XCHG || (WS % XG == 0 && XG <= XG_MAX), "the exchange group must divide the rotation period");
+  typedef typename Vec<C>::T vC;
+  constexpr int NX = 2 * WH / C;       // lanes that also load the right-hand halo piece
+  constexpr int NWIN = 2 * WH + C;     // window floats per lane
+  __shared__ __attribute__((aligned(16))) float rowbuf[XCHG ? XW : 1][2 * 64 * C];  // 64 C + 16 floats used, the rest is a dump
+  __shared__ __attribute__((aligned(16))) float xbuf[XCHG ? 2 * XG * XW * 64 * C : 4];
+  vC oprev;  // XCHG: the row of the gradient image this wave adds a group's row to, requested at the group's start
+  __shared__ double fin_red[4];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = XCHG ? (int)(threadIdx.x >> 6) : 0;
+  const int nb = XCHG ? (int)(blockDim.x >> 6) : 1;
+
+  if (XCHG && a.fin_partials && (int)blockIdx.x < a.fin_n) {  // (block-uniform; the host asks only with >= 256 threads)
+    // finalize_rows_kernel's summation order: 256 strided threads, wave butterflies, the four wave sums in order
+    if (threadIdx.x < 256) {
+      const double* row = a.fin_partials + (size_t)blockIdx.x * a.fin_count;
+      double s = 0.0;
+      for (int i = threadIdx.x; i < a.fin_count; i += 256) s += row[i];
+      s = wave_sum(s);
+      if (lane == 0) fin_red[wv] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double total = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) total += fin_red[i];
+      a.table->loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.table->loss_offset[blockIdx.x]);
+    }
+  }
+
+  // consecutive tiles of one XCD (blockIdx % 8) are vertical neighbours in a strip: their halo rows hit in that L2
+  const int n_tiles = a.strips * a.tiles_y;
+  const int per_xcd = (n_tiles + 7) / 8;
+  const int q = blockIdx.x / 8;
+  const int dsel = (!XCHG && a.n_batch > 0) ? q / per_xcd : 0;  // batched forward launch: dataset-major
+  const int tile = (blockIdx.x % 8) * per_xcd + q % per_xcd;
+  if (tile >= n_tiles) return;  // (block-uniform)
+  const int sx = tile / a.tiles_y, ty = tile - sx * a.tiles_y;
+
+  // (global address space stated: pointers that come out of the table are generic to the compiler, and generic loads are
+  // `flat_` instructions, which complete out of order and force a full s_waitcnt at every step)
+  typedef const float __attribute__((address_space(1)))* gcp;
+  typedef float __attribute__((address_space(1)))* gp;
+  typedef const vC __attribute__((address_space(1)))* gcv;
+  typedef vC __attribute__((address_space(1)))* gv;
+  const bool batch = a.n_batch > 0;
+  const int d = XCHG ? a.d_base + wv : dsel;
+  const gcp in = (gcp)(batch && !POISSON ? a.table->g[d] : a.in);
+  const gcp in_scale = (gcp)(batch ? a.table->scale[d] : a.in_scale);
+  const gcp op = (gcp)(batch ? a.table->op[d] : a.op);
+  const gcp out_scale = (gcp)(batch ? a.table->scale[d] : a.out_scale);
+  const gcp background = (gcp)(batch ? a.table->bkg[d] : a.background);
+  const gcp counts = (gcp)(batch ? a.table->cnt[d] : a.counts);
+  const gp out = (gp)(POISSON && batch ? a.table->g[d] : a.out);
+  const gp npred_out = (gp)a.npred_out;
+
+  // taps -> SGPRs
+  float tu[WK], tv[WK];
+  {
+    if ((int)op[0] != 1 && lane == 0) *a.guard = 1;  // not a rank-1 operator: the host reports it at its next call
+    float mu = 0.f, mv = 0.f;
+    const int iu = lane - a.offy, iv = lane - a.offx;
+    if (iu >= 0 && iu < a.kh) mu = op[a.taps_u + iu];
+    if (iv >= 0 && iv < a.kw) mv = op[a.taps_v + iv];
+#pragma unroll
+    for (int t = 0; t < WK; ++t) {
+      tu[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), t));
+      tv[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mv), t));
+    }
+  }
+
+  const int X0 = sx * 64 * C;
+  const int xm = X0 - WH + C * lane;           // image column of the lane's piece of the window
+  const int xe = X0 - WH + 64 * C + C * lane;  // right-hand halo piece (lanes < NX)
+  const int xo = X0 + C * lane;                // the lane's output columns
+  const bool vm = xm >= 0 && xm < a.W, ve = lane < NX && xe < a.W, vo = xo < a.W;
+  // lanes without a halo piece re-load the piece of lane (lane % NX) (same cache lines) and store it behind the window:
+  // every lane issues the same loads and stores in every step, no branch -- the compiler can then count the loads in
+  // flight exactly (s_waitcnt vmcnt(n)) instead of draining them at every merge point
+  const int xd = X0 - WH + 64 * C + C * (lane % NX);
+  const unsigned om = vm ? xm : 0, oe = ve ? xe : (xd < a.W ? xd : 0), oo = vo ? xo : 0;
+  const int Y0 = ty * a.rows, y_end = min(Y0 + a.rows, a.H);
+  const int r_begin = Y0 - WH, r_end = min(y_end + WH, a.H);  // image rows >= H contribute nothing
+  float* rb = rowbuf[wv];
+
+  struct Row { vC a, s, xa, xs; };
+  struct Epi { vC p, q; };  // POISSON: background, counts; plain: out_scale, previous out
+  auto row_ok = [&](int rr) { return rr >= 0 && rr < r_end; };
+  // (rows outside [0, r_end) are loaded from the nearest row inside -- cache hits -- and never used)
+  auto load_row = [&](int rr, Row& w) {
+    const size_t base = (size_t)min(max(rr, 0), r_end - 1) * a.W;
+    const gcp pin = in + base;
+    w.a = *(gcv)(pin + om);
+    if (IN_SCALE) w.s = *(gcv)(in_scale + base + om);
+#ifdef JD_WALK_MASKED_HALO
+    if (lane < NX)  // only the NX lanes with a halo piece load (and the compiler's load count becomes a bound)
+#endif
+    {
+      w.xa = *(gcv)(pin + oe);
+      if (IN_SCALE) w.xs = *(gcv)(in_scale + base + oe);
+    }
+  };
+  auto epi_ok = [&](int y) { return y >= Y0 && y < y_end; };
+  auto load_epi = [&](int y, Epi& e) {
+    const size_t base = (size_t)min(max(y, Y0), y_end - 1) * a.W;
+    if (POISSON) {
+      e.p = *(gcv)(background + base + oo);
+      e.q = *(gcv)(counts + base + oo);
+    } else {
+      if (out_scale) e.p = *(gcv)(out_scale + base + oo);
+      if (!XCHG && a.accumulate) e.q = *(gcv)(out + base + oo);
+    }
+  };
+
+  // WS = 18 accumulator slots for the 17 live outputs: with a rotation period of 18 the prefetch registers (period P,
+  // P | 18) rotate statically too -- a register that is the target of a load in flight is never moved
+  vC acc[WS];
+#pragma unroll
+  for (int s = 0; s < WS; ++s)
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[s][c] = 0.f;
+  static_assert(WS % P == 0, "prefetch depth must divide the rotation period");
+  Row pf[P];
+  Epi ep[P];
+  double loss = 0.0;
+
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    load_row(r_begin + p, pf[p]);
+    load_epi(r_begin + p - WH, ep[p]);
+  }
+
+  for (int r0 = r_begin; r0 < y_end + WH + (XCHG ? XG - 1 : 0); r0 += WS) {  // (+: the last group's flush step)
+#pragma unroll
+    for (int i = 0; i < WS; ++i) {
+      const int rr = r0 + i;
+      Row& cur = pf[i % P];
+      Epi& ce = ep[i % P];
+      const bool live = row_ok(rr);
+      if (live) {
+        // ---- products of this row -> LDS ----------------------------------------------------------------------
+        vC prod = cur.a;
+        if (IN_SCALE) prod = prod * cur.s;
+#pragma unroll
+        for (int c = 0; c < C; ++c) prod[c] = vm ? prod[c] : 0.f;
+        *reinterpret_cast<vC*>(rb + C * lane) = prod;
+        vC px = cur.xa;
+        if (IN_SCALE) px = px * cur.xs;
+#pragma unroll
+        for (int c = 0; c < C; ++c) px[c] = ve ? px[c] : 0.f;
+        *reinterpret_cast<vC*>(rb + 64 * C + C * lane) = px;  // (lanes >= NX: behind the window, never read)
+      }
+      load_row(rr + P, cur);  // the row P steps ahead takes this row's registers
+      if (live) {
+        wave_lds_fence();
+        float w[NWIN];
+#pragma unroll
+        for (int k = 0; k < NWIN / C; ++k) {
+          const vC t = *reinterpret_cast<const vC*>(rb + C * lane + C * k);
+#pragma unroll
+          for (int c = 0; c < C; ++c) w[C * k + c] = t[c];
+        }
+        wave_lds_fence();
+        // ---- row pass: h[c] = sum_t tv[t] w[c + t] -----------------------------------------------------------
+        float h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = tv[0] * w[c];
+#pragma unroll
+        for (int t = 1; t < WK; ++t)
+#pragma unroll
+          for (int c = 0; c < C; ++c) h[c] = fmaf(tv[t], w[c + t], h[c]);
+        // ---- column pass, scatter form: out[rr + 8 - t] += tu[t] h ------------------------------------------
+#pragma unroll
+        for (int t = 0; t < WK; ++t) {
+          const int s = (i + WH - t + WS) % WS;
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[s][c] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], acc[s][c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[(i + WH) % WS][c] = 0.f;
+      }
+
+      // ---- output row y = rr - 8 is complete ------------------------------------------------------------------
+      const int y = rr - WH;
+      if (epi_ok(y)) {
+        const vC conv = acc[(i + WS - WH) % WS];
+        const size_t off = (size_t)y * a.W;
+        if (POISSON) {
+          vC gvec, nvec;
+          float rowsum = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const float n = fmaxf(conv[c], 0.f) + ce.p[c];  // clip, then the un-convolved background (npred.py:191)
+            float term, g;
+            poisson_point(n, ce.q[c], a.eps, a.inv_n, term, g);
+            rowsum += term;
+            nvec[c] = n;
+            gvec[c] = conv[c] >= 0.f ? g : 0.f;  // clamp backward
+          }
+          if (vo) {
+            loss += (double)rowsum;
+            if (a.write_grad) *(gv)(out + off + oo) = gvec;
+            if (npred_out) *(gv)(npred_out + off + oo) = nvec;
+          }
+        } else {
+          vC pv;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            pv[c] = a.coef * conv[c];
+            if (out_scale) pv[c] = pv[c] * ce.p[c];
+          }
+          if (!XCHG) {
+            if (a.accumulate) pv = ce.q + pv;
+            if (vo) *(gv)(out + off + oo) = pv;
+          } else if constexpr (XCHG) {
+            const int k = (y - Y0) / XG, gy = (i + WS - 2 * WH) % XG;  // (tiles start on a group boundary: gy is static)
+            *reinterpret_cast<vC*>(xbuf + (size_t)((((k & 1) * XG + gy) * XW + wv) * 64 + lane) * C) = pv;
+          }
+        }
+      }
+      if constexpr (XCHG) {
+        // Every vector-memory operation of the exchange sits at a STATIC place of the unrolled loop and is issued by every
+        // wave, needed or not (rows clamped into the tile): the compiler counts the loads in flight exactly and never has
+        // to drain the prefetched rows to get at the gradient row.
+        const int gy = (i + WS - 2 * WH) % XG;
+        const int mine = wv < XG ? wv : XG - 1;  // the row of a group this wave adds up (waves >= XG: unused duplicates)
+        if (gy == 0) {
+          const int yy = min(max(y + mine, Y0), y_end - 1);
+          oprev = *(gcv)(out + (size_t)yy * a.W + oo);
+        }
+        if (gy == XG - 1 && y - gy >= Y0 && y - gy < y_end) {  // (block-uniform) the group is complete
+          __syncthreads();
+          const int k = (y - Y0) / XG, yy = y - gy + mine;
+          vC res = oprev;
+          for (int dd = 0; dd < nb; ++dd) {
+            const vC pd = *reinterpret_cast<const vC*>(xbuf + (size_t)((((k & 1) * XG + mine) * XW + dd) * 64 + lane) * C);
+            res = dd == 0 && !a.accumulate ? pd : res + pd;
+          }
+          if (vo && wv < XG && yy < y_end) *(gv)(out + (size_t)yy * a.W + oo) = res;
+        }
+      }
+      load_epi(y + P, ce);
+    }
+  }
+  if (POISSON) {
+    loss = wave_sum(loss);
+    if (lane == 0) a.partials[(size_t)d * n_tiles + tile] = loss;
+  }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Does the walk kernel take a launch over n datasets of (H, W) pixels with this PSF geometry?  Option JD_SEP_WALK: 0
+// never, 1 whenever the geometry allows (then independent of n: a batched step and the per-dataset calls it stands for
+// choose alike and agree bit for bit), unset: where it is the faster kernel -- which depends on n, so that by default
+// a batched step at a large size and its per-dataset form agree to fp32 rounding only.
+bool walk_geometry(int H, int W, int n, int kh, int kw, int oy, int ox, int adjoint, int* offy, int* offx) {
+  const int mode = opt_value(OPT_SEP_WALK, -1);
+  if (mode == 0) return false;
+  if (kh > WK || kw > WK || W % 4 != 0) return false;
+  const int oy0 = adjoint ? -oy : oy - (kh - 1), ox0 = adjoint ? -ox : ox - (kw - 1);
+  *offy = WH + oy0, *offx = WH + ox0;
+  if (*offy < 0 || *offy + kh > WK || *offx < 0 || *offx + kw > WK) return false;
+  if (mode < 0 && (size_t)H * W * n < WALK_MIN_PIXELS) return false;
+  return true;
+}
+
+int device_cus() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+
+bool walk_setup(WalkArgs& a, int n, int kh, int kw, int oy, int ox, int adjoint) {
+  if (!walk_geometry(a.H, a.W, n, kh, kw, oy, ox, adjoint, &a.offy, &a.offx)) return false;
+  const SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
+  const int taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
+  a.kh = kh, a.kw = kw;
+  a.taps_u = taps_off, a.taps_v = taps_off + g.khp + g.shiftx;
+  return true;
+}
+
+void walk_tiles(WalkArgs& a, int C, int rows) {
+  a.rows = rows;
+  a.strips = (a.W + 64 * C - 1) / (64 * C);
+  a.tiles_y = (a.H + rows - 1) / rows;
+}
+
+// (C, rows) of a launch over `n` datasets.  Measured inside the fit (tools/ab.py, MI355X): the launch is fastest with 6-7
+// waves per CU -- all resident at once (capacity 12 at C = 4) and long enough that the 16 warm-up rows of a tile stay a
+// small part of it: forward + Poisson launch of 2048^2 x 8 at C = 4, rows 74 / 92 / 110 / 128 / 146 = 130 / 122 / 127 /
+// 138 / 152 us (5.75 waves per CU at 92); 4096^2 x 1 forward + adjoint, rows 38 / 56 / 74 = 156 / 172 / 178 us (6.75 at
+// 38).  Rows = 18 k - 16: the walk advances in rounds of WS = 18 rows.
+void walk_shape(const WalkArgs& a, int n, bool adjoint, int* C, int* rows) {
+  const long want = (long)((n > 1 ? 6.0 : 7.25) * device_cus());
+  auto waves = [&](int c, int r) { return (long)((a.W + 64 * c - 1) / (64 * c)) * ((a.H + r - 1) / r) * n; };
+  *C = waves(4, 38) >= want * 5 / 8 ? 4 : 2;
+  *rows = 38;
+  while (*rows < 4096 && waves(*C, *rows) > want) *rows += WS;
+  const int oc = opt_value(adjoint ? OPT_SEP_WALK_ADJ_COLS : OPT_SEP_WALK_COLS, 0);
+  const int orows = opt_value(adjoint ? OPT_SEP_WALK_ADJ_ROWS : OPT_SEP_WALK_ROWS, 0);
+  if (oc == 2 || oc == 4) *C = oc;
+  if (orows >= 20 && orows <= 4096) *rows = orows;
+}
+
+template <bool POISSON, bool IN_SCALE>
+int launch_walk(WalkArgs a, int C, int n_grid, hipStream_t stream) {
+  int rc = sep_guard_check(&a.guard);
+  if (rc) return rc;
+  const int n_tiles = a.strips * a.tiles_y;
+  const unsigned blocks = (unsigned)(((n_tiles + 7) / 8) * 8 * n_grid);
+  ProfScope prof(POISSON ? JD_KERNEL_POISSON_FUSED : JD_KERNEL_SEP_CONV, stream);
+  if (C == 4)
+    hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH, POISSON, IN_SCALE, 0>), dim3(blocks), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, POISSON, IN_SCALE, 0>), dim3(blocks), dim3(64), 0, stream, a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+// one dataset of a batch: operator registered with rank 1, every image 16-byte aligned
+bool dataset_walkable(const SepBatchTable& t, int i, int d) {
+  return sep_operator_rank(t.op[i]) == 1 && aligned16(t.scale[i]) && aligned16(t.g[i]) && aligned16(t.bkg[d]) &&
+         aligned16(t.cnt[d]);
+}
+
+}  // namespace
+
+bool walk_takes_launch(int H, int W, int n_datasets, int kh, int kw, int oy, int ox) {
+  int offy, offx;
+  return walk_geometry(H, W, n_datasets, kh, kw, oy, ox, 0, &offy, &offx) && walk_geometry(H, W, n_datasets, kh, kw, oy, ox, 1, &offy, &offx);
+}
+
+bool sep_batch_is_mixed(int n, int n_comp, const SepBatchTable& table, int H, int W, int kh, int kw, int oy, int ox) {
+  int offy, offx;
+  // (the per-dataset calls a mixed batch falls back to decide with n = 1)
+  if (n_comp != 1 || !walk_geometry(H, W, n, kh, kw, oy, ox, 0, &offy, &offx) || !walk_geometry(H, W, n, kh, kw, oy, ox, 1, &offy, &offx))
+    return false;  // no dataset takes the walk kernels
+  int yes = 0;
+  for (int d = 0; d < n; ++d) yes += dataset_walkable(table, d, d) ? 1 : 0;
+  return yes != 0 && yes != n;
+}
+
+// out (+)= coef * out_scale * conv/corr_same(in * in_scale, psf)      [launch_sep_conv's contract]
+int walk_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H, int W,
+              int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream) {
+  if (sep_operator_rank(op) != 1) return JD_WALK_NOT_TAKEN;
+  if (!aligned16(in) || !aligned16(in_scale) || !aligned16(out) || !aligned16(out_scale)) return JD_WALK_NOT_TAKEN;
+  WalkArgs a{};
+  a.in = in, a.in_scale = in_scale, a.op = op, a.out = out, a.out_scale = out_scale;
+  a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate;
+  if (!walk_setup(a, 1, kh, kw, oy, ox, adjoint)) return JD_WALK_NOT_TAKEN;
+  int C, rows;
+  walk_shape(a, 1, adjoint != 0, &C, &rows);
+  walk_tiles(a, C, rows);
+  return in_scale ? launch_walk<false, true>(a, C, 1, stream) : launch_walk<false, false>(a, C, 1, stream);
+}
+
+// launch_sep_conv_poisson's contract; *n_partials = partial sums written
+int walk_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh, int kw,
+                      int oy, int ox, const float* background, const float* counts, float* npred_out, double* partials,
+                      float eps, float inv_n, int write_grad, int* n_partials, hipStream_t stream) {
+  if (sep_operator_rank(op) != 1 || !in_scale) return JD_WALK_NOT_TAKEN;
+  if (!aligned16(in) || !aligned16(in_scale) || !aligned16(g_out) || !aligned16(background) || !aligned16(counts) ||
+      !aligned16(npred_out))
+    return JD_WALK_NOT_TAKEN;
+  WalkArgs a{};
+  a.in = in, a.in_scale = in_scale, a.op = op, a.out = g_out;
+  a.H = H, a.W = W, a.coef = 1.f;
+  a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = partials;
+  a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
+  if (!walk_setup(a, 1, kh, kw, oy, ox, 0)) return JD_WALK_NOT_TAKEN;
+  int C, rows;
+  walk_shape(a, 1, false, &C, &rows);
+  walk_tiles(a, C, rows);
+  *n_partials = a.strips * a.tiles_y;
+  return launch_walk<true, true>(a, C, 1, stream);
+}
+
+// One flux component: all forward models + Poisson passes of a joint step in one launch (dataset-major grid);
+// *n_partials = partial sums per dataset, partials[d * *n_partials + tile]
+int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev, int H,
+                            int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
+                            int write_grad, int* n_partials, hipStream_t stream) {
+  if (!aligned16(flux)) return JD_WALK_NOT_TAKEN;
+  for (int d = 0; d < n; ++d)
+    if (!dataset_walkable(table, d, d)) return JD_WALK_NOT_TAKEN;
+  WalkArgs a{};
+  a.in = flux, a.H = H, a.W = W, a.coef = 1.f, a.partials = partials;
+  a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_batch = n, a.table = table_dev;
+  if (!walk_setup(a, n, kh, kw, oy, ox, 0)) return JD_WALK_NOT_TAKEN;
+  int C, rows;
+  walk_shape(a, n, false, &C, &rows);
+  walk_tiles(a, C, rows);
+  *n_partials = a.strips * a.tiles_y;
+  return launch_walk<true, true>(a, C, n, stream);
+}
+
+// grad (+)= coef * sum_d scale[d] * corr_same(g[d], psf_d), the datasets added in order: one wave per dataset, up to 8
+// datasets per launch, later chunks accumulate (the same additions in the same order).  With fin_partials, blocks
+// d < n of the first launch also turn the fin_count partial sums of dataset d into its loss (*fin_done <- 1)
+int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H, int W,
+                            int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream,
+                            const double* fin_partials, double fin_scale, int fin_count, int* fin_done) {
+  *fin_done = 0;
+  if (!aligned16(grad)) return JD_WALK_NOT_TAKEN;
+  for (int d = 0; d < n; ++d)
+    if (!dataset_walkable(table, d, d)) return JD_WALK_NOT_TAKEN;
+  WalkArgs a{};
+  a.out = grad, a.H = H, a.W = W, a.coef = coef, a.table = table_dev;
+  if (!walk_setup(a, n, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
+  // rows per tile: a multiple of every exchange group size, the smallest that leaves all blocks resident at once with a
+  // margin (measured at 2048^2 x 8, 2 blocks of 8 waves per CU: rows 36 / 54 / 72 / 90 / 108 = 102 / 101 / 83 / 95 / 107 us:
+  // 54 rows need a second, nearly empty round of blocks)
+  const int m0 = n < XW ? n : XW;
+  const int xg = m0 >= 6 ? 6 : m0 >= 3 ? 3 : 2;
+  const int lds = (2 * xg * XW * 128 + XW * 256) * 4;  // exchange buffer + row buffers (C = 2)
+  int per_cu = 160 * 1024 / lds;
+  if (per_cu > 20 / m0) per_cu = 20 / m0;  // (86 registers: 5 waves per SIMD)
+  if (per_cu < 1) per_cu = 1;
+  const long slots = (long)device_cus() * per_cu * 15 / 16;
+  const int strips = (W + 127) / 128;
+  int rows = 36;
+  while (rows < 4096 && (long)strips * ((H + rows - 1) / rows) > slots) rows += 18;
+  const int orows = opt_value(OPT_SEP_WALK_ADJ_ROWS, 0);
+  if (orows >= 18) rows = orows;
+  rows = (rows + 5) / 6 * 6;
+  walk_tiles(a, 2, rows);
+  int rc = sep_guard_check(&a.guard);
+  if (rc) return rc;
+  const int n_tiles = a.strips * a.tiles_y;
+  const unsigned blocks = (unsigned)(((n_tiles + 7) / 8) * 8);
+  for (int d0 = 0; d0 < n; d0 += XW) {
+    const int m = n - d0 < XW ? n - d0 : XW;
+    a.d_base = d0, a.n_batch = m, a.accumulate = d0 == 0 ? accumulate : 1;
+    a.fin_partials = nullptr;
+    if (d0 == 0 && fin_partials && m >= 4 && (int)blocks >= n) {  // (the fold needs 256 threads and a block per dataset)
+      a.fin_partials = fin_partials, a.fin_scale = fin_scale, a.fin_count = fin_count, a.fin_n = n;
+      *fin_done = 1;
+    }
+    ProfScope prof(JD_KERNEL_SEP_CONV, stream);
+    if (m >= 6)
+      hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (m >= 3)
+      hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (m == 2)
+      hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else {  // a single dataset: the plain walk (same arithmetic: out (+)= (coef * corr) * scale)
+      WalkArgs b = a;
+      b.n_batch = 0, b.table = nullptr, b.in = table.g[d0], b.op = table.op[d0], b.out_scale = table.scale[d0];
+      int C, r1;
+      walk_shape(b, 1, true, &C, &r1);
+      walk_tiles(b, C, r1);
+      const unsigned blocks1 = (unsigned)(((b.strips * b.tiles_y + 7) / 8) * 8);
+      if (C == 4)
+        hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
+      else
+        hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
+    }
+    JD_LAUNCH_CHECK();
+  }
+  return JD_OK;
+}
+
+}  // namespace jd

@@ -127,6 +127,10 @@ class ConvPlan:
             _hip.lib().jd_conv_plan_destroy(self._handle)
             self._handle = None
 
+    def takes_walk(self, n_datasets=1):
+        """True when a launch over ``n_datasets`` datasets runs on the strip-walk kernels (jd_conv_plan_takes_walk)."""
+        return bool(_hip.lib().jd_conv_plan_takes_walk(self._handle, int(n_datasets)))
+
     # --- kernel spectrum (once per dataset and component) -----------------------------------
     def psf_spectrum(self, psf):
         psf = require_hip_tensor(psf, "psf")

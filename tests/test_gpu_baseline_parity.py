@@ -156,14 +156,14 @@ def c2_prior_oracle():
 
 @pytest.mark.parametrize("image", ["noisy", "smooth"])
 @pytest.mark.parametrize("variant", ["screen_ksplit", "screen_all_components", "dense_fp32", "bucketed_backward"])
-def test_c2_prior_value_argmax_gradient(c2_prior_oracle, variant, image, monkeypatch):
+def test_c2_prior_value_argmax_gradient(c2_prior_oracle, variant, image, jd_option):
     """GMMPatchPrior at 1024^2, K = 128 against the oracle: value, arg-max, gradient -- through every kernel path.
     `screen_all_components` = gmm_screen_kernel<2, false>, the kernel of the 2048^2 headline (forced here; the
     default at this size is the KSPLIT variant)."""
     env = {"screen_ksplit": {"JD_GMM_KSPLIT": "1"}, "screen_all_components": {"JD_GMM_KSPLIT": "0"},
            "dense_fp32": {"JD_GMM_SCREEN": "0"}, "bucketed_backward": {"JD_GMM_FUSED_BWD": "0"}}[variant]
     for key, val in env.items():
-        monkeypatch.setenv(key, val)
+        jd_option(key, val)
     img, shifts, (value_o, grad_o, arg_o, margin) = c2_prior_oracle[image]
     gmm, _ = _gmm_pair()
     flux = torch.from_numpy(img).to(DEV)

@@ -87,7 +87,7 @@ def test_bench_two_ranks_over_gloo_reports_what_the_backend_saw(tmp_path):
         env.pop(key, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), str(REPO / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup",
-           str(warmup), "--no-general-psf"]
+           str(warmup), "--no-general-psf", "--repeats", "1", "--settle-seconds", "0"]
     done = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1400)
     assert done.returncode == 0, done.stderr[-3000:]
     lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]

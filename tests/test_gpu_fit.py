@@ -505,14 +505,18 @@ def test_fit_writes_the_file_the_reference_writes(tmp_path):
     assert again.config["checkpoint_path"] == str(tmp_path / "ckpt")
 
 
-def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch):
+@pytest.mark.parametrize("kernels,n_obs", [("tile", 5), ("walk", 5), ("walk", 8), ("walk", 11), ("walk", 2)])
+def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch, jd_option, kernels, n_obs):
     """fit_mode="joint" with one separable component runs all datasets of a step in three launches
     (jd_npred_poisson_batch_fwd_bwd).  Same trajectory as the per-dataset loop, bit for bit: the datasets' gradient
-    contributions are added in the same order."""
+    contributions are added in the same order -- with the tile kernel (the block walks over the datasets) and with the
+    strip-walk kernels (one wave per dataset, rows exchanged through LDS and added in dataset order; groups of 2 / 3 / 6
+    rows by the number of datasets, more than 8 datasets in two launches)."""
     from jolideco_amd import MAPDeconvolver, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import synthetic_observations
 
-    datasets, _, flux_init = synthetic_observations(shape=(96, 160), n_obs=5, seed=3)
+    jd_option("JD_SEP_WALK", 1 if kernels == "walk" else 0)
+    datasets, _, flux_init = synthetic_observations(shape=(96, 160), n_obs=n_obs, seed=3)
     # a smaller batch on the same (cached) convolution plan first: the plan's batch work space has to grow afterwards
     few = {name: datasets[name] for name in list(datasets)[:2]}
     comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=UniformPrior())

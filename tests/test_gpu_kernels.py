@@ -276,12 +276,12 @@ def test_product_path_fails_loudly_without_gpu_tensors():
      ((256, 256), (5, 16))],
 )
 @pytest.mark.parametrize("direct_kernel", ["split_fp16", "fp32"])
-def test_direct_conv_matches_fft_and_float64(shape, kshape, direct_kernel, monkeypatch):
+def test_direct_conv_matches_fft_and_float64(shape, kshape, direct_kernel, jd_option):
     """The MFMA Toeplitz kernels (split-fp16 x 3, the default where its window planes and fragment table fit in LDS --
     not at 33 x 33 -- and the fp32 one, JD_DIRECT_FP32=1), rocFFT on the fast grid and rocFFT on the reference's exact
     grid all compute the same 'same' convolution and its adjoint (ragged tiles, even / 1-pixel PSFs)."""
     if direct_kernel == "fp32":
-        monkeypatch.setenv("JD_DIRECT_FP32", "1")
+        jd_option("JD_DIRECT_FP32", "1")
     from scipy.signal import convolve2d
 
     from jolideco_amd.ops import ConvPlan
@@ -435,7 +435,7 @@ def test_large_psf_falls_back_to_fft():
         ConvPlan(96, 96, 41, 41, DEV, method="direct")
 
 
-def test_gmm_triangular_skip_is_bit_identical_to_dense(golden, monkeypatch):
+def test_gmm_triangular_skip_is_bit_identical_to_dense(golden, jd_option):
     """The block-skipping (upper triangular P) and the dense variants of the GMM kernels give the
     same bits: the skipped terms are exact zeros at the end of every fmaf chain."""
     from jolideco_amd import _hip
@@ -452,7 +452,7 @@ def test_gmm_triangular_skip_is_bit_identical_to_dense(golden, monkeypatch):
     out = {}
     for variant in ("tri", "dense"):
         if variant == "dense":
-            monkeypatch.setenv("JD_GMM_DENSE", "1")
+            jd_option("JD_GMM_DENSE", "1")
         value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
         argmax = torch.zeros(n_patches, dtype=torch.int32, device=DEV)
         handle.prior_fwd_bwd(flux, 4, (1, -2), value, scale, grad=grad, grad_coef=scale, argmax_out=argmax)
@@ -564,7 +564,7 @@ def test_marginalized_prior_fit_matches_oracle():
     [((96, 128), 8, 0, 0.0), ((257, 131), 37, 1, 0.0), ((512, 512), 128, 2, 0.0), ((64, 64), 1, 3, 0.0),
      ((200, 168), 64, 4, 0.02), ((120, 136), 16, 5, 1.0)],
 )
-def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, mean_scale, monkeypatch):
+def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, mean_scale, jd_option):
     """Max mode through the bf16 screen + exact fp32 re-evaluation of the survivors (csrc/gmm.hip, gmm_screen_kernel)
     returns exactly the dense fp32 kernel's numbers: same arg-max for every patch, same value bits, same gradient
     bits -- on noise, on smooth structure with bright points, with filtered patches and with cycle-spin shifts; also
@@ -592,7 +592,7 @@ def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, mean_scal
         for shifts in [(0, 0), (-2, 1)]:
             out = {}
             for mode in ("1", "0"):
-                monkeypatch.setenv("JD_GMM_SCREEN", mode)
+                jd_option("JD_GMM_SCREEN", mode)
                 value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
                 argmax = torch.full((n_patches,), -7, dtype=torch.int32, device=DEV)
                 handle.prior_fwd_bwd(flux, 4, shifts, value, 0.25, grad=grad, grad_coef=0.5, argmax_out=argmax)
@@ -606,7 +606,7 @@ def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, mean_scal
     rows = (shape[0] - 8) // 4 + 1
     vals = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("JD_GMM_SCREEN", mode)
+        jd_option("JD_GMM_SCREEN", mode)
         parts = []
         for r0, r1 in ((0, rows // 3), (rows // 3, rows)):
             v = torch.zeros(1, device=DEV)
@@ -617,7 +617,7 @@ def test_gmm_screened_argmax_is_bit_identical_to_dense(shape, K, seed, mean_scal
 
 
 @pytest.mark.parametrize("method,shape", [("separable", (97, 150)), ("direct", (97, 150)), ("direct", (200, 192))])
-def test_poisson_epilogue_of_the_convolution_matches_the_two_kernel_path(monkeypatch, method, shape):
+def test_poisson_epilogue_of_the_convolution_matches_the_two_kernel_path(monkeypatch, method, shape, jd_option):
     """One component without up-sampling: the Poisson pass runs as the epilogue of the forward convolution
     (sep_conv_kernel<.., POISSON> / direct_conv_kernel<.., POISSON>).  Same loss, predicted counts and gradient as
     convolution + poisson_fused_kernel (JD_SEP_NO_FUSION=1), on a ragged image (scalar epilogue) and on one with
@@ -649,7 +649,7 @@ def test_poisson_epilogue_of_the_convolution_matches_the_two_kernel_path(monkeyp
     results = {}
     for fusion in ("fused", "split"):
         if fusion == "split":
-            monkeypatch.setenv("JD_SEP_NO_FUSION", "1")
+            jd_option("JD_SEP_NO_FUSION", "1")
         loss, grad, npred = torch.zeros(1, device=DEV), torch.full_like(flux, 3.0), torch.empty_like(flux)
         models.fwd_bwd([flux], counts, stirling_mean(data["counts"]), loss, grads=[grad], npred_out=npred, accumulate=True,
                        grad_scale=0.5)
@@ -666,10 +666,10 @@ def test_poisson_epilogue_of_the_convolution_matches_the_two_kernel_path(monkeyp
     assert rel_linf(a[2] - 3.0, b[2] - 3.0) < 1e-6  # gradient: same g, same adjoint kernel
 
 
-def _prior_both_ways(handle, flux, n_patches, monkeypatch, shifts=(1, -2)):
+def _prior_both_ways(handle, flux, n_patches, jd_option, shifts=(1, -2)):
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("JD_GMM_SCREEN", mode)
+        jd_option("JD_GMM_SCREEN", mode)
         value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
         argmax = torch.full((n_patches,), -7, dtype=torch.int32, device=DEV)
         handle.prior_fwd_bwd(flux, 4, shifts, value, 1.0, grad=grad, grad_coef=1.0, argmax_out=argmax)
@@ -710,7 +710,7 @@ def test_gmm_record_buffer_grows_after_a_pass_that_ran_out_of_it():
     assert np.all(results[0][2] < 16)                       # ties go to the lowest component, like torch.max
 
 
-def test_gmm_screen_falls_back_to_the_dense_kernel(monkeypatch):
+def test_gmm_screen_falls_back_to_the_dense_kernel(jd_option):
     """The two situations in which the screen gives up (device flag -> the always-enqueued dense kernel overwrites
     the result, no host sync): more candidates than a wave's record list holds, and non-finite screening values."""
     from jolideco_amd.data import synthetic_gmm
@@ -726,7 +726,7 @@ def test_gmm_screen_falls_back_to_the_dense_kernel(monkeypatch):
         np.repeat(means, K, axis=0), np.repeat(covs, K, axis=0), np.full(K, 1.0 / K), meta=GaussianMixtureModelMeta(stride=4)
     )
     flux = torch.from_numpy(rs.gamma(20, size=shape).astype(np.float32)).to(DEV)
-    screened, dense = _prior_both_ways(gmm.handle(DEV), flux, n_patches, monkeypatch)
+    screened, dense = _prior_both_ways(gmm.handle(DEV), flux, n_patches, jd_option)
     assert np.array_equal(screened[2], dense[2]) and np.all(dense[2] == 0)  # ties -> the lowest component, like torch.max
     assert screened[0] == pytest.approx(dense[0], rel=2e-7) and np.array_equal(screened[1], dense[1])
     # (b) an infinite pixel: the patches that contain it have no finite log-likelihood
@@ -735,7 +735,7 @@ def test_gmm_screen_falls_back_to_the_dense_kernel(monkeypatch):
     image = rs.gamma(20, size=shape).astype(np.float32)
     image[40, 50] = np.inf
     flux = torch.from_numpy(image).to(DEV)
-    screened, dense = _prior_both_ways(gmm.handle(DEV), flux, n_patches, monkeypatch)
+    screened, dense = _prior_both_ways(gmm.handle(DEV), flux, n_patches, jd_option)
     assert np.array_equal(screened[2], dense[2])
     assert np.array_equal(np.isnan(screened[1]), np.isnan(dense[1]))
     finite = np.isfinite(dense[1])
@@ -743,7 +743,7 @@ def test_gmm_screen_falls_back_to_the_dense_kernel(monkeypatch):
     assert (np.isnan(screened[0]) and np.isnan(dense[0])) or screened[0] == dense[0]
 
 
-def test_gmm_fused_backward_equals_the_bucketed_backward(monkeypatch):
+def test_gmm_fused_backward_equals_the_bucketed_backward(jd_option):
     """Screened arg-max with a gradient: by default the exact kernel also writes the gradient row of every surviving
     record and the gather kernel reads the winner's row (no second sort, no backward kernel); JD_GMM_FUSED_BWD=0 keeps
     the bucketed backward pass.  Same bits -- whole image, a patch-row shard, with and without the arg-max asked for,
@@ -757,7 +757,7 @@ def test_gmm_fused_backward_equals_the_bucketed_backward(monkeypatch):
     rs = np.random.RandomState(5)
 
     def run(handle, flux, fused, rows=(0, -1), want_argmax=True):
-        monkeypatch.setenv("JD_GMM_FUSED_BWD", "1" if fused else "0")
+        jd_option("JD_GMM_FUSED_BWD", "1" if fused else "0")
         value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
         argmax = torch.full((n_py * n_px,), -7, dtype=torch.int32, device=DEV) if want_argmax else None
         handle.prior_fwd_bwd(flux, 4, (3, -5), value, 0.25, grad=grad, grad_coef=-0.7, patch_rows=rows, argmax_out=argmax)
@@ -798,7 +798,7 @@ def test_gmm_fused_backward_equals_the_bucketed_backward(monkeypatch):
     assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.isfinite(a[0])
 
 
-def test_gmm_screen_large_k_and_huge_dynamic_range(monkeypatch):
+def test_gmm_screen_large_k_and_huge_dynamic_range(jd_option):
     """K above the popularity-order limit (natural order is kept) and fluxes / precisions far outside the fp16 range
     (the power-of-two operand scales keep the screen exact): still the dense kernel's bits."""
     from jolideco_amd.data import synthetic_gmm
@@ -814,7 +814,7 @@ def test_gmm_screen_large_k_and_huge_dynamic_range(monkeypatch):
     for scale in (1e-12, 1.0, 3e7):
         flux = torch.from_numpy((scale * rs.gamma(20, size=shape)).astype(np.float32)).to(DEV)
         for _ in range(2):  # the second call uses the component order learnt in the first
-            screened, dense = _prior_both_ways(handle, flux, n_patches, monkeypatch)
+            screened, dense = _prior_both_ways(handle, flux, n_patches, jd_option)
             assert np.array_equal(screened[2], dense[2]), scale
             assert screened[0] == pytest.approx(dense[0], rel=2e-7), scale
             assert np.array_equal(screened[1], dense[1]), scale
@@ -822,7 +822,7 @@ def test_gmm_screen_large_k_and_huge_dynamic_range(monkeypatch):
 
 @pytest.mark.parametrize("stride", [4, 5, 8])
 @pytest.mark.parametrize("marginalize", [False, True])
-def test_gmm_tiled_gather_equals_the_per_pixel_gather(monkeypatch, stride, marginalize):
+def test_gmm_tiled_gather_equals_the_per_pixel_gather(jd_option, stride, marginalize):
     """The overlap-add of the patch gradients runs tile-wise through LDS for strides >= 4 (`gmm_gather_tile_kernel`);
     JD_GMM_GATHER_TILED=0 selects the per-pixel kernel.  Same additions in the same order: same bits -- whole image,
     patch-row shards (tile boundaries inside the shard), filtered patches, image sizes that are no multiple of the
@@ -841,8 +841,8 @@ def test_gmm_tiled_gather_equals_the_per_pixel_gather(monkeypatch, stride, margi
     n_rows = (shape[0] - 8) // stride + 1
 
     def run(tiled, rows, fused=True):
-        monkeypatch.setenv("JD_GMM_GATHER_TILED", "1" if tiled else "0")
-        monkeypatch.setenv("JD_GMM_FUSED_BWD", "1" if fused else "0")
+        jd_option("JD_GMM_GATHER_TILED", "1" if tiled else "0")
+        jd_option("JD_GMM_FUSED_BWD", "1" if fused else "0")
         value, grad = torch.zeros(1, device=DEV), torch.full_like(flux, 0.5)  # accumulates into a non-zero image
         handle.prior_fwd_bwd(flux, stride, (3, -5), value, 0.25, grad=grad, grad_coef=-0.7, patch_rows=rows,
                              marginalize=marginalize)
@@ -906,55 +906,98 @@ def test_prior_bands_of_a_sharded_prior_add_up_to_the_whole(marginalize):
     assert rel_linf(g2.cpu().numpy(), g1.cpu().numpy()) < 1e-6
 
 
-_ALIAS_SCRIPT = r"""
-import os, sys
-import numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from jolideco_amd import FluxComponents, NPredModels, SpatialFluxComponent
-from jolideco_amd.data import gaussian_kernel
-from jolideco_amd.ops import stirling_mean
+def _separable_step_outputs(shape, psf, seed=3):
+    """loss, gradient, predicted counts, gradient of the call without npred, plain convolution and adjoint of one
+    dataset on the separable plan, as numpy arrays"""
+    from jolideco_amd import FluxComponents, NPredModels, SpatialFluxComponent
+    from jolideco_amd.ops import stirling_mean
 
-rs = np.random.RandomState(3)
-shape = (200, 328)
-data = {"counts": rs.poisson(3.0, size=shape).astype(np.float32), "psf": gaussian_kernel(2.0, (17, 17)).astype(np.float32),
-        "exposure": rs.uniform(0.5, 1.5, size=shape).astype(np.float32),
-        "background": rs.uniform(0.2, 1.0, size=shape).astype(np.float32)}
-flux = torch.from_numpy(rs.gamma(3.0, size=shape).astype(np.float32)).cuda()
-comps = FluxComponents()
-comps["flux"] = SpatialFluxComponent.from_numpy(flux=flux.cpu().numpy())
-models = NPredModels.from_dataset_numpy(dataset=data, components=comps, device="cuda:0")
-assert models.plan.method == "separable"
-counts = torch.from_numpy(data["counts"]).cuda()
-out = {}
-for mode in ("alias", "plain"):
-    if mode == "plain":
-        os.environ["JD_SEP_NO_ALIAS"] = "1"
-    loss, grad, npred = torch.zeros(1, device="cuda"), torch.zeros_like(flux), torch.empty_like(flux)
+    rs = np.random.RandomState(seed)
+    data = {"counts": rs.poisson(3.0, size=shape).astype(np.float32), "psf": psf.astype(np.float32),
+            "exposure": rs.uniform(0.5, 1.5, size=shape).astype(np.float32),
+            "background": rs.uniform(0.2, 1.0, size=shape).astype(np.float32)}
+    flux = torch.from_numpy(rs.gamma(3.0, size=shape).astype(np.float32)).to(DEV)
+    comps = FluxComponents()
+    comps["flux"] = SpatialFluxComponent.from_numpy(flux=flux.cpu().numpy())
+    models = NPredModels.from_dataset_numpy(dataset=data, components=comps, device=DEV)
+    assert models.plan.method == "separable"
+    counts = torch.from_numpy(data["counts"]).to(DEV)
+    loss, grad, npred = torch.zeros(1, device=DEV), torch.zeros_like(flux), torch.empty_like(flux)
     models.fwd_bwd([flux], counts, stirling_mean(data["counts"]), loss, grads=[grad], npred_out=npred)
     grad2 = torch.zeros_like(flux)
     models.fwd_bwd([flux], counts, stirling_mean(data["counts"]), loss, grads=[grad2])  # fused epilogue, no npred
     conv = models.plan.conv_same(flux, models["flux"].exposure[0, 0], models["flux"].khat)
+    adj = models.plan.conv_same_adjoint(grad, models["flux"].exposure[0, 0], models["flux"].khat)
     torch.cuda.synchronize()
-    out[mode] = [t.cpu().numpy() for t in (loss, grad, npred, grad2, conv)]
-for a, b in zip(out["alias"], out["plain"]):
-    assert np.array_equal(a, b)
-assert np.abs(out["alias"][1]).max() > 0
-print("ALIAS-OK")
-"""
+    # (the model's exposure is the edge-corrected one, models/npred.py:108-113)
+    return [t.cpu().numpy() for t in (loss, grad, npred, grad2, conv, adj)], (
+        data, flux.cpu().numpy(), models["flux"].exposure[0, 0].cpu().numpy())
 
 
-def test_separable_convolution_lds_aliasing_changes_no_bit(tmp_path):
-    """With rank-1 operators only, the row-pass image of `sep_conv_kernel` shares the LDS of the input window (a sixth
-    block per CU for the fused forward + Poisson launch); JD_SEP_NO_ALIAS=1 keeps them apart.  Same arithmetic, same
-    bits: loss, gradient, predicted counts, plain convolution.  Runs in a fresh process -- the library enables the
-    aliasing only while no operator of rank > 1 has been built in the process."""
-    import subprocess
-    import sys
-    from pathlib import Path
+def test_separable_convolution_lds_aliasing_changes_no_bit(jd_option):
+    """For a rank-1 operator the row-pass image of `sep_conv_kernel` shares the LDS of the input window (a sixth block
+    per CU for the fused forward + Poisson launch); option JD_SEP_NO_ALIAS keeps them apart.  Same arithmetic, same
+    bits: loss, gradient, predicted counts, plain convolution, adjoint.  (The rank is the one the library registered for
+    the operator buffer when it built it, checked again on the device.)"""
+    from jolideco_amd.data import gaussian_kernel
 
-    script = tmp_path / "alias_check.py"
-    script.write_text(_ALIAS_SCRIPT)
-    repo = Path(__file__).resolve().parent.parent
-    env = {k: v for k, v in __import__("os").environ.items() if k not in ("JD_SEP_NO_ALIAS", "JOLIDECO_CONV_METHOD")}
-    done = subprocess.run([sys.executable, str(script), str(repo)], capture_output=True, text=True, timeout=600, env=env)
-    assert done.returncode == 0 and "ALIAS-OK" in done.stdout, done.stderr[-2000:]
+    jd_option("JD_SEP_WALK", 0)  # the tile kernel is the one under test
+    out = {}
+    for mode in ("alias", "plain"):
+        jd_option("JD_SEP_NO_ALIAS", 1 if mode == "plain" else None)
+        out[mode], _ = _separable_step_outputs((200, 328), gaussian_kernel(2.0, (17, 17)))
+    for a, b in zip(out["alias"], out["plain"]):
+        assert np.array_equal(a, b)
+    assert np.abs(out["alias"][1]).max() > 0
+
+
+@pytest.mark.parametrize("shape,kshape", [((200, 328), (17, 17)), ((75, 260), (9, 13)), ((130, 516), (16, 17)),
+                                          ((64, 132), (5, 7))], ids=["17x17", "9x13", "16x17", "5x7"])
+def test_strip_walk_kernels_match_the_tile_kernel_and_float64(jd_option, shape, kshape):
+    """csrc/walkconv.hip (strip-walk form of the separable convolution: forward model + Poisson pass, plain
+    convolution, adjoint) against csrc/sepconv.hip's tile kernel on the same inputs, and the plain convolution against
+    float64 (scipy): different summation orders of the same 'same' convolution (utils/torch.py:347-370)."""
+    from scipy.signal import fftconvolve
+
+    from jolideco_amd.data import gaussian_kernel
+
+    psf = gaussian_kernel(1.7, kshape)
+    out = {}
+    for walk in (0, 1):
+        jd_option("JD_SEP_WALK", walk)
+        out[walk], (data, flux, exposure) = _separable_step_outputs(shape, psf)
+    names = ("loss", "gradient", "npred", "gradient (no npred)", "convolution", "adjoint")
+    for name, a, b in zip(names, out[1], out[0]):
+        assert rel_linf(a, b) < 2e-6, name
+    assert np.array_equal(out[1][1], out[1][3])
+    ref = fftconvolve(flux.astype(np.float64) * exposure, data["psf"].astype(np.float64), mode="full")
+    oy, ox = (kshape[0] - 1) // 2, (kshape[1] - 1) // 2
+    assert rel_linf(out[1][4], ref[oy:oy + shape[0], ox:ox + shape[1]]) < 1e-6
+
+
+def test_an_operator_buffer_overwritten_behind_the_library_is_reported(jd_option):
+    """The kernels that assume a rank-1 operator (walk kernels, LDS aliasing) are launched on the rank the library
+    registered when it built the buffer; they re-check op[0] on the device and the next call fails loudly if the
+    buffer was overwritten with an operator of another rank (never a silently wrong convolution)."""
+    from jolideco_amd.data import gaussian_kernel
+    from jolideco_amd.ops import ConvPlan
+
+    jd_option("JD_SEP_WALK", 1)
+    H, W = 64, 128
+    plan = ConvPlan(H, W, 17, 17, DEV, method="separable")
+    g1 = torch.from_numpy(gaussian_kernel(2.0, (17, 17)).astype(np.float32)).to(DEV)
+    g2 = torch.from_numpy((0.6 * gaussian_kernel(1.5, (17, 17)) + 0.4 * gaussian_kernel(4.0, (17, 17))).astype(np.float32)).to(DEV)
+    k1, k2 = plan.psf_spectrum(g1), plan.psf_spectrum(g2)  # rank 1 and rank 2
+    image = torch.rand(H, W, device=DEV)
+    ok = plan.conv_same(image, None, k1)
+    k1.copy_(k2)  # the caller overwrites the rank-1 buffer with a rank-2 operator
+    plan.conv_same(image, None, k1)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="rank"):
+        plan.conv_same(image, None, k1)
+    # a copy the library has never seen takes the general path and is right
+    k3 = k2.clone()
+    got = plan.conv_same(image, None, k3).cpu().numpy()
+    ref = plan.conv_same(image, None, k2).cpu().numpy()
+    assert np.array_equal(got, ref) and np.isfinite(ok.cpu().numpy()).all()
+    plan.close()

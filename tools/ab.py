@@ -1,7 +1,8 @@
 """A/B timing of the bench step under different environment switches IN ONE PROCESS (box-to-box clock differences
 are +-10 %, so variants must be compared inside one gpurun call, interleaved):
     python tools/ab.py [config=c3] [rounds=5] [steps=30] -- NAME1:VAR=VAL,VAR2=VAL NAME2: ...
-Every variant is a set of environment variables read by the library at launch time (getenv)."""
+Every variant is a set of library switches (JD_*: jd_set_option) and / or environment variables read by the Python
+side at launch time (JOLIDECO_*)."""
 import os, sys, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
@@ -31,8 +32,11 @@ res = {name: {"ms": [], "k": {}} for name, _ in parsed}
 for r in range(rounds):
     for name, env in parsed:
         for k in all_keys:
-            os.environ.pop(k, None)
-        os.environ.update(env)
+            if k.startswith("JD_"):
+                _hip.set_option(k, env.get(k))
+            else:
+                os.environ.pop(k, None)
+        os.environ.update({k: v for k, v in env.items() if not k.startswith("JD_")})
         for _ in range(3):
             session.epoch()
         torch.cuda.synchronize()

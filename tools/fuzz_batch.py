@@ -1,24 +1,32 @@
 """Randomised comparison of the batched joint step (jd_npred_poisson_batch_multi_fwd_bwd) against the per-dataset loop on
 the GPU: random image shapes (odd widths too), PSF shapes (odd, even, non-square, up to 33), 2-6 observations, 1-3 flux
 components with their own PSFs (Gaussian: rank 1; sum of two Gaussians: rank 2).  Two joint steps; the fluxes of all
-components must agree bit for bit.  GPU box: `python tools/fuzz_batch.py [n_cases] [seed]`."""
+components must agree bit for bit.  GPU box: `python tools/fuzz_batch.py [n_cases] [seed] [walk]` (walk: option
+JD_SEP_WALK = 1 -- the strip-walk kernels wherever their geometry allows, half the PSFs then at most 17 x 17 and the widths
+multiples of 4, with up to 11 observations)."""
 import os
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from jolideco_amd import FluxComponents, MAPDeconvolver, SpatialFluxComponent, UniformPrior  # noqa: E402
+from jolideco_amd import FluxComponents, MAPDeconvolver, SpatialFluxComponent, UniformPrior, _hip  # noqa: E402
 from jolideco_amd.data import gaussian_kernel  # noqa: E402
 
 DEV = "cuda:0"
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+walk = len(sys.argv) > 3 and sys.argv[3] == "walk"
+if walk:
+    _hip.set_option("JD_SEP_WALK", 1)
 bad = skipped = 0
 for case in range(n_cases):
     H, W = int(rs.randint(20, 150)), int(rs.randint(20, 200))
     kh, kw = int(rs.randint(3, 34)), int(rs.randint(3, 34))
     n_obs, n_comp = int(rs.randint(2, 7)), int(rs.randint(1, 4))
+    if walk and case % 2 == 0:
+        W, kh, kw, n_comp = (W + 3) // 4 * 4, int(rs.randint(3, 18)), int(rs.randint(3, 18)), 1
+        n_obs = int(rs.randint(2, 12))
     names = ["a", "b", "c"][:n_comp]
 
     def psf():

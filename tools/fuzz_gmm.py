@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from jolideco_amd import _hip  # noqa: E402
 from jolideco_amd.data import synthetic_gmm  # noqa: E402
 from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta  # noqa: E402
 
@@ -18,7 +19,7 @@ rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
 
 def run(handle, flux, stride, shifts, rows, screen, n_patches):
-    os.environ["JD_GMM_SCREEN"] = "1" if screen else "0"
+    _hip.set_option("JD_GMM_SCREEN", 1 if screen else 0)
     value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
     argmax = torch.full((n_patches,), -7, dtype=torch.int32, device=DEV)
     handle.prior_fwd_bwd(flux, stride, shifts, value, 0.5, grad=grad, grad_coef=1.5, patch_rows=rows, argmax_out=argmax)
