@@ -273,6 +273,8 @@ class MAPDeconvolver:
                 n_epochs_run = epoch + 1
 
                 filename = ""
+                if self.checkpoint_path is not None:
+                    session.gather_calibrations()  # (a collective: every rank, not only the one that writes)
                 if write_checkpoints:
                     # like the reference (core.py:234-245): written before this epoch's trace row exists
                     filename = self._default_checkpoint_filename.format(epoch=epoch)
@@ -304,6 +306,7 @@ class MAPDeconvolver:
                         total=row["total"], datasets_total=row["datasets-total"], priors_total=row["priors-total"]
                     )
 
+        session.gather_calibrations()
         trace = total_loss.trace
         values = trace_dev[:n_epochs_run].cpu().numpy()
         for epoch in range(n_epochs_run):
@@ -357,8 +360,9 @@ class FitSession:
     def __init__(self, deconvolver, datasets, datasets_validation, components, dist, calibrations=None):
         self.cfg = deconvolver
         self.dist = dist
-        if calibrations is not None and deconvolver.fit_mode == "joint" and dist.world_size > 1:
-            raise NotImplementedError("NPredCalibrations in a sharded joint fit are not implemented in jolideco_amd")
+        # (sharded joint fit: a dataset's calibration lives -- parameters, gradients, its small optimizer -- on the rank
+        # that owns the dataset; `gather_calibrations` hands the values to every rank for results and checkpoints)
+        self.calibrations = calibrations
         device = deconvolver.device
         self.components = components = components.to(device)
         self.joint = deconvolver.fit_mode == "joint"
@@ -422,6 +426,30 @@ class FitSession:
         # sequential mode: the per-epoch trace evaluates every dataset on the same stale flux -- one batched launch
         self.batch_trace = (not self.joint) and batchable
 
+    def gather_calibrations(self):
+        """Sharded joint fit: every rank receives the current calibration parameters of the datasets the other ranks
+        own (one small all-reduce: each owner contributes its (shift_x, shift_y, log background norm), the others
+        zeros).  A collective: every rank must call it.  No-op for a single process or without calibrations."""
+        cals, dist = self.calibrations, self.dist
+        if cals is None or not (self.joint and dist.world_size > 1) or dist.dry_run:
+            return
+        names = self.total_loss.poisson_loss.names_all_global
+        mine = {names[gslot] for gslot, _ in self.local_idx}
+        flat = torch.zeros(3 * len(names), dtype=torch.float32, device=self.comm.device)
+        for i, name in enumerate(names):
+            if name in mine and name in cals:
+                cal = cals[name]
+                flat[3 * i : 3 * i + 2] = cal.shift_xy.detach().reshape(-1).to(flat.device)
+                flat[3 * i + 2] = cal._background_norm.detach().reshape(-1)[0].to(flat.device)
+        dist.all_reduce_sum(flat)
+        host = flat.cpu()
+        for i, name in enumerate(names):
+            if name not in mine and name in cals:
+                cal = cals[name]
+                with torch.no_grad():
+                    cal.shift_xy.copy_(host[3 * i : 3 * i + 2].reshape(1, 2))
+                    cal._background_norm.copy_(host[3 * i + 2 : 3 * i + 3])
+
     def _setup_sharded_prior(self, overlap):
         """Sharded joint fit: every rank evaluates the GMM prior on its band of patch rows.  With ``overlap`` (default)
         the band of the prior gradient travels in ONE all-gather of compact pieces [bands of the shardable priors |
@@ -441,6 +469,11 @@ class FitSession:
                 state.append(int(np.frombuffer(generator.get_state().numpy().tobytes(), dtype=np.uint8).astype(np.int64).sum()))
                 state.append(int(generator.initial_seed() % (1 << 62)))
         dist.assert_same_on_all_ranks(state or [0], "the state of the cycle-spin generators")
+        # the schedule itself must agree too: a rank with another JOLIDECO_DIST_OVERLAP or another set of frozen
+        # components would issue different collectives (a hang, or a size mismatch deep inside the backend)
+        frozen = [int(st.frozen) for st in self.states]
+        dist.assert_same_on_all_ranks([int(bool(overlap)), len(self.states)] + frozen, "the collective schedule (JOLIDECO_DIST_OVERLAP, "
+                                      "frozen components)")
         if not overlap:
             return
         plan, offset = [], 0
@@ -466,6 +499,7 @@ class FitSession:
         self.band_chunk = chunk
         self.band_send = torch.zeros(chunk, dtype=torch.float32, device=device)
         self.band_recv = torch.zeros(chunk * dist.world_size, dtype=torch.float32, device=device)
+        dist.assert_same_on_all_ranks([len(plan), chunk], "the band plan of the sharded prior")
 
     def _slot(self, i):
         return self.scalars[i : i + 1]

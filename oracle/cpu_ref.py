@@ -546,15 +546,23 @@ def joint_loss(data, fluxes, prior_list, beta):
     return sum(loss_datasets) - beta * sum(loss_priors), loss_datasets, loss_priors
 
 
-def map_fit_joint(datasets, flux_inits, priors, n_epochs, beta=1.0, learning_rate=0.1, record_steps=False):
+def map_fit_joint(datasets, flux_inits, priors, n_epochs, beta=1.0, learning_rate=0.1, record_steps=False,
+                  calibrations=None, upsampling_factors=None):
     """Joint mode harness: ONE Adam step per epoch on the summed objective.  The trace row of an
     epoch is made of the values of that step's forward pass (pre-step fluxes, no extra prior
-    evaluation and therefore no extra RNG draw)."""
+    evaluation and therefore no extra RNG draw).  `calibrations` (name -> CalibrationRef): their parameters join
+    the one optimizer, as in jolideco/core.py:197-204."""
     names_c = list(flux_inits)
     names_d = list(datasets)
-    thetas = [log_flux_parameter(flux_inits[n]) for n in names_c]
-    data = [DatasetRef.from_numpy(datasets[n], names_c) for n in names_d]
-    optimizer = torch.optim.Adam(thetas, lr=learning_rate)
+    ups = [(upsampling_factors or {}).get(n) for n in names_c]
+    thetas = [log_flux_parameter(flux_inits[n], u) for n, u in zip(names_c, ups)]
+    calibrations = calibrations or {}
+    data = [DatasetRef.from_numpy(datasets[n], names_c, ups if any(ups) or calibrations else None, calibrations.get(n))
+            for n in names_d]
+    parameters = list(thetas)
+    for cal in calibrations.values():
+        parameters.extend(cal.parameters())
+    optimizer = torch.optim.Adam(parameters, lr=learning_rate)
     prior_list = [priors[n] for n in names_c]
     trace, steps = [], []
     for _ in range(n_epochs):

@@ -419,3 +419,62 @@ def test_c4_full_size_step_4096():
         runs.append(vals)
         del session
     assert np.array_equal(runs[0], runs[1])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 5 shape: two flux components with their own PSFs, batched joint step
+# ---------------------------------------------------------------------------------------------------------
+def test_c5_shaped_two_component_joint_step_1024_4obs():
+    """BASELINE config 5 in its batched form (jd_npred_poisson_batch_multi_fwd_bwd: every dataset's forward model walks
+    over the components inside the block, clips each -- models/npred.py:241-261 -- and writes one masked gradient image
+    per component; one adjoint launch per component) at 1024^2 x 4 observations x 2 components with per-component PSFs,
+    "extended" under the GMM patch prior (K = 128), "points" under the inverse-Gamma prior: BOTH gradient buffers and all
+    scalars of one joint step against autograd of cpu_ref.joint_loss (prior in bands, one backward per dataset)."""
+    from jolideco_amd import FluxComponents, GMMPatchPrior, InverseGammaPrior, MAPDeconvolver, SpatialFluxComponent
+    from jolideco_amd.data import gaussian_kernel, synthetic_observations
+
+    shape, n_obs = (1024, 1024), 4
+    datasets, truth, flux_init = synthetic_observations(shape=shape, n_obs=n_obs, seed=0)
+    for i, d in enumerate(datasets.values()):  # per-component PSFs: the point sources see a sharper core (bench.py c5)
+        d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
+    gmm, gmm_o = _gmm_pair()
+    comps = FluxComponents()
+    comps["extended"] = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+    comps["points"] = SpatialFluxComponent.from_numpy(flux=0.05 * flux_init, prior=InverseGammaPrior(alpha=10, beta=1.5))
+    deco = MAPDeconvolver(n_epochs=1, display_progress=False, device=DEV, fit_mode="joint")
+    session = deco.session(datasets, components=comps)
+    assert session.batch_joint
+    session.cfg._optimizer_step = lambda states, step: None  # keep the gradient buffers, no update
+    session.epoch()
+    torch.cuda.synchronize()
+    shifts = session.priors[0].last_shifts
+    n = shape[0] * shape[1]
+    comm = session.comm.cpu().numpy()
+    grads = {"extended": comm[:n].reshape(shape), "points": comm[n : 2 * n].reshape(shape)}
+    scalars = comm[2 * n :]
+    seen = {name: st.flux_cur.cpu().numpy() for name, st in zip(("extended", "points"), session.states)}
+
+    # the oracle: GMM prior of "extended" in bands, inverse-Gamma prior and the datasets by autograd
+    value_gmm, grad_prior, arg_o, margin = oracle_prior_banded(seen["extended"], gmm_o, shifts)
+    fl = {name: torch.from_numpy(np.ascontiguousarray(v))[None, None].requires_grad_(True) for name, v in seen.items()}
+    losses = []
+    for d in datasets.values():
+        loss = cpu_ref.DatasetRef.from_numpy(d, ["extended", "points"]).loss((fl["extended"], fl["points"]))
+        loss.backward()
+        losses.append(float(loss))
+    ig = cpu_ref.InverseGammaPriorRef(alpha=10, beta=1.5)
+    value_ig = ig(fl["points"])
+    (-1.0 * value_ig).backward()
+    grad_o = {"extended": fl["extended"].grad.numpy()[0, 0] - grad_prior, "points": fl["points"].grad.numpy()[0, 0]}
+    scalars_o = np.array(losses + [value_gmm, float(value_ig)])
+    np.testing.assert_allclose(scalars, scalars_o, rtol=5e-6)
+    err_points = rel_linf(grads["points"], grad_o["points"])
+    assert err_points < 1e-5, err_points
+    argmax = torch.empty((arg_o.size,), dtype=torch.int32, device=DEV)
+    session.priors[0].gmm.handle(DEV).prior_fwd_bwd(session.states[0].flux_cur, STRIDE, shifts, torch.zeros(1, device=DEV), 1.0,
+                                                    argmax_out=argmax)
+    got = argmax.cpu().numpy()
+    flips = assert_prior_grad_matches(grads["extended"], grad_o["extended"], got, arg_o, shape, STRIDE, shifts, margin=margin,
+                                      max_flip_fraction=1e-3)
+    print(f"c5-shaped 1024^2 x 4 x 2 components: gradients within 1e-5 of the oracle (points {err_points:.1e}), {flips} "
+          f"near-tie flips, scalars max rel {np.max(np.abs(scalars / scalars_o - 1)):.1e}")

@@ -50,6 +50,82 @@ def _worker(rank, world_size, port, out_dir, overlap):
     torch.distributed.destroy_process_group()
 
 
+def _calibrated_joint_fit(n_epochs=8):
+    """The joint fit of the calibration fixture's three observations (trained sub-pixel shift + background norm, a zero
+    shift that must stay zero, a frozen calibration), GMM patch prior: result, calibration initial values"""
+    from conftest import unpack_datasets
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    c = dict(np.load(REPO / "tests" / "golden" / "calibration.npz"))
+    datasets = unpack_datasets(c, "u1/data/")
+    gmm = GaussianMixtureModel.from_numpy(c["u1/gmm_means"], c["u1/gmm_covariances"], c["u1/gmm_weights"],
+                                          meta=GaussianMixtureModelMeta(stride=4))
+    cals = NPredCalibrations()
+    for name in datasets:
+        sx, sy, norm, psf_scale, frozen = (float(v) for v in c[f"u1/cal_init/{name}"])
+        cals[name] = NPredCalibration(shift_x=sx, shift_y=sy, background_norm=norm, psf_scale=psf_scale, frozen=bool(frozen))
+    comp = SpatialFluxComponent.from_numpy(flux=c["u1/flux_init"], prior=GMMPatchPrior(gmm=gmm))
+    res = MAPDeconvolver(n_epochs=n_epochs, display_progress=False, device="cuda:0", fit_mode="joint").run(
+        datasets, components=comp, calibrations=cals
+    )
+    cal_values = np.array([[d["shift_x"], d["shift_y"], d["background_norm"], d["psf_scale"]]
+                           for d in (res.calibrations[name].to_dict() for name in datasets)])
+    return res, cal_values, c, datasets
+
+
+def _worker_calibrated(rank, world_size, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
+                      LOCAL_RANK=str(rank), JOLIDECO_DIST_BACKEND="gloo", JOLIDECO_DIST_OVERLAP="1")
+    from jolideco_amd.distributed import init_from_env
+
+    ctx = init_from_env()
+    assert ctx.world_size == world_size and ctx.rank == rank
+    res, cal_values, _, _ = _calibrated_joint_fit()
+    np.savez(Path(out_dir) / f"rank{rank}.npz", flux=res.flux_total, cal=cal_values,
+             **{f"trace/{n}": np.asarray(res.trace_loss[n]) for n in res.trace_loss.colnames if n != "filename"})
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_calibrated_joint_fit(tmp_path):
+    """NPredCalibrations in a SHARDED joint fit (both reference examples calibrate every observation,
+    examples/fermi-vela-junior.py:193-203; model: jolideco/models/npred.py:298-402, optimizer: core.py:197-204): a
+    dataset's calibration -- parameters, gradients, its Adam state -- lives on the rank that owns the dataset; the
+    values are gathered for the result.  Both ranks end with identical fluxes AND identical calibrations; they agree
+    with the single-process fit to rounding (the prior's bands are added in another order) and with the oracle's
+    joint harness (one Adam over fluxes and calibration parameters) within the north-star tolerance."""
+    from conftest import rel_linf
+    from oracle import cpu_ref
+
+    mp.spawn(_worker_calibrated, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = dict(np.load(tmp_path / "rank0.npz")), dict(np.load(tmp_path / "rank1.npz"))
+    assert np.array_equal(r0["flux"], r1["flux"]) and np.array_equal(r0["cal"], r1["cal"])
+    res, cal_single, c, datasets = _calibrated_joint_fit()
+    assert rel_linf(r0["flux"], res.flux_total) < 2e-6
+    np.testing.assert_allclose(r0["cal"], cal_single, rtol=1e-5, atol=1e-6)
+    for name in res.trace_loss.colnames:
+        if name != "filename":
+            np.testing.assert_allclose(r0[f"trace/{name}"], np.asarray(res.trace_loss[name]), rtol=2e-5, atol=1e-6, err_msg=name)
+    # the oracle: jolideco's pieces in the joint harness, calibration parameters in the same optimizer
+    gmm_o = cpu_ref.GMM.from_numpy(c["u1/gmm_means"], c["u1/gmm_covariances"], c["u1/gmm_weights"], stride=4)
+    cals_o = {}
+    for name in datasets:
+        sx, sy, norm, psf_scale, frozen = c[f"u1/cal_init/{name}"]
+        cals_o[name] = cpu_ref.CalibrationRef.create(sx, sy, norm, psf_scale, bool(frozen))
+    final_o, trace_o = cpu_ref.map_fit_joint(datasets, {"flux": c["u1/flux_init"]}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o)},
+                                             n_epochs=8, calibrations=cals_o, upsampling_factors={"flux": 1})
+    err = rel_linf(r0["flux"], final_o["flux"])
+    print("2-rank calibrated joint fit vs oracle: rel Linf", err)
+    assert err < 1e-5
+    for i, name in enumerate(datasets):
+        d = cals_o[name].to_dict()
+        want = np.array([d["shift_x"], d["shift_y"], d["background_norm"], d["psf_scale"]])
+        np.testing.assert_allclose(r0["cal"][i], want, rtol=2e-4, atol=2e-5, err_msg=name)
+    assert r0["cal"][1][0] == 0.0  # the zero shift of o1 never moves (utils/torch.py:211)
+    np.testing.assert_allclose(r0["trace/total"], [row["total"] for row in trace_o], rtol=2e-5)
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("overlap", ["1", "0"])
 def test_two_rank_joint_fit_matches_the_single_process_reference(tmp_path, golden, overlap):
