@@ -395,6 +395,24 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
       if ((rc = launch_shift_fwd(flux[0], p->shifted[0], p->H, p->W, cal.shift_xy, cal.shift_scale, s))) return rc;
       in = p->shifted[0];
     }
+    if (p->method == JD_CONV_SEPARABLE && grad_flux && !npred_out) {
+      // forward model, Poisson pass and adjoint in one launch where the strip-walk kernels apply
+      SepBatchTable one{};
+      one.scale[0] = exposure[0], one.op[0] = khat[0], one.bkg[0] = background, one.cnt[0] = counts;
+      float* target = cal.shift_xy ? p->gshift[0] : grad_flux[0];
+      rc = walk_joint_step(1, in, one, nullptr, target, p->H, p->W, p->kh, p->kw, p->oy, p->ox, p->partials, eps,
+                           (float)(1.0 / n_pix), grad_scale, cal.shift_xy ? 0 : accumulate, &n_partials, s);
+      if (rc != JD_WALK_NOT_TAKEN) {
+        if (rc) return rc;
+        if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s))) return rc;
+        if (!cal.shift_xy) return JD_OK;
+        int n_blocks = 0;
+        if ((rc = launch_shift_bwd(flux[0], p->gshift[0], grad_flux[0], accumulate, p->H, p->W, cal.shift_xy, cal.shift_scale,
+                                   p->partials_cal, &n_blocks, s)))
+          return rc;
+        return cal.grad_shift_xy ? launch_finalize_multi(p->partials_cal, n_blocks, 2, 1.0, cal.grad_shift_xy, 0, s) : JD_OK;
+      }
+    }
     rc = p->method == JD_CONV_SEPARABLE
              ? launch_sep_conv_poisson(in, exposure[0], khat[0], p->pad[0], p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                                        background, counts, npred_out, p->partials, eps, (float)(1.0 / n_pix),
@@ -543,6 +561,13 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
   SepBatchTable* const table_dev = p->table_dev[slot];
   const double n_pix = (double)p->H * (double)p->W;
   int n_part = 0;  // partial sums per dataset the forward launch wrote (<= tiles)
+  if (n_comp == 1 && grad_flux) {
+    // one launch for the whole likelihood step where the strip-walk kernels apply (the g images are never written)
+    int rc = walk_joint_step(n_datasets, flux[0], table, table_dev, grad_flux[0], p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                             p->partials_batch, eps, (float)(1.0 / n_pix), grad_scale, accumulate, &n_part, s);
+    if (rc != JD_WALK_NOT_TAKEN)
+      return rc ? rc : launch_finalize_rows(p->partials_batch, n_part, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s);
+  }
   int rc = launch_sep_conv_poisson_batch(n_datasets, n_comp, flux, table, table_dev, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                                          p->partials_batch, eps, (float)(1.0 / n_pix), grad_flux ? 1 : 0, &n_part, s);
   if (rc) return rc;

@@ -65,7 +65,7 @@ enum JdOption {
   OPT_SEP_WALK_COLS, OPT_SEP_WALK_ROWS, OPT_SEP_WALK_ADJ_COLS, OPT_SEP_WALK_ADJ_ROWS, OPT_DIRECT_FP32,
   OPT_CONV_BLOCKS_PER_CU, OPT_POISSON_ROWS, OPT_GMM_NO_HOST_STATS, OPT_GMM_BLOCK_TILES, OPT_GMM_DENSE, OPT_GMM_KSPLIT,
   OPT_GMM_SCREEN_NP, OPT_GMM_SCREEN_NO_LDS_CONSTS, OPT_GMM_SCREEN_DEBUG, OPT_GMM_SCREEN, OPT_GMM_FUSED_BWD,
-  OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_COUNT
+  OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_SEP_JOINT, OPT_SEP_JOINT_ROWS, OPT_SEP_JOINT_CHUNK, OPT_COUNT
 };
 bool opt_is_set(int id);
 int opt_value(int id, int unset_value);
@@ -141,6 +141,10 @@ int walk_conv_poisson(const float* in, const float* in_scale, const float* op, f
 int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev, int H,
                             int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
                             int write_grad, int* n_partials, hipStream_t stream);
+// forward models + Poisson passes + adjoints + the sum over the datasets of a joint step in one launch (per 8 datasets)
+int walk_joint_step(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H,
+                    int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n, float coef,
+                    int accumulate, int* n_partials, hipStream_t stream);
 int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H, int W,
                             int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream,
                             const double* fin_partials, double fin_scale, int fin_count, int* fin_done);

@@ -332,6 +332,278 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The whole likelihood step of a joint fit in ONE launch: forward model, Poisson pass, adjoint convolution and the sum
+// over the datasets.  A wave walks its strip once and carries TWO convolutions: the forward one (input row r -> output
+// row r - 8) feeds the Poisson pass, whose g row goes -- through a second LDS row -- straight into the adjoint one
+// (g row r - 8 -> gradient row r - 16).  The g images (4 B written + 4 B read per pixel and dataset) never exist and the
+// exposure is fetched from HBM once (its second use, 16 rows later, is an L2 hit): 13 B per (pixel, dataset) from HBM
+// instead of 29.  The adjoint needs g in an 8-pixel halo around its outputs, so a strip of 64 C forward columns yields
+// 64 C - 16 gradient columns and a tile of R gradient rows walks R + 32 input rows; the redundant forward work in the
+// halo is the price.  Same arithmetic in the same order as the two-launch path (walk_kernel forward + adjoint), so the
+// gradient is the same bit for bit; the loss is summed over other tiles (equal to rounding).
+// XG = 0: one dataset per launch (single wave per block, no exchange).
+struct JointArgs {
+  const float* flux;
+  // one dataset (n_batch == 0)
+  const float* exposure;
+  const float* op;
+  const float* background;
+  const float* counts;
+  float* grad;          // (+)= coef * sum_d E_d corr(g_d)
+  double* partials;     // [dataset][tile] sums of n - c log(n + eps) over the tile's own pixels
+  int H, W, strips, tiles_y, rows;
+  int taps_u, taps_v, kh, kw, offy, offx;  // FORWARD taps in the 17-tap frame (the adjoint uses them reversed)
+  float coef;
+  int accumulate;
+  float eps, inv_n;
+  int n_batch, d_base;
+  const SepBatchTable* table;
+  int* guard;
+};
+
+template <int C, int P, int XG>
+__global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs a) {
+#pragma clang fp contract(off)
+  typedef typename Vec<C>::T vC;
+  constexpr bool XCHG = XG > 0;
+  static_assert(!XCHG || (WS % XG == 0 && XG <= XG_MAX), "the exchange group must divide the rotation period");
+  static_assert(WS % P == 0, "prefetch depth must divide the rotation period");
+  constexpr int NX = 2 * WH / C;
+  constexpr int NWIN = 2 * WH + C;
+  constexpr int SW = 64 * C - 2 * WH;  // gradient columns per strip
+  __shared__ __attribute__((aligned(16))) float rowbuf[XCHG ? XW : 1][2 * 64 * C];
+  __shared__ __attribute__((aligned(16))) float gbuf[XCHG ? XW : 1][64 * C + 2 * WH];
+  __shared__ __attribute__((aligned(16))) float xbuf[XCHG ? 2 * XG * XW * 64 * C : 4];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = XCHG ? (int)(threadIdx.x >> 6) : 0;
+  const int nb = XCHG ? (int)(blockDim.x >> 6) : 1;
+  const int n_tiles = a.strips * a.tiles_y;
+  const int per_xcd = (n_tiles + 7) / 8;
+  const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= per_xcd || tile >= n_tiles) return;  // (block-uniform)
+  const int sx = tile / a.tiles_y, ty = tile - sx * a.tiles_y;
+
+  typedef const float __attribute__((address_space(1)))* gcp;
+  typedef float __attribute__((address_space(1)))* gp;
+  typedef const vC __attribute__((address_space(1)))* gcv;
+  typedef vC __attribute__((address_space(1)))* gv;
+  const bool batch = a.n_batch > 0;
+  const int d = a.d_base + wv;
+  const gcp flux = (gcp)a.flux;
+  const gcp expo = (gcp)(batch ? a.table->scale[d] : a.exposure);
+  const gcp op = (gcp)(batch ? a.table->op[d] : a.op);
+  const gcp background = (gcp)(batch ? a.table->bkg[d] : a.background);
+  const gcp counts = (gcp)(batch ? a.table->cnt[d] : a.counts);
+  const gp out = (gp)a.grad;
+
+  float tu[WK], tv[WK];
+  {
+    if ((int)op[0] != 1 && lane == 0) *a.guard = 1;
+    float mu = 0.f, mv = 0.f;
+    const int iu = lane - a.offy, iv = lane - a.offx;
+    if (iu >= 0 && iu < a.kh) mu = op[a.taps_u + iu];
+    if (iv >= 0 && iv < a.kw) mv = op[a.taps_v + iv];
+#pragma unroll
+    for (int t = 0; t < WK; ++t) {
+      tu[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), t));
+      tv[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mv), t));
+    }
+  }
+
+  const int X0 = sx * SW - WH;                 // first FORWARD-output column of the strip
+  const int xm = X0 - WH + C * lane;           // the lane's piece of the product window
+  const int xe = X0 - WH + 64 * C + C * lane;  // right-hand halo piece (lanes < NX)
+  const int xo = X0 + C * lane;                // the lane's forward-output (g) columns = its gradient columns if inner
+  const bool vm = xm >= 0 && xm < a.W, ve = lane < NX && xe >= 0 && xe < a.W, vg = xo >= 0 && xo < a.W;
+  const bool inner = C * lane >= WH && C * lane < 64 * C - WH;
+  const bool vo = inner && vg;
+  const int xd = X0 - WH + 64 * C + C * (lane % NX);
+  const unsigned om = vm ? xm : 0, oe = ve ? xe : (xd >= 0 && xd < a.W ? xd : 0), oo = vg ? xo : 0;
+  const int Y0 = ty * a.rows, y_end = min(Y0 + a.rows, a.H);
+  const int r_begin = Y0 - 2 * WH, r_end = min(y_end + 2 * WH, a.H);
+  const int g_lo = max(Y0 - WH, 0), g_hi = min(y_end + WH, a.H);  // g rows this tile needs that exist
+  float* rb = rowbuf[wv];
+  float* gb = gbuf[wv];
+
+  struct Row { vC a, s, xa, xs; };
+  struct EpiF { vC b, c; };
+  auto row_ok = [&](int rr) { return rr >= 0 && rr < r_end; };
+  auto load_row = [&](int rr, Row& w) {
+    const size_t base = (size_t)min(max(rr, 0), r_end - 1) * a.W;
+    w.a = *(gcv)(flux + base + om);
+    w.s = *(gcv)(expo + base + om);
+    w.xa = *(gcv)(flux + base + oe);
+    w.xs = *(gcv)(expo + base + oe);
+  };
+  auto load_epf = [&](int y, EpiF& e) {
+    const size_t base = (size_t)min(max(y, g_lo), g_hi - 1) * a.W;
+    e.b = *(gcv)(background + base + oo);
+    e.c = *(gcv)(counts + base + oo);
+  };
+  struct EpiA { vC e, o; };  // exposure and (one dataset per launch, accumulate) the previous gradient of a gradient row
+  auto load_epa = [&](int y, EpiA& e) {
+    const size_t base = (size_t)min(max(y, Y0), y_end - 1) * a.W;
+    e.e = *(gcv)(expo + base + oo);
+    if (!XCHG && a.accumulate) e.o = *(gcv)(out + base + oo);
+  };
+
+  vC accF[WS], accA[WS];
+#pragma unroll
+  for (int s = 0; s < WS; ++s)
+#pragma unroll
+    for (int c = 0; c < C; ++c) accF[s][c] = 0.f, accA[s][c] = 0.f;
+  Row pf[P];
+  EpiF epf[P];
+  EpiA epa[P];
+  vC oprev;
+  double loss = 0.0;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    load_row(r_begin + p, pf[p]);
+    load_epf(r_begin + p - WH, epf[p]);
+    load_epa(r_begin + p - 2 * WH, epa[p]);
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) oprev[c] = 0.f;
+
+  for (int r0 = r_begin; r0 < y_end + 2 * WH + (XCHG ? XG - 1 : 0); r0 += WS) {
+#pragma unroll
+    for (int i = 0; i < WS; ++i) {
+      const int rr = r0 + i;
+      Row& cur = pf[i % P];
+      EpiF& cf = epf[i % P];
+      EpiA& ca = epa[i % P];
+      // ---- forward convolution: input row rr ------------------------------------------------------------------
+      const bool live = row_ok(rr);
+      if (live) {
+        vC prod = cur.a * cur.s;
+#pragma unroll
+        for (int c = 0; c < C; ++c) prod[c] = vm ? prod[c] : 0.f;
+        *reinterpret_cast<vC*>(rb + C * lane) = prod;
+        vC px = cur.xa * cur.xs;
+#pragma unroll
+        for (int c = 0; c < C; ++c) px[c] = ve ? px[c] : 0.f;
+        *reinterpret_cast<vC*>(rb + 64 * C + C * lane) = px;
+      }
+      load_row(rr + P, cur);
+      if (live) {
+        wave_lds_fence();
+        float w[NWIN];
+#pragma unroll
+        for (int k = 0; k < NWIN / C; ++k) {
+          const vC t = *reinterpret_cast<const vC*>(rb + C * lane + C * k);
+#pragma unroll
+          for (int c = 0; c < C; ++c) w[C * k + c] = t[c];
+        }
+        wave_lds_fence();
+        float h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = tv[0] * w[c];
+#pragma unroll
+        for (int t = 1; t < WK; ++t)
+#pragma unroll
+          for (int c = 0; c < C; ++c) h[c] = fmaf(tv[t], w[c + t], h[c]);
+#pragma unroll
+        for (int t = 0; t < WK; ++t) {
+          const int s = (i + WH - t + WS) % WS;
+#pragma unroll
+          for (int c = 0; c < C; ++c) accF[s][c] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], accF[s][c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) accF[(i + WH) % WS][c] = 0.f;
+      }
+
+      // ---- Poisson pass on forward-output row y1 = rr - 8; g is zero outside the image --------------------------
+      const int y1 = rr - WH;
+      const bool grow = y1 >= g_lo && y1 < g_hi;  // (rows above g_lo only feed gradient rows this tile does not own)
+      if (grow) {
+        const vC conv = accF[(i + WS - WH) % WS];
+        vC gvec;
+        float rowsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float n = fmaxf(conv[c], 0.f) + cf.b[c];
+          float term, g;
+          poisson_point(n, cf.c[c], a.eps, a.inv_n, term, g);
+          rowsum += term;
+          gvec[c] = vg && conv[c] >= 0.f ? g : 0.f;
+        }
+        if (vo && y1 >= Y0 && y1 < y_end) loss += (double)rowsum;
+        *reinterpret_cast<vC*>(gb + WH + C * lane) = gvec;
+      }
+      load_epf(y1 + P, cf);
+      // ---- adjoint convolution: g row y1 -> gradient rows y1 - 8 .. y1 + 8 (taps reversed) -----------------------
+      if (grow) {
+        wave_lds_fence();
+        float w[NWIN];
+#pragma unroll
+        for (int k = 0; k < NWIN / C; ++k) {
+          const vC t = *reinterpret_cast<const vC*>(gb + C * lane + C * k);
+#pragma unroll
+          for (int c = 0; c < C; ++c) w[C * k + c] = t[c];
+        }
+        wave_lds_fence();
+        float h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = tv[WK - 1] * w[c];
+#pragma unroll
+        for (int t = 1; t < WK; ++t)
+#pragma unroll
+          for (int c = 0; c < C; ++c) h[c] = fmaf(tv[WK - 1 - t], w[c + t], h[c]);
+#pragma unroll
+        for (int t = 0; t < WK; ++t) {
+          const int s = (i - t + WS) % WS;
+#pragma unroll
+          for (int c = 0; c < C; ++c) accA[s][c] = t == 0 ? tu[WK - 1] * h[c] : fmaf(tu[WK - 1 - t], h[c], accA[s][c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) accA[i % WS][c] = 0.f;
+      }
+
+      // ---- gradient row y2 = rr - 16 is complete --------------------------------------------------------------
+      const int y2 = rr - 2 * WH;
+      if (y2 >= Y0 && y2 < y_end) {
+        const vC corr = accA[(i + WS - 2 * WH) % WS];
+        vC pv;
+#pragma unroll
+        for (int c = 0; c < C; ++c) pv[c] = (a.coef * corr[c]) * ca.e[c];
+        if constexpr (!XCHG) {
+          if (a.accumulate) pv = ca.o + pv;
+          if (vo) *(gv)(out + (size_t)y2 * a.W + oo) = pv;
+        } else {
+          const int k = (y2 - Y0) / XG, gy = (i + 2 * WS - 4 * WH) % XG;
+          *reinterpret_cast<vC*>(xbuf + (size_t)((((k & 1) * XG + gy) * XW + wv) * 64 + lane) * C) = pv;
+        }
+      }
+      if constexpr (XCHG) {
+        const int gy = (i + 2 * WS - 4 * WH) % XG;  // (y2 - Y0 = i - 32 mod 18: tiles start on a group boundary, static)
+        const int mine = wv < XG ? wv : XG - 1;
+        if (gy == 0) {
+          const int yy = min(max(y2 + mine, Y0), y_end - 1);
+          oprev = *(gcv)(out + (size_t)yy * a.W + oo);
+        }
+        if (gy == XG - 1 && y2 - gy >= Y0 && y2 - gy < y_end) {  // (block-uniform) the group is complete
+          __syncthreads();
+          const int k = (y2 - Y0) / XG, yy = y2 - gy + mine;
+          vC res = oprev;
+          for (int dd = 0; dd < nb; ++dd) {
+            const vC pd = *reinterpret_cast<const vC*>(xbuf + (size_t)((((k & 1) * XG + mine) * XW + dd) * 64 + lane) * C);
+            res = dd == 0 && !(a.accumulate || a.d_base > 0) ? pd : res + pd;
+          }
+          if (vo && wv < XG && yy < y_end) *(gv)(out + (size_t)yy * a.W + oo) = res;
+        }
+      }
+      load_epa(y2 + P, ca);
+    }
+  }
+  loss = wave_sum(loss);
+  if (lane == 0) a.partials[(size_t)d * n_tiles + tile] = loss;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Does the walk kernel take a launch over n datasets of (H, W) pixels with this PSF geometry?  Option JD_SEP_WALK: 0
@@ -497,29 +769,34 @@ int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTab
   WalkArgs a{};
   a.out = grad, a.H = H, a.W = W, a.coef = coef, a.table = table_dev;
   if (!walk_setup(a, n, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
-  // rows per tile: a multiple of every exchange group size, the smallest that leaves all blocks resident at once with a
-  // margin (measured at 2048^2 x 8, 2 blocks of 8 waves per CU: rows 36 / 54 / 72 / 90 / 108 = 102 / 101 / 83 / 95 / 107 us:
-  // 54 rows need a second, nearly empty round of blocks)
-  const int m0 = n < XW ? n : XW;
-  const int xg = m0 >= 6 ? 6 : m0 >= 3 ? 3 : 2;
-  const int lds = (2 * xg * XW * 128 + XW * 256) * 4;  // exchange buffer + row buffers (C = 2)
-  int per_cu = 160 * 1024 / lds;
-  if (per_cu > 20 / m0) per_cu = 20 / m0;  // (86 registers: 5 waves per SIMD)
-  if (per_cu < 1) per_cu = 1;
-  const long slots = (long)device_cus() * per_cu * 15 / 16;
-  const int strips = (W + 127) / 128;
-  int rows = 36;
-  while (rows < 4096 && (long)strips * ((H + rows - 1) / rows) > slots) rows += 18;
-  const int orows = opt_value(OPT_SEP_WALK_ADJ_ROWS, 0);
-  if (orows >= 18) rows = orows;
-  rows = (rows + 5) / 6 * 6;
-  walk_tiles(a, 2, rows);
+  // Block shape.  6-8 datasets: 4 columns per lane (1 KB per row and stream), exchange groups of 6 rows: 112 KB of LDS, ONE
+  // block of 6-8 waves per CU; fewer datasets: 2 columns per lane, as many blocks per CU as LDS (exchange buffer) and
+  // registers (86: 5 waves per SIMD) allow.  Rows per tile: a multiple of every exchange group size, the smallest that
+  // leaves all blocks resident at once.  Measured inside the fit at 2048^2 x 8 (tools/ab.py): C = 4, rows 36 / 66 / 72 /
+  // 84 = 98 / 77.5 / 85 / 89 us (66 rows: 8 strips x 32 tiles = one block for every CU); C = 2 (two blocks per CU), rows
+  // 54 / 72 / 90 = 111 / 85 / 97 us.
   int rc = sep_guard_check(&a.guard);
   if (rc) return rc;
-  const int n_tiles = a.strips * a.tiles_y;
-  const unsigned blocks = (unsigned)(((n_tiles + 7) / 8) * 8);
   for (int d0 = 0; d0 < n; d0 += XW) {
-    const int m = n - d0 < XW ? n - d0 : XW;
+    const int m = n - d0 < XW ? n - d0 : XW;  // datasets (= waves) of this launch: its block shape follows from it
+    const int xg = m >= 6 ? 6 : m >= 3 ? 3 : 2;
+    const bool wide = m >= 6 && opt_value(OPT_SEP_WALK_ADJ_COLS, 4) != 2;
+    const int C = wide ? 4 : 2;
+    const int lds = (2 * xg * XW * 64 * C + XW * 128 * C) * 4;  // exchange buffer + row buffers
+    int per_cu = 160 * 1024 / lds;
+    const int by_regs = (wide ? 12 : 20) / m;  // (136 registers at C = 4: 3 waves per SIMD; 86 at C = 2: 5)
+    if (per_cu > by_regs) per_cu = by_regs;
+    if (per_cu < 1) per_cu = 1;
+    const long slots = (long)device_cus() * per_cu * (per_cu > 1 ? 15 : 16) / 16;
+    const int strips = (W + 64 * C - 1) / (64 * C);
+    int rows = 36;
+    while (rows < 4096 && (long)strips * ((H + rows - 1) / rows) > slots) rows += 6;
+    const int orows = opt_value(OPT_SEP_WALK_ADJ_ROWS, 0);
+    if (orows >= 18) rows = orows;
+    rows = (rows + 5) / 6 * 6;
+    walk_tiles(a, C, rows);
+    const int n_tiles = a.strips * a.tiles_y;
+    const unsigned blocks = (unsigned)(((n_tiles + 7) / 8) * 8);
     a.d_base = d0, a.n_batch = m, a.accumulate = d0 == 0 ? accumulate : 1;
     a.fin_partials = nullptr;
     if (d0 == 0 && fin_partials && m >= 4 && (int)blocks >= n) {  // (the fold needs 256 threads and a block per dataset)
@@ -527,7 +804,9 @@ int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTab
       *fin_done = 1;
     }
     ProfScope prof(JD_KERNEL_SEP_CONV, stream);
-    if (m >= 6)
+    if (m >= 6 && wide)
+      hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (m >= 6)
       hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m >= 3)
       hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
@@ -545,6 +824,75 @@ int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTab
       else
         hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
     }
+    JD_LAUNCH_CHECK();
+  }
+  return JD_OK;
+}
+
+// The likelihood step of n datasets (one flux component) in one launch per 8 datasets: loss partial sums (*n_partials per
+// dataset) and grad (+)= coef * sum_d E_d corr(g_d).  JD_WALK_NOT_TAKEN when the fused kernel is not eligible or not the
+// faster choice (option JD_SEP_JOINT: 0 never, 1 whenever eligible).
+int walk_joint_step(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H,
+                    int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n, float coef,
+                    int accumulate, int* n_partials, hipStream_t stream) {
+  // Measured inside the fit (tools/ab.py, 2048^2 x 8): 201-205 us against 125 + 77.5 us for the forward and the adjoint
+  // launch -- the kernel saves 45 % of the HBM traffic but issues 40 % more instructions (halo, two columns per lane), and
+  // with its 150 registers only two waves per SIMD hide each other's latencies; 4 datasets: 134 against 63 + 49 us.  So it
+  // runs only on request (option JD_SEP_JOINT = 1); its results are those of the two-launch path bit for bit.
+  const int mode = opt_value(OPT_SEP_JOINT, 0);
+  if (mode != 1 || !aligned16(flux) || !aligned16(grad)) return JD_WALK_NOT_TAKEN;
+  for (int d = 0; d < n; ++d)
+    if (!dataset_walkable(table, d, d)) return JD_WALK_NOT_TAKEN;
+  if (!table_dev && n != 1) return JD_WALK_NOT_TAKEN;  // (without a device table: one dataset, pointers by value)
+  JointArgs a{};
+  a.flux = flux, a.grad = grad, a.partials = partials, a.H = H, a.W = W, a.coef = coef, a.eps = eps, a.inv_n = inv_n;
+  int offy_adj, offx_adj;
+  if (!walk_geometry(H, W, n, kh, kw, oy, ox, 0, &a.offy, &a.offx) || !walk_geometry(H, W, n, kh, kw, oy, ox, 1, &offy_adj, &offx_adj))
+    return JD_WALK_NOT_TAKEN;
+  const SepGeom g = sep_geom(kh, kw, oy, ox, false);
+  a.kh = kh, a.kw = kw, a.taps_u = 4, a.taps_v = 4 + g.khp + g.shiftx;
+  constexpr int C = 2;
+  a.strips = (W + (64 * C - 2 * WH) - 1) / (64 * C - 2 * WH);
+  // datasets per block (= waves; option JD_SEP_JOINT_CHUNK): two launches of 4 were measured slower than one of 8
+  // (2 x 134 against 201 us)
+  int chunk = opt_value(OPT_SEP_JOINT_CHUNK, 0);
+  if (chunk < 1 || chunk > XW) chunk = n < XW ? n : XW;
+  const int m0 = n < chunk ? n : chunk;
+  // rows per tile (a multiple of 6): all blocks resident at once
+  int per_cu = 12 / m0;
+  const int xg = m0 >= 6 ? 6 : m0 >= 3 ? 3 : m0 >= 2 ? 2 : 0;
+  if (xg) {
+    const int lds = (2 * xg * XW * 64 * C + XW * (2 * 64 * C + 64 * C + 2 * WH)) * 4;
+    if (per_cu > 160 * 1024 / lds) per_cu = 160 * 1024 / lds;
+  }
+  long slots = (long)device_cus() * per_cu;
+  if (m0 == 1) slots = slots * 7 / 12;  // single waves: ~7 per CU (see walk_shape)
+  else slots = slots * 31 / 32;
+  int rows = 36;
+  while (rows < 8192 && (long)a.strips * ((H + rows - 1) / rows) > slots) rows += 6;
+  const int orows = opt_value(OPT_SEP_JOINT_ROWS, 0);
+  if (orows >= 18) rows = (orows + 5) / 6 * 6;
+  a.rows = rows, a.tiles_y = (H + rows - 1) / rows;
+  int rc = sep_guard_check(&a.guard);
+  if (rc) return rc;
+  const int n_tiles = a.strips * a.tiles_y;
+  *n_partials = n_tiles;
+  const unsigned blocks = (unsigned)(((n_tiles + 7) / 8) * 8);
+  for (int d0 = 0; d0 < n; d0 += chunk) {
+    const int m = n - d0 < chunk ? n - d0 : chunk;
+    a.d_base = d0, a.n_batch = m, a.table = table_dev, a.accumulate = d0 == 0 ? accumulate : 1;
+    if (!table_dev) {
+      a.n_batch = 0, a.exposure = table.scale[0], a.op = table.op[0], a.background = table.bkg[0], a.counts = table.cnt[0];
+    }
+    ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
+    if (m >= 6)
+      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (m >= 3)
+      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (m == 2)
+      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else
+      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 0>), dim3(blocks), dim3(64), 0, stream, a);
     JD_LAUNCH_CHECK();
   }
   return JD_OK;

@@ -1001,3 +1001,50 @@ def test_an_operator_buffer_overwritten_behind_the_library_is_reported(jd_option
     ref = plan.conv_same(image, None, k2).cpu().numpy()
     assert np.array_equal(got, ref) and np.isfinite(ok.cpu().numpy()).all()
     plan.close()
+
+
+@pytest.mark.parametrize("shape,kshape,n_obs", [((100, 260), (17, 17), 8), ((130, 300), (17, 8), 3), ((64, 128), (9, 13), 2),
+                                                ((96, 256), (5, 5), 1), ((200, 512), (16, 17), 11)],
+                         ids=["8obs", "3obs", "2obs", "1obs", "11obs"])
+def test_fused_likelihood_step_equals_the_two_launch_path_bit_for_bit(jd_option, shape, kshape, n_obs):
+    """Option JD_SEP_JOINT = 1: forward model, Poisson pass, adjoint convolution and the sum over the datasets in ONE
+    launch (walk_joint_kernel: the g images are never written).  Same arithmetic in the same order as the strip-walk
+    forward + adjoint launches: the gradient of the joint step is the same bit for bit (batched and per dataset), the
+    losses are summed over other tiles and agree to rounding."""
+    from jolideco_amd.data import gaussian_kernel
+    from jolideco_amd.ops import ConvPlan, stirling_mean
+
+    H, W = shape
+    rs = np.random.RandomState(H + W + n_obs)
+    flux = torch.from_numpy(rs.gamma(5.0, size=shape).astype(np.float32)).to(DEV)
+    plan = ConvPlan(H, W, kshape[0], kshape[1], DEV, method="separable")
+    data = []
+    for i in range(n_obs):
+        psf = torch.from_numpy(gaussian_kernel(1.2 + 0.3 * i, kshape).astype(np.float32)).to(DEV)
+        exposure = (1.0 + 0.1 * i) * (1.0 + 0.4 * np.linspace(-1, 1, H)[:, None] * np.ones(shape))
+        counts = rs.poisson(5.0, size=shape).astype(np.float32)
+        data.append((plan.psf_spectrum(psf), torch.from_numpy(exposure.astype(np.float32)).to(DEV),
+                     torch.full(shape, 0.5 + 0.1 * i, device=DEV), torch.from_numpy(counts).to(DEV), stirling_mean(counts)))
+
+    def step(batch):
+        losses = [torch.zeros(1, device=DEV) for _ in range(n_obs)]
+        grad = torch.full(shape, 0.25, device=DEV)  # accumulate into a non-zero image
+        if batch:
+            plan.npred_poisson_batch_fwd_bwd(flux, [d[1] for d in data], [d[0] for d in data], [d[2] for d in data],
+                                             [d[3] for d in data], [d[4] for d in data], losses, grad=grad, accumulate=True)
+        else:
+            for i, d in enumerate(data):
+                plan.npred_poisson_fwd_bwd([flux], [d[1]], [d[0]], d[2], d[3], d[4], losses[i], grads=[grad], accumulate=True)
+        torch.cuda.synchronize()
+        return grad.cpu().numpy(), np.array([float(v) for v in losses])
+
+    jd_option("JD_SEP_WALK", 1)
+    jd_option("JD_SEP_JOINT", 0)
+    ref_grad, ref_loss = step(batch=True)
+    jd_option("JD_SEP_JOINT", 1)
+    for batch in (True, False):
+        grad, loss = step(batch)
+        assert np.array_equal(grad, ref_grad), f"batch={batch}"
+        np.testing.assert_allclose(loss, ref_loss, rtol=1e-6)
+    assert np.abs(ref_grad - 0.25).max() > 0
+    plan.close()

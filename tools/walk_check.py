@@ -86,8 +86,18 @@ def check():
         res = {}
         for walk in (0, 1):
             for batch in (True, False):
-                with _hip.options(JD_SEP_WALK=walk):
+                with _hip.options(JD_SEP_WALK=walk, JD_SEP_JOINT=0):
                     res[walk, batch] = run_step(plan, fdev, khats, data_dev, stirlings, batch)
+        # the fused likelihood step (forward + Poisson + adjoint + dataset sum in one launch): same gradient bits as
+        # the walk kernels' two launches, batched and per dataset; losses equal to rounding
+        for batch in (True, False):
+            with _hip.options(JD_SEP_WALK=1, JD_SEP_JOINT=1):
+                fused = run_step(plan, fdev, khats, data_dev, stirlings, batch)
+            okf = np.array_equal(fused[1], res[1, True][1]) and np.allclose(fused[0], res[1, True][0], rtol=1e-6, atol=0)
+            bad += not okf
+            print(f"{H}x{W} psf {kshape} n={n}: fused step ({'batch' if batch else 'loop'}) == walk kernels: gradient "
+                  f"{np.array_equal(fused[1], res[1, True][1])}, max |grad diff| {np.abs(fused[1] - res[1, True][1]).max():.1e}, "
+                  f"loss rel {np.abs(fused[0] / res[1, True][0] - 1).max():.1e} {'ok' if okf else 'BAD'}")
         same = np.array_equal(res[1, True][1], res[1, False][1])
         same_old = np.array_equal(res[0, True][1], res[0, False][1])
         eg = np.abs(res[1, True][1] - res[0, True][1]).max() / np.abs(res[0, True][1]).max()
@@ -127,7 +137,7 @@ def flush_caches():
     FLUSH.add_(1.0)
 
 
-def bench(only=None, rows_list=(38, 56, 74, 128), cold=False):
+def bench(only=None, rows_list=(38, 56, 74, 128), cold=False, joint_rows=()):
     for name, (H, W, n) in {"c3": (2048, 2048, 8), "c4": (4096, 4096, 1), "c2": (1024, 1024, 1), "seq": (2048, 2048, 1),
                             "r4": (2048, 2048, 4), "r2": (2048, 2048, 2)}.items():
         if only and name not in only:
@@ -152,11 +162,13 @@ def bench(only=None, rows_list=(38, 56, 74, 128), cold=False):
                 plan.npred_poisson_fwd_bwd([fdev], [data_dev[0][1]], [khats[0]], data_dev[0][2], data_dev[0][3], stirlings[0],
                                            losses[0], grads=[grad], accumulate=False)
 
-        variants = [dict(JD_SEP_WALK=0)]
-        for cols in (2, 4):
+        variants = [dict(JD_SEP_WALK=0, JD_SEP_JOINT=0), dict(JD_SEP_WALK=1, JD_SEP_JOINT=0)]
+        for rows in joint_rows:
+            variants.append(dict(JD_SEP_WALK=1, JD_SEP_JOINT=1, JD_SEP_JOINT_ROWS=rows))
+        for cols in (() if joint_rows else (2, 4)):
             for rows in rows_list:
-                variants.append(dict(JD_SEP_WALK=1, JD_SEP_WALK_COLS=cols, JD_SEP_WALK_ROWS=rows, JD_SEP_WALK_ADJ_COLS=cols,
-                                     JD_SEP_WALK_ADJ_ROWS=rows))
+                variants.append(dict(JD_SEP_WALK=1, JD_SEP_JOINT=0, JD_SEP_WALK_COLS=cols, JD_SEP_WALK_ROWS=rows,
+                                     JD_SEP_WALK_ADJ_COLS=cols, JD_SEP_WALK_ADJ_ROWS=rows))
         for v in variants:
             with _hip.options(**v):
                 for _ in range(3):
@@ -166,7 +178,7 @@ def bench(only=None, rows_list=(38, 56, 74, 128), cold=False):
                 t = timed(step, n=20, warm=0)
                 prof = _hip.profile_read()
             fw = prof["poisson_fused"][0] / max(prof["poisson_fused"][1], 1) * 1e3
-            ad = prof["sep_conv"][0] / max(prof["sep_conv"][1], 1) * 1e3
+            ad = prof["sep_conv"][0] / max(prof["sep_conv"][1], 1) * 1e3 or float("nan")  # (fused step: no adjoint launch)
             fb, ab = 20 * H * W * n, (8 * n + 8) * H * W
             print(f"{name}{' cold' if cold else ''} {v}: step {t:.1f} us; fwd+poisson {fw:.1f} us = {fb / fw / 1e6:.2f} TB/s ({fb / fw / 8e6 * 100:.0f} %); "
                   f"adjoint {ad:.1f} us = {ab / ad / 1e6:.2f} TB/s ({ab / ad / 8e6 * 100:.0f} %)", flush=True)
@@ -182,6 +194,7 @@ if __name__ == "__main__":
         if w.startswith("time"):
             parts = w.split(":")
             bench(only=parts[1].split(",") if len(parts) > 1 and parts[1] else None,
-                  rows_list=tuple(int(r) for r in parts[2].split(",")) if len(parts) > 2 else (38, 56, 74, 128),
-                  cold=w.startswith("timecold"))
+                  rows_list=tuple(int(r) for r in parts[2].split(",") if r) if len(parts) > 2 else (38, 56, 74, 128),
+                  cold=w.startswith("timecold"),
+                  joint_rows=tuple(int(r) for r in parts[3].split(",")) if len(parts) > 3 else ())
     sys.exit(1 if rc else 0)
