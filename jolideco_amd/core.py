@@ -194,7 +194,8 @@ class MAPDeconvolver:
                 check(
                     lib.jd_adam_step(
                         ptr(st.theta), ptr(st.flux_cur), ptr(st.flux[1 - st.cur]), ptr(st.grad), ptr(st.exp_avg),
-                        ptr(st.exp_avg_sq), ptr(st.mask), n, step_size, beta1, beta2, 1 - beta1, 1 - beta2, bias2_sqrt, eps, 1,
+                        ptr(st.exp_avg_sq), ptr(st.mask), n, step_size, beta1, beta2, 1 - beta1, 1 - beta2, bias2_sqrt, eps,
+                        0,  # no zeroing pass: the first gradient term of every step OVERWRITES the buffer (FitSession.epoch)
                         int(st.use_log_flux), stream,
                     )
                 )
@@ -202,7 +203,7 @@ class MAPDeconvolver:
                 check(
                     lib.jd_sgd_step(
                         ptr(st.theta), ptr(st.flux_cur), ptr(st.flux[1 - st.cur]), ptr(st.grad), ptr(st.mask), n, lr,
-                        1, int(st.use_log_flux), stream,
+                        0, int(st.use_log_flux), stream,
                     )
                 )
             st.cur = 1 - st.cur

@@ -1310,10 +1310,29 @@ struct GmmExactArgs {
   // to the lowest component); gmm_best_kernel turns the winning key into the row the gather kernel reads
   const float* gfrag;
   float* grec;
+#ifdef JD_EXACT_STAMPS  // diagnostic build only (tools/build_variant.sh stamps -DJD_EXACT_STAMPS=1): s_memtime per phase of every group
+  unsigned long long* stamps;  // [group][8]
+#endif
 };
 
+#ifdef JD_EXACT_STAMPS
+#define EXACT_STAMP(i)                                                              \
+  do {                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    if (lane == 0) a.stamps[(size_t)grp * 8 + (i)] = t_;                            \
+  } while (0)
+#else
+#define EXACT_STAMP(i) do {} while (0)
+#endif
 
 constexpr int EXACT_PITCH = 68;  // floats per staged patch (64 + pad: 16-byte aligned rows, 2-way bank spread)
+#ifndef JD_EXACT_DRAW
+#define JD_EXACT_DRAW 1
+#endif
+constexpr int EXACT_DRAW = JD_EXACT_DRAW;  // groups a wave draws from the work counter at a time
+constexpr int EXACT_OFF_LDS = 1025;        // bucket offsets kept in LDS up to K = 1024
 
 // l(n, k) exactly as gmm_fwd_kernel computes it (same mean order, same MFMA chains, same epilogue), for groups of 32
 // surviving records that share the component; merged per patch with an order-independent atomic max.  The patches
@@ -1329,23 +1348,45 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
   const int n_waves = gridDim.x * 4;
   const int n_groups = a.offsets[a.K] >> 5;
   float* st = stage[wave];
-  // a contiguous run of groups per wave: the 40 KB of P'_k fragments are loaded once per component, not per group
-  const int per_wave = (n_groups + n_waves - 1) / n_waves;
-  const int g_begin = wave_global * per_wave, g_end = g_begin + per_wave < n_groups ? g_begin + per_wave : n_groups;
+  // Work distribution.  Phase stamps of the groups (diagnostic build -DJD_EXACT_STAMPS, profiles/r03/exact_stamps.txt): a
+  // group takes 36 k cycles where its two products need 5 k -- dependent memory round trips at ~2 us each under load --
+  // with a q90 / q50 spread of 1.7 in every phase, so with a fixed run of 4 groups per wave the launch lasts as long as
+  // its unluckiest wave (85 us against 55 us per wave on average).  A block therefore owns a contiguous run of groups
+  // (one or two components: their fragments stay in this CU's L1) and its four waves DRAW them, EXACT_DRAW at a time,
+  // from a counter in LDS; the bucket offsets they search sit in LDS too.  (One global counter for all waves was
+  // measured at 137-207 us: 3072 returning atomics on one address serialise at ~40 ns each.)  Results do not depend on
+  // who evaluates a group (atomicMax merge, gradient rows by bucket slot).
+  (void)n_waves, (void)wave_global;
+  __shared__ int s_off[EXACT_OFF_LDS];
+  __shared__ int s_next;
+  const bool off_lds = a.K + 1 <= EXACT_OFF_LDS;
+  const int per_block = (n_groups + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int b_begin = (int)blockIdx.x * per_block, b_end = b_begin + per_block < n_groups ? b_begin + per_block : n_groups;
+  if (threadIdx.x == 0) s_next = b_begin;
+  if (off_lds)
+    for (int i = threadIdx.x; i <= a.K; i += 256) s_off[i] = a.offsets[i];
+  __syncthreads();
+  auto offset_of = [&](int kk) { return off_lds ? s_off[kk] : a.offsets[kk]; };
   int k = -1;
   float ck = 0.f;
   float4 A[4][4], M[4];
+  for (;;) {
+    int g_begin = 0;
+    if (lane == 0) g_begin = atomicAdd(&s_next, EXACT_DRAW);
+    g_begin = __builtin_amdgcn_readfirstlane(g_begin);
+    if (g_begin >= b_end) break;  // (every wave ends here: the counter only grows)
+    const int g_end = g_begin + EXACT_DRAW < b_end ? g_begin + EXACT_DRAW : b_end;
   for (int grp = g_begin; grp < g_end; ++grp) {
+    EXACT_STAMP(0);  // group start
     int kg = k;
-    if (kg < 0) {  // first group: the last k with offsets[k] <= 32 grp (buckets are padded to 32: no straddling)
+    if (kg < 0 || offset_of(kg) > 32 * grp || offset_of(kg + 1) <= 32 * grp) {
+      // the last k with offsets[k] <= 32 grp (buckets are padded to 32: no straddling)
       int lo = 0, hi = a.K;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (a.offsets[mid] <= 32 * grp) lo = mid; else hi = mid;
+        if (offset_of(mid) <= 32 * grp) lo = mid; else hi = mid;
       }
       kg = lo;
-    } else {
-      while (a.offsets[kg + 1] <= 32 * grp) ++kg;  // groups ascend, so do the buckets
     }
     if (kg != k) {
       k = kg;
@@ -1360,7 +1401,12 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
           if (!TRI || st4 <= jb) A[jb][st4] = ak[(jb * 4 + st4) * 64];
       }
     }
-    const int nvalid = a.counts[k] - (32 * grp - a.offsets[k]);  // >= 1
+    const int nvalid = a.counts[k] - (32 * grp - offset_of(k));  // >= 1
+#ifdef JD_EXACT_STAMPS
+    if (lane == 0) a.stamps[(size_t)grp * 8 + 7] = (unsigned long long)((nvalid << 8) | (k & 255));
+    { float touch = A[0][0].x + M[0].x; asm volatile("" ::"v"(touch)); }  // the fragment loads have arrived
+#endif
+    EXACT_STAMP(1);  // bucket found, fragments of a new component in registers
     // ---- stage: lane (q = lane / 2, hh = lane % 2) fetches columns 4 hh .. 4 hh + 3 of the 8 rows of record q
     {
       const int q = lane >> 1, hh = lane & 1;
@@ -1384,6 +1430,7 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
 #pragma unroll
       for (int r = 0; r < 8; ++r) *reinterpret_cast<float4*>(st + q * EXACT_PITCH + 8 * r + 4 * hh) = rows[r];
     }
+    EXACT_STAMP(2);  // record indices read, patch rows fetched and stored to LDS
     int n[2];
     bool valid[2];
     float x[2][16];
@@ -1398,6 +1445,10 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
 #pragma unroll
       for (int s4 = 0; s4 < 16; ++s4) x[nb][s4] -= mean;
     }
+#ifdef JD_EXACT_STAMPS
+    { float touch = x[0][0] + x[1][15]; asm volatile("" ::"v"(touch)); }
+#endif
+    EXACT_STAMP(3);  // patches read back from LDS, means subtracted
     f32x4 y[4][2];
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
@@ -1412,16 +1463,26 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
             y[jb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4_get(A[jb][st4], e), x[nb][4 * st4 + e], y[jb][nb], 0, 0, 0);
       }
     }
+#ifdef JD_EXACT_STAMPS
+    { float touch = y[3][1][3] + y[0][0][0]; asm volatile("" ::"v"(touch)); }
+#endif
+    EXACT_STAMP(4);  // first product (40 x 2 MFMAs) done
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const float l = fmaf(-0.5f, sum_lane_groups(sum_squares(y, nb)), ck);  // = finish_tile of the forward kernel
       const int tie = a.grec ? 32 * grp + 16 * nb + n16 : k;
       if (g == 0 && valid[nb] && l > -INFINITY) atomicMax(a.best + n[nb], best_key(l, tie));  // NaN never wins (l > b)
     }
+    EXACT_STAMP(5);  // value epilogue, atomicMax issued
     if (a.grec) {
       float* rows[2] = {a.grec + (size_t)(32 * grp + n16) * D, a.grec + (size_t)(32 * grp + 16 + n16) * D};
       patch_gradient_rows<TRI>(y, a.gfrag, k, lane, valid, rows);
     }
+#ifdef JD_EXACT_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);  // the gradient rows have left the wave
+#endif
+    EXACT_STAMP(6);  // second product + gradient rows stored
+  }
   }
 }
 
@@ -1758,7 +1819,7 @@ struct jd_gmm {
   int* blk_counts = nullptr;  // per-block bin counts of the bucket sort
   size_t blk_counts_cap = 0;
   int* korder = nullptr;      // K: visiting order of the components (most survivors in the previous call first)
-  int* screen_ctl = nullptr;  // [0] fallback flag (generation stamped) | counts (K) | unused (K) | offsets (K + 1)
+  int* screen_ctl = nullptr;  // [0] fallback flag (generation stamped) | counts (K) | unused (K) | offsets (K + 1) | ticket
   int gen = 0;                // generation of the current screened pass (1 .. 2^30, never 0)
   // fused backward pass of the screened path
   float* grec = nullptr;      // gradient rows of the surviving records, by bucket slot
@@ -2152,11 +2213,58 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   ex.gfrag = g->gfrag, ex.grec = fused ? g->grec : nullptr;
   ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
   ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
+#ifdef JD_EXACT_STAMPS
+  static unsigned long long* stamps_dev = nullptr;
+  static size_t stamps_cap = 0;
+  const size_t max_groups = slots / 32 + g->K + 8;
+  if (stamps_cap < max_groups) {
+    if (stamps_dev) (void)hipFree(stamps_dev);
+    JD_HIP(hipMalloc(&stamps_dev, max_groups * 8 * sizeof(unsigned long long)));
+    stamps_cap = max_groups;
+  }
+  ex.stamps = stamps_dev;
+#endif
   {
     ProfScope stage(JD_KERNEL_GMM_EXACT, s);
     gmm_exact_kernel<true><<<(unsigned)(g->n_cu * 3), 256, 0, s>>>(ex);
   }
   JD_LAUNCH_CHECK();
+#ifdef JD_EXACT_STAMPS
+  if (opt_is_set(OPT_GMM_SCREEN_DEBUG)) {  // phase histogram of this launch (synchronises)
+    JD_HIP(hipStreamSynchronize(s));
+    int total_slots = 0;
+    JD_HIP(hipMemcpy(&total_slots, bk.offsets + g->K, sizeof(int), hipMemcpyDeviceToHost));
+    const int n_groups = total_slots >> 5;
+    std::vector<unsigned long long> st((size_t)n_groups * 8);
+    JD_HIP(hipMemcpy(st.data(), stamps_dev, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    const char* names[6] = {"bucket + fragments", "indices + patch rows -> LDS", "LDS read-back + mean", "first product (80 MFMAs)",
+                            "value epilogue + atomicMax", "second product + gradient rows"};
+    double sum[6] = {0};
+    std::vector<double> per[6];
+    unsigned long long t_min = ~0ull, t_max = 0;
+    for (int gi = 0; gi < n_groups; ++gi) {
+      const unsigned long long* t = &st[(size_t)gi * 8];
+      for (int ph = 0; ph < 6; ++ph) {
+        const double dt = (double)(t[ph + 1] - t[ph]);
+        sum[ph] += dt;
+        per[ph].push_back(dt);
+      }
+      t_min = t[0] < t_min ? t[0] : t_min, t_max = t[6] > t_max ? t[6] : t_max;
+    }
+    fprintf(stderr, "[jd exact stamps] %d groups of 32 records, first stamp to last stamp %.0f shader cycles\n", n_groups,
+            (double)(t_max - t_min));
+    double total = 0;
+    for (int ph = 0; ph < 6; ++ph) total += sum[ph];
+    for (int ph = 0; ph < 6; ++ph) {
+      std::sort(per[ph].begin(), per[ph].end());
+      const size_t m = per[ph].size();
+      fprintf(stderr, "[jd exact stamps] %-34s mean %8.0f cycles (%4.1f %%)  q10 %7.0f  q50 %7.0f  q90 %7.0f  q99 %7.0f\n", names[ph],
+              sum[ph] / n_groups, 100.0 * sum[ph] / total, per[ph][m / 10], per[ph][m / 2], per[ph][m * 9 / 10], per[ph][m * 99 / 100]);
+    }
+    fprintf(stderr, "[jd exact stamps] per group %.0f cycles; groups per wave %.2f; waves %d\n", total / n_groups,
+            (double)n_groups / (double)(g->n_cu * 12), g->n_cu * 12);
+  }
+#endif
 
   // fallback: the dense fp32 kernel, gated on the device flag (returns at once in the normal case)
   GmmFwdArgs dense = a;
