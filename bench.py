@@ -337,7 +337,11 @@ def main():
     torch.cuda.synchronize(device)
     scal = session.scalars.detach().cpu().numpy()
     epochs_run = args.warmup + settled["steps"] + args.steps * len(times)
+    if world > 1:
+        session.comm_events = []
     prof = profile_phase(session, device, n_obs)
+    comm_ms = session.comm_times_ms() if world > 1 else None
+    session.comm_events = None
 
     # sanity: the fit must have produced finite numbers
     if not np.all(np.isfinite(scal)):
@@ -501,6 +505,11 @@ def main():
         "kernel_ms_per_step": kernel_ms_per_step,
         "dominant_kernel": dominant,
     }
+    if comm_ms is not None:
+        # rank 0's compute stream, per step: time between enqueueing the wait for the all-reduce that was started before
+        # the prior and its completion (what the overlap did NOT hide), the all-gather of the prior bands, or the one
+        # blocking all-reduce of the non-overlapped schedule
+        out["comm_ms_per_step"] = comm_ms
     # which convolution the fit used: Gaussian PSFs are rank 1, so "auto" takes the separable kernel
     out["config"]["conv_method"] = "+".join(methods)
     # convolution kernel, HBM bound: forward reads flux + exposure and writes the convolution (12 B/pixel), the
@@ -517,7 +526,7 @@ def main():
             if conv_key != "sep_conv":
                 names = ("direct_conv_kernel",)
             elif poisson_in_conv and walk:
-                names = ("walk_kernel<2, 2, false, false, 6>",) if per_launch >= 6 else ("walk_kernel<4, 2, false, false, 0>",)
+                names = ("walk_kernel<4, 3, false, false, 6>",) if per_launch >= 6 else ("walk_kernel<4, 2, false, false, 0>",)
             elif poisson_in_conv:
                 names = ("sep_conv_kernel<true, false, false",)
             else:

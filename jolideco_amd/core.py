@@ -417,6 +417,9 @@ class FitSession:
         slot_d = {name: i for i, name in enumerate(names_all)}
         self.local_idx = [(slot_d[name], i) for i, name in enumerate(local_names)]  # (global slot, local index)
         self.step = 0
+        # comm_events = []: a sharded step brackets its collectives with event pairs on the compute stream (bench.py reads
+        # them after an untimed phase: how long the stream waited for the all-reduce it overlapped, and for the all-gather)
+        self.comm_events = None
         import os
 
         self._setup_sharded_prior(os.environ.get("JOLIDECO_DIST_OVERLAP", "1") != "0")
@@ -520,6 +523,26 @@ class FitSession:
             return self.dist.shard_range(prior.n_patch_rows(state.shape))
         return None
 
+    def _timed(self, name, fn):
+        """Run fn(); with `comm_events` set, bracketed by an event pair on the current stream."""
+        if self.comm_events is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.comm_events.append((name, e0, e1))
+        return out
+
+    def comm_times_ms(self):
+        """{collective: mean ms per step} of the event pairs collected since `comm_events = []` (synchronises)."""
+        torch.cuda.synchronize()
+        sums, counts = {}, {}
+        for name, e0, e1 in self.comm_events or []:
+            sums[name] = sums.get(name, 0.0) + e0.elapsed_time(e1)
+            counts[name] = counts.get(name, 0) + 1
+        return {name: sums[name] / counts[name] for name in sums}
+
     def epoch(self):
         cfg, dist, states, priors, total_loss = self.cfg, self.dist, self.states, self.priors, self.total_loss
         n_d, n_c = self.n_d, self.n_c
@@ -568,9 +591,9 @@ class FitSession:
                         patch_rows=item["rows"], band_out=self.band_send[item["offset"] : item["offset"] + item["size"]],
                     )
                     item["shifts"] = prior.last_shifts
-                dist.all_gather_flat(self.band_recv, self.band_send)
+                self._timed("all_gather_bands", lambda: dist.all_gather_flat(self.band_recv, self.band_send))
                 if pending is not None:
-                    pending.wait()
+                    self._timed("all_reduce_wait", pending.wait)
                 pieces = self.band_recv.view(dist.world_size, self.band_chunk)
                 for ci, item in banded.items():
                     add_rolled_bands(states[ci].grad, item["shifts"], self.band_recv[item["offset"] :], self.band_chunk,
@@ -581,7 +604,7 @@ class FitSession:
                     else:
                         torch.sum(pieces[:, item["value"]], dim=0, keepdim=True, out=slot(n_d + ci))
             elif dist.world_size > 1:
-                dist.all_reduce_sum(self.comm)
+                self._timed("all_reduce_blocking", lambda: dist.all_reduce_sum(self.comm))
             self.step += 1
             cfg._optimizer_step(states, self.step)
             for _, li in self.local_idx:

@@ -34,6 +34,10 @@ constexpr int XW = 8;   // waves (= datasets) per block of the batched adjoint
 #define JD_WALK_PREFETCH 2
 #endif
 constexpr int WALK_PREFETCH = JD_WALK_PREFETCH;  // rows the streaming loads run ahead of the arithmetic
+// the batched adjoint on 4 columns per lane has one block of 8 waves per CU: its 32 KB in flight per CU at two rows
+// ahead are the latency-bandwidth product of its 3.9 TB/s; three rows ahead: 80 -> 75 us in the fit (the forward launch
+// loses 3 % with the extra registers: it stays at two)
+constexpr int WALK_PREFETCH_ADJ = 3;
 // Launches below this many (pixel, dataset) pairs stay with the tile kernel, which has four times the waves for the
 // same image: measured on MI355X (tools/walk_check.py) forward + adjoint of one 2048^2 dataset 38.9 us (tile) against
 // 51.8 (walk), of two 65 / 77, of four 129 / 112, of eight 282 / 199, of one 4096^2 dataset 138 / 118
@@ -805,7 +809,7 @@ int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTab
     }
     ProfScope prof(JD_KERNEL_SEP_CONV, stream);
     if (m >= 6 && wide)
-      hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+      hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH_ADJ, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m >= 6)
       hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m >= 3)

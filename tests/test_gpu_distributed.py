@@ -172,6 +172,9 @@ def test_bench_two_ranks_over_gloo_reports_what_the_backend_saw(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == steps and out["warmup"] == warmup
     assert out["distributed"] == {"backend": "gloo", "world_size_seen_by_backend": 2, "rank": 0}
     assert out["scaling"] == "strong" and out["value"] > 0 and "cpu_baseline" not in out
+    # the line says how long rank 0's stream waited for the collectives it overlaps (a SCALE run diagnoses itself)
+    assert set(out["comm_ms_per_step"]) == {"all_gather_bands", "all_reduce_wait"}
+    assert all(v >= 0 for v in out["comm_ms_per_step"].values())
     # the same fit in this process: identical scalars (the replicas apply the identical update after the all-reduce)
     session = bench.build_session("c3", torch.device("cuda:0"))
     for _ in range(warmup + steps):
