@@ -222,6 +222,29 @@ int jd_gmm_prior_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int strid
                          float value_scale, float* value_out, int accumulate_value, float grad_coef,
                          float* grad_flux_accum, int32_t* argmax_out, void* stream);
 
+/* The same evaluation with the OPTIMIZER STEP of the component in the epilogue of its last kernel (new: one pass over
+ * the gradient image and one launch less per step; jolideco/core.py:229 is the step it folds in).  Where
+ * jd_gmm_prior_fwd_bwd adds grad_coef * d(sum v_patch)/d flux into the gradient image, this call forms
+ *   g = step->grad_flux[pixel] + grad_coef * d(sum v_patch)/d flux[pixel]      (grad_flux: all other terms, read only)
+ * and applies jd_adam_step's (or jd_sgd_step's) update to every pixel of the image: theta, exp_avg, exp_avg_sq in
+ * place, flux_out = exp(theta_new) [* mask].  Same bits as the two separate calls.  Whole prior only (no shard);
+ * stride >= 4; JD_ERR_INVALID otherwise (the caller then makes the two calls). */
+typedef struct {
+  float* theta;
+  const float* flux_in;
+  float* flux_out;
+  const float* grad_flux; /* d loss / d flux of everything but this prior */
+  float* exp_avg;         /* NULL with sgd */
+  float* exp_avg_sq;
+  const float* mask;      /* nullable */
+  float step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps; /* as jd_adam_step */
+  float lr;               /* sgd */
+  int use_log_flux, sgd;
+} jd_step;
+int jd_gmm_prior_fwd_bwd_step(jd_gmm* gmm, const float* flux, int H, int W, int stride, int shift_y, int shift_x,
+                              int marginalize, float value_scale, float* value_out, int accumulate_value,
+                              float grad_coef, const jd_step* step, void* stream);
+
 /* Diagnostics of the screened arg-max path, read without synchronisation from host-mapped memory the last block of a
  * pass writes: out[0..4] = {generation of the last finished pass, it fell back to the dense fp32 kernel (0 / 1), bucket
  * slots its surviving records used, patches it covered, gradient rows per patch the record buffer has room for now}.

@@ -69,6 +69,10 @@ EXPORTS = {
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
          c_float, c_void_p, c_void_p, c_void_p],
     ),
+    "jd_gmm_prior_fwd_bwd_step": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p],
+    ),
     "jd_gmm_screen_stats": (c_int, [c_void_p, POINTER(c_int)]),
     "jd_gmm_prior_band_fwd_bwd": (
         c_int,
@@ -97,6 +101,18 @@ EXPORTS = {
     "jd_kernel_name": (c_char_p, [c_int]),
     "jd_clock_probe": (c_int, [c_double, POINTER(c_double), c_void_p]),
 }
+
+class Step(ctypes.Structure):
+    """`jd_step` of include/jolideco_hip.h: the optimizer step a prior evaluation applies in its epilogue."""
+
+    _fields_ = [
+        ("theta", c_void_p), ("flux_in", c_void_p), ("flux_out", c_void_p), ("grad_flux", c_void_p), ("exp_avg", c_void_p),
+        ("exp_avg_sq", c_void_p), ("mask", c_void_p),
+        ("step_size", c_float), ("beta1", c_float), ("beta2", c_float), ("one_minus_beta1", c_float),
+        ("one_minus_beta2", c_float), ("bias2_sqrt", c_float), ("eps", c_float), ("lr", c_float),
+        ("use_log_flux", c_int), ("sgd", c_int),
+    ]
+
 
 KERNEL_IDS = {
     "poisson_fused": 0, "gmm_fwd": 1, "gmm_bwd": 2, "gmm_gather": 3, "pad_mul": 4, "cmul": 5,

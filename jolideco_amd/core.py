@@ -176,15 +176,38 @@ class MAPDeconvolver:
         return "\n".join(lines)
 
     # ------------------------------------------------------------------------------------------
-    def _optimizer_step(self, states, step):
+    def _step_args(self, st, step):
+        """`_hip.Step` of component state ``st`` for optimizer step number ``step``: what a prior needs to apply the
+        update in the epilogue of its own last kernel (`device_fwd_bwd_step`)."""
+        lr = self.optimizer_kwargs["lr"]
+        args = _hip.Step()
+        args.theta, args.flux_in, args.flux_out = st.theta.data_ptr(), st.flux_cur.data_ptr(), st.flux[1 - st.cur].data_ptr()
+        args.grad_flux = st.grad.data_ptr()
+        args.mask = None if st.mask is None else st.mask.data_ptr()
+        args.use_log_flux = int(st.use_log_flux)
+        if self.optimizer_type == "adam":
+            beta1, beta2 = self.optimizer_kwargs.get("betas", (0.9, 0.999))
+            args.step_size, args.bias2_sqrt = adam_bias_terms(step, lr, beta1, beta2)
+            args.beta1, args.beta2, args.one_minus_beta1, args.one_minus_beta2 = beta1, beta2, 1 - beta1, 1 - beta2
+            args.eps = self.optimizer_kwargs.get("eps", 1e-8)
+            args.exp_avg, args.exp_avg_sq = st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr()
+            args.sgd = 0
+        else:
+            args.lr, args.sgd = lr, 1
+        return args
+
+    def _optimizer_step(self, states, step, stepped=()):
         """Fused chain rule + optimizer update of every non-frozen component; swaps the flux
-        buffers so `flux_prev` is the flux the step was computed with."""
+        buffers so `flux_prev` is the flux the step was computed with.  ``stepped``: components whose prior has
+        already applied the update (`device_fwd_bwd_step`): only their buffers are swapped."""
         lib = _hip.lib()
         lr = self.optimizer_kwargs["lr"]
-        for st in states:
+        for ci, st in enumerate(states):
             n = st.theta.numel()
             stream = stream_ptr(st.theta.device)
-            if st.frozen:
+            if ci in stepped:
+                pass
+            elif st.frozen:
                 st.flux[1 - st.cur].copy_(st.flux_cur)
                 st.grad.zero_()
             elif self.optimizer_type == "adam":
@@ -523,6 +546,18 @@ class FitSession:
             return self.dist.shard_range(prior.n_patch_rows(state.shape))
         return None
 
+    def _fuse_step(self, st, prior):
+        """The prior of this component applies the optimizer step itself (`device_fwd_bwd_step`): single process (the
+        gradient buffer is complete when the prior runs), not frozen, a prior that supports it, stride >= 4, and the
+        session's own `_optimizer_step` (tests that replace it to record or suppress the step see every gradient)."""
+        import os
+
+        return (
+            self.dist.world_size == 1 and not st.frozen and getattr(prior, "supports_fused_step", False)
+            and getattr(prior, "stride", 0) >= 4 and "_optimizer_step" not in vars(self.cfg)
+            and not os.environ.get("JOLIDECO_NO_FUSED_STEP")
+        )
+
     def _timed(self, name, fn):
         """Run fn(); with `comm_events` set, bracketed by an event pair on the current stream."""
         if self.comm_events is None:
@@ -570,11 +605,18 @@ class FitSession:
                 for g in grads:
                     g.zero_()
             banded = {item["ci"]: item for item in (self.band_plan or [])}
+            stepped = set()
             for ci, (st, prior) in enumerate(zip(states, priors)):
                 if ci in banded:
                     continue
                 if dist.world_size > 1 and not prior.shardable and dist.rank != 0:
                     continue  # cheap element-wise priors: rank 0 only, summed by the all-reduce
+                if self._fuse_step(st, prior):
+                    # single process: the prior is the last gradient term of its component -- its gather kernel applies
+                    # the optimizer step (one pass over the gradient image and one launch less)
+                    prior.device_fwd_bwd_step(st.flux_cur, slot(n_d + ci), -float(cfg.beta), cfg._step_args(st, self.step + 1))
+                    stepped.add(ci)
+                    continue
                 prior.device_fwd_bwd(
                     st.flux_cur, slot(n_d + ci), grad=st.grad, coef=-float(cfg.beta),
                     patch_rows=self._prior_rows(prior, st),
@@ -606,7 +648,7 @@ class FitSession:
             elif dist.world_size > 1:
                 self._timed("all_reduce_blocking", lambda: dist.all_reduce_sum(self.comm))
             self.step += 1
-            cfg._optimizer_step(states, self.step)
+            cfg._optimizer_step(states, self.step, stepped)
             for _, li in self.local_idx:
                 self._cal_step(li)
         else:
@@ -617,10 +659,15 @@ class FitSession:
                 self._cal_zero_grad(li)
                 total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
                 coef = -float(cfg.beta) / total_loss.prior_weight
+                stepped = set()
                 for ci, (st, prior) in enumerate(zip(states, priors)):
-                    prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef)
+                    if self._fuse_step(st, prior):
+                        prior.device_fwd_bwd_step(st.flux_cur, slot(n_d + ci), coef, cfg._step_args(st, self.step + 1))
+                        stepped.add(ci)
+                    else:
+                        prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef)
                 self.step += 1
-                cfg._optimizer_step(states, self.step)
+                cfg._optimizer_step(states, self.step, stepped)
                 self._cal_step(li)
             # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------------
             stale = [st.flux_trace for st in states]

@@ -7,6 +7,7 @@
 
 #include "jd_common.h"
 #include "kernels.h"
+#include "jd_adam.h"
 
 namespace jd {
 
@@ -431,32 +432,6 @@ __global__ __launch_bounds__(BLOCK) void poisson_nll_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // K6: chain rule + Adam (torch.optim.Adam single-tensor formula) + exp of the new theta
 // ------------------------------------------------------------------------------------------
-struct AdamArgs {
-  float* theta;
-  const float* flux_in;
-  float* flux_out;
-  float* grad_flux;
-  float* m;
-  float* v;
-  const float* mask;
-  size_t n;
-  float step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, lr;
-  int zero_grad, sgd;
-  int linear;  // use_log_flux=False: theta IS the flux (models/core.py:586-594), no exp / chain rule
-};
-
-__device__ inline void adam_update(float& th, float& m, float& v, float g, const AdamArgs& a) {
-  if (a.sgd) {
-    th = th - a.lr * g;
-    return;
-  }
-  // exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-  m = m + a.one_minus_beta1 * (g - m);
-  v = v * a.beta2 + a.one_minus_beta2 * (g * g);
-  const float denom = sqrtf(v) / a.bias2_sqrt + a.eps;
-  th = th - a.step_size * (m / denom);
-}
-
 template <int VEC>
 __global__ __launch_bounds__(BLOCK) void adam_kernel(AdamArgs a) {
   const size_t stride = (size_t)gridDim.x * BLOCK * VEC;
@@ -475,6 +450,7 @@ __global__ __launch_bounds__(BLOCK) void adam_kernel(AdamArgs a) {
         m[0] = m4.x, m[1] = m4.y, m[2] = m4.z, m[3] = m4.w;
         v[0] = v4.x, v[1] = v4.y, v[2] = v4.z, v[3] = v4.w;
       }
+      mk[0] = mk[1] = mk[2] = mk[3] = 1.f;
       if (a.mask) {
         const float4 k4 = *reinterpret_cast<const float4*>(a.mask + i);
         mk[0] = k4.x, mk[1] = k4.y, mk[2] = k4.z, mk[3] = k4.w;
@@ -482,16 +458,10 @@ __global__ __launch_bounds__(BLOCK) void adam_kernel(AdamArgs a) {
     } else {
       th[0] = a.theta[i], f[0] = a.flux_in[i], gf[0] = a.grad_flux[i];
       if (!a.sgd) m[0] = a.m[i], v[0] = a.v[i];
-      if (a.mask) mk[0] = a.mask[i];
+      mk[0] = a.mask ? a.mask[i] : 1.f;
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      // d flux / d theta = exp(theta) * mask = flux  (models/core.py:588-592); linear: = mask
-      const float dfdth = a.linear ? (a.mask ? mk[k] : 1.f) : f[k];
-      adam_update(th[k], m[k], v[k], gf[k] * dfdth, a);
-      f[k] = a.linear ? th[k] : expf(th[k]);
-      if (a.mask) f[k] *= mk[k];
-    }
+    for (int k = 0; k < VEC; ++k) adam_pixel(th[k], f[k], m[k], v[k], gf[k], mk[k], a);
     if constexpr (VEC == 4) {
       *reinterpret_cast<float4*>(a.theta + i) = make_float4(th[0], th[1], th[2], th[3]);
       *reinterpret_cast<float4*>(a.flux_out + i) = make_float4(f[0], f[1], f[2], f[3]);

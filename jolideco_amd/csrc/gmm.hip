@@ -30,6 +30,7 @@
 
 #include "jd_common.h"
 #include "kernels.h"
+#include "jd_adam.h"
 
 namespace jd {
 
@@ -1600,6 +1601,14 @@ struct GmmGatherArgs {
   // [y_begin, y_end) of the ROLLED frame are written (assigned; 0 where no patch of the shard covers a pixel) to
   // band[(Y - y_begin) * W + X] -- the compact piece a rank of a sharded prior exchanges (jd_add_rolled_bands)
   float* band;
+  // tile kernel: W % 4 == 0 and 16-byte aligned images: the pixel groups of a thread start at X = shift_x (mod 4), so that
+  // their un-rolled column is a multiple of 4 and the gradient image is read and written with 16-byte accesses
+  int vec;
+  // fused optimizer step (do_step; tile kernel, whole image): instead of grad += coef * sum the kernel forms
+  // g = step.grad_flux[pixel] + coef * sum (the other gradient terms, read only) and applies the update of adam_kernel to
+  // the pixel -- one pass less over the gradient image and one launch less per step
+  int do_step;
+  AdamArgs step;
 };
 
 __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
@@ -1650,14 +1659,16 @@ __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
 #ifndef JD_GATHER_MAX_P
 #define JD_GATHER_MAX_P 9
 #endif
-// patches per tile and dimension: the tile origin is a multiple of 32 above y_begin = row_begin * stride, so for stride
-// 4 (and 8) it is aligned with the patch grid: 9 (4); strides 5, 6, 7 have at most floor(38 / s) + 1 = 8, 7, 6
-constexpr int GATHER_T = 32, GATHER_MAX_P = JD_GATHER_MAX_P;
+// patches per tile and dimension: the tile's first row is a multiple of 32 above y_begin = row_begin * stride, so for
+// stride 4 (and 8) it is aligned with the patch grid: 9 rows of patches (4); strides 5, 6, 7 have at most
+// floor(38 / s) + 1 = 8, 7, 6.  Columns: the tile's first column is shift_x (mod 4), not aligned with the grid: 10.
+constexpr int GATHER_T = 32, GATHER_MAX_P = JD_GATHER_MAX_P, GATHER_MAX_PX = JD_GATHER_MAX_P + 1;
 
 __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
-  __shared__ __attribute__((aligned(16))) float rows[GATHER_MAX_P * GATHER_MAX_P][D];
+  __shared__ __attribute__((aligned(16))) float rows[GATHER_MAX_P * GATHER_MAX_PX][D];
   const int tid = threadIdx.x;
-  const int X0 = blockIdx.x * GATHER_T, Y0 = a.y_begin + blockIdx.y * GATHER_T;
+  const int xoff = a.vec ? ((a.shift_x % 4) + 4) & 3 : 0;
+  const int X0 = (int)blockIdx.x * GATHER_T - ((4 - xoff) & 3), Y0 = a.y_begin + blockIdx.y * GATHER_T;
   auto ceil_div_pos = [](int v, int s) { return v <= 0 ? 0 : (v + s - 1) / s; };
   int py0 = ceil_div_pos(Y0 - (P - 1), a.stride), py1 = (Y0 + GATHER_T - 1) / a.stride;
   int px0 = ceil_div_pos(X0 - (P - 1), a.stride), px1 = (X0 + GATHER_T - 1) / a.stride;
@@ -1665,30 +1676,33 @@ __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
   if (py1 > a.row_end - 1) py1 = a.row_end - 1;
   if (px1 > a.nPx - 1) px1 = a.nPx - 1;
   int npx = px1 - px0 + 1, npy = py1 - py0 + 1;
-  if (npx > GATHER_MAX_P) npx = GATHER_MAX_P, px1 = px0 + npx - 1;  // (cannot happen, see GATHER_MAX_P: keeps LDS in bounds)
+  if (npx > GATHER_MAX_PX) npx = GATHER_MAX_PX, px1 = px0 + npx - 1;  // (cannot happen, see above: keeps LDS in bounds)
   if (npy > GATHER_MAX_P) npy = GATHER_MAX_P, py1 = py0 + npy - 1;
-  if (npx <= 0 || npy <= 0) {  // no patch of the shard touches this tile
+  const bool touched = npx > 0 && npy > 0;  // (block-uniform) some patch of the shard touches this tile
+  if (!touched && !a.do_step) {
     if (a.band) {
       const int Y = Y0 + (tid >> 3);
       for (int i = 0; i < 4; ++i) {
         const int X = X0 + (tid & 7) * 4 + i;
-        if (Y < a.y_end && X < a.W) a.band[(size_t)(Y - a.y_begin) * a.W + X] = 0.f;
+        if (Y < a.y_end && X >= 0 && X < a.W) a.band[(size_t)(Y - a.y_begin) * a.W + X] = 0.f;
       }
     }
     return;
   }
-  const bool slots = a.winner && *a.flag != a.gen;
-  for (int p = tid >> 4; p < npy * npx; p += 16) {
-    const int py = py0 + p / npx, px = px0 + p % npx;
-    const float* src;
-    if (slots) {
-      const int slot = a.winner[(size_t)py * a.nPx + px];
-      src = slot >= 0 ? a.grec + (size_t)slot * D : nullptr;
-    } else {
-      src = a.gpatch + ((size_t)(py - a.row_begin) * a.nPx + px) * D;
+  if (touched) {
+    const bool slots = a.winner && *a.flag != a.gen;
+    for (int p = tid >> 4; p < npy * npx; p += 16) {
+      const int py = py0 + p / npx, px = px0 + p % npx;
+      const float* src;
+      if (slots) {
+        const int slot = a.winner[(size_t)py * a.nPx + px];
+        src = slot >= 0 ? a.grec + (size_t)slot * D : nullptr;
+      } else {
+        src = a.gpatch + ((size_t)(py - a.row_begin) * a.nPx + px) * D;
+      }
+      const float4 v = src ? reinterpret_cast<const float4*>(src)[tid & 15] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&rows[p][(tid & 15) * 4]) = v;
     }
-    const float4 v = src ? reinterpret_cast<const float4*>(src)[tid & 15] : make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(&rows[p][(tid & 15) * 4]) = v;
   }
   __syncthreads();
   const int Y = Y0 + (tid >> 3);
@@ -1697,26 +1711,88 @@ __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
   if (py_lo < py0) py_lo = py0;
   if (py_hi > py1) py_hi = py1;
   const int yy = wrap(Y - a.shift_y, a.H);
+  const int Xg = X0 + (tid & 7) * 4;  // the thread's group of four pixels of the rolled frame
+  float sum[4];
+  bool any[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int X = X0 + (tid & 7) * 4 + i;
-    if (X >= a.W) break;
+    const int X = Xg + i;
+    sum[i] = 0.f, any[i] = false;
+    if (X < 0 || X >= a.W || !touched) continue;
     int px_hi = X / a.stride, px_lo = ceil_div_pos(X - (P - 1), a.stride);
     if (px_lo < px0) px_lo = px0;
     if (px_hi > px1) px_hi = px1;
-    float sum = 0.f;
-    bool any = false;
     for (int py = py_lo; py <= py_hi; ++py) {
       const int r = Y - py * a.stride;
       for (int px = px_lo; px <= px_hi; ++px) {
-        sum += rows[(py - py0) * npx + (px - px0)][r * P + (X - px * a.stride)];  // (a zero row where a patch has no gradient)
-        any = true;
+        sum[i] += rows[(py - py0) * npx + (px - px0)][r * P + (X - px * a.stride)];  // (a zero row where a patch has no gradient)
+        any[i] = true;
       }
     }
-    if (a.band)
-      a.band[(size_t)(Y - a.y_begin) * a.W + X] = any ? a.coef * sum : 0.f;
-    else if (any)
-      a.grad[(size_t)yy * a.W + wrap(X - a.shift_x, a.W)] += a.coef * sum;
+  }
+  if (a.band) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (Xg + i >= 0 && Xg + i < a.W) a.band[(size_t)(Y - a.y_begin) * a.W + Xg + i] = any[i] ? a.coef * sum[i] : 0.f;
+    return;
+  }
+  const size_t row = (size_t)yy * a.W;
+  if (a.vec && Xg >= 0 && Xg + 3 < a.W) {
+    // the un-rolled column of the group is a multiple of 4 and the group does not wrap (W % 4 == 0)
+    const size_t idx = row + wrap(Xg - a.shift_x, a.W);
+    if (a.do_step) {
+      const AdamArgs& st = a.step;
+      const float4 g4 = *reinterpret_cast<const float4*>(st.grad_flux + idx);
+      float g[4] = {g4.x, g4.y, g4.z, g4.w};
+      const float4 t4 = *reinterpret_cast<const float4*>(st.theta + idx), f4 = *reinterpret_cast<const float4*>(st.flux_in + idx);
+      float th[4] = {t4.x, t4.y, t4.z, t4.w}, f[4] = {f4.x, f4.y, f4.z, f4.w}, m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+      float mk[4] = {1.f, 1.f, 1.f, 1.f};
+      if (!st.sgd) {
+        const float4 m4 = *reinterpret_cast<const float4*>(st.m + idx), v4 = *reinterpret_cast<const float4*>(st.v + idx);
+        m[0] = m4.x, m[1] = m4.y, m[2] = m4.z, m[3] = m4.w, v[0] = v4.x, v[1] = v4.y, v[2] = v4.z, v[3] = v4.w;
+      }
+      if (st.mask) {
+        const float4 k4 = *reinterpret_cast<const float4*>(st.mask + idx);
+        mk[0] = k4.x, mk[1] = k4.y, mk[2] = k4.z, mk[3] = k4.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (any[i]) g[i] += a.coef * sum[i];
+        adam_pixel(th[i], f[i], m[i], v[i], g[i], mk[i], st);
+      }
+      *reinterpret_cast<float4*>(st.theta + idx) = make_float4(th[0], th[1], th[2], th[3]);
+      *reinterpret_cast<float4*>(st.flux_out + idx) = make_float4(f[0], f[1], f[2], f[3]);
+      if (!st.sgd) {
+        *reinterpret_cast<float4*>(st.m + idx) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<float4*>(st.v + idx) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    } else if (any[0] || any[1] || any[2] || any[3]) {
+      float4 g4 = *reinterpret_cast<const float4*>(a.grad + idx);
+      if (any[0]) g4.x += a.coef * sum[0];
+      if (any[1]) g4.y += a.coef * sum[1];
+      if (any[2]) g4.z += a.coef * sum[2];
+      if (any[3]) g4.w += a.coef * sum[3];
+      *reinterpret_cast<float4*>(a.grad + idx) = g4;
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // a group that straddles the image border (or W % 4 != 0): pixel by pixel
+    const int X = Xg + i;
+    if (X < 0 || X >= a.W) continue;
+    const size_t idx = row + wrap(X - a.shift_x, a.W);
+    if (a.do_step) {
+      const AdamArgs& st = a.step;
+      float g = st.grad_flux[idx];
+      if (any[i]) g += a.coef * sum[i];
+      float th = st.theta[idx], f = st.flux_in[idx], m = st.sgd ? 0.f : st.m[idx], v = st.sgd ? 0.f : st.v[idx];
+      const float mk = st.mask ? st.mask[idx] : 1.f;
+      adam_pixel(th, f, m, v, g, mk, st);
+      st.theta[idx] = th, st.flux_out[idx] = f;
+      if (!st.sgd) st.m[idx] = m, st.v[idx] = v;
+    } else if (any[i]) {
+      a.grad[idx] += a.coef * sum[i];
+    }
   }
 }
 
@@ -2316,7 +2392,8 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
                           int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                           float value_scale, float* value_out, int accumulate_value, float grad_coef,
-                          float* grad_flux_accum, int32_t* argmax_out, float* band_out, void* stream) {
+                          float* grad_flux_accum, int32_t* argmax_out, float* band_out, void* stream,
+                          const AdamArgs* step = nullptr) {
   JD_REQUIRE(g && flux && value_out, "jd_gmm_prior_fwd_bwd: null argument");
   JD_REQUIRE(H >= P && W >= P, "jd_gmm_prior_fwd_bwd: image (%d, %d) smaller than a patch", H, W);
   JD_REQUIRE(stride >= 1 && stride <= P, "jd_gmm_prior_fwd_bwd: stride = %d not in [1, 8]", stride);
@@ -2334,6 +2411,11 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     return JD_OK;
   }
   if (band_out) grad_flux_accum = band_out;  // "a gradient is wanted"; the gather writes the band instead
+  if (step) {
+    JD_REQUIRE(!band_out && patch_row_begin == 0 && patch_row_end == nPy && stride >= 4 && opt_value(OPT_GMM_GATHER_TILED, 1) != 0,
+               "jd_gmm_prior_fwd_bwd_step: needs the whole prior (no shard, no band) and stride >= 4");
+    grad_flux_accum = step->grad_flux;  // "a gradient is wanted"; the gather reads it and applies the step instead
+  }
   const long n = n_end - n_begin;
   int rc;
   if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
@@ -2434,10 +2516,18 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   ga.band = band_out;
   if (fused) ga.winner = g->winner, ga.grec = g->grec, ga.flag = g->screen_ctl, ga.gen = g->gen;
   {
+    auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    ga.vec = W % 4 == 0 && aligned(grad_flux_accum) ? 1 : 0;
+    if (step) {
+      ga.do_step = 1, ga.step = *step, ga.y_begin = 0, ga.y_end = H;  // every pixel of the image takes the step
+      ga.vec = ga.vec && aligned(step->theta) && aligned(step->flux_in) && aligned(step->flux_out) && aligned(step->m) &&
+               aligned(step->v) && aligned(step->mask);
+    }
     ProfScope prof(JD_KERNEL_GMM_GATHER, s);
     // option JD_GMM_GATHER_TILED = 0: the per-pixel kernel (testing)
     if (stride >= 4 && opt_value(OPT_GMM_GATHER_TILED, 1) != 0) {
-      dim3 grid((W + GATHER_T - 1) / GATHER_T, (ga.y_end - ga.y_begin + GATHER_T - 1) / GATHER_T);
+      // (x: the first tile starts up to 3 pixels left of the image so that the pixel groups are aligned un-rolled)
+      dim3 grid((W + 3 + GATHER_T - 1) / GATHER_T, (ga.y_end - ga.y_begin + GATHER_T - 1) / GATHER_T);
       gmm_gather_tile_kernel<<<grid, 256, 0, s>>>(ga);
     } else {
       dim3 grid((W + 255) / 256, ga.y_end - ga.y_begin);
@@ -2464,6 +2554,21 @@ extern "C" int jd_gmm_screen_stats(const jd_gmm* g, int* out) {
   for (int i = 0; i < 4; ++i) out[i] = g->host_stats ? reinterpret_cast<volatile int*>(g->host_stats)[i] : 0;
   out[4] = g->rows_per_patch;
   return JD_OK;
+}
+
+extern "C" int jd_gmm_prior_fwd_bwd_step(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y, int shift_x,
+                                         int marginalize, float value_scale, float* value_out, int accumulate_value,
+                                         float grad_coef, const jd_step* step, void* stream) {
+  JD_REQUIRE(step && step->theta && step->flux_in && step->flux_out && step->grad_flux, "jd_gmm_prior_fwd_bwd_step: null argument");
+  JD_REQUIRE(step->sgd || (step->exp_avg && step->exp_avg_sq), "jd_gmm_prior_fwd_bwd_step: Adam needs its moment images");
+  AdamArgs a{};
+  a.theta = step->theta, a.flux_in = step->flux_in, a.flux_out = step->flux_out, a.grad_flux = const_cast<float*>(step->grad_flux);
+  a.m = step->exp_avg, a.v = step->exp_avg_sq, a.mask = step->mask, a.n = (size_t)H * W;
+  a.step_size = step->step_size, a.beta1 = step->beta1, a.beta2 = step->beta2, a.one_minus_beta1 = step->one_minus_beta1;
+  a.one_minus_beta2 = step->one_minus_beta2, a.bias2_sqrt = step->bias2_sqrt, a.eps = step->eps, a.lr = step->lr;
+  a.zero_grad = 0, a.sgd = step->sgd ? 1 : 0, a.linear = step->use_log_flux ? 0 : 1;
+  return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, 0, -1, marginalize, value_scale, value_out, accumulate_value,
+                        grad_coef, nullptr, nullptr, nullptr, stream, &a);
 }
 
 extern "C" int jd_gmm_prior_band_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,

@@ -311,6 +311,21 @@ class GmmHandle:
             )
         )
 
+    def prior_fwd_bwd_step(self, flux, stride, shifts, value_out, value_scale, grad_coef, step, marginalize=False,
+                           accumulate_value=False):
+        """The whole prior with the component's optimizer step in the epilogue of its gather kernel
+        (jd_gmm_prior_fwd_bwd_step; ``step``: a filled `_hip.Step`).  Raises RuntimeError where the library does not
+        support it (stride < 4): the caller then evaluates the prior and steps separately."""
+        flux = require_hip_tensor(flux, "flux")
+        H, W = flux.shape[-2:]
+        sy, sx = (0, 0) if shifts is None else shifts
+        check(
+            _hip.lib().jd_gmm_prior_fwd_bwd_step(
+                self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(bool(marginalize)), c_float(value_scale),
+                ptr(value_out), int(accumulate_value), c_float(grad_coef), ctypes.byref(step), stream_ptr(flux.device),
+            )
+        )
+
     def screen_stats(self):
         """(generation, fell_back, bucket_slots, patches, rows_per_patch) of the last screened pass that has finished
         (jd_gmm_screen_stats; no synchronisation)."""

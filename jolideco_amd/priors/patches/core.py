@@ -106,6 +106,21 @@ class GMMPatchPrior(Prior):
             marginalize=self.marginalize, patch_rows=patch_rows or (0, -1), band_out=band_out,
         )
 
+    # the optimizer step of the component can ride in the epilogue of this prior's last kernel (`device_fwd_bwd_step`)
+    supports_fused_step = True
+
+    def device_fwd_bwd_step(self, flux, value_out, coef, step, shifts="draw"):
+        """`device_fwd_bwd` of the WHOLE prior with the component's optimizer step applied by its gather kernel:
+        ``step.grad_flux`` holds every other gradient term; theta, the moments and the new flux are written in place
+        (jd_gmm_prior_fwd_bwd_step).  Same numbers as `device_fwd_bwd` followed by the stand-alone step."""
+        if isinstance(shifts, str):
+            shifts = self.draw_shifts()
+        scale = self.log_like_weight / flux.numel()
+        self.gmm.handle(flux.device).prior_fwd_bwd_step(
+            flux.reshape(flux.shape[-2:]), self.stride, shifts, value_out, scale, coef * scale, step,
+            marginalize=self.marginalize,
+        )
+
     def hessian_ones(self, flux):
         """Every patch has its mean subtracted before the mixture sees it, so a constant vector is in the null
         space of each patch's quadratic form: Hessian x ones is exactly zero (the reference's double backward

@@ -599,3 +599,36 @@ def test_batched_joint_step_with_four_components(monkeypatch):
             assert np.array_equal(results["batch"][name], results["loop"][name]), (n_comp, name)
         assert np.allclose(results["batch"]["c"], flux_init / 3.0, rtol=1e-6)  # frozen
         assert not np.array_equal(results["batch"]["a"], flux_init)
+
+
+@pytest.mark.parametrize("fit_mode,optimizer,shape", [("joint", "adam", (96, 160)), ("sequential", "adam", (75, 132)),
+                                                      ("joint", "sgd", (64, 75)), ("joint", "adam", (200, 328))])
+def test_optimizer_step_in_the_priors_gather_kernel_changes_no_bit(monkeypatch, fit_mode, optimizer, shape):
+    """Single process: the GMM prior is the last gradient term of its component, so its gather kernel applies the
+    optimizer step (jd_gmm_prior_fwd_bwd_step: g = likelihood gradient + prior gradient, then the update of
+    jd_adam_step / jd_sgd_step, pixel groups aligned in the un-rolled frame).  Same trajectory as the separate
+    prior + step calls, bit for bit: fluxes and every trace column (odd widths take the pixel-by-pixel path)."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+    from jolideco_amd.data import synthetic_gmm, synthetic_observations
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=3, seed=4)
+    means, covs, weights = synthetic_gmm(16, 64, seed=1)
+    results = {}
+    for mode in ("fused", "separate"):
+        if mode == "separate":
+            monkeypatch.setenv("JOLIDECO_NO_FUSED_STEP", "1")
+        gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+        comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+        kwargs = {"optimizer_type": optimizer}
+        if optimizer == "sgd":
+            kwargs["learning_rate"] = 1e-3
+        deco = MAPDeconvolver(n_epochs=5, display_progress=False, device=DEV, fit_mode=fit_mode, **kwargs)
+        session = deco.session(datasets, components=comp)
+        assert session._fuse_step(session.states[0], session.priors[0]) == (mode == "fused")
+        res = deco.run(datasets, components=comp)
+        results[mode] = (res.flux_total, {n: np.asarray(res.trace_loss[n]) for n in res.trace_loss.colnames if n != "filename"})
+    assert np.array_equal(results["fused"][0], results["separate"][0])
+    assert not np.array_equal(results["fused"][0], flux_init.astype(np.float32))
+    for name, column in results["separate"][1].items():
+        assert np.array_equal(results["fused"][1][name], column), name
