@@ -15,7 +15,8 @@
  *   - all work is enqueued asynchronously on the `stream` argument (a hipStream_t passed as
  *     void*); no call synchronises except *_create and *_destroy
  *   - scalar outputs (`*_out`) are DEVICE pointers to one float
- *   - no C++ exceptions cross this boundary; handles are not thread-safe
+ *   - no C++ exceptions cross this boundary; handles are not thread-safe, and a handle belongs to ONE stream at a
+ *     time (its work buffers and cached device tables are reused from call to call without cross-stream events)
  */
 #ifndef JOLIDECO_HIP_H
 #define JOLIDECO_HIP_H
