@@ -426,7 +426,9 @@ def main():
     #  * otherwise the stand-alone kernel: conv_c, background, counts in, g_c out: 8 C + 8 (16 B at C = 1).
     fused_one = methods in (["separable"], ["direct"]) and n_comp == 1 and _hip.get_option("JD_SEP_NO_FUSION") is None
     fused_multi = methods == ["separable"] and n_comp > 1 and batched
-    walk = methods == ["separable"] and n_comp == 1 and models_all[0].plan.takes_walk(per_launch)
+    # (the strip-walk kernels take launches of >= 2^24 (pixel, dataset, component) triples; several components: batched only)
+    walk = (methods == ["separable"] and (n_comp == 1 or (batched and n_comp <= 4))
+            and models_all[0].plan.takes_walk(per_launch * n_comp))
     if fused_one:
         poi_px_bytes = 20
         poi_kernel = ("direct_conv_kernel<" if methods == ["direct"] else
@@ -434,7 +436,8 @@ def main():
         poi_what = "forward convolution + Poisson pass"
     elif fused_multi:
         poi_px_bytes = 12 * n_comp + 8
-        poi_kernel, poi_what = "sep_conv_kernel<true, true, true, true>", f"forward convolutions of {n_comp} components + Poisson pass"
+        poi_kernel = "walk_multi_kernel<4, 2>" if walk else "sep_conv_kernel<true, true, true, true>"
+        poi_what = f"forward convolutions of {n_comp} components + Poisson pass"
     else:
         poi_px_bytes = 8 * n_comp + 8
         poi_kernel, poi_what = "poisson_fused_kernel", "stand-alone Poisson pass"

@@ -388,7 +388,7 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   // Poisson pass is the epilogue of the convolution
   const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
                      upsampling == 1 && !cal.log_bkg_norm && !opt_is_set(OPT_SEP_NO_FUSION);
-  p->allow_walk = n_comp == 1;  // (a multi-component batch runs the tile kernel: its per-dataset form must round alike)
+  p->allow_walk = true;  // (the batched multi-component step has a walk form too: both round alike)
   if (fused) {
     const float* in = flux[0];
     if (cal.shift_xy) {

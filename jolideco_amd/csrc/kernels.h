@@ -145,9 +145,13 @@ int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table
 int walk_joint_step(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H,
                     int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n, float coef,
                     int accumulate, int* n_partials, hipStream_t stream);
-int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H, int W,
-                            int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream,
-                            const double* fin_partials, double fin_scale, int fin_count, int* fin_done);
+int walk_conv_poisson_batch_multi(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
+                                  const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
+                                  double* partials, float eps, float inv_n, int write_grad, int* n_partials,
+                                  hipStream_t stream);
+int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
+                            float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
+                            hipStream_t stream, const double* fin_partials, double fin_scale, int fin_count, int* fin_done);
 // out[d][0] = scale * sum(partials[d * n .. d * n + n - 1]) + offset[d]   (one block per output, fixed order)
 int launch_finalize_rows(const double* partials, int n, int n_out, double scale, const float* offset_host,
                          float* const* out, hipStream_t stream);

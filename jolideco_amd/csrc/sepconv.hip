@@ -645,11 +645,11 @@ int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, c
                                   hipStream_t stream) {
   int rc = check_batch(n, n_comp);
   if (rc) return rc;
-  if (n_comp == 1) {
-    rc = walk_conv_poisson_batch(n, flux[0], table, table_dev, H, W, kh, kw, oy, ox, partials, eps, inv_n, write_grad,
-                                 n_partials, stream);
-    if (rc != JD_WALK_NOT_TAKEN) return rc;
-  }
+  rc = n_comp == 1 ? walk_conv_poisson_batch(n, flux[0], table, table_dev, H, W, kh, kw, oy, ox, partials, eps, inv_n,
+                                             write_grad, n_partials, stream)
+                   : walk_conv_poisson_batch_multi(n, n_comp, flux, table, table_dev, H, W, kh, kw, oy, ox, partials, eps,
+                                                   inv_n, write_grad, n_partials, stream);
+  if (rc != JD_WALK_NOT_TAKEN) return rc;
   *n_partials = sep_conv_tiles(H, W);
   SepArgs a{};
   a.in = flux[0], a.in_c1 = n_comp > 1 ? flux[1] : nullptr, a.in_c2 = n_comp > 2 ? flux[2] : nullptr;
@@ -677,10 +677,10 @@ int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTab
   if (rc) return rc;
   if (comp < 0 || comp >= n_comp) return fail(JD_ERR_INVALID, "separable batch: component %d not in [0, %d)", comp, n_comp);
   if (fin_done) *fin_done = 0;
-  if (n_comp == 1) {
+  {
     int folded = 0;
-    rc = walk_conv_adjoint_batch(n, table, table_dev, grad, H, W, kh, kw, oy, ox, coef, accumulate, stream, fin_partials,
-                                 fin_scale, fin_count, &folded);
+    rc = walk_conv_adjoint_batch(n, n_comp, comp, table, table_dev, grad, H, W, kh, kw, oy, ox, coef, accumulate, stream,
+                                 fin_partials, fin_scale, fin_count, &folded);
     if (rc != JD_WALK_NOT_TAKEN) {
       if (fin_done) *fin_done = folded;
       return rc;

@@ -18,6 +18,9 @@
 // PER DATASET walking the same strip; finished rows go to an LDS exchange buffer in groups of 4, and the waves add them
 // in dataset order -- the additions of the per-dataset launches, bit for bit -- into the gradient image, which is read
 // and written once.
+#include <cmath>
+#include <utility>
+
 #include "jd_common.h"
 #include "kernels.h"
 
@@ -43,6 +46,15 @@ constexpr int WALK_PREFETCH_ADJ = 3;
 // 51.8 (walk), of two 65 / 77, of four 129 / 112, of eight 282 / 199, of one 4096^2 dataset 138 / 118
 constexpr size_t WALK_MIN_PIXELS = (size_t)1 << 24;
 
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 template <int C> struct Vec;
 template <> struct Vec<2> { typedef float T __attribute__((ext_vector_type(2))); };
 template <> struct Vec<4> { typedef float T __attribute__((ext_vector_type(4))); };
@@ -67,6 +79,7 @@ struct WalkArgs {
   int n_batch;                 // > 0: per-dataset pointers come from `table`
   const SepBatchTable* table;
   int d_base;                  // batched adjoint: first dataset of this launch (wave w = dataset d_base + w)
+  int n_comp, comp;            // batched adjoint: components per dataset and the one of this launch (table entry d * n_comp + comp)
   const double* fin_partials;  // batched adjoint: blocks < fin_n finalise the losses of the forward launch
   double fin_scale;
   int fin_count, fin_n;
@@ -132,10 +145,11 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
   typedef vC __attribute__((address_space(1)))* gv;
   const bool batch = a.n_batch > 0;
   const int d = XCHG ? a.d_base + wv : dsel;
-  const gcp in = (gcp)(batch && !POISSON ? a.table->g[d] : a.in);
-  const gcp in_scale = (gcp)(batch ? a.table->scale[d] : a.in_scale);
-  const gcp op = (gcp)(batch ? a.table->op[d] : a.op);
-  const gcp out_scale = (gcp)(batch ? a.table->scale[d] : a.out_scale);
+  const int slot = XCHG ? d * a.n_comp + a.comp : d;  // (a batched forward launch of this kernel has one component)
+  const gcp in = (gcp)(batch && !POISSON ? a.table->g[slot] : a.in);
+  const gcp in_scale = (gcp)(batch ? a.table->scale[slot] : a.in_scale);
+  const gcp op = (gcp)(batch ? a.table->op[slot] : a.op);
+  const gcp out_scale = (gcp)(batch ? a.table->scale[slot] : a.out_scale);
   const gcp background = (gcp)(batch ? a.table->bkg[d] : a.background);
   const gcp counts = (gcp)(batch ? a.table->cnt[d] : a.counts);
   const gp out = (gp)(POISSON && batch ? a.table->g[d] : a.out);
@@ -331,6 +345,216 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
     }
   }
   if (POISSON) {
+    loss = wave_sum(loss);
+    if (lane == 0) a.partials[(size_t)d * n_tiles + tile] = loss;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Forward models + Poisson pass of datasets with SEVERAL flux components (models/npred.py:241-261: the components are
+// clipped one by one, summed, then the background is added).  A block is one wave PER COMPONENT walking the same strip of
+// the same dataset: every wave convolves its component exactly as walk_kernel does (same arithmetic, same bits), parks
+// the finished rows in LDS in groups of MG, and after a barrier every wave runs the Poisson pass of the group's rows on
+// the sum of all components' clipped rows and writes the gradient image of ITS component (masked where its own
+// convolution is negative).  Background and counts are fetched by every wave (the second fetch is an L2 hit) so that
+// each wave issues the same loads in every step (see walk_kernel).
+constexpr int MG = 6;         // rows per group (a divisor of WS)
+constexpr int MULTI_MAX = 4;  // components (= waves per block)
+
+struct MultiArgs {
+  const float* flux[MULTI_MAX];
+  double* partials;
+  int H, W, strips, tiles_y, rows;
+  int taps_u, taps_v, kh, kw, offy, offx;
+  float eps, inv_n;
+  int write_grad, n_comp;
+  const SepBatchTable* table;
+  int* guard;
+};
+
+template <int C, int P>
+__global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a) {
+#pragma clang fp contract(off)
+  typedef typename Vec<C>::T vC;
+  static_assert(WS % MG == 0 && WS % P == 0, "group size and prefetch depth must divide the rotation period");
+  constexpr int NX = 2 * WH / C;
+  constexpr int NWIN = 2 * WH + C;
+  // LDS (dynamic, n_comp x 64 C x (2 + 3 MG) floats): per wave a row buffer; [row of the group][component][lane * C]
+  // finished convolution rows; per wave [row][background | counts][lane * C]
+  extern __shared__ __attribute__((aligned(16))) float multi_lds[];
+  const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6), nc = a.n_comp;
+  float* const cbuf = multi_lds + nc * 2 * 64 * C;
+  float* const bcbase = cbuf + MG * nc * 64 * C;
+  const int n_tiles = a.strips * a.tiles_y;
+  const int per_xcd = (n_tiles + 7) / 8;
+  const int q = blockIdx.x / 8;
+  const int d = q / per_xcd;  // dataset-major grid
+  const int tile = (blockIdx.x % 8) * per_xcd + q % per_xcd;
+  if (tile >= n_tiles) return;  // (block-uniform)
+  const int sx = tile / a.tiles_y, ty = tile - sx * a.tiles_y;
+
+  typedef const float __attribute__((address_space(1)))* gcp;
+  typedef float __attribute__((address_space(1)))* gp;
+  typedef const vC __attribute__((address_space(1)))* gcv;
+  typedef vC __attribute__((address_space(1)))* gv;
+  const int slot = d * nc + wv;
+  const gcp in = (gcp)(wv == 0 ? a.flux[0] : wv == 1 ? a.flux[1] : wv == 2 ? a.flux[2] : a.flux[3]);
+  const gcp in_scale = (gcp)a.table->scale[slot];
+  const gcp op = (gcp)a.table->op[slot];
+  const gcp background = (gcp)a.table->bkg[d];
+  const gcp counts = (gcp)a.table->cnt[d];
+  const gp out = (gp)a.table->g[slot];
+
+  float tu[WK], tv[WK];
+  {
+    if ((int)op[0] != 1 && lane == 0) *a.guard = 1;
+    float mu = 0.f, mv = 0.f;
+    const int iu = lane - a.offy, iv = lane - a.offx;
+    if (iu >= 0 && iu < a.kh) mu = op[a.taps_u + iu];
+    if (iv >= 0 && iv < a.kw) mv = op[a.taps_v + iv];
+#pragma unroll
+    for (int t = 0; t < WK; ++t) {
+      tu[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), t));
+      tv[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mv), t));
+    }
+  }
+
+  const int X0 = sx * 64 * C;
+  const int xm = X0 - WH + C * lane, xe = X0 - WH + 64 * C + C * lane, xo = X0 + C * lane;
+  const bool vm = xm >= 0 && xm < a.W, ve = lane < NX && xe < a.W, vo = xo < a.W;
+  const int xd = X0 - WH + 64 * C + C * (lane % NX);
+  const unsigned om = vm ? xm : 0, oe = ve ? xe : (xd < a.W ? xd : 0), oo = vo ? xo : 0;
+  const int Y0 = ty * a.rows, y_end = min(Y0 + a.rows, a.H);
+  const int r_begin = Y0 - WH, r_end = min(y_end + WH, a.H);
+  float* rb = multi_lds + wv * 2 * 64 * C;
+  float* bc = bcbase + wv * MG * 2 * 64 * C;
+
+  struct Row { vC a, s, xa, xs; };
+  struct Epi { vC p, q; };
+  auto row_ok = [&](int rr) { return rr >= 0 && rr < r_end; };
+  auto load_row = [&](int rr, Row& w) {
+    const size_t base = (size_t)min(max(rr, 0), r_end - 1) * a.W;
+    w.a = *(gcv)(in + base + om);
+    w.s = *(gcv)(in_scale + base + om);
+    w.xa = *(gcv)(in + base + oe);
+    w.xs = *(gcv)(in_scale + base + oe);
+  };
+  auto epi_ok = [&](int y) { return y >= Y0 && y < y_end; };
+  auto load_epi = [&](int y, Epi& e) {
+    const size_t base = (size_t)min(max(y, Y0), y_end - 1) * a.W;
+    e.p = *(gcv)(background + base + oo);
+    e.q = *(gcv)(counts + base + oo);
+  };
+
+  vC acc[WS];
+#pragma unroll
+  for (int s = 0; s < WS; ++s)
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[s][c] = 0.f;
+  Row pf[P];
+  Epi ep[P];
+  double loss = 0.0;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    load_row(r_begin + p, pf[p]);
+    load_epi(r_begin + p - WH, ep[p]);
+  }
+
+  for (int r0 = r_begin; r0 < y_end + WH + MG - 1; r0 += WS) {
+    // (the 18 rotation states as a compile-time sequence: with `#pragma unroll` this kernel's accumulators ended up in
+    // scratch at C = 4 -- the unrolling came after the last scalar-replacement pass)
+    static_for<WS>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int rr = r0 + i;
+      Row& cur = pf[i % P];
+      Epi& ce = ep[i % P];
+      const bool live = row_ok(rr);
+      if (live) {
+        vC prod = cur.a * cur.s;
+#pragma unroll
+        for (int c = 0; c < C; ++c) prod[c] = vm ? prod[c] : 0.f;
+        *reinterpret_cast<vC*>(rb + C * lane) = prod;
+        vC px = cur.xa * cur.xs;
+#pragma unroll
+        for (int c = 0; c < C; ++c) px[c] = ve ? px[c] : 0.f;
+        *reinterpret_cast<vC*>(rb + 64 * C + C * lane) = px;
+      }
+      load_row(rr + P, cur);
+      if (live) {
+        wave_lds_fence();
+        float w[NWIN];
+#pragma unroll
+        for (int k = 0; k < NWIN / C; ++k) {
+          const vC t = *reinterpret_cast<const vC*>(rb + C * lane + C * k);
+#pragma unroll
+          for (int c = 0; c < C; ++c) w[C * k + c] = t[c];
+        }
+        wave_lds_fence();
+        float h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = tv[0] * w[c];
+#pragma unroll
+        for (int t = 1; t < WK; ++t)
+#pragma unroll
+          for (int c = 0; c < C; ++c) h[c] = fmaf(tv[t], w[c + t], h[c]);
+#pragma unroll
+        for (int t = 0; t < WK; ++t) {
+          const int s = (i + WH - t + WS) % WS;
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[s][c] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], acc[s][c]);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[(i + WH) % WS][c] = 0.f;
+      }
+
+      // ---- output row y = rr - 8 of this component is complete: park it (and this wave's copy of background, counts)
+      const int y = rr - WH;
+      constexpr int gy = (i + WS - 2 * WH) % MG;  // (y - Y0 = i - 16 mod 18: tiles start on a group boundary, static)
+      if (epi_ok(y)) {
+        *reinterpret_cast<vC*>(cbuf + (size_t)((gy * nc + wv) * 64 + lane) * C) = acc[(i + WS - WH) % WS];
+        *reinterpret_cast<vC*>(bc + (size_t)((gy * 2 + 0) * 64 + lane) * C) = ce.p;
+        *reinterpret_cast<vC*>(bc + (size_t)((gy * 2 + 1) * 64 + lane) * C) = ce.q;
+      }
+      load_epi(y + P, ce);
+      if (gy == MG - 1 && y - gy >= Y0 && y - gy < y_end) {  // (block-uniform) the group is complete in every wave
+        __syncthreads();
+#pragma unroll
+        for (int g2 = 0; g2 < MG; ++g2) {
+          const int yy = y - gy + g2;
+          if (yy >= y_end) continue;
+          vC nsum;
+#pragma unroll
+          for (int c = 0; c < C; ++c) nsum[c] = 0.f;
+          vC own = nsum;
+          for (int k = 0; k < nc; ++k) {  // 0 + clip(conv_0) + clip(conv_1) + ...: the order of poisson_fused_kernel
+            const vC cv = *reinterpret_cast<const vC*>(cbuf + (size_t)((g2 * nc + k) * 64 + lane) * C);
+#pragma unroll
+            for (int c = 0; c < C; ++c) nsum[c] += fmaxf(cv[c], 0.f);
+            if (k == wv) own = cv;
+          }
+          const vC b = *reinterpret_cast<const vC*>(bc + (size_t)((g2 * 2 + 0) * 64 + lane) * C);
+          const vC cn = *reinterpret_cast<const vC*>(bc + (size_t)((g2 * 2 + 1) * 64 + lane) * C);
+          vC gvec;
+          float rowsum = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const float n = nsum[c] + b[c];
+            float term, g;
+            poisson_point(n, cn[c], a.eps, a.inv_n, term, g);
+            rowsum += term;
+            gvec[c] = own[c] >= 0.f ? g : 0.f;
+          }
+          if (vo) {
+            if (wv == 0) loss += (double)rowsum;
+            if (a.write_grad) *(gv)(out + (size_t)yy * a.W + oo) = gvec;
+          }
+        }
+        __syncthreads();  // the group's LDS rows may be overwritten
+      }
+    });
+  }
+  if (wv == 0) {
     loss = wave_sum(loss);
     if (lane == 0) a.partials[(size_t)d * n_tiles + tile] = loss;
   }
@@ -698,11 +922,13 @@ bool walk_takes_launch(int H, int W, int n_datasets, int kh, int kw, int oy, int
 bool sep_batch_is_mixed(int n, int n_comp, const SepBatchTable& table, int H, int W, int kh, int kw, int oy, int ox) {
   int offy, offx;
   // (the per-dataset calls a mixed batch falls back to decide with n = 1)
-  if (n_comp != 1 || !walk_geometry(H, W, n, kh, kw, oy, ox, 0, &offy, &offx) || !walk_geometry(H, W, n, kh, kw, oy, ox, 1, &offy, &offx))
+  if (n_comp > MULTI_MAX || !walk_geometry(H, W, n * n_comp, kh, kw, oy, ox, 0, &offy, &offx) ||
+      !walk_geometry(H, W, n * n_comp, kh, kw, oy, ox, 1, &offy, &offx))
     return false;  // no dataset takes the walk kernels
   int yes = 0;
-  for (int d = 0; d < n; ++d) yes += dataset_walkable(table, d, d) ? 1 : 0;
-  return yes != 0 && yes != n;
+  for (int d = 0; d < n; ++d)
+    for (int c = 0; c < n_comp; ++c) yes += dataset_walkable(table, d * n_comp + c, d) ? 1 : 0;
+  return yes != 0 && yes != n * n_comp;
 }
 
 // out (+)= coef * out_scale * conv/corr_same(in * in_scale, psf)      [launch_sep_conv's contract]
@@ -760,19 +986,88 @@ int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table
   return launch_walk<true, true>(a, C, n, stream);
 }
 
+// Several flux components: forward models + Poisson passes of all datasets in one launch, one wave per component
+// (walk_multi_kernel); *n_partials = partial sums per dataset
+int walk_conv_poisson_batch_multi(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
+                                  const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
+                                  double* partials, float eps, float inv_n, int write_grad, int* n_partials,
+                                  hipStream_t stream) {
+  if (n_comp < 2 || n_comp > MULTI_MAX) return JD_WALK_NOT_TAKEN;
+  for (int c = 0; c < n_comp; ++c)
+    if (!aligned16(flux[c])) return JD_WALK_NOT_TAKEN;
+  for (int d = 0; d < n; ++d)
+    for (int c = 0; c < n_comp; ++c)
+      if (!dataset_walkable(table, d * n_comp + c, d)) return JD_WALK_NOT_TAKEN;
+  MultiArgs a{};
+  for (int c = 0; c < n_comp; ++c) a.flux[c] = flux[c];
+  a.partials = partials, a.H = H, a.W = W, a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_comp = n_comp;
+  a.table = table_dev;
+  if (!walk_geometry(H, W, n * n_comp, kh, kw, oy, ox, 0, &a.offy, &a.offx)) return JD_WALK_NOT_TAKEN;
+  const SepGeom g = sep_geom(kh, kw, oy, ox, false);
+  a.kh = kh, a.kw = kw, a.taps_u = 4, a.taps_v = 4 + g.khp + g.shiftx;
+  // 4 columns per lane (184 registers: 2 waves per SIMD) unless that leaves CUs without a block
+  int C = opt_value(OPT_SEP_WALK_COLS, 0);
+  const int per_cu4 = 8 / n_comp;
+  auto blocks_of = [&](int c, int r) { return (long)((W + 64 * c - 1) / (64 * c)) * ((H + r - 1) / r) * n; };
+  if (C != 2 && C != 4) C = blocks_of(4, 36) >= (long)device_cus() * per_cu4 / 2 ? 4 : 2;
+  const int per_cu = (C == 4 ? 8 : 16) / n_comp;  // (126 registers at C = 2: 4 waves per SIMD)
+  // Rows per tile (a multiple of MG).  Measured inside the fit, 2048^2 x 16 x 2 components, C = 4: 72 / 96 / 120 / 144 /
+  // 168 / 192 / 240 / 294 rows = 432 / 434 / 456 / 416-436 / 465 / 505 / 550 / 510 us: unlike the one-component launch this
+  // one prefers SEVERAL rounds of short blocks to one round of long ones, and loses what its last round leaves empty
+  // (120 rows: 2.25 rounds).  The tallest tile of 72-168 rows whose last round is at least 90 % full.
+  const long slots = (long)device_cus() * (per_cu < 1 ? 1 : per_cu);
+  int rows = 72;
+  double best = 0.0;
+  for (int r = 168; r >= 72; r -= MG) {
+    const double rounds = (double)blocks_of(C, r) / (double)slots;
+    const double eff = rounds / std::ceil(rounds);
+    if (eff >= 0.9) {
+      rows = r;
+      break;
+    }
+    if (eff > best) best = eff, rows = r;
+  }
+  if (rows > (H + MG - 1) / MG * MG) rows = (H + MG - 1) / MG * MG;
+  const int orows = opt_value(OPT_SEP_WALK_ROWS, 0);
+  if (orows >= 18) rows = orows;
+  rows = (rows + MG - 1) / MG * MG;
+  a.rows = rows, a.strips = (W + 64 * C - 1) / (64 * C), a.tiles_y = (H + rows - 1) / rows;
+  int rc = sep_guard_check(&a.guard);
+  if (rc) return rc;
+  const int n_tiles = a.strips * a.tiles_y;
+  *n_partials = n_tiles;
+  const unsigned blocks = (unsigned)(((n_tiles + 7) / 8) * 8 * n);
+  const size_t lds = (size_t)n_comp * 64 * C * (2 + 3 * MG) * sizeof(float);
+  ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
+  if (C == 4) {
+    static size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+      JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(walk_multi_kernel<4, WALK_PREFETCH>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_set = lds;
+    }
+    hipLaunchKernelGGL((walk_multi_kernel<4, WALK_PREFETCH>), dim3(blocks), dim3(64 * n_comp), lds, stream, a);
+  } else {
+    hipLaunchKernelGGL((walk_multi_kernel<2, WALK_PREFETCH>), dim3(blocks), dim3(64 * n_comp), lds, stream, a);
+  }
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
 // grad (+)= coef * sum_d scale[d] * corr_same(g[d], psf_d), the datasets added in order: one wave per dataset, up to 8
 // datasets per launch, later chunks accumulate (the same additions in the same order).  With fin_partials, blocks
 // d < n of the first launch also turn the fin_count partial sums of dataset d into its loss (*fin_done <- 1)
-int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTable* table_dev, float* grad, int H, int W,
-                            int kh, int kw, int oy, int ox, float coef, int accumulate, hipStream_t stream,
-                            const double* fin_partials, double fin_scale, int fin_count, int* fin_done) {
+int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
+                            float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
+                            hipStream_t stream, const double* fin_partials, double fin_scale, int fin_count, int* fin_done) {
   *fin_done = 0;
   if (!aligned16(grad)) return JD_WALK_NOT_TAKEN;
   for (int d = 0; d < n; ++d)
-    if (!dataset_walkable(table, d, d)) return JD_WALK_NOT_TAKEN;
+    for (int c = 0; c < n_comp; ++c)  // (all components: the forward launch of the step must have been a walk launch too)
+      if (!dataset_walkable(table, d * n_comp + c, d)) return JD_WALK_NOT_TAKEN;
   WalkArgs a{};
-  a.out = grad, a.H = H, a.W = W, a.coef = coef, a.table = table_dev;
-  if (!walk_setup(a, n, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
+  a.out = grad, a.H = H, a.W = W, a.coef = coef, a.table = table_dev, a.n_comp = n_comp, a.comp = comp;
+  if (!walk_setup(a, n * n_comp, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
   // Block shape.  6-8 datasets: 4 columns per lane (1 KB per row and stream), exchange groups of 6 rows: 112 KB of LDS, ONE
   // block of 6-8 waves per CU; fewer datasets: 2 columns per lane, as many blocks per CU as LDS (exchange buffer) and
   // registers (86: 5 waves per SIMD) allow.  Rows per tile: a multiple of every exchange group size, the smallest that
@@ -818,7 +1113,8 @@ int walk_conv_adjoint_batch(int n, const SepBatchTable& table, const SepBatchTab
       hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else {  // a single dataset: the plain walk (same arithmetic: out (+)= (coef * corr) * scale)
       WalkArgs b = a;
-      b.n_batch = 0, b.table = nullptr, b.in = table.g[d0], b.op = table.op[d0], b.out_scale = table.scale[d0];
+      const int slot = d0 * n_comp + comp;
+      b.n_batch = 0, b.table = nullptr, b.in = table.g[slot], b.op = table.op[slot], b.out_scale = table.scale[slot];
       int C, r1;
       walk_shape(b, 1, true, &C, &r1);
       walk_tiles(b, C, r1);

@@ -536,15 +536,19 @@ def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch, jd_option, 
         np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
 
 
+@pytest.mark.parametrize("kernels", ["tile", "walk"])
 @pytest.mark.parametrize("shape", [(72, 136), (40, 75)], ids=["w136_vector", "w75_scalar"])
-def test_batched_joint_step_with_two_components(monkeypatch, shape):
+def test_batched_joint_step_with_two_components(monkeypatch, jd_option, shape, kernels):
     """The batched joint step with several flux components (BASELINE config 5 in small: "extended" + "points", per-component
     PSFs, jd_npred_poisson_batch_multi_fwd_bwd): every dataset's forward model walks over the components inside the
     block, clips each, and writes one masked gradient image per component; one adjoint launch per component.  Same
-    trajectory as the per-dataset loop, bit for bit, for both components."""
+    trajectory as the per-dataset loop, bit for bit, for both components -- with the tile kernel and with the strip-walk
+    kernels (walk_multi_kernel: one wave per component, the finished rows meet in LDS for the Poisson pass; the width
+    that is not a multiple of 4 stays with the tile kernel either way)."""
     from jolideco_amd import FluxComponents, InverseGammaPrior, MAPDeconvolver, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import gaussian_kernel, synthetic_observations
 
+    jd_option("JD_SEP_WALK", 1 if kernels == "walk" else 0)
     datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=4, seed=11)
     for i, d in enumerate(datasets.values()):
         d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
@@ -570,12 +574,14 @@ def test_batched_joint_step_with_two_components(monkeypatch, shape):
         np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
 
 
-def test_batched_joint_step_with_four_components(monkeypatch):
+@pytest.mark.parametrize("kernels", ["tile", "walk"])
+def test_batched_joint_step_with_four_components(monkeypatch, jd_option, kernels):
     """Four flux components (the most the batched step takes; a fifth falls back to the per-dataset loop), one of them
     frozen: same bits as the loop."""
     from jolideco_amd import FluxComponents, MAPDeconvolver, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import gaussian_kernel, synthetic_observations
 
+    jd_option("JD_SEP_WALK", 1 if kernels == "walk" else 0)
     datasets, _, flux_init = synthetic_observations(shape=(48, 80), n_obs=3, seed=5)
     names = ["a", "b", "c", "d", "e"]
     for n_comp in (4, 5):

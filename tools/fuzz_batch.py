@@ -25,7 +25,7 @@ for case in range(n_cases):
     kh, kw = int(rs.randint(3, 34)), int(rs.randint(3, 34))
     n_obs, n_comp = int(rs.randint(2, 7)), int(rs.randint(1, 4))
     if walk and case % 2 == 0:
-        W, kh, kw, n_comp = (W + 3) // 4 * 4, int(rs.randint(3, 18)), int(rs.randint(3, 18)), 1
+        W, kh, kw, n_comp = (W + 3) // 4 * 4, int(rs.randint(3, 18)), int(rs.randint(3, 18)), int(rs.randint(1, 4))
         n_obs = int(rs.randint(2, 12))
     names = ["a", "b", "c"][:n_comp]
 
