@@ -546,6 +546,14 @@ class FitSession:
             return self.dist.shard_range(prior.n_patch_rows(state.shape))
         return None
 
+    def _apply_step(self, states, stepped):
+        """The optimizer step of the components the prior's gather kernel has not stepped already.  The hook keeps its
+        two-argument form `(states, step)` for a replacement installed by a test (which also switches the fusion off)."""
+        if stepped:
+            self.cfg._optimizer_step(states, self.step, stepped)
+        else:
+            self.cfg._optimizer_step(states, self.step)
+
     def _fuse_step(self, st, prior):
         """The prior of this component applies the optimizer step itself (`device_fwd_bwd_step`): single process (the
         gradient buffer is complete when the prior runs), not frozen, a prior that supports it, stride >= 4, and the
@@ -648,7 +656,7 @@ class FitSession:
             elif dist.world_size > 1:
                 self._timed("all_reduce_blocking", lambda: dist.all_reduce_sum(self.comm))
             self.step += 1
-            cfg._optimizer_step(states, self.step, stepped)
+            self._apply_step(states, stepped)
             for _, li in self.local_idx:
                 self._cal_step(li)
         else:
@@ -667,7 +675,7 @@ class FitSession:
                     else:
                         prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef)
                 self.step += 1
-                cfg._optimizer_step(states, self.step, stepped)
+                self._apply_step(states, stepped)
                 self._cal_step(li)
             # ---- trace on the STALE fluxes of the last step (core.py:247) ---------------------
             stale = [st.flux_trace for st in states]

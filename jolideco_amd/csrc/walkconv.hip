@@ -605,7 +605,7 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
   __shared__ __attribute__((aligned(16))) float xbuf[XCHG ? 2 * XG * XW * 64 * C : 4];
 
   const int lane = threadIdx.x & 63;
-  const int wv = XCHG ? (int)(threadIdx.x >> 6) : 0;
+  const int wv = XCHG ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;  // (scalar: table pointers stay in SGPRs)
   const int nb = XCHG ? (int)(blockDim.x >> 6) : 1;
   const int n_tiles = a.strips * a.tiles_y;
   const int per_xcd = (n_tiles + 7) / 8;
@@ -617,6 +617,8 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
   typedef float __attribute__((address_space(1)))* gp;
   typedef const vC __attribute__((address_space(1)))* gcv;
   typedef vC __attribute__((address_space(1)))* gv;
+  typedef const char __attribute__((address_space(1)))* gcb;
+  typedef char __attribute__((address_space(1)))* gb8;
   const bool batch = a.n_batch > 0;
   const int d = a.d_base + wv;
   const gcp flux = (gcp)a.flux;
@@ -649,6 +651,10 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
   const bool vo = inner && vg;
   const int xd = X0 - WH + 64 * C + C * (lane % NX);
   const unsigned om = vm ? xm : 0, oe = ve ? xe : (xd >= 0 && xd < a.W ? xd : 0), oo = vg ? xo : 0;
+  // (uniform row pointer + 32-bit lane byte offset: the loads take the scalar-base addressing form, no 64-bit VALU adds)
+  const unsigned omb = om * 4u, oeb = oe * 4u, oob = oo * 4u;
+  auto ld = [](gcp p, size_t row, unsigned off) -> vC { return *(gcv)((gcb)(p + row) + off); };
+  auto st = [](gp p, size_t row, unsigned off, vC v) { *(gv)((gb8)(p + row) + off) = v; };
   const int Y0 = ty * a.rows, y_end = min(Y0 + a.rows, a.H);
   const int r_begin = Y0 - 2 * WH, r_end = min(y_end + 2 * WH, a.H);
   const int g_lo = max(Y0 - WH, 0), g_hi = min(y_end + WH, a.H);  // g rows this tile needs that exist
@@ -660,21 +666,21 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
   auto row_ok = [&](int rr) { return rr >= 0 && rr < r_end; };
   auto load_row = [&](int rr, Row& w) {
     const size_t base = (size_t)min(max(rr, 0), r_end - 1) * a.W;
-    w.a = *(gcv)(flux + base + om);
-    w.s = *(gcv)(expo + base + om);
-    w.xa = *(gcv)(flux + base + oe);
-    w.xs = *(gcv)(expo + base + oe);
+    w.a = ld(flux, base, omb);
+    w.s = ld(expo, base, omb);
+    w.xa = ld(flux, base, oeb);
+    w.xs = ld(expo, base, oeb);
   };
   auto load_epf = [&](int y, EpiF& e) {
     const size_t base = (size_t)min(max(y, g_lo), g_hi - 1) * a.W;
-    e.b = *(gcv)(background + base + oo);
-    e.c = *(gcv)(counts + base + oo);
+    e.b = ld(background, base, oob);
+    e.c = ld(counts, base, oob);
   };
   struct EpiA { vC e, o; };  // exposure and (one dataset per launch, accumulate) the previous gradient of a gradient row
   auto load_epa = [&](int y, EpiA& e) {
     const size_t base = (size_t)min(max(y, Y0), y_end - 1) * a.W;
-    e.e = *(gcv)(expo + base + oo);
-    if (!XCHG && a.accumulate) e.o = *(gcv)(out + base + oo);
+    e.e = ld(expo, base, oob);
+    if (!XCHG && a.accumulate) e.o = ld((gcp)out, base, oob);
   };
 
   vC accF[WS], accA[WS];
@@ -697,8 +703,8 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
   for (int c = 0; c < C; ++c) oprev[c] = 0.f;
 
   for (int r0 = r_begin; r0 < y_end + 2 * WH + (XCHG ? XG - 1 : 0); r0 += WS) {
-#pragma unroll
-    for (int i = 0; i < WS; ++i) {
+    static_for<WS>([&](auto ic) {  // (compile-time rotation state: the accumulators stay in registers)
+      constexpr int i = decltype(ic)::value;
       const int rr = r0 + i;
       Row& cur = pf[i % P];
       EpiF& cf = epf[i % P];
@@ -733,12 +739,16 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
         for (int t = 1; t < WK; ++t)
 #pragma unroll
           for (int c = 0; c < C; ++c) h[c] = fmaf(tv[t], w[c + t], h[c]);
+        vC hv;
 #pragma unroll
-        for (int t = 0; t < WK; ++t) {
-          const int s = (i + WH - t + WS) % WS;
+        for (int c = 0; c < C; ++c) hv[c] = h[c];
+        static_for<WK>([&](auto tc) {  // (packed FMAs: the same fused operation per element)
+          constexpr int t = decltype(tc)::value, s = (i + WH - t + WS) % WS;
+          vC tt;
 #pragma unroll
-          for (int c = 0; c < C; ++c) accF[s][c] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], accF[s][c]);
-        }
+          for (int c = 0; c < C; ++c) tt[c] = tu[t];
+          accF[s] = t == 0 ? tt * hv : __builtin_elementwise_fma(tt, hv, accF[s]);
+        });
       } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) accF[(i + WH) % WS][c] = 0.f;
@@ -781,12 +791,16 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
         for (int t = 1; t < WK; ++t)
 #pragma unroll
           for (int c = 0; c < C; ++c) h[c] = fmaf(tv[WK - 1 - t], w[c + t], h[c]);
+        vC hv;
 #pragma unroll
-        for (int t = 0; t < WK; ++t) {
-          const int s = (i - t + WS) % WS;
+        for (int c = 0; c < C; ++c) hv[c] = h[c];
+        static_for<WK>([&](auto tc) {
+          constexpr int t = decltype(tc)::value, s = (i - t + WS) % WS;
+          vC tt;
 #pragma unroll
-          for (int c = 0; c < C; ++c) accA[s][c] = t == 0 ? tu[WK - 1] * h[c] : fmaf(tu[WK - 1 - t], h[c], accA[s][c]);
-        }
+          for (int c = 0; c < C; ++c) tt[c] = tu[WK - 1 - t];
+          accA[s] = t == 0 ? tt * hv : __builtin_elementwise_fma(tt, hv, accA[s]);
+        });
       } else {
 #pragma unroll
         for (int c = 0; c < C; ++c) accA[i % WS][c] = 0.f;
@@ -801,7 +815,7 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
         for (int c = 0; c < C; ++c) pv[c] = (a.coef * corr[c]) * ca.e[c];
         if constexpr (!XCHG) {
           if (a.accumulate) pv = ca.o + pv;
-          if (vo) *(gv)(out + (size_t)y2 * a.W + oo) = pv;
+          if (vo) st(out, (size_t)y2 * a.W, oob, pv);
         } else {
           const int k = (y2 - Y0) / XG, gy = (i + 2 * WS - 4 * WH) % XG;
           *reinterpret_cast<vC*>(xbuf + (size_t)((((k & 1) * XG + gy) * XW + wv) * 64 + lane) * C) = pv;
@@ -812,7 +826,7 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
         const int mine = wv < XG ? wv : XG - 1;
         if (gy == 0) {
           const int yy = min(max(y2 + mine, Y0), y_end - 1);
-          oprev = *(gcv)(out + (size_t)yy * a.W + oo);
+          oprev = ld((gcp)out, (size_t)yy * a.W, oob);
         }
         if (gy == XG - 1 && y2 - gy >= Y0 && y2 - gy < y_end) {  // (block-uniform) the group is complete
           __syncthreads();
@@ -822,11 +836,11 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
             const vC pd = *reinterpret_cast<const vC*>(xbuf + (size_t)((((k & 1) * XG + mine) * XW + dd) * 64 + lane) * C);
             res = dd == 0 && !(a.accumulate || a.d_base > 0) ? pd : res + pd;
           }
-          if (vo && wv < XG && yy < y_end) *(gv)(out + (size_t)yy * a.W + oo) = res;
+          if (vo && wv < XG && yy < y_end) st(out, (size_t)yy * a.W, oob, res);
         }
       }
       load_epa(y2 + P, ca);
-    }
+    });
   }
   loss = wave_sum(loss);
   if (lane == 0) a.partials[(size_t)d * n_tiles + tile] = loss;
@@ -1137,8 +1151,10 @@ int walk_joint_step(int n, const float* flux, const SepBatchTable& table, const 
                     int accumulate, int* n_partials, hipStream_t stream) {
   // Measured inside the fit (tools/ab.py, 2048^2 x 8): 201-205 us against 125 + 77.5 us for the forward and the adjoint
   // launch -- the kernel saves 45 % of the HBM traffic but issues 40 % more instructions (halo, two columns per lane), and
-  // with its 150 registers only two waves per SIMD hide each other's latencies; 4 datasets: 134 against 63 + 49 us.  So it
-  // runs only on request (option JD_SEP_JOINT = 1); its results are those of the two-launch path bit for bit.
+  // with its 150 registers only two waves per SIMD hide each other's latencies; 4 datasets: 134 against 63 + 49 us.
+  // Packed FMAs in the two column passes (13 % fewer vector instructions) took the kernel alone from 201 to 197 us:
+  // it is not the instruction count that bounds it.  So it runs only on request (option JD_SEP_JOINT = 1); its results
+  // are those of the two-launch path bit for bit.
   const int mode = opt_value(OPT_SEP_JOINT, 0);
   if (mode != 1 || !aligned16(flux) || !aligned16(grad)) return JD_WALK_NOT_TAKEN;
   for (int d = 0; d < n; ++d)
