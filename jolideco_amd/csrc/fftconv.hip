@@ -575,6 +575,13 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
   // launch less per step)
   if (!grad_flux) return launch_finalize_rows(p->partials_batch, n_part, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s);
   int folded = 0;
+  // all components in one adjoint launch where the strip-walk kernels apply (several components, or 9-16 datasets)
+  rc = walk_conv_adjoint_batch_all(n_datasets, n_comp, table, table_dev, grad_flux, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
+                                   grad_scale, accumulate, s, p->partials_batch, 1.0 / n_pix, n_part, &folded);
+  if (rc != JD_WALK_NOT_TAKEN) {
+    if (rc || folded) return rc;
+    return launch_finalize_rows(p->partials_batch, n_part, n_datasets, 1.0 / n_pix, stirling_mean, loss_out, s);
+  }
   for (int c = 0; c < n_comp; ++c) {
     int done = 0;
     if ((rc = launch_sep_conv_adjoint_batch(n_datasets, n_comp, c, table, table_dev, grad_flux[c], p->H, p->W, p->kh,

@@ -65,7 +65,8 @@ enum JdOption {
   OPT_SEP_WALK_COLS, OPT_SEP_WALK_ROWS, OPT_SEP_WALK_ADJ_COLS, OPT_SEP_WALK_ADJ_ROWS, OPT_DIRECT_FP32,
   OPT_CONV_BLOCKS_PER_CU, OPT_POISSON_ROWS, OPT_GMM_NO_HOST_STATS, OPT_GMM_BLOCK_TILES, OPT_GMM_DENSE, OPT_GMM_KSPLIT,
   OPT_GMM_SCREEN_NP, OPT_GMM_SCREEN_NO_LDS_CONSTS, OPT_GMM_SCREEN_DEBUG, OPT_GMM_SCREEN, OPT_GMM_FUSED_BWD,
-  OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_SEP_JOINT, OPT_SEP_JOINT_ROWS, OPT_SEP_JOINT_CHUNK, OPT_COUNT
+  OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_SEP_JOINT, OPT_SEP_JOINT_ROWS, OPT_SEP_JOINT_CHUNK,
+  OPT_SEP_WALK_ADJ_ALL, OPT_COUNT
 };
 bool opt_is_set(int id);
 int opt_value(int id, int unset_value);
@@ -152,6 +153,12 @@ int walk_conv_poisson_batch_multi(int n, int n_comp, const float* const* flux, c
 int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
                             float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
                             hipStream_t stream, const double* fin_partials, double fin_scale, int fin_count, int* fin_done);
+// the same for ALL components of up to 16 datasets in ONE launch (grads[c] (+)= ...); JD_WALK_NOT_TAKEN where the
+// per-component launches above are the better (or the only) choice
+int walk_conv_adjoint_batch_all(int n, int n_comp, const SepBatchTable& table, const SepBatchTable* table_dev,
+                                float* const* grads, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
+                                hipStream_t stream, const double* fin_partials, double fin_scale, int fin_count,
+                                int* fin_done);
 // out[d][0] = scale * sum(partials[d * n .. d * n + n - 1]) + offset[d]   (one block per output, fixed order)
 int launch_finalize_rows(const double* partials, int n, int n_out, double scale, const float* offset_host,
                          float* const* out, hipStream_t stream);

@@ -84,6 +84,8 @@ struct WalkArgs {
   double fin_scale;
   int fin_count, fin_n;
   int* guard;                  // host-mapped: set when an operator is not rank 1
+  int comp_blocks;             // batched adjoint over ALL components: blocks per component (0: component `comp` only)
+  float* out_comp[4];          //   and their gradient images
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -92,17 +94,18 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// XG > 0: the batched adjoint (one wave per dataset, rows exchanged in groups of XG, wave w < XG adds up row w of a group)
-template <int C, int P, bool POISSON, bool IN_SCALE, int XG>
-__global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
+// XG > 0: the batched adjoint (one wave per dataset -- at most XWT of them --, rows exchanged in groups of XG, wave
+// w < XG adds up row w of a group); with a.comp_blocks > 0 the grid covers all flux components, comp_blocks blocks each
+template <int C, int P, bool POISSON, bool IN_SCALE, int XG, int XWT = XW>
+__global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
 #pragma clang fp contract(off)  // every fused multiply-add below is an explicit fmaf: batched and per-dataset paths round alike
   constexpr bool XCHG = XG > 0;
   static_assert(!XCHG || (WS % XG == 0 && XG <= XG_MAX), "the exchange group must divide the rotation period");
   typedef typename Vec<C>::T vC;
   constexpr int NX = 2 * WH / C;       // lanes that also load the right-hand halo piece
   constexpr int NWIN = 2 * WH + C;     // window floats per lane
-  __shared__ __attribute__((aligned(16))) float rowbuf[XCHG ? XW : 1][2 * 64 * C];  // 64 C + 16 floats used, the rest is a dump
-  __shared__ __attribute__((aligned(16))) float xbuf[XCHG ? 2 * XG * XW * 64 * C : 4];
+  __shared__ __attribute__((aligned(16))) float rowbuf[XCHG ? XWT : 1][2 * 64 * C];  // 64 C + 16 floats used, the rest is a dump
+  __shared__ __attribute__((aligned(16))) float xbuf[XCHG ? 2 * XG * XWT * 64 * C : 4];
   vC oprev;  // XCHG: the row of the gradient image this wave adds a group's row to, requested at the group's start
   __shared__ double fin_red[4];
 
@@ -131,9 +134,11 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
   // consecutive tiles of one XCD (blockIdx % 8) are vertical neighbours in a strip: their halo rows hit in that L2
   const int n_tiles = a.strips * a.tiles_y;
   const int per_xcd = (n_tiles + 7) / 8;
-  const int q = blockIdx.x / 8;
+  int bid = blockIdx.x, comp = a.comp;
+  if (XCHG && a.comp_blocks) comp = bid / a.comp_blocks, bid -= comp * a.comp_blocks;  // (comp_blocks: a multiple of 8)
+  const int q = bid / 8;
   const int dsel = (!XCHG && a.n_batch > 0) ? q / per_xcd : 0;  // batched forward launch: dataset-major
-  const int tile = (blockIdx.x % 8) * per_xcd + q % per_xcd;
+  const int tile = (bid % 8) * per_xcd + q % per_xcd;
   if (tile >= n_tiles) return;  // (block-uniform)
   const int sx = tile / a.tiles_y, ty = tile - sx * a.tiles_y;
 
@@ -145,14 +150,14 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
   typedef vC __attribute__((address_space(1)))* gv;
   const bool batch = a.n_batch > 0;
   const int d = XCHG ? a.d_base + wv : dsel;
-  const int slot = XCHG ? d * a.n_comp + a.comp : d;  // (a batched forward launch of this kernel has one component)
+  const int slot = XCHG ? d * a.n_comp + comp : d;  // (a batched forward launch of this kernel has one component)
   const gcp in = (gcp)(batch && !POISSON ? a.table->g[slot] : a.in);
   const gcp in_scale = (gcp)(batch ? a.table->scale[slot] : a.in_scale);
   const gcp op = (gcp)(batch ? a.table->op[slot] : a.op);
   const gcp out_scale = (gcp)(batch ? a.table->scale[slot] : a.out_scale);
   const gcp background = (gcp)(batch ? a.table->bkg[d] : a.background);
   const gcp counts = (gcp)(batch ? a.table->cnt[d] : a.counts);
-  const gp out = (gp)(POISSON && batch ? a.table->g[d] : a.out);
+  const gp out = (gp)(POISSON && batch ? a.table->g[d] : XCHG && a.comp_blocks ? a.out_comp[comp] : a.out);
   const gp npred_out = (gp)a.npred_out;
 
   // taps -> SGPRs
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
             if (vo) *(gv)(out + off + oo) = pv;
           } else if constexpr (XCHG) {
             const int k = (y - Y0) / XG, gy = (i + WS - 2 * WH) % XG;  // (tiles start on a group boundary: gy is static)
-            *reinterpret_cast<vC*>(xbuf + (size_t)((((k & 1) * XG + gy) * XW + wv) * 64 + lane) * C) = pv;
+            *reinterpret_cast<vC*>(xbuf + (size_t)((((k & 1) * XG + gy) * XWT + wv) * 64 + lane) * C) = pv;
           }
         }
       }
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_kernel(WalkArgs a) {
           const int k = (y - Y0) / XG, yy = y - gy + mine;
           vC res = oprev;
           for (int dd = 0; dd < nb; ++dd) {
-            const vC pd = *reinterpret_cast<const vC*>(xbuf + (size_t)((((k & 1) * XG + mine) * XW + dd) * 64 + lane) * C);
+            const vC pd = *reinterpret_cast<const vC*>(xbuf + (size_t)((((k & 1) * XG + mine) * XWT + dd) * 64 + lane) * C);
             res = dd == 0 && !a.accumulate ? pd : res + pd;
           }
           if (vo && wv < XG && yy < y_end) *(gv)(out + (size_t)yy * a.W + oo) = res;
@@ -1140,6 +1145,77 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
     }
     JD_LAUNCH_CHECK();
   }
+  return JD_OK;
+}
+
+// The same sum for ALL flux components of up to 16 datasets in ONE launch: grads[c] (+)= coef * sum_d scale[d, c] *
+// corr_same(g[d, c], psf_(d, c)).  The grid is n_comp x tiles, a block is one wave per dataset (up to 16: a full 1024
+// threads, two columns per lane so that 128 registers do), the datasets are added in order as above -- the same bits as
+// the per-component launches in chunks of 8, which at the benchmark's two-component case (1024^2 x 16 x 2) meant four
+// launches that each filled under half of the chip.  Option JD_SEP_WALK_ADJ_ALL = 0: never.
+constexpr int XW2 = 16;
+int walk_conv_adjoint_batch_all(int n, int n_comp, const SepBatchTable& table, const SepBatchTable* table_dev,
+                                float* const* grads, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
+                                hipStream_t stream, const double* fin_partials, double fin_scale, int fin_count,
+                                int* fin_done) {
+  static_assert(MULTI_MAX <= 4, "WalkArgs::out_comp");
+  *fin_done = 0;
+  if (opt_value(OPT_SEP_WALK_ADJ_ALL, 1) == 0) return JD_WALK_NOT_TAKEN;
+  if (n < 2 || n > XW2 || n_comp < 1 || n_comp > MULTI_MAX || (n <= XW && n_comp < 2) || !table_dev) return JD_WALK_NOT_TAKEN;
+  // One component, 9-16 datasets: two launches of the 4-column kernel are the faster form where they fill the chip
+  // (2048^2 x 16: 2 x 75.7 us against 163 us), this one where even 36-row tiles leave CUs without a block (1024^2 x
+  // 16: 60 us against 2 x 49 us).  Two components at 2048^2 x 16: 296 us against 4 x 78 us.
+  if (n_comp == 1 && (long)((W + 255) / 256) * ((H + 35) / 36) >= device_cus()) return JD_WALK_NOT_TAKEN;
+  WalkArgs a{};
+  for (int c = 0; c < n_comp; ++c) {
+    if (!aligned16(grads[c])) return JD_WALK_NOT_TAKEN;
+    a.out_comp[c] = grads[c];
+  }
+  for (int d = 0; d < n; ++d)
+    for (int c = 0; c < n_comp; ++c)
+      if (!dataset_walkable(table, d * n_comp + c, d)) return JD_WALK_NOT_TAKEN;
+  a.out = grads[0], a.H = H, a.W = W, a.coef = coef, a.table = table_dev, a.n_comp = n_comp, a.comp = 0;
+  if (!walk_setup(a, n * n_comp, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
+  int rc = sep_guard_check(&a.guard);
+  if (rc) return rc;
+  const bool big = n > XW;
+  const int xg = n >= 6 ? 6 : n >= 3 ? 3 : 2;
+  const bool wide = !big && n >= 6 && opt_value(OPT_SEP_WALK_ADJ_COLS, 4) != 2;
+  const int C = wide ? 4 : 2;
+  const int xw = big ? XW2 : XW;
+  const int lds = (2 * xg * xw * 64 * C + xw * 128 * C) * 4;
+  int per_cu = 160 * 1024 / lds;
+  const int by_regs = (big ? 16 : wide ? 12 : 20) / n;
+  if (per_cu > by_regs) per_cu = by_regs;
+  if (per_cu < 1) per_cu = 1;
+  const long slots = (long)device_cus() * per_cu * (per_cu > 1 ? 15 : 16) / 16;
+  const int strips = (W + 64 * C - 1) / (64 * C);
+  int rows = 36;
+  while (rows < 4096 && (long)strips * ((H + rows - 1) / rows) * n_comp > slots) rows += 6;
+  const int orows = opt_value(OPT_SEP_WALK_ADJ_ROWS, 0);
+  if (orows >= 18) rows = orows;
+  rows = (rows + 5) / 6 * 6;
+  walk_tiles(a, C, rows);
+  const int n_tiles = a.strips * a.tiles_y;
+  a.comp_blocks = ((n_tiles + 7) / 8) * 8;
+  const unsigned blocks = (unsigned)a.comp_blocks * n_comp;
+  a.d_base = 0, a.n_batch = n, a.accumulate = accumulate;
+  if (fin_partials && n >= 4 && (int)blocks >= n) {
+    a.fin_partials = fin_partials, a.fin_scale = fin_scale, a.fin_count = fin_count, a.fin_n = n;
+    *fin_done = 1;
+  }
+  ProfScope prof(JD_KERNEL_SEP_CONV, stream);
+  if (big)
+    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6, XW2>), dim3(blocks), dim3(64 * n), 0, stream, a);
+  else if (wide)
+    hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH_ADJ, false, false, 6>), dim3(blocks), dim3(64 * n), 0, stream, a);
+  else if (n >= 6)
+    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * n), 0, stream, a);
+  else if (n >= 3)
+    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * n), 0, stream, a);
+  else
+    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * n), 0, stream, a);
+  JD_LAUNCH_CHECK();
   return JD_OK;
 }
 

@@ -505,13 +505,13 @@ def test_fit_writes_the_file_the_reference_writes(tmp_path):
     assert again.config["checkpoint_path"] == str(tmp_path / "ckpt")
 
 
-@pytest.mark.parametrize("kernels,n_obs", [("tile", 5), ("walk", 5), ("walk", 8), ("walk", 11), ("walk", 2)])
+@pytest.mark.parametrize("kernels,n_obs", [("tile", 5), ("walk", 5), ("walk", 8), ("walk", 11), ("walk", 16), ("walk", 2)])
 def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch, jd_option, kernels, n_obs):
     """fit_mode="joint" with one separable component runs all datasets of a step in three launches
     (jd_npred_poisson_batch_fwd_bwd).  Same trajectory as the per-dataset loop, bit for bit: the datasets' gradient
     contributions are added in the same order -- with the tile kernel (the block walks over the datasets) and with the
     strip-walk kernels (one wave per dataset, rows exchanged through LDS and added in dataset order; groups of 2 / 3 / 6
-    rows by the number of datasets, more than 8 datasets in two launches)."""
+    rows by the number of datasets, 9 to 16 datasets in blocks of up to 16 waves)."""
     from jolideco_amd import MAPDeconvolver, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import synthetic_observations
 
@@ -536,12 +536,13 @@ def test_batched_joint_step_equals_the_per_dataset_loop(monkeypatch, jd_option, 
         np.testing.assert_allclose(results["batch"][1][name], column, rtol=1e-6, err_msg=name)
 
 
-@pytest.mark.parametrize("kernels", ["tile", "walk"])
+@pytest.mark.parametrize("kernels,n_obs", [("tile", 4), ("walk", 4), ("walk", 10)])
 @pytest.mark.parametrize("shape", [(72, 136), (40, 75)], ids=["w136_vector", "w75_scalar"])
-def test_batched_joint_step_with_two_components(monkeypatch, jd_option, shape, kernels):
+def test_batched_joint_step_with_two_components(monkeypatch, jd_option, shape, kernels, n_obs):
     """The batched joint step with several flux components (BASELINE config 5 in small: "extended" + "points", per-component
     PSFs, jd_npred_poisson_batch_multi_fwd_bwd): every dataset's forward model walks over the components inside the
-    block, clips each, and writes one masked gradient image per component; one adjoint launch per component.  Same
+    block, clips each, and writes one masked gradient image per component; one adjoint launch per component (tile
+    kernel) or one for all components (strip-walk kernels, blocks of one wave per dataset, up to 16).  Same
     trajectory as the per-dataset loop, bit for bit, for both components -- with the tile kernel and with the strip-walk
     kernels (walk_multi_kernel: one wave per component, the finished rows meet in LDS for the Poisson pass; the width
     that is not a multiple of 4 stays with the tile kernel either way)."""
@@ -549,7 +550,7 @@ def test_batched_joint_step_with_two_components(monkeypatch, jd_option, shape, k
     from jolideco_amd.data import gaussian_kernel, synthetic_observations
 
     jd_option("JD_SEP_WALK", 1 if kernels == "walk" else 0)
-    datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=4, seed=11)
+    datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=n_obs, seed=11)
     for i, d in enumerate(datasets.values()):
         d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
     results = {}

@@ -3,7 +3,7 @@ the GPU: random image shapes (odd widths too), PSF shapes (odd, even, non-square
 components with their own PSFs (Gaussian: rank 1; sum of two Gaussians: rank 2).  Two joint steps; the fluxes of all
 components must agree bit for bit.  GPU box: `python tools/fuzz_batch.py [n_cases] [seed] [walk]` (walk: option
 JD_SEP_WALK = 1 -- the strip-walk kernels wherever their geometry allows, half the PSFs then at most 17 x 17 and the widths
-multiples of 4, with up to 11 observations)."""
+multiples of 4, with up to 16 observations)."""
 import os
 import sys
 
@@ -26,7 +26,7 @@ for case in range(n_cases):
     n_obs, n_comp = int(rs.randint(2, 7)), int(rs.randint(1, 4))
     if walk and case % 2 == 0:
         W, kh, kw, n_comp = (W + 3) // 4 * 4, int(rs.randint(3, 18)), int(rs.randint(3, 18)), int(rs.randint(1, 4))
-        n_obs = int(rs.randint(2, 12))
+        n_obs = int(rs.randint(2, 17))
     names = ["a", "b", "c"][:n_comp]
 
     def psf():

@@ -139,7 +139,7 @@ def flush_caches():
 
 def bench(only=None, rows_list=(38, 56, 74, 128), cold=False, joint_rows=()):
     for name, (H, W, n) in {"c3": (2048, 2048, 8), "c4": (4096, 4096, 1), "c2": (1024, 1024, 1), "seq": (2048, 2048, 1),
-                            "r4": (2048, 2048, 4), "r2": (2048, 2048, 2)}.items():
+                            "r4": (2048, 2048, 4), "r2": (2048, 2048, 2), "r16": (2048, 2048, 16), "s16": (1024, 1024, 16)}.items():
         if only and name not in only:
             continue
         flux, data = scene(H, W, n, (17, 17), seed=1)
@@ -163,6 +163,8 @@ def bench(only=None, rows_list=(38, 56, 74, 128), cold=False, joint_rows=()):
                                            losses[0], grads=[grad], accumulate=False)
 
         variants = [dict(JD_SEP_WALK=0, JD_SEP_JOINT=0), dict(JD_SEP_WALK=1, JD_SEP_JOINT=0)]
+        if n > 8:
+            variants.append(dict(JD_SEP_WALK=1, JD_SEP_JOINT=0, JD_SEP_WALK_ADJ_ALL=0))
         for rows in joint_rows:
             variants.append(dict(JD_SEP_WALK=1, JD_SEP_JOINT=1, JD_SEP_JOINT_ROWS=rows))
         for cols in (() if joint_rows else (2, 4)):
