@@ -432,7 +432,7 @@ def main():
     if fused_one:
         poi_px_bytes = 20
         poi_kernel = ("direct_conv_kernel<" if methods == ["direct"] else
-                      "walk_kernel<4, 2, true, true, 0>" if walk else "sep_conv_kernel<true, true, true, false>")
+                      "walk_kernel<4, 2, true, true, 0, 8>" if walk else "sep_conv_kernel<true, true, true, false>")
         poi_what = "forward convolution + Poisson pass"
     elif fused_multi:
         poi_px_bytes = 12 * n_comp + 8
@@ -523,19 +523,27 @@ def main():
         # (with the Poisson pass fused into the forward launch only the adjoint carries this timer: 16 B/pixel)
         # a batched adjoint reads g + exposure per dataset and reads / writes the gradient once: (8 n + 8) B/pixel
         conv_bytes = ((8 * per_launch + 8) if ((poisson_in_conv or fused_multi) and per_launch > 1) else 16 if poisson_in_conv else 14) * H * W
+        # several components, strip-walk kernels: ONE launch adds up the datasets of every component (blocks of one wave
+        # per dataset, up to 16; walk_conv_adjoint_batch_all)
+        adjoint_all = fused_multi and walk and 2 <= per_launch <= 16
+        if adjoint_all:
+            conv_bytes *= n_comp
         achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
         conv_traffic = None
         if world == 1 and fake is None:
             if conv_key != "sep_conv":
                 names = ("direct_conv_kernel",)
+            elif adjoint_all:
+                names = ("walk_kernel<2, 2, false, false, 6, 16>",) if per_launch > 8 else ()
             elif poisson_in_conv and walk:
-                names = ("walk_kernel<4, 3, false, false, 6>",) if per_launch >= 6 else ("walk_kernel<4, 2, false, false, 0>",)
+                names = (("walk_kernel<4, 3, false, false, 6, 8>",) if per_launch >= 6 else
+                         ("walk_kernel<4, 2, false, false, 0, 8>",))
             elif poisson_in_conv:
                 names = ("sep_conv_kernel<true, false, false",)
             else:
                 names = ("sep_conv_kernel<true, true, false", "sep_conv_kernel<true, false, false")
             parts = [pmc_traffic_bytes(args.config, name) for name in names]
-            conv_traffic = sum(parts) / len(parts) if all(p is not None for p in parts) else None
+            conv_traffic = sum(parts) / len(parts) if parts and all(p is not None for p in parts) else None
         out["roofline_conv"] = {
             "kernel": ("walk_kernel (adjoint)" if conv_key == "sep_conv" and walk else
                        _hip.lib().jd_kernel_name(_hip.KERNEL_IDS[conv_key]).decode()), "bound": "hbm",

@@ -11,10 +11,11 @@ python3 bench.py --steps 20 --warmup 5 > $OUT/c3_n1_bench_driver_flags.json 2>> 
 for cfg in c2 c4 c5; do
   python3 bench.py --config $cfg --steps 100 --warmup 10 > $OUT/${cfg}_n1_bench.json 2> $OUT/${cfg}_n1_bench.err
 done
-for cfg in c3 c4; do
+for cfg in c3 c4 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$cfg -o $cfg -- \
       python3 bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-general-psf > $OUT/prof_$cfg.log 2>&1
   cp $(find $OUT/prof_$cfg -name "*kernel_stats.csv" | head -1) $OUT/${cfg}_n1_kernel_stats.csv
+  [ $cfg = c5 ] && continue  # (counters: the two configurations the roofline objects quote)
   for counter in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $counter --output-format csv -d $OUT/pmc_${cfg}_$counter -o pmc -- \
         python3 bench.py --config $cfg --steps 5 --warmup 2 --repeats 1 --settle-seconds 0 --no-cpu-baseline --no-general-psf \
