@@ -94,6 +94,28 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// acc (+)= tap * h on packed fp32 (two pixels per instruction), the tap being the low (SEL = 0) or high (SEL = 1) half
+// of a register pair broadcast to both elements through the operand-select bits -- hipcc has no pattern for that and
+// otherwise spends a register pair per tap.  The same fused multiply-add (or plain product) per element as fmaf / *.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int SEL>
+__device__ __forceinline__ v2f pk_fma_tap(v2f taps, v2f h, v2f acc) {
+  if constexpr (SEL == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(taps), "v"(h));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(taps), "v"(h));
+  return acc;
+}
+template <int SEL>
+__device__ __forceinline__ v2f pk_mul_tap(v2f taps, v2f h) {
+  v2f r;
+  if constexpr (SEL == 0)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(taps), "v"(h));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(taps), "v"(h));
+  return r;
+}
+
 // XG > 0: the batched adjoint (one wave per dataset -- at most XWT of them --, rows exchanged in groups of XG, wave
 // w < XG adds up row w of a group); with a.comp_blocks > 0 the grid covers all flux components, comp_blocks blocks each
 template <int C, int P, bool POISSON, bool IN_SCALE, int XG, int XWT = XW>
@@ -175,6 +197,20 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
     }
   }
 
+  // the column taps once more, two per VGPR pair, for the packed FMAs of the column pass at 4 columns per lane (two
+  // columns per lane: scalar FMAs on the SGPR taps -- those kernels live on 128 registers); the empty asm keeps the
+  // compiler from moving the (uniform) values back to SGPRs
+  constexpr bool PK = C == 4;
+  v2f tup[PK ? (WK + 1) / 2 : 1];
+  if constexpr (PK) {
+#pragma unroll
+    for (int j = 0; j < (WK + 1) / 2; ++j) {
+      float lo = tu[2 * j], hi = 2 * j + 1 < WK ? tu[2 * j + 1] : 0.f;
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      tup[j] = v2f{lo, hi};
+    }
+  }
+
   const int X0 = sx * 64 * C;
   const int xm = X0 - WH + C * lane;           // image column of the lane's piece of the window
   const int xe = X0 - WH + 64 * C + C * lane;  // right-hand halo piece (lanes < NX)
@@ -220,11 +256,11 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
 
   // WS = 18 accumulator slots for the 17 live outputs: with a rotation period of 18 the prefetch registers (period P,
   // P | 18) rotate statically too -- a register that is the target of a load in flight is never moved
-  vC acc[WS];
+  v2f acc[WS][C / 2];  // (pairs of columns: the operands of the packed FMAs)
 #pragma unroll
   for (int s = 0; s < WS; ++s)
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[s][c] = 0.f;
+    for (int c = 0; c < C; ++c) acc[s][c / 2][c % 2] = 0.f;
   static_assert(WS % P == 0, "prefetch depth must divide the rotation period");
   Row pf[P];
   Epi ep[P];
@@ -236,37 +272,48 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
     load_epi(r_begin + p - WH, ep[p]);
   }
 
-  for (int r0 = r_begin; r0 < y_end + WH + (XCHG ? XG - 1 : 0); r0 += WS) {  // (+: the last group's flush step)
+  // The row exchange is software-pipelined: in step i the products of row rr + 1 go to LDS and its window is READ BACK
+  // at once into the other of two window register sets, and only then the FMAs of row rr run on the window that was
+  // requested one step earlier -- the LDS round trip (write, read, ~200 cycles that two waves per SIMD do not hide)
+  // overlaps with 100-200 FMAs.  Measured with the read-back removed (wrong results, timing only): forward launch of
+  // 2048^2 x 8 125 -> 85 us, adjoint 74 -> 58 us -- the round trip was a third of the launch.  LDS operations of one wave
+  // execute in order, so one row buffer per wave still does (the next row's write cannot pass this row's read).
+  float W[2][NWIN];
+  // (rows outside the image go through the exchange too -- clamped loads, never used: every step issues the same LDS
+  // operations, so the compiler counts the ones in flight exactly instead of waiting for all of them at a join)
+  auto produce = [&](int rr1, Row& nx, float (&w)[NWIN]) {
+    // ---- products of the row -> LDS ----------------------------------------------------------------------------
+    vC prod = nx.a;
+    if (IN_SCALE) prod = prod * nx.s;
 #pragma unroll
-    for (int i = 0; i < WS; ++i) {
+    for (int c = 0; c < C; ++c) prod[c] = vm ? prod[c] : 0.f;
+    *reinterpret_cast<vC*>(rb + C * lane) = prod;
+    vC px = nx.xa;
+    if (IN_SCALE) px = px * nx.xs;
+#pragma unroll
+    for (int c = 0; c < C; ++c) px[c] = ve ? px[c] : 0.f;
+    *reinterpret_cast<vC*>(rb + 64 * C + C * lane) = px;  // (lanes >= NX: behind the window, never read)
+    load_row(rr1 + P, nx);  // the row P steps ahead takes this row's registers
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NWIN / C; ++k) {
+      const vC t = *reinterpret_cast<const vC*>(rb + C * lane + C * k);
+#pragma unroll
+      for (int c = 0; c < C; ++c) w[C * k + c] = t[c];
+    }
+    wave_lds_fence();
+  };
+  produce(r_begin, pf[0], W[0]);
+
+  for (int r0 = r_begin; r0 < y_end + WH + (XCHG ? XG - 1 : 0); r0 += WS) {  // (+: the last group's flush step)
+    static_for<WS>([&](auto ic) {  // (the 18 rotation states as compile-time constants: see walk_multi_kernel)
+      constexpr int i = decltype(ic)::value;
       const int rr = r0 + i;
-      Row& cur = pf[i % P];
       Epi& ce = ep[i % P];
       const bool live = row_ok(rr);
+      produce(rr + 1, pf[(i + 1) % P], W[(i + 1) & 1]);
       if (live) {
-        // ---- products of this row -> LDS ----------------------------------------------------------------------
-        vC prod = cur.a;
-        if (IN_SCALE) prod = prod * cur.s;
-#pragma unroll
-        for (int c = 0; c < C; ++c) prod[c] = vm ? prod[c] : 0.f;
-        *reinterpret_cast<vC*>(rb + C * lane) = prod;
-        vC px = cur.xa;
-        if (IN_SCALE) px = px * cur.xs;
-#pragma unroll
-        for (int c = 0; c < C; ++c) px[c] = ve ? px[c] : 0.f;
-        *reinterpret_cast<vC*>(rb + 64 * C + C * lane) = px;  // (lanes >= NX: behind the window, never read)
-      }
-      load_row(rr + P, cur);  // the row P steps ahead takes this row's registers
-      if (live) {
-        wave_lds_fence();
-        float w[NWIN];
-#pragma unroll
-        for (int k = 0; k < NWIN / C; ++k) {
-          const vC t = *reinterpret_cast<const vC*>(rb + C * lane + C * k);
-#pragma unroll
-          for (int c = 0; c < C; ++c) w[C * k + c] = t[c];
-        }
-        wave_lds_fence();
+        const float (&w)[NWIN] = W[i & 1];
         // ---- row pass: h[c] = sum_t tv[t] w[c + t] -----------------------------------------------------------
         float h[C];
 #pragma unroll
@@ -275,22 +322,34 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
         for (int t = 1; t < WK; ++t)
 #pragma unroll
           for (int c = 0; c < C; ++c) h[c] = fmaf(tv[t], w[c + t], h[c]);
-        // ---- column pass, scatter form: out[rr + 8 - t] += tu[t] h ------------------------------------------
+        // ---- column pass, scatter form: out[rr + 8 - t] += tu[t] h; 4 columns per lane: on packed FMAs (the same fused
+        // operation per element; with one or two waves per SIMD a packed FMA costs well under two scalar ones)
+        v2f hp[C / 2];
 #pragma unroll
-        for (int t = 0; t < WK; ++t) {
-          const int s = (i + WH - t + WS) % WS;
+        for (int c = 0; c < C; ++c) hp[c / 2][c % 2] = h[c];
+        static_for<WK>([&](auto tc) {
+          constexpr int t = decltype(tc)::value, s = (i + WH - t + WS) % WS;
+          if constexpr (PK) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) acc[s][c] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], acc[s][c]);
-        }
+            for (int j = 0; j < C / 2; ++j)
+              acc[s][j] = t == 0 ? pk_mul_tap<0>(tup[0], hp[j]) : pk_fma_tap<t % 2>(tup[t / 2], hp[j], acc[s][j]);
+          } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              acc[s][c / 2][c % 2] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], acc[s][c / 2][c % 2]);
+          }
+        });
       } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[(i + WH) % WS][c] = 0.f;
+        for (int c = 0; c < C; ++c) acc[(i + WH) % WS][c / 2][c % 2] = 0.f;
       }
 
       // ---- output row y = rr - 8 is complete ------------------------------------------------------------------
       const int y = rr - WH;
       if (epi_ok(y)) {
-        const vC conv = acc[(i + WS - WH) % WS];
+        vC conv;
+#pragma unroll
+        for (int c = 0; c < C; ++c) conv[c] = acc[(i + WS - WH) % WS][c / 2][c % 2];
         const size_t off = (size_t)y * a.W;
         if (POISSON) {
           vC gvec, nvec;
@@ -347,7 +406,7 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
         }
       }
       load_epi(y + P, ce);
-    }
+    });
   }
   if (POISSON) {
     loss = wave_sum(loss);
@@ -424,6 +483,17 @@ __global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a)
     }
   }
 
+  constexpr bool PK = C == 4;  // packed FMAs in the column pass: see walk_kernel
+  v2f tup[PK ? (WK + 1) / 2 : 1];
+  if constexpr (PK) {
+#pragma unroll
+    for (int j = 0; j < (WK + 1) / 2; ++j) {
+      float lo = tu[2 * j], hi = 2 * j + 1 < WK ? tu[2 * j + 1] : 0.f;
+      asm volatile("" : "+v"(lo), "+v"(hi));
+      tup[j] = v2f{lo, hi};
+    }
+  }
+
   const int X0 = sx * 64 * C;
   const int xm = X0 - WH + C * lane, xe = X0 - WH + 64 * C + C * lane, xo = X0 + C * lane;
   const bool vm = xm >= 0 && xm < a.W, ve = lane < NX && xe < a.W, vo = xo < a.W;
@@ -451,11 +521,11 @@ __global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a)
     e.q = *(gcv)(counts + base + oo);
   };
 
-  vC acc[WS];
+  v2f acc[WS][C / 2];
 #pragma unroll
   for (int s = 0; s < WS; ++s)
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[s][c] = 0.f;
+    for (int c = 0; c < C; ++c) acc[s][c / 2][c % 2] = 0.f;
   Row pf[P];
   Epi ep[P];
   double loss = 0.0;
@@ -502,22 +572,34 @@ __global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a)
         for (int t = 1; t < WK; ++t)
 #pragma unroll
           for (int c = 0; c < C; ++c) h[c] = fmaf(tv[t], w[c + t], h[c]);
+        v2f hp[C / 2];
 #pragma unroll
-        for (int t = 0; t < WK; ++t) {
-          const int s = (i + WH - t + WS) % WS;
+        for (int c = 0; c < C; ++c) hp[c / 2][c % 2] = h[c];
+        static_for<WK>([&](auto tc) {
+          constexpr int t = decltype(tc)::value, s = (i + WH - t + WS) % WS;
+          if constexpr (PK) {
 #pragma unroll
-          for (int c = 0; c < C; ++c) acc[s][c] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], acc[s][c]);
-        }
+            for (int j = 0; j < C / 2; ++j)
+              acc[s][j] = t == 0 ? pk_mul_tap<0>(tup[0], hp[j]) : pk_fma_tap<t % 2>(tup[t / 2], hp[j], acc[s][j]);
+          } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+              acc[s][c / 2][c % 2] = t == 0 ? tu[0] * h[c] : fmaf(tu[t], h[c], acc[s][c / 2][c % 2]);
+          }
+        });
       } else {
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[(i + WH) % WS][c] = 0.f;
+        for (int c = 0; c < C; ++c) acc[(i + WH) % WS][c / 2][c % 2] = 0.f;
       }
 
       // ---- output row y = rr - 8 of this component is complete: park it (and this wave's copy of background, counts)
       const int y = rr - WH;
       constexpr int gy = (i + WS - 2 * WH) % MG;  // (y - Y0 = i - 16 mod 18: tiles start on a group boundary, static)
       if (epi_ok(y)) {
-        *reinterpret_cast<vC*>(cbuf + (size_t)((gy * nc + wv) * 64 + lane) * C) = acc[(i + WS - WH) % WS];
+        vC conv;
+#pragma unroll
+        for (int c = 0; c < C; ++c) conv[c] = acc[(i + WS - WH) % WS][c / 2][c % 2];
+        *reinterpret_cast<vC*>(cbuf + (size_t)((gy * nc + wv) * 64 + lane) * C) = conv;
         *reinterpret_cast<vC*>(bc + (size_t)((gy * 2 + 0) * 64 + lane) * C) = ce.p;
         *reinterpret_cast<vC*>(bc + (size_t)((gy * 2 + 1) * 64 + lane) * C) = ce.q;
       }
@@ -595,6 +677,11 @@ struct JointArgs {
   int* guard;
 };
 
+#ifndef JD_JOINT_PREFETCH
+#define JD_JOINT_PREFETCH 2
+#endif
+constexpr int JOINT_PREFETCH = JD_JOINT_PREFETCH;  // rows in flight per stream (a divisor of WS)
+
 template <int C, int P, int XG>
 __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs a) {
 #pragma clang fp contract(off)
@@ -645,6 +732,15 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
       tu[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mu), t));
       tv[t] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mv), t));
     }
+  }
+
+  static_assert(C == 2, "the packed column passes below take one register pair per accumulator row");
+  v2f tup[(WK + 1) / 2];  // the column taps in VGPR pairs for the packed FMAs (see walk_kernel)
+#pragma unroll
+  for (int j = 0; j < (WK + 1) / 2; ++j) {
+    float lo = tu[2 * j], hi = 2 * j + 1 < WK ? tu[2 * j + 1] : 0.f;
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    tup[j] = v2f{lo, hi};
   }
 
   const int X0 = sx * SW - WH;                 // first FORWARD-output column of the strip
@@ -749,10 +845,7 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
         for (int c = 0; c < C; ++c) hv[c] = h[c];
         static_for<WK>([&](auto tc) {  // (packed FMAs: the same fused operation per element)
           constexpr int t = decltype(tc)::value, s = (i + WH - t + WS) % WS;
-          vC tt;
-#pragma unroll
-          for (int c = 0; c < C; ++c) tt[c] = tu[t];
-          accF[s] = t == 0 ? tt * hv : __builtin_elementwise_fma(tt, hv, accF[s]);
+          accF[s] = t == 0 ? pk_mul_tap<0>(tup[0], hv) : pk_fma_tap<t % 2>(tup[t / 2], hv, accF[s]);
         });
       } else {
 #pragma unroll
@@ -801,10 +894,8 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
         for (int c = 0; c < C; ++c) hv[c] = h[c];
         static_for<WK>([&](auto tc) {
           constexpr int t = decltype(tc)::value, s = (i - t + WS) % WS;
-          vC tt;
-#pragma unroll
-          for (int c = 0; c < C; ++c) tt[c] = tu[WK - 1 - t];
-          accA[s] = t == 0 ? tt * hv : __builtin_elementwise_fma(tt, hv, accA[s]);
+          constexpr int r = WK - 1 - t;  // (taps reversed)
+          accA[s] = t == 0 ? pk_mul_tap<r % 2>(tup[r / 2], hv) : pk_fma_tap<r % 2>(tup[r / 2], hv, accA[s]);
         });
       } else {
 #pragma unroll
@@ -1278,13 +1369,13 @@ int walk_joint_step(int n, const float* flux, const SepBatchTable& table, const 
     }
     ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
     if (m >= 6)
-      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+      hipLaunchKernelGGL((walk_joint_kernel<C, JOINT_PREFETCH, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m >= 3)
-      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
+      hipLaunchKernelGGL((walk_joint_kernel<C, JOINT_PREFETCH, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m == 2)
-      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
+      hipLaunchKernelGGL((walk_joint_kernel<C, JOINT_PREFETCH, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else
-      hipLaunchKernelGGL((walk_joint_kernel<C, WALK_PREFETCH, 0>), dim3(blocks), dim3(64), 0, stream, a);
+      hipLaunchKernelGGL((walk_joint_kernel<C, JOINT_PREFETCH, 0>), dim3(blocks), dim3(64), 0, stream, a);
     JD_LAUNCH_CHECK();
   }
   return JD_OK;
