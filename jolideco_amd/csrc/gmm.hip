@@ -409,11 +409,18 @@ struct GmmBucketArgs {
   int gen;      //           need more than slot_cap slots
   int slot_cap;
   int* korder;  // nullable: the scan kernel also ranks the bins by size (order of the components for the next screen)
+  // logsumexp screen: records count while their upper bound reaches lfinal - margin (0 in max mode), and the scatter
+  // kernel also lists every patch's records: ptab[patch * ptab_rows + j] = bucket slot, j < pcount[patch] (more than
+  // ptab_rows records of one patch raise the fallback flag)
+  float margin;
+  int* pcount;
+  int32_t* ptab;
+  int ptab_rows;
 };
 
 // component of element n, or a negative number if it takes no part (-1: filtered patch)
 __device__ __forceinline__ int bucket_key(const GmmBucketArgs& a, int n) {
-  if (a.seg_cnt && !(a.rec_ub[n] >= a.lfinal[a.rec_n[n]])) return -2;  // stale record
+  if (a.seg_cnt && !(a.rec_ub[n] >= a.lfinal[a.rec_n[n]] - a.margin)) return -2;  // stale record
   return a.argmax[n];
 }
 // number of elements of chunk c that are in use
@@ -540,6 +547,14 @@ __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a
         const int pos = atomicAdd(&hist[k], 1);
         a.order[pos] = n;
         if (a.order_n) a.order_n[pos] = a.rec_n[n];
+        if (a.ptab) {  // (the order of a patch's entries is whatever the atomics make it: the combine kernel sorts them)
+          const int patch = a.rec_n[n];
+          const int j = atomicAdd(a.pcount + patch, 1);
+          if (j < a.ptab_rows)
+            a.ptab[(size_t)patch * a.ptab_rows + j] = pos;
+          else
+            __hip_atomic_store(a.flag, a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       } else if (k == -1 && a.gpatch) {  // filtered patch (patches/core.py:215-216): no gradient
         float4* row = reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D);
         for (int q = 0; q < D / 4; ++q) row[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -753,6 +768,8 @@ struct GmmBwdLseArgs {
   const float* value_patch;  // logsumexp per patch (global patch index), NaN for filtered patches
   float* gpatch;             // (n_end - n_begin) * 64
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+  const int* run_flag;       // nullable: the kernel returns at once unless *run_flag == run_gen (fallback of the
+  int run_gen;               //           logsumexp screen)
 };
 
 struct GFrag {
@@ -799,6 +816,7 @@ __device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr
 
 template <bool TRI, int GRP>
 __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
+  if (a.run_flag && *a.run_flag != a.run_gen) return;
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, n16 = lane & 15;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -950,6 +968,7 @@ struct GmmStageArgs {
   float* xs2;                // s_x^2
   int* ok;                   // patch takes part (inside the shard, passes the -1e5 filter)
   unsigned long long* best;  // per patch (global index): initialised here
+  int* pcount;               // nullable (logsumexp screen): records per patch (global index), zeroed here
 };
 
 __global__ __launch_bounds__(256) void gmm_stage_kernel(GmmStageArgs a) {
@@ -1012,6 +1031,7 @@ __global__ __launch_bounds__(256) void gmm_stage_kernel(GmmStageArgs a) {
     a.xs2[tile * 32 + c] = ldexpf(1.f, 2 * (ex - 14));
     a.ok[tile * 32 + c] = ok ? 1 : 0;
     if (valid) a.best[n] = ok ? best_key(-INFINITY, 0) : 0ull;
+    if (valid && a.pcount) a.pcount[n] = 0;
   }
 }
 
@@ -1082,6 +1102,10 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
 // the maximum; records made before L rose are dropped later (bucket_key) against the final L.  Visiting the
 // components most-popular-first makes L rise early, so few stale records are written.
 // The issue slots beside the MFMAs are the budget (about six 4-cycle VALU instructions hide per 32-cycle MFMA).
+// LSE (logsumexp screen): a component is recorded while its upper bound reaches L - LSE_MARGIN -- whatever is left out is
+// below exp(-25) = 1.4e-11 of the largest term of the sum, 128 components of it below 2e-9 of the sum.
+constexpr float LSE_MARGIN = 25.f;
+template <bool LSE = false>
 __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], const f32x16 (&accB)[2], float ck, float ack,
                                                    float mnorm, float efro, float xn, float s2, bool ok, float& L,
                                                    float& qacc, int n, int k, int lane, int& cnt, int32_t* rec_n,
@@ -1096,7 +1120,7 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   const float l = fmaf(-0.5f, q, ck);
   const float B = fmaf(__builtin_amdgcn_sqrtf(q), e1, fmaf(2e-5f, q, c2));
   const float ub = l + B;
-  const bool cand = ok && ub >= L;
+  const bool cand = ok && ub >= (LSE ? L - LSE_MARGIN : L);
   // L = max(L, l - B) as ONE v_max_f32 (fmaxf adds a canonicalising v_max in front; a NaN operand loses either way
   // and is caught through qacc)
   asm("v_max_f32 %0, %1, %2" : "=v"(L) : "v"(L), "v"(l - B));
@@ -1128,7 +1152,7 @@ constexpr int SCREEN_KC_MAX = 512;  // components whose per-component constants 
 // uniform values; as vector loads from global memory their latency was exposed once per component (a load of
 // korder[kk + 1] followed at once by the wait for it).  From LDS they are fetched TWO positions ahead, so that the
 // component index is in a register a whole component before the fragment prefetch needs it for its address.
-template <int NP, bool KSPLIT, bool KC_LDS>
+template <int NP, bool KSPLIT, bool KC_LDS, bool LSE = false>
 __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScreenArgs a) {
   constexpr int NT = 2 * NP;
   __shared__ float st_L[KSPLIT ? 4 * NT * 32 : 1];
@@ -1249,18 +1273,18 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
       // pair 1 of k on the matrix pipe while pair 0 of k finishes in its shadow, then pair 0 of k + 1 | pair 1 of k
       issue_pair(acc[1], fa, 1);
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // unconditional (clamped) prefetch
-      screen_finish_pair(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
+      screen_finish_pair<LSE>(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
                          cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
       flush(false);
       issue_pair(acc[0], fb, 0);
-      screen_finish_pair(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[NP - 1], ps2[NP - 1] * sk2, pok[NP - 1], pL[NP - 1],
+      screen_finish_pair<LSE>(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[NP - 1], ps2[NP - 1] * sk2, pok[NP - 1], pL[NP - 1],
                          pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
       flush(false);
     } else {
       // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the accumulator buffers alternate
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // (fa's MFMAs were issued by the previous component)
       issue_pair(acc[1 - PHASE], fb, 0);
-      screen_finish_pair(acc[PHASE][0], acc[PHASE][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k,
+      screen_finish_pair<LSE>(acc[PHASE][0], acc[PHASE][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k,
                          lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
       flush(false);
     }
@@ -1311,6 +1335,7 @@ struct GmmExactArgs {
   // to the lowest component); gmm_best_kernel turns the winning key into the row the gather kernel reads
   const float* gfrag;
   float* grec;
+  float* lrec;  // nullable (logsumexp screen): l of every surviving record by bucket slot, instead of the max merge
 #ifdef JD_EXACT_STAMPS  // diagnostic build only (tools/build_variant.sh stamps -DJD_EXACT_STAMPS=1): s_memtime per phase of every group
   unsigned long long* stamps;  // [group][8]
 #endif
@@ -1472,7 +1497,11 @@ __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
     for (int nb = 0; nb < 2; ++nb) {
       const float l = fmaf(-0.5f, sum_lane_groups(sum_squares(y, nb)), ck);  // = finish_tile of the forward kernel
       const int tie = a.grec ? 32 * grp + 16 * nb + n16 : k;
-      if (g == 0 && valid[nb] && l > -INFINITY) atomicMax(a.best + n[nb], best_key(l, tie));  // NaN never wins (l > b)
+      if (a.lrec) {
+        if (g == 0 && valid[nb]) a.lrec[32 * grp + 16 * nb + n16] = l;
+      } else if (g == 0 && valid[nb] && l > -INFINITY) {
+        atomicMax(a.best + n[nb], best_key(l, tie));  // NaN never wins (l > b)
+      }
     }
     EXACT_STAMP(5);  // value epilogue, atomicMax issued
     if (a.grec) {
@@ -1582,6 +1611,110 @@ __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
       a.host_stats[3] = a.n_end - a.n_begin;
       __threadfence_system();
       a.host_stats[0] = a.gen;  // last: marks the other three as belonging to this pass
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Logsumexp mode through the screen (marginalize = True, patches/core.py:242-243): the screen keeps every component whose
+// upper bound reaches L - 25 (L = the lower bound of the patch's maximum), the exact kernel evaluates l and the
+// gradient row of each surviving (patch, component) record, and this kernel combines the records of a patch:
+//   v = m + log sum_j exp(l_j - m),  row = sum_j exp(l_j - m) row_j / sum_j exp(l_j - m)   (m = max_j l_j)
+// in ascending order of the bucket slot (= of the component: deterministic, whatever order the scatter kernel's atomics
+// listed them in).  What the screen left out is below 2e-9 of the sum.  16 lanes per patch, each with one float4 of the
+// 256-byte rows; a block = 16 patches.  After a fallback (*flag == gen) the gated dense kernels have done the work.
+struct GmmLseCombineArgs {
+  const int* pcount;      // records per patch (global index)
+  const int32_t* ptab;    // [patch][rows] bucket slots
+  int rows;
+  const float* lrec;      // l by bucket slot
+  const float* grec;      // gradient rows by bucket slot
+  float* gpatch;          // (n_end - n_begin) * 64: the combined rows
+  double* partials;       // one per block: sum of v over its patches
+  int n_begin, n_end;
+  const int* flag;
+  int gen;
+};
+
+constexpr int LSE_ROWS = 32;  // records per patch the patch table holds (more: fallback to the dense kernels)
+
+__global__ __launch_bounds__(256) void gmm_lse_combine_kernel(GmmLseCombineArgs a) {
+  __shared__ int s_slot[16][LSE_ROWS];
+  __shared__ float s_l[16][LSE_ROWS];
+  __shared__ double s_v[16];
+  if (*a.flag == a.gen) return;  // (block-uniform)
+  const int grp = threadIdx.x >> 4, part = threadIdx.x & 15;
+  const int n = a.n_begin + (int)blockIdx.x * 16 + grp;
+  const bool live = n < a.n_end;
+  int c = live ? a.pcount[n] : 0;
+  if (c > a.rows) c = a.rows;  // (cannot be: the scatter kernel raised the flag)
+  // the patch's records, two per lane; rank by bucket slot -> LDS in ascending order
+  int slot[2];
+  float l[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int j = part + 16 * u;
+    slot[u] = j < c ? a.ptab[(size_t)n * a.rows + j] : 0x7fffffff;
+    l[u] = j < c ? a.lrec[slot[u]] : -INFINITY;
+  }
+  int rank[2] = {0, 0};
+  for (int j = 0; j < c; ++j) {  // (c is uniform over the 16 lanes of the patch)
+    const int other = __shfl(j < 16 ? slot[0] : slot[1], (threadIdx.x & 48) + (j & 15), 64);
+    rank[0] += other < slot[0] ? 1 : 0;
+    rank[1] += other < slot[1] ? 1 : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (part + 16 * u < c) s_slot[grp][rank[u]] = slot[u], s_l[grp][rank[u]] = l[u];
+  float m = fmaxf(l[0], l[1]);
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));  // (stays inside the 16 lanes)
+  __syncthreads();
+  float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
+  float S = 0.f;
+  for (int r = 0; r < c; ++r) {
+    const float e = expf(s_l[grp][r] - m);
+    const float4 row = reinterpret_cast<const float4*>(a.grec + (size_t)s_slot[grp][r] * D)[part];
+    S += e;
+    G.x = fmaf(e, row.x, G.x), G.y = fmaf(e, row.y, G.y), G.z = fmaf(e, row.z, G.z), G.w = fmaf(e, row.w, G.w);
+  }
+  if (live) {
+    const float inv = c > 0 ? 1.f / S : 0.f;  // (no record: a filtered patch -- no value, no gradient)
+    reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D)[part] = make_float4(G.x * inv, G.y * inv, G.z * inv, G.w * inv);
+  }
+  if (part == 0) s_v[grp] = live && c > 0 ? (double)(m + logf(S)) : 0.0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double total = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) total += s_v[i];
+    a.partials[blockIdx.x] = total;
+  }
+}
+
+// value_out = [value_out +] scale * sum(partials): those of the combine kernel, or of the dense kernel after a
+// fallback; also leaves the pass statistics for the host (see GmmBestArgs::host_stats)
+__global__ __launch_bounds__(256) void gmm_lse_finalize_kernel(const double* combined, int n_combined, const double* dense,
+                                                               int n_dense, const int* flag, int gen, double scale,
+                                                               float* value_out, int accumulate, int* host_stats,
+                                                               const int* slots_used, int patches) {
+  __shared__ double smem[4];
+  const bool fell_back = *flag == gen;
+  const double* src = fell_back ? dense : combined;
+  const int count = fell_back ? n_dense : n_combined;
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) acc += src[i];
+  const double total = block_sum<256>(acc, smem);
+  if (threadIdx.x == 0) {
+    double v = scale * total;
+    if (accumulate) v += (double)value_out[0];
+    value_out[0] = (float)v;
+    if (host_stats) {
+      host_stats[1] = fell_back ? 1 : 0;
+      host_stats[2] = *slots_used;
+      host_stats[3] = patches;
+      __threadfence_system();
+      host_stats[0] = gen;
     }
   }
 }
@@ -1885,6 +2018,22 @@ struct jd_gmm {
   size_t rec_order_n_cap = 0;
   int* seg_cnt = nullptr;
   size_t seg_cnt_cap = 0;
+  // logsumexp screen: l per bucket slot, records per patch and their bucket slots, the combine kernel's partial sums
+  float* lrec = nullptr;
+  size_t lrec_cap = 0;
+  int* pcount = nullptr;
+  size_t pcount_cap = 0;
+  int32_t* ptab = nullptr;
+  size_t ptab_cap = 0;
+  double* partials_lse = nullptr;
+  size_t partials_lse_cap = 0;
+  // Where (nearly) all components are within the margin of the maximum -- smooth images under a mixture with similar
+  // constants -- the logsumexp screen cannot pay: every pass overflows a record list and falls back to the dense
+  // kernels after 0.5 ms of screening.  Once a pass has fallen back with the record buffer at its largest, the next
+  // lse_skip passes go to the dense kernels directly; then the screen is tried again.
+  int lse_skip = 0;
+  int lse_seen_gen = 0;
+  bool last_pass_lse = false;
   // Gradient rows per patch the record buffer has room for (x 256 B x patches).  Starts at 4; a pass that fell back
   // because it needed more, or filled more than 60 % of it, doubles it for the following passes (up to 32) -- known
   // from the host-mapped statistics the last block of gmm_best_kernel leaves behind, read without synchronisation.
@@ -2093,6 +2242,10 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->best) (void)hipFree(g->best);
   if (g->lfinal) (void)hipFree(g->lfinal);
   if (g->xfrag) (void)hipFree(g->xfrag);
+  if (g->lrec) (void)hipFree(g->lrec);
+  if (g->pcount) (void)hipFree(g->pcount);
+  if (g->ptab) (void)hipFree(g->ptab);
+  if (g->partials_lse) (void)hipFree(g->partials_lse);
   if (g->xstat) (void)hipFree(g->xstat);
   if (g->xok) (void)hipFree(g->xok);
   if (g->rec) (void)hipFree(g->rec);
@@ -2173,8 +2326,12 @@ static int launch_fwd(const GmmFwdArgs& a, bool tri, int n_cu, hipStream_t s, in
 // 1024 patches, exactly the numbers gmm_fwd_kernel<MODE_MAX> produces.
 // fused: the exact kernel also writes the gradient row of every surviving record and gmm_best_kernel the winning row
 // of every patch (g->grec, g->winner); after a fallback the components are in fallback_argmax instead.
+// lse: logsumexp mode (always with the gradient; see gmm_lse_combine_kernel): the screen keeps the components within
+// LSE_MARGIN of the lower bound, the exact kernel stores l per record, the combine kernel turns the records of a patch
+// into its value and its gradient row (g->gpatch); the dense logsumexp kernels are enqueued behind the device flag.
 static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* n_partials, bool fused,
-                            int32_t* fallback_argmax, double value_scale, float* value_out, int accumulate_value) {
+                            int32_t* fallback_argmax, double value_scale, float* value_out, int accumulate_value,
+                            bool lse = false) {
   const long n = a.n_end - a.n_begin;
   // every wave its own 128 patches and all components, unless that leaves CUs without a block: then the four waves of
   // a block share 128 patches and split the components (see gmm_screen_kernel)
@@ -2219,6 +2376,13 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     if ((rc = grow(&g->grec, &g->grec_cap, grec_rows * D))) return rc;
     if ((rc = grow(&g->winner, &g->winner_cap, (size_t)a.n_end))) return rc;
   }
+  const unsigned combine_blocks = (unsigned)((n + 15) / 16);
+  if (lse) {
+    if ((rc = grow(&g->lrec, &g->lrec_cap, bucket_slots))) return rc;
+    if ((rc = grow(&g->pcount, &g->pcount_cap, (size_t)a.n_end))) return rc;
+    if ((rc = grow(&g->ptab, &g->ptab_cap, (size_t)a.n_end * LSE_ROWS))) return rc;
+    if ((rc = grow(&g->partials_lse, &g->partials_lse_cap, (size_t)combine_blocks))) return rc;
+  }
 
   const size_t n_tiles = (size_t)blocks * (ksplit ? T : 4 * T);  // tiles the screen's waves touch
   if ((rc = grow(&g->xfrag, &g->xfrag_cap, n_tiles * 4 * 64))) return rc;
@@ -2236,6 +2400,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   GmmStageArgs stg{};
   stg.flux = a.flux, stg.H = a.H, stg.W = a.W, stg.stride = a.stride, stg.nPx = a.nPx, stg.shift_y = a.shift_y, stg.shift_x = a.shift_x;
   stg.n_begin = a.n_begin, stg.n_end = a.n_end, stg.n_tiles = (int)n_tiles;
+  stg.pcount = lse ? g->pcount : nullptr;
   stg.xfrag = g->xfrag, stg.xn = g->xstat, stg.xs2 = g->xstat + n_tiles * 32, stg.ok = g->xok, stg.best = g->best;
   GmmScreenArgs sc{};
   sc.xfrag = g->xfrag, sc.xn = stg.xn, sc.xs2 = stg.xs2, sc.ok = g->xok;
@@ -2251,7 +2416,11 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   JD_LAUNCH_CHECK();
   {
     ProfScope stage(JD_KERNEL_GMM_SCREEN, s);
-    if (np1)
+    if (lse && ksplit)  // (the caller has checked K <= SCREEN_KC_MAX: the constants table is in LDS)
+      gmm_screen_kernel<2, true, true, true><<<blocks, 256, 0, s>>>(sc);
+    else if (lse)
+      gmm_screen_kernel<2, false, true, true><<<blocks, 256, 0, s>>>(sc);
+    else if (np1)
       gmm_screen_kernel<1, false, true><<<blocks, 256, 0, s>>>(sc);
     else if (ksplit && kc_lds)
       gmm_screen_kernel<2, true, true><<<blocks, 256, 0, s>>>(sc);
@@ -2273,6 +2442,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   bk.chunk = SCREEN_CAP;  // one record segment per chunk
   bk.korder = g->K <= KORDER_MAX_K ? g->korder : nullptr;
   if (fused) bk.flag = flag, bk.gen = g->gen, bk.slot_cap = (int)std::min<size_t>(grec_rows, (size_t)INT32_MAX);
+  if (lse) bk.margin = LSE_MARGIN, bk.pcount = g->pcount, bk.ptab = g->ptab, bk.ptab_rows = LSE_ROWS;
   bk.blk_counts = g->blk_counts;
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   {
@@ -2286,7 +2456,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   GmmExactArgs ex{};
   ex.flux = a.flux, ex.afrag = g->afrag, ex.mfrag = g->mfrag, ex.const_k = g->const_k;
   ex.order_n = g->rec_order_n, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag, ex.gen = g->gen;
-  ex.gfrag = g->gfrag, ex.grec = fused ? g->grec : nullptr;
+  ex.gfrag = g->gfrag, ex.grec = fused ? g->grec : nullptr, ex.lrec = lse ? g->lrec : nullptr;
   ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
   ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
 #ifdef JD_EXACT_STAMPS
@@ -2341,6 +2511,41 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
             (double)n_groups / (double)(g->n_cu * 12), g->n_cu * 12);
   }
 #endif
+
+  if (lse) {
+    // fallback: the dense logsumexp kernels, gated on the device flag (forward: per-patch values + partial sums;
+    // backward: g->gpatch), then the records of every patch -> value and gradient row, then the value
+    GmmFwdArgs dense = a;
+    dense.run_flag = flag, dense.run_gen = g->gen;
+    const int tb = pick_block_tiles(n, g->n_cu);
+    const int n_dense = (int)((n + 32L * tb - 1) / (32L * tb));
+    switch (tb) {
+      case 16: rc = launch_fwd_tb<16, MODE_LSE, true>(dense, (unsigned)n_dense, s); break;
+      case 8: rc = launch_fwd_tb<8, MODE_LSE, true>(dense, (unsigned)n_dense, s); break;
+      default: rc = launch_fwd_tb<4, MODE_LSE, true>(dense, (unsigned)n_dense, s); break;
+    }
+    if (rc) return rc;
+    GmmBwdLseArgs b{};
+    b.flux = a.flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
+    b.value_patch = a.value_patch, b.gpatch = g->gpatch, b.K = g->K;
+    b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x;
+    b.n_begin = a.n_begin, b.n_end = a.n_end, b.run_flag = flag, b.run_gen = g->gen;
+    long bblocks = ((n + 31) / 32 + 2 * 4 - 1) / (2 * 4);
+    if (bblocks > g->n_cu) bblocks = g->n_cu;
+    gmm_bwd_lse_kernel<true, 2><<<(unsigned)bblocks, 256, 0, s>>>(b);
+    JD_LAUNCH_CHECK();
+    GmmLseCombineArgs cb{};
+    cb.pcount = g->pcount, cb.ptab = g->ptab, cb.rows = LSE_ROWS, cb.lrec = g->lrec, cb.grec = g->grec, cb.gpatch = g->gpatch;
+    cb.partials = g->partials_lse, cb.n_begin = a.n_begin, cb.n_end = a.n_end, cb.flag = flag, cb.gen = g->gen;
+    gmm_lse_combine_kernel<<<combine_blocks, 256, 0, s>>>(cb);
+    JD_LAUNCH_CHECK();
+    gmm_lse_finalize_kernel<<<1, 256, 0, s>>>(g->partials_lse, (int)combine_blocks, g->partials, n_dense, flag, g->gen,
+                                              value_scale, value_out, accumulate_value, g->host_stats_dev,
+                                              bk.offsets + g->K, (int)n);
+    JD_LAUNCH_CHECK();
+    *n_partials = 0;
+    return JD_OK;
+  }
 
   // fallback: the dense fp32 kernel, gated on the device flag (returns at once in the normal case)
   GmmFwdArgs dense = a;
@@ -2424,6 +2629,19 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   // screened arg-max with a gradient: the exact kernel also produces the gradient rows (no second sort, no separate
   // backward kernel); JD_GMM_FUSED_BWD=0 keeps the bucketed backward pass (testing / tuning)
   const bool fused = screened && grad_flux_accum && g->triangular && opt_value(OPT_GMM_FUSED_BWD, 1) != 0;
+  // logsumexp mode with a gradient: through the screen as well (option JD_GMM_LSE_SCREEN = 0: the dense kernels)
+  bool lse_screened = marginalize && grad_flux_accum && g->screen_ok && g->triangular && g->K <= SCREEN_KC_MAX &&
+                      opt_value(OPT_GMM_LSE_SCREEN, 1) != 0 && !opt_is_set(OPT_GMM_DENSE);
+  if (lse_screened && g->host_stats && opt_value(OPT_GMM_LSE_SCREEN, 1) != 2) {  // (2: always, for tests and timing)
+    volatile int* hs = g->host_stats;
+    const int seen = hs[0];
+    if (g->last_pass_lse && seen == g->gen && seen != g->lse_seen_gen) {  // the previous pass has landed and was screened
+      g->lse_seen_gen = seen;
+      if (hs[1] != 0 && g->rows_per_patch >= 32) g->lse_skip = 32;
+    }
+    if (g->lse_skip > 0) --g->lse_skip, lse_screened = false;
+  }
+  g->last_pass_lse = lse_screened;
   int32_t* arg = argmax_out;
   if (grad_flux_accum && (!arg || fused)) {  // fused: the internal buffer holds the components after a fallback
     if ((rc = grow(&g->argmax, &g->argmax_cap, (size_t)nPy * nPx))) return rc;
@@ -2439,7 +2657,9 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   }
   if (grad_flux_accum && (rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;  // (the fused fallback writes it)
   int n_waves = 0;
-  if (marginalize)
+  if (lse_screened)
+    rc = screened_forward(g, a, s, &n_waves, true, nullptr, (double)value_scale, value_out, accumulate_value, true);
+  else if (marginalize)
     rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
   else if (screened)
     rc = screened_forward(g, a, s, &n_waves, fused, fused ? g->argmax : nullptr, (double)value_scale, value_out, accumulate_value);
@@ -2447,12 +2667,15 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     rc = launch_fwd<MODE_MAX>(a, g->triangular, g->n_cu, s, &n_waves);
   if (rc) return rc;
   // (screened path: the last block of gmm_best_kernel has written the value already)
-  if (!screened && (rc = launch_finalize_sum(g->partials, n_waves, (double)value_scale, 0.0, value_out, accumulate_value, s)))
+  if (!screened && !lse_screened &&
+      (rc = launch_finalize_sum(g->partials, n_waves, (double)value_scale, 0.0, value_out, accumulate_value, s)))
     return rc;
   if (!grad_flux_accum) return JD_OK;
 
   if ((rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;
-  if (marginalize) {
+  if (lse_screened) {
+    // the combine kernel (or, after a fallback, the gated dense backward kernel) has written g->gpatch
+  } else if (marginalize) {
     GmmBwdLseArgs b{};
     b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
     b.value_patch = g->vpatch, b.gpatch = g->gpatch, b.K = g->K;

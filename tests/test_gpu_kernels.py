@@ -487,8 +487,11 @@ def test_gmm_non_triangular_precisions_use_the_dense_variant():
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=5e-4)
 
 
-def test_gmm_prior_marginalized_gradient_exact_inputs():
-    """logsumexp gradient against the CPU oracle on bit-identical inputs (no exp(log(.)) round trip).
+@pytest.mark.parametrize("path", ["screened", "dense"])
+def test_gmm_prior_marginalized_gradient_exact_inputs(jd_option, path):
+    """logsumexp gradient against the CPU oracle on bit-identical inputs (no exp(log(.)) round trip) -- through the
+    screen (default: the components within 25 of the bound, their records combined per patch) and through the dense
+    kernels (JD_GMM_LSE_SCREEN=0).
     Tolerance 5e-5 instead of the 1e-5 of the max mode: the responsibilities exponentiate the ABSOLUTE
     fp32 error of the log-likelihoods (|l| ~ 1e2..1e3, so ~1e-5 per component whatever the summation
     order), which no fp32 implementation can avoid; measured 1.9e-5 here."""
@@ -496,6 +499,7 @@ def test_gmm_prior_marginalized_gradient_exact_inputs():
     from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
     from oracle import cpu_ref
 
+    jd_option("JD_GMM_LSE_SCREEN", "1" if path == "screened" else "0")
     rs = np.random.RandomState(12)
     means, covs, weights = synthetic_gmm(9, 64, seed=6)
     means = 0.05 * rs.normal(size=means.shape)
@@ -525,6 +529,55 @@ def test_gmm_prior_marginalized_gradient_exact_inputs():
                              patch_rows=(lo, hi), accumulate_value=True)
     np.testing.assert_allclose(float(pv), float(value), rtol=1e-6)
     assert rel_linf(pg.cpu().numpy(), grad.cpu().numpy()) < 1e-6
+
+
+def test_gmm_logsumexp_screen_equals_the_dense_kernels(jd_option):
+    """marginalize=True through the screen against the dense logsumexp kernels (both are gated against the oracle and
+    its float64 run above): value to 2e-6, gradient to 5e-5 of its largest entry (two fp32 evaluations of the
+    responsibilities: see the tolerance note of the oracle test) -- on a noisy image, a smooth one, a patch-row shard,
+    with filtered patches; and bit-identical to the dense kernels where the pass falls back on the device: 40 equal
+    components (more records per patch than the patch table holds) and an infinite pixel."""
+    from jolideco_amd.data import synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    shape = (136, 172)
+    rs = np.random.RandomState(8)
+    yy, xx = np.mgrid[: shape[0], : shape[1]]
+    smooth = (50.0 + 30.0 * np.exp(-((yy - 60.0) ** 2 + (xx - 90.0) ** 2) / 800.0)).astype(np.float32)
+    noisy = rs.gamma(20, size=shape).astype(np.float32)
+    noisy[60:64, 80:90] = -2e5  # filtered patches: no value, no gradient
+
+    def run(handle, image, screen, rows=(0, -1)):
+        jd_option("JD_GMM_LSE_SCREEN", "2" if screen else "0")  # (2: every pass, whatever the earlier ones did)
+        flux = torch.from_numpy(image).to(DEV)
+        value, grad = torch.zeros(1, device=DEV), torch.zeros_like(flux)
+        handle.prior_fwd_bwd(flux, 4, (3, -5), value, 0.25, grad=grad, grad_coef=-0.7, patch_rows=rows, marginalize=True)
+        torch.cuda.synchronize()
+        return float(value), grad.cpu().numpy()
+
+    means, covs, weights = synthetic_gmm(24, 64, seed=9)
+    handle = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4)).handle(DEV)
+    for image in (noisy, smooth):
+        for rows in ((0, -1), (5, 19)):
+            for _ in range(3):  # (the record buffer of a handle grows over the first passes: all of them must be right)
+                a, b = run(handle, image, True, rows), run(handle, image, False, rows)
+                np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
+                assert rel_linf(a[1], b[1]) < 5e-5 and np.abs(b[1]).max() > 0
+    # fallbacks on the device: the gated dense kernels take the pass -> the same bits as the dense path
+    means, covs, weights = synthetic_gmm(1, 64, seed=3)
+    gmm40 = GaussianMixtureModel.from_numpy(np.repeat(means, 40, axis=0), np.repeat(covs, 40, axis=0), np.full(40, 1 / 40),
+                                            meta=GaussianMixtureModelMeta(stride=4))
+    a, b = run(gmm40.handle(DEV), noisy, True), run(gmm40.handle(DEV), noisy, False)
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    bad = noisy.copy()
+    bad[20, 30] = np.inf
+    a, b = run(handle, bad, True), run(handle, bad, False)
+    assert np.array_equal(np.isnan(a[1]), np.isnan(b[1]))
+    finite = np.isfinite(b[1])
+    assert np.array_equal(a[1][finite], b[1][finite])
+    a, b = run(handle, noisy, True), run(handle, noisy, False)  # ... and the next pass is back on the screen
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6)
+    assert rel_linf(a[1], b[1]) < 5e-5
 
 
 def test_marginalized_prior_fit_matches_oracle():

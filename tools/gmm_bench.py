@@ -27,9 +27,9 @@ else:
 flux = torch.from_numpy(flux_np.astype(np.float32)).to(dev)
 v = torch.zeros(1, device=dev)
 g = torch.zeros_like(flux) if with_grad else None
-for _ in range(3):
+for _ in range(8):  # (the record buffer of the screened paths grows over the first passes)
     h.prior_fwd_bwd(flux, 4, (1, -1), v, 1.0, grad=g, grad_coef=1.0, marginalize=lse)
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
 _hip.profile_enable(capacity=4096)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 10
