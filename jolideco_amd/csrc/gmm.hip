@@ -765,7 +765,7 @@ struct GmmBwdLseArgs {
   const float* mfrag;
   const float* gfrag;
   const float* const_k;
-  const float* value_patch;  // logsumexp per patch (global patch index), NaN for filtered patches
+  double* partials;          // one per block: the sum of the logsumexp values of its patches
   float* gpatch;             // (n_end - n_begin) * 64
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
   const int* run_flag;       // nullable: the kernel returns at once unless *run_flag == run_gen (fallback of the
@@ -786,9 +786,14 @@ __device__ __forceinline__ void load_gfrags(GFrag& f, const float4* gf, int k) {
       if (!TRI || jb >= ib) f.a[ib][jb] = gk[(ib * 4 + jb) * 64];
 }
 
+// One component of the logsumexp pass (value AND gradient in one sweep over the components, the way an online softmax
+// is accumulated): y = P'^T xbar - m', l = c_k - |y|^2 / 2; the running maximum m of the patch rises to max(m, l), the sum
+// S and the gradient accumulator G are rescaled by exp(m_old - m_new) -- a wave-uniform branch, taken only while some
+// patch of the wave still sees its maximum rise -- and the component enters with the weight e = exp(l - m):
+// S += e, G += P' (e y).  At the end v = m + log S and the gradient row is G / S.
 template <bool TRI, int GRP>
 __device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr, float ck, const float4 (&x)[GRP][8],
-                                              const float (&v)[GRP][2], f32x4 (&G)[GRP][4][2]) {
+                                              float (&m)[GRP][2], float (&S)[GRP][2], f32x4 (&G)[GRP][4][2]) {
 #pragma unroll
   for (int gi = 0; gi < GRP; ++gi) {
     f32x4 y[4][2];
@@ -796,11 +801,23 @@ __device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
       const float l = fmaf(-0.5f, sum_lane_groups(sum_squares(y, nb)), ck);
-      const float r = (v[gi][nb] == v[gi][nb]) ? expf(l - v[gi][nb]) : 0.f;  // NaN marks a filtered patch
+      const bool rises = l > m[gi][nb];
+      if (__ballot(rises) != 0ull) {
+        const float m_new = rises ? l : m[gi][nb];
+        const float scale = rises ? expf(m[gi][nb] - m_new) : 1.f;  // (exp(-inf) = 0 the first time: S and G are 0 anyway)
+        m[gi][nb] = m_new;
+        S[gi][nb] *= scale;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) G[gi][ib][nb][e] *= scale;
+      }
+      const float w = expf(l - m[gi][nb]);  // (a NaN l -- a non-finite pixel -- never rises and poisons S: NaN out)
+      S[gi][nb] += w;
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[jb][nb][e] *= r;
+        for (int e = 0; e < 4; ++e) y[jb][nb][e] *= w;
     }
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
@@ -814,9 +831,15 @@ __device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr
   }
 }
 
+// Logsumexp value and gradient rows of all patches in ONE pass over the components (dense path of marginalize = True
+// with a gradient, and the gated fallback of the screened one): per patch v = logsumexp_k l_k -> one fp64 partial sum
+// per block, gamma = -sum_k r_k P'_k y_k minus its mean -> gpatch.  (Until late in round 3 a forward kernel computed v
+// first and this kernel evaluated every l_k a second time to form r_k = exp(l_k - v): three matrix products per
+// component instead of two.)
 template <bool TRI, int GRP>
 __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
   if (a.run_flag && *a.run_flag != a.run_gen) return;
+  __shared__ double red[4];
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, n16 = lane & 15;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -825,10 +848,11 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
   const float4* af = reinterpret_cast<const float4*>(a.afrag) + lane;
   const float4* mf = reinterpret_cast<const float4*>(a.mfrag) + g;
   const float4* gf = reinterpret_cast<const float4*>(a.gfrag) + lane;
+  double local = 0.0;
   for (int grp0 = wave_global * GRP; grp0 < n_groups; grp0 += n_waves * GRP) {
     int n[GRP][2];
-    bool valid[GRP][2];
-    float v[GRP][2];
+    bool valid[GRP][2], sel[GRP][2];
+    float m[GRP][2], S[GRP][2];
     float4 x[GRP][8];
     f32x4 G[GRP][4][2];
 #pragma unroll
@@ -837,16 +861,21 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
       for (int nb = 0; nb < 2; ++nb) {
         n[gi][nb] = a.n_begin + (grp0 + gi) * 32 + nb * 16 + n16;
         valid[gi][nb] = n[gi][nb] < a.n_end;
-        v[gi][nb] = valid[gi][nb] ? a.value_patch[n[gi][nb]] : NAN;
+        m[gi][nb] = -INFINITY, S[gi][nb] = 0.f;
         const int py = valid[gi][nb] ? n[gi][nb] / a.nPx : 0, px = valid[gi][nb] ? n[gi][nb] % a.nPx : 0;
         float xv[16];
+        int keep = 1;
 #pragma unroll
         for (int st = 0; st < 16; ++st) {
           const int p = 4 * st + g;
           const int yy = wrap(py * a.stride + (p >> 3) - a.shift_y, a.H);
           const int xx = wrap(px * a.stride + (p & 7) - a.shift_x, a.W);
           xv[st] = valid[gi][nb] ? a.flux[(size_t)yy * a.W + xx] : 0.f;
+          keep &= xv[st] > -1e5f ? 1 : 0;  // patches/core.py:215
         }
+        keep &= __shfl_xor(keep, 16, 64);  // the four lane groups hold 16 pixels of the patch each
+        keep &= __shfl_xor(keep, 32, 64);
+        sel[gi][nb] = valid[gi][nb] && keep != 0;
         const float mean = patch_mean_groups(xv);
 #pragma unroll
         for (int st4 = 0; st4 < 4; ++st4)
@@ -864,21 +893,26 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
       const int kn = k + 1 < a.K ? k + 1 : k;
       load_frags<TRI>(f1, af, mf, kn);
       load_gfrags<TRI>(g1, gf, kn);
-      lse_component<TRI, GRP>(f0, g0, a.const_k[k], x, v, G);
+      lse_component<TRI, GRP>(f0, g0, a.const_k[k], x, m, S, G);
       const int kn2 = k + 2 < a.K ? k + 2 : k;
       load_frags<TRI>(f0, af, mf, kn2);
       load_gfrags<TRI>(g0, gf, kn2);
-      if (k + 1 < a.K) lse_component<TRI, GRP>(f1, g1, a.const_k[k + 1], x, v, G);
+      if (k + 1 < a.K) lse_component<TRI, GRP>(f1, g1, a.const_k[k + 1], x, m, S, G);
     }
 
-    // gamma = -G, minus its mean over the 64 pixels (adjoint of the patch-mean subtraction)
+    // v = m + log S; gamma = -G / S, minus its mean over the 64 pixels (adjoint of the patch-mean subtraction); a
+    // filtered patch has no value and no gradient
 #pragma unroll
     for (int gi = 0; gi < GRP; ++gi)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
+        const float inv = sel[gi][nb] ? 1.f / S[gi][nb] : 0.f;
         float sum = 0.f;
 #pragma unroll
-        for (int ib = 0; ib < 4; ++ib) sum += (G[gi][ib][nb][0] + G[gi][ib][nb][1]) + (G[gi][ib][nb][2] + G[gi][ib][nb][3]);
+        for (int ib = 0; ib < 4; ++ib) {
+          G[gi][ib][nb] *= inv;
+          sum += (G[gi][ib][nb][0] + G[gi][ib][nb][1]) + (G[gi][ib][nb][2] + G[gi][ib][nb][3]);
+        }
         const float mean = sum_lane_groups(sum) * (1.f / 64.f);
         if (valid[gi][nb]) {
           float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(n[gi][nb] - a.n_begin) * D);
@@ -886,9 +920,14 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
           for (int ib = 0; ib < 4; ++ib)
             out[4 * ib + g] = make_float4(mean - G[gi][ib][nb][0], mean - G[gi][ib][nb][1], mean - G[gi][ib][nb][2],
                                           mean - G[gi][ib][nb][3]);
+          if (g == 0 && sel[gi][nb]) local += (double)(m[gi][nb] + logf(S[gi][nb]));
         }
       }
   }
+  local = wave_sum(local);
+  if (lane == 0) red[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) a.partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2513,25 +2552,16 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 #endif
 
   if (lse) {
-    // fallback: the dense logsumexp kernels, gated on the device flag (forward: per-patch values + partial sums;
-    // backward: g->gpatch), then the records of every patch -> value and gradient row, then the value
-    GmmFwdArgs dense = a;
-    dense.run_flag = flag, dense.run_gen = g->gen;
-    const int tb = pick_block_tiles(n, g->n_cu);
-    const int n_dense = (int)((n + 32L * tb - 1) / (32L * tb));
-    switch (tb) {
-      case 16: rc = launch_fwd_tb<16, MODE_LSE, true>(dense, (unsigned)n_dense, s); break;
-      case 8: rc = launch_fwd_tb<8, MODE_LSE, true>(dense, (unsigned)n_dense, s); break;
-      default: rc = launch_fwd_tb<4, MODE_LSE, true>(dense, (unsigned)n_dense, s); break;
-    }
-    if (rc) return rc;
+    // fallback: the dense logsumexp kernel (value partial sums + g->gpatch in one pass), gated on the device flag; then
+    // the records of every patch -> value and gradient row; then the value from whichever path ran
     GmmBwdLseArgs b{};
     b.flux = a.flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
-    b.value_patch = a.value_patch, b.gpatch = g->gpatch, b.K = g->K;
+    b.partials = g->partials, b.gpatch = g->gpatch, b.K = g->K;
     b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x;
     b.n_begin = a.n_begin, b.n_end = a.n_end, b.run_flag = flag, b.run_gen = g->gen;
     long bblocks = ((n + 31) / 32 + 2 * 4 - 1) / (2 * 4);
     if (bblocks > g->n_cu) bblocks = g->n_cu;
+    const int n_dense = (int)bblocks;
     gmm_bwd_lse_kernel<true, 2><<<(unsigned)bblocks, 256, 0, s>>>(b);
     JD_LAUNCH_CHECK();
     GmmLseCombineArgs cb{};
@@ -2651,15 +2681,30 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   a.flux = flux, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
   a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x;
   a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = fused ? argmax_out : arg, a.value_patch = nullptr, a.partials = g->partials;
-  if (marginalize && grad_flux_accum) {
-    if ((rc = grow(&g->vpatch, &g->vpatch_cap, (size_t)nPy * nPx))) return rc;
-    a.value_patch = g->vpatch;
-  }
   if (grad_flux_accum && (rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;  // (the fused fallback writes it)
   int n_waves = 0;
   if (lse_screened)
     rc = screened_forward(g, a, s, &n_waves, true, nullptr, (double)value_scale, value_out, accumulate_value, true);
-  else if (marginalize)
+  else if (marginalize && grad_flux_accum) {
+    // value and gradient rows in one pass over the components (gmm_bwd_lse_kernel)
+    GmmBwdLseArgs b{};
+    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
+    b.partials = g->partials, b.gpatch = g->gpatch, b.K = g->K;
+    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
+    b.n_begin = n_begin, b.n_end = n_end;
+    const long groups = (n + 31) / 32;
+    long blocks = (groups + 2 * 4 - 1) / (2 * 4);  // 2 groups per wave, 4 waves per block
+    if (blocks > g->n_cu) blocks = g->n_cu;       // one block per CU (one wave per SIMD), grid-stride over the rest
+    if ((rc = grow(&g->partials, &g->partials_cap, (size_t)blocks))) return rc;
+    b.partials = g->partials;
+    n_waves = (int)blocks;
+    ProfScope prof(JD_KERNEL_GMM_BWD, s);
+    if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
+      gmm_bwd_lse_kernel<true, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+    else
+      gmm_bwd_lse_kernel<false, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+    JD_LAUNCH_CHECK();
+  } else if (marginalize)
     rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
   else if (screened)
     rc = screened_forward(g, a, s, &n_waves, fused, fused ? g->argmax : nullptr, (double)value_scale, value_out, accumulate_value);
@@ -2676,22 +2721,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   if (lse_screened) {
     // the combine kernel (or, after a fallback, the gated dense backward kernel) has written g->gpatch
   } else if (marginalize) {
-    GmmBwdLseArgs b{};
-    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
-    b.value_patch = g->vpatch, b.gpatch = g->gpatch, b.K = g->K;
-    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
-    b.n_begin = n_begin, b.n_end = n_end;
-    const long groups = (n + 31) / 32;
-    long blocks = (groups + 2 * 4 - 1) / (2 * 4);  // 2 groups per wave, 4 waves per block
-    if (blocks > g->n_cu) blocks = g->n_cu;       // one block per CU (one wave per SIMD), grid-stride over the rest
-    {
-      ProfScope prof(JD_KERNEL_GMM_BWD, s);
-      if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
-        gmm_bwd_lse_kernel<true, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
-      else
-        gmm_bwd_lse_kernel<false, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
-    }
-    JD_LAUNCH_CHECK();
+    // gmm_bwd_lse_kernel has written the rows together with the value
   } else if (fused) {
     // the rows are in g->grec already (after a fallback: in g->gpatch, written by gmm_best_kernel's blocks)
   } else {
