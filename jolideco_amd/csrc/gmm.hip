@@ -416,11 +416,13 @@ struct GmmBucketArgs {
   int* pcount;
   int32_t* ptab;
   int ptab_rows;
+  const int* dense_mark;  // records of marked patches do not count (the dense kernel evaluates those patches)
 };
 
 // component of element n, or a negative number if it takes no part (-1: filtered patch)
 __device__ __forceinline__ int bucket_key(const GmmBucketArgs& a, int n) {
   if (a.seg_cnt && !(a.rec_ub[n] >= a.lfinal[a.rec_n[n]] - a.margin)) return -2;  // stale record
+  if (a.dense_mark && a.dense_mark[a.rec_n[n]] != 0) return -2;
   return a.argmax[n];
 }
 // number of elements of chunk c that are in use
@@ -768,8 +770,17 @@ struct GmmBwdLseArgs {
   double* partials;          // one per block: the sum of the logsumexp values of its patches
   float* gpatch;             // (n_end - n_begin) * 64
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
-  const int* run_flag;       // nullable: the kernel returns at once unless *run_flag == run_gen (fallback of the
-  int run_gen;               //           logsumexp screen)
+  // Behind the logsumexp screen (mark != nullptr): the kernel evaluates the 32-patch groups that hold a marked patch
+  // (more candidates than a patch may keep: smooth patches, where most components are within the margin) -- or, after a
+  // fallback of the pass (*run_flag == run_gen), all of them -- and leaves v per patch in vpatch (0 for a filtered
+  // patch) instead of the partial sums; rows and values of unmarked patches of a visited group are NOT written (the
+  // combine kernel owns them).
+  const int* run_flag;
+  int run_gen;
+  const int* mark;
+  float* vpatch;
+  const int32_t* list;       // the marked patches, compacted (gmm_lse_list_kernel), and their number: a wave works on 64
+  const int* list_count;     // of THEM at a time, so that the launch takes as long as their share of the image
 };
 
 struct GFrag {
@@ -838,7 +849,7 @@ __device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr
 // component instead of two.)
 template <bool TRI, int GRP>
 __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
-  if (a.run_flag && *a.run_flag != a.run_gen) return;
+  const bool everything = !a.mark || *a.run_flag == a.run_gen;
   __shared__ double red[4];
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, n16 = lane & 15;
@@ -849,9 +860,11 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
   const float4* mf = reinterpret_cast<const float4*>(a.mfrag) + g;
   const float4* gf = reinterpret_cast<const float4*>(a.gfrag) + lane;
   double local = 0.0;
-  for (int grp0 = wave_global * GRP; grp0 < n_groups; grp0 += n_waves * GRP) {
+  const int n_listed = everything ? 0 : *a.list_count;
+  const int n_steps = everything ? n_groups : (n_listed + 31) / 32;
+  for (int grp0 = wave_global * GRP; grp0 < n_steps; grp0 += n_waves * GRP) {
     int n[GRP][2];
-    bool valid[GRP][2], sel[GRP][2];
+    bool valid[GRP][2], sel[GRP][2], mine[GRP][2];
     float m[GRP][2], S[GRP][2];
     float4 x[GRP][8];
     f32x4 G[GRP][4][2];
@@ -859,8 +872,20 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
     for (int gi = 0; gi < GRP; ++gi)
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
-        n[gi][nb] = a.n_begin + (grp0 + gi) * 32 + nb * 16 + n16;
-        valid[gi][nb] = n[gi][nb] < a.n_end;
+        const int idx = (grp0 + gi) * 32 + nb * 16 + n16;
+        if (everything) {
+          n[gi][nb] = a.n_begin + idx;
+          valid[gi][nb] = n[gi][nb] < a.n_end;
+        } else {
+          valid[gi][nb] = idx < n_listed;
+          n[gi][nb] = valid[gi][nb] ? a.list[idx] : a.n_begin;
+        }
+        mine[gi][nb] = valid[gi][nb];
+      }
+#pragma unroll
+    for (int gi = 0; gi < GRP; ++gi)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
         m[gi][nb] = -INFINITY, S[gi][nb] = 0.f;
         const int py = valid[gi][nb] ? n[gi][nb] / a.nPx : 0, px = valid[gi][nb] ? n[gi][nb] % a.nPx : 0;
         float xv[16];
@@ -914,16 +939,19 @@ __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
           sum += (G[gi][ib][nb][0] + G[gi][ib][nb][1]) + (G[gi][ib][nb][2] + G[gi][ib][nb][3]);
         }
         const float mean = sum_lane_groups(sum) * (1.f / 64.f);
-        if (valid[gi][nb]) {
+        if (mine[gi][nb]) {
           float4* out = reinterpret_cast<float4*>(a.gpatch + (size_t)(n[gi][nb] - a.n_begin) * D);
 #pragma unroll
           for (int ib = 0; ib < 4; ++ib)
             out[4 * ib + g] = make_float4(mean - G[gi][ib][nb][0], mean - G[gi][ib][nb][1], mean - G[gi][ib][nb][2],
                                           mean - G[gi][ib][nb][3]);
-          if (g == 0 && sel[gi][nb]) local += (double)(m[gi][nb] + logf(S[gi][nb]));
+          const float v = sel[gi][nb] ? m[gi][nb] + logf(S[gi][nb]) : 0.f;
+          if (g == 0 && a.vpatch) a.vpatch[n[gi][nb]] = v;
+          if (g == 0 && sel[gi][nb]) local += (double)v;
         }
       }
   }
+  if (a.vpatch) return;  // (the values are summed by gmm_lse_value_kernel)
   local = wave_sum(local);
   if (lane == 0) red[threadIdx.x >> 6] = local;
   __syncthreads();
@@ -988,6 +1016,9 @@ struct GmmScreenArgs {
   // of a handle) here; every later kernel of the pass compares the flag with gen.  Nothing ever has to clear it.
   int* flag;
   int gen;
+  int* dense_mark;           // logsumexp screen: per patch (global index), zeroed by the staging kernel; set to 1 for a
+                             // patch with more candidates than a patch may keep -- its records are dropped and the
+                             // dense kernel evaluates it
 };
 
 struct __attribute__((packed, aligned(4))) F4U {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
@@ -1008,9 +1039,12 @@ struct GmmStageArgs {
   int* ok;                   // patch takes part (inside the shard, passes the -1e5 filter)
   unsigned long long* best;  // per patch (global index): initialised here
   int* pcount;               // nullable (logsumexp screen): records per patch (global index), zeroed here
+  int* dense_mark;           //   and the "evaluate densely" mark of the patch
+  int* dense_count;          //   and (one int) the length of the list of marked patches
 };
 
 __global__ __launch_bounds__(256) void gmm_stage_kernel(GmmStageArgs a) {
+  if (a.pcount && blockIdx.x == 0 && threadIdx.x == 0) *a.dense_count = 0;
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= a.n_tiles) return;
@@ -1070,7 +1104,7 @@ __global__ __launch_bounds__(256) void gmm_stage_kernel(GmmStageArgs a) {
     a.xs2[tile * 32 + c] = ldexpf(1.f, 2 * (ex - 14));
     a.ok[tile * 32 + c] = ok ? 1 : 0;
     if (valid) a.best[n] = ok ? best_key(-INFINITY, 0) : 0ull;
-    if (valid && a.pcount) a.pcount[n] = 0;
+    if (valid && a.pcount) a.pcount[n] = 0, a.dense_mark[n] = 0;
   }
 }
 
@@ -1144,11 +1178,12 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
 // LSE (logsumexp screen): a component is recorded while its upper bound reaches L - LSE_MARGIN -- whatever is left out is
 // below exp(-25) = 1.4e-11 of the largest term of the sum, 128 components of it below 2e-9 of the sum.
 constexpr float LSE_MARGIN = 25.f;
+constexpr int LSE_KEEP = 28;  // candidates a patch may keep (a multiple of 4; <= LSE_ROWS, and 128 x (LSE_KEEP + 1) <= SCREEN_CAP)
 template <bool LSE = false>
 __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], const f32x16 (&accB)[2], float ck, float ack,
                                                    float mnorm, float efro, float xn, float s2, bool ok, float& L,
                                                    float& qacc, int n, int k, int lane, int& cnt, int32_t* rec_n,
-                                                   int32_t* rec_k, float* rec_ub, int cap) {
+                                                   int32_t* rec_k, float* rec_ub, int cap, int& pc, int keep) {
   const float qa = screen_q_half(accA), qb = screen_q_half(accB);
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
   // lanes 0-31: tile A, lanes 32-63: tile B; s2 = (s_x s_k)^2 undoes the power-of-two operand scales (exactly)
@@ -1159,7 +1194,11 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   const float l = fmaf(-0.5f, q, ck);
   const float B = fmaf(__builtin_amdgcn_sqrtf(q), e1, fmaf(2e-5f, q, c2));
   const float ub = l + B;
-  const bool cand = ok && ub >= (LSE ? L - LSE_MARGIN : L);
+  bool cand = ok && ub >= (LSE ? L - LSE_MARGIN : L);
+  if (LSE) {  // a patch keeps at most `keep` candidates; one more marks it for the dense kernel (its records are dropped)
+    pc += cand ? 1 : 0;
+    cand = cand && pc <= keep;
+  }
   // L = max(L, l - B) as ONE v_max_f32 (fmaxf adds a canonicalising v_max in front; a NaN operand loses either way
   // and is caught through qacc)
   asm("v_max_f32 %0, %1, %2" : "=v"(L) : "v"(L), "v"(l - B));
@@ -1249,6 +1288,10 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
   float pxn[NP], pL[NP], pq[NP], ps2[NP];
   bool pok[NP];
   int pn[NP];
+  int pc[NP];  // (logsumexp screen) candidates of the lane's patch so far
+  // candidates a patch may keep: 30 x 128 patches fit a wave's record list, and the four waves of a KSPLIT block, which
+  // share the patches, stay below the 32 rows of the patch table together
+  const int keep = KSPLIT ? LSE_KEEP / 4 : LSE_KEEP;
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     ps2[p] = h ? xs2[2 * p + 1] : xs2[2 * p];
@@ -1257,6 +1300,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
     pn[p] = h ? nidx[2 * p + 1] : nidx[2 * p];
     pL[p] = -INFINITY;
     pq[p] = 0.f;
+    pc[p] = 0;
   }
 
   ScreenFrags f0, f1;
@@ -1313,18 +1357,18 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
       issue_pair(acc[1], fa, 1);
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // unconditional (clamped) prefetch
       screen_finish_pair<LSE>(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
-                         cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
+                         cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep);
       flush(false);
       issue_pair(acc[0], fb, 0);
       screen_finish_pair<LSE>(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[NP - 1], ps2[NP - 1] * sk2, pok[NP - 1], pL[NP - 1],
-                         pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
+                         pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[NP - 1], keep);
       flush(false);
     } else {
       // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the accumulator buffers alternate
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // (fa's MFMAs were issued by the previous component)
       issue_pair(acc[1 - PHASE], fb, 0);
       screen_finish_pair<LSE>(acc[PHASE][0], acc[PHASE][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k,
-                         lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
+                         lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep);
       flush(false);
     }
   };
@@ -1336,6 +1380,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     trouble = trouble || (pok[p] && !(pq[p] < 3.0e38f));
+    if (LSE && pc[p] > keep && pn[p] < a.n_end) a.dense_mark[pn[p]] = 1;  // (several waves may store the same 1)
     if (KSPLIT)
       st_L[wave * (NT * 32) + (2 * p + h) * 32 + c] = pL[p];
     else if (pn[p] < a.n_end)
@@ -1669,7 +1714,8 @@ struct GmmLseCombineArgs {
   const float* lrec;      // l by bucket slot
   const float* grec;      // gradient rows by bucket slot
   float* gpatch;          // (n_end - n_begin) * 64: the combined rows
-  double* partials;       // one per block: sum of v over its patches
+  float* vpatch;          // v per patch (global index); 0 for a filtered patch
+  const int* mark;        // patches the dense kernel evaluates: not touched here
   int n_begin, n_end;
   const int* flag;
   int gen;
@@ -1680,11 +1726,10 @@ constexpr int LSE_ROWS = 32;  // records per patch the patch table holds (more: 
 __global__ __launch_bounds__(256) void gmm_lse_combine_kernel(GmmLseCombineArgs a) {
   __shared__ int s_slot[16][LSE_ROWS];
   __shared__ float s_l[16][LSE_ROWS];
-  __shared__ double s_v[16];
   if (*a.flag == a.gen) return;  // (block-uniform)
   const int grp = threadIdx.x >> 4, part = threadIdx.x & 15;
   const int n = a.n_begin + (int)blockIdx.x * 16 + grp;
-  const bool live = n < a.n_end;
+  const bool live = n < a.n_end && a.mark[n < a.n_end ? n : a.n_begin] == 0;
   int c = live ? a.pcount[n] : 0;
   if (c > a.rows) c = a.rows;  // (cannot be: the scatter kernel raised the flag)
   // the patch's records, two per lane; rank by bucket slot -> LDS in ascending order
@@ -1721,35 +1766,96 @@ __global__ __launch_bounds__(256) void gmm_lse_combine_kernel(GmmLseCombineArgs 
     const float inv = c > 0 ? 1.f / S : 0.f;  // (no record: a filtered patch -- no value, no gradient)
     reinterpret_cast<float4*>(a.gpatch + (size_t)(n - a.n_begin) * D)[part] = make_float4(G.x * inv, G.y * inv, G.z * inv, G.w * inv);
   }
-  if (part == 0) s_v[grp] = live && c > 0 ? (double)(m + logf(S)) : 0.0;
+  if (part == 0 && live) a.vpatch[n] = c > 0 ? m + logf(S) : 0.f;
+}
+
+// The marked patches of the pass, compacted: a block ranks the marks of its 1024 patches and reserves its piece of the
+// list with one atomicAdd (the order of the pieces is whatever the atomics make it -- every result is stored by patch
+// index, so none depends on it)
+__global__ __launch_bounds__(256) void gmm_lse_list_kernel(const int* mark, int n_begin, int n_end, const int* flag, int gen,
+                                                           int32_t* list, int* count) {
+  __shared__ int wave_cnt[4][4];
+  __shared__ int base;
+  if (*flag == gen) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int first = n_begin + (int)blockIdx.x * 1024;
+  bool marked[4];
+  int rank[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = first + i * 256 + (int)threadIdx.x;
+    marked[i] = n < n_end && mark[n] != 0;
+    const unsigned long long b = __ballot(marked[i]);
+    rank[i] = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[i][wave] = __popcll(b);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double total = 0.0;
+    int total = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) total += s_v[i];
-    a.partials[blockIdx.x] = total;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int c = wave_cnt[i][w];
+        wave_cnt[i][w] = total;
+        total += c;
+      }
+    base = total ? atomicAdd(count, total) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (marked[i]) list[base + wave_cnt[i][wave] + rank[i]] = first + i * 256 + (int)threadIdx.x;
+}
+
+// Partial sums of the per-patch values in a fixed order (1024 patches per block, thread t adds patches t, t + 256, ...)
+// and the number of patches the dense kernel had to take
+__global__ __launch_bounds__(256) void gmm_lse_value_kernel(const float* vpatch, const int* mark, int n_begin, int n_end,
+                                                            double* partials, int* marked) {
+  __shared__ double red[4];
+  __shared__ int redm[4];
+  const int base = n_begin + (int)blockIdx.x * 1024;
+  double local = 0.0;
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = base + i * 256 + (int)threadIdx.x;
+    const bool marked = n < n_end && mark[n] != 0;
+    if (n < n_end) local += (double)vpatch[n];
+    cnt += __popcll(__ballot(marked));
+  }
+  local = wave_sum(local);  // (cnt: the wave's marked patches, the same number in every lane)
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local, redm[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    marked[blockIdx.x] = (redm[0] + redm[1]) + (redm[2] + redm[3]);
   }
 }
 
-// value_out = [value_out +] scale * sum(partials): those of the combine kernel, or of the dense kernel after a
-// fallback; also leaves the pass statistics for the host (see GmmBestArgs::host_stats)
-__global__ __launch_bounds__(256) void gmm_lse_finalize_kernel(const double* combined, int n_combined, const double* dense,
-                                                               int n_dense, const int* flag, int gen, double scale,
-                                                               float* value_out, int accumulate, int* host_stats,
-                                                               const int* slots_used, int patches) {
+// value_out = [value_out +] scale * sum(partials); also leaves the pass statistics for the host (see
+// GmmBestArgs::host_stats): "fell back" = 1 after a fallback, 2 when the dense kernel took more than 60 % of the patches
+__global__ __launch_bounds__(256) void gmm_lse_finalize_kernel(const double* partials, const int* marked, int count,
+                                                               const int* flag, int gen, double scale, float* value_out,
+                                                               int accumulate, int* host_stats, const int* slots_used,
+                                                               int patches) {
   __shared__ double smem[4];
-  const bool fell_back = *flag == gen;
-  const double* src = fell_back ? dense : combined;
-  const int count = fell_back ? n_dense : n_combined;
+  __shared__ int smem_i[4];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < count; i += 256) acc += src[i];
+  int cnt = 0;
+  for (int i = threadIdx.x; i < count; i += 256) acc += partials[i], cnt += marked[i];
   const double total = block_sum<256>(acc, smem);
+  for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);  // patches the dense kernel took
+  if ((threadIdx.x & 63) == 0) smem_i[threadIdx.x >> 6] = cnt;
+  __syncthreads();
   if (threadIdx.x == 0) {
     double v = scale * total;
     if (accumulate) v += (double)value_out[0];
     value_out[0] = (float)v;
     if (host_stats) {
-      host_stats[1] = fell_back ? 1 : 0;
+      const int n_marked = (smem_i[0] + smem_i[1]) + (smem_i[2] + smem_i[3]);
+      // (screen + sort + records cost about a third of a dense pass: beyond 60 % of the patches the dense pass alone is cheaper)
+      host_stats[1] = *flag == gen ? 1 : (5 * (long)n_marked > 3 * (long)patches ? 2 : 0);
       host_stats[2] = *slots_used;
       host_stats[3] = patches;
       __threadfence_system();
@@ -2066,6 +2172,12 @@ struct jd_gmm {
   size_t ptab_cap = 0;
   double* partials_lse = nullptr;
   size_t partials_lse_cap = 0;
+  int* dense_mark = nullptr;   // patches the dense kernel evaluates (too many candidates)
+  size_t dense_mark_cap = 0;
+  int* marked_lse = nullptr;   // their number per block of the value kernel
+  size_t marked_lse_cap = 0;
+  int32_t* dense_list = nullptr;  // the marked patches, compacted (+ one int in front: their number)
+  size_t dense_list_cap = 0;
   // Where (nearly) all components are within the margin of the maximum -- smooth images under a mixture with similar
   // constants -- the logsumexp screen cannot pay: every pass overflows a record list and falls back to the dense
   // kernels after 0.5 ms of screening.  Once a pass has fallen back with the record buffer at its largest, the next
@@ -2285,6 +2397,9 @@ extern "C" int jd_gmm_destroy(jd_gmm* g) {
   if (g->pcount) (void)hipFree(g->pcount);
   if (g->ptab) (void)hipFree(g->ptab);
   if (g->partials_lse) (void)hipFree(g->partials_lse);
+  if (g->dense_mark) (void)hipFree(g->dense_mark);
+  if (g->marked_lse) (void)hipFree(g->marked_lse);
+  if (g->dense_list) (void)hipFree(g->dense_list);
   if (g->xstat) (void)hipFree(g->xstat);
   if (g->xok) (void)hipFree(g->xok);
   if (g->rec) (void)hipFree(g->rec);
@@ -2415,12 +2530,16 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     if ((rc = grow(&g->grec, &g->grec_cap, grec_rows * D))) return rc;
     if ((rc = grow(&g->winner, &g->winner_cap, (size_t)a.n_end))) return rc;
   }
-  const unsigned combine_blocks = (unsigned)((n + 15) / 16);
+  const unsigned combine_blocks = (unsigned)((n + 15) / 16), value_blocks = (unsigned)((n + 1023) / 1024);
   if (lse) {
     if ((rc = grow(&g->lrec, &g->lrec_cap, bucket_slots))) return rc;
     if ((rc = grow(&g->pcount, &g->pcount_cap, (size_t)a.n_end))) return rc;
+    if ((rc = grow(&g->dense_mark, &g->dense_mark_cap, (size_t)a.n_end))) return rc;
+    if ((rc = grow(&g->vpatch, &g->vpatch_cap, (size_t)a.n_end))) return rc;
     if ((rc = grow(&g->ptab, &g->ptab_cap, (size_t)a.n_end * LSE_ROWS))) return rc;
-    if ((rc = grow(&g->partials_lse, &g->partials_lse_cap, (size_t)combine_blocks))) return rc;
+    if ((rc = grow(&g->partials_lse, &g->partials_lse_cap, (size_t)value_blocks))) return rc;
+    if ((rc = grow(&g->marked_lse, &g->marked_lse_cap, (size_t)value_blocks))) return rc;
+    if ((rc = grow(&g->dense_list, &g->dense_list_cap, (size_t)n + 1))) return rc;
   }
 
   const size_t n_tiles = (size_t)blocks * (ksplit ? T : 4 * T);  // tiles the screen's waves touch
@@ -2439,7 +2558,8 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   GmmStageArgs stg{};
   stg.flux = a.flux, stg.H = a.H, stg.W = a.W, stg.stride = a.stride, stg.nPx = a.nPx, stg.shift_y = a.shift_y, stg.shift_x = a.shift_x;
   stg.n_begin = a.n_begin, stg.n_end = a.n_end, stg.n_tiles = (int)n_tiles;
-  stg.pcount = lse ? g->pcount : nullptr;
+  stg.pcount = lse ? g->pcount : nullptr, stg.dense_mark = lse ? g->dense_mark : nullptr;
+  stg.dense_count = lse ? reinterpret_cast<int*>(g->dense_list) : nullptr;
   stg.xfrag = g->xfrag, stg.xn = g->xstat, stg.xs2 = g->xstat + n_tiles * 32, stg.ok = g->xok, stg.best = g->best;
   GmmScreenArgs sc{};
   sc.xfrag = g->xfrag, sc.xn = stg.xn, sc.xs2 = stg.xs2, sc.ok = g->xok;
@@ -2447,7 +2567,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
   sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
-  sc.seg_cnt = g->seg_cnt, sc.flag = flag, sc.gen = g->gen;
+  sc.seg_cnt = g->seg_cnt, sc.flag = flag, sc.gen = g->gen, sc.dense_mark = lse ? g->dense_mark : nullptr;
   {
     ProfScope stage(JD_KERNEL_GMM_STAGE, s);
     gmm_stage_kernel<<<(unsigned)((n_tiles + 3) / 4), 256, 0, s>>>(stg);
@@ -2481,7 +2601,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   bk.chunk = SCREEN_CAP;  // one record segment per chunk
   bk.korder = g->K <= KORDER_MAX_K ? g->korder : nullptr;
   if (fused) bk.flag = flag, bk.gen = g->gen, bk.slot_cap = (int)std::min<size_t>(grec_rows, (size_t)INT32_MAX);
-  if (lse) bk.margin = LSE_MARGIN, bk.pcount = g->pcount, bk.ptab = g->ptab, bk.ptab_rows = LSE_ROWS;
+  if (lse) bk.margin = LSE_MARGIN, bk.pcount = g->pcount, bk.ptab = g->ptab, bk.ptab_rows = LSE_ROWS, bk.dense_mark = g->dense_mark;
   bk.blk_counts = g->blk_counts;
   const size_t hist_bytes = (size_t)g->K * sizeof(int);
   {
@@ -2552,26 +2672,31 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 #endif
 
   if (lse) {
-    // fallback: the dense logsumexp kernel (value partial sums + g->gpatch in one pass), gated on the device flag; then
-    // the records of every patch -> value and gradient row; then the value from whichever path ran
+    // the dense logsumexp kernel on the groups that hold a marked patch (after a fallback of the pass: on all of them),
+    // the records of every other patch -> value and gradient row, the values summed in a fixed order
     GmmBwdLseArgs b{};
     b.flux = a.flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
     b.partials = g->partials, b.gpatch = g->gpatch, b.K = g->K;
     b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x;
     b.n_begin = a.n_begin, b.n_end = a.n_end, b.run_flag = flag, b.run_gen = g->gen;
+    b.mark = g->dense_mark, b.vpatch = g->vpatch;
+    b.list = g->dense_list + 1, b.list_count = reinterpret_cast<const int*>(g->dense_list);
+    gmm_lse_list_kernel<<<value_blocks, 256, 0, s>>>(g->dense_mark, a.n_begin, a.n_end, flag, g->gen, g->dense_list + 1,
+                                                     reinterpret_cast<int*>(g->dense_list));
+    JD_LAUNCH_CHECK();
     long bblocks = ((n + 31) / 32 + 2 * 4 - 1) / (2 * 4);
     if (bblocks > g->n_cu) bblocks = g->n_cu;
-    const int n_dense = (int)bblocks;
     gmm_bwd_lse_kernel<true, 2><<<(unsigned)bblocks, 256, 0, s>>>(b);
     JD_LAUNCH_CHECK();
     GmmLseCombineArgs cb{};
     cb.pcount = g->pcount, cb.ptab = g->ptab, cb.rows = LSE_ROWS, cb.lrec = g->lrec, cb.grec = g->grec, cb.gpatch = g->gpatch;
-    cb.partials = g->partials_lse, cb.n_begin = a.n_begin, cb.n_end = a.n_end, cb.flag = flag, cb.gen = g->gen;
+    cb.vpatch = g->vpatch, cb.mark = g->dense_mark, cb.n_begin = a.n_begin, cb.n_end = a.n_end, cb.flag = flag, cb.gen = g->gen;
     gmm_lse_combine_kernel<<<combine_blocks, 256, 0, s>>>(cb);
     JD_LAUNCH_CHECK();
-    gmm_lse_finalize_kernel<<<1, 256, 0, s>>>(g->partials_lse, (int)combine_blocks, g->partials, n_dense, flag, g->gen,
-                                              value_scale, value_out, accumulate_value, g->host_stats_dev,
-                                              bk.offsets + g->K, (int)n);
+    gmm_lse_value_kernel<<<value_blocks, 256, 0, s>>>(g->vpatch, g->dense_mark, a.n_begin, a.n_end, g->partials_lse, g->marked_lse);
+    JD_LAUNCH_CHECK();
+    gmm_lse_finalize_kernel<<<1, 256, 0, s>>>(g->partials_lse, g->marked_lse, (int)value_blocks, flag, g->gen, value_scale,
+                                              value_out, accumulate_value, g->host_stats_dev, bk.offsets + g->K, (int)n);
     JD_LAUNCH_CHECK();
     *n_partials = 0;
     return JD_OK;
@@ -2667,7 +2792,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     const int seen = hs[0];
     if (g->last_pass_lse && seen == g->gen && seen != g->lse_seen_gen) {  // the previous pass has landed and was screened
       g->lse_seen_gen = seen;
-      if (hs[1] != 0 && g->rows_per_patch >= 32) g->lse_skip = 32;
+      if (hs[1] == 2 || (hs[1] == 1 && g->rows_per_patch >= 32)) g->lse_skip = 32;
     }
     if (g->lse_skip > 0) --g->lse_skip, lse_screened = false;
   }

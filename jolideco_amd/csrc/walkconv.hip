@@ -483,7 +483,10 @@ __global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a)
     }
   }
 
-  constexpr bool PK = C == 4;  // packed FMAs in the column pass: see walk_kernel
+#ifndef JD_WALK_MULTI_PK
+#define JD_WALK_MULTI_PK 1
+#endif
+  constexpr bool PK = C == 4 && JD_WALK_MULTI_PK;  // packed FMAs in the column pass: see walk_kernel
   v2f tup[PK ? (WK + 1) / 2 : 1];
   if constexpr (PK) {
 #pragma unroll

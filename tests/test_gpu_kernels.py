@@ -532,11 +532,12 @@ def test_gmm_prior_marginalized_gradient_exact_inputs(jd_option, path):
 
 
 def test_gmm_logsumexp_screen_equals_the_dense_kernels(jd_option):
-    """marginalize=True through the screen against the dense logsumexp kernels (both are gated against the oracle and
+    """marginalize=True through the screen against the dense logsumexp kernel (both are gated against the oracle and
     its float64 run above): value to 2e-6, gradient to 5e-5 of its largest entry (two fp32 evaluations of the
-    responsibilities: see the tolerance note of the oracle test) -- on a noisy image, a smooth one, a patch-row shard,
-    with filtered patches; and bit-identical to the dense kernels where the pass falls back on the device: 40 equal
-    components (more records per patch than the patch table holds) and an infinite pixel."""
+    responsibilities: see the tolerance note of the oracle test) -- on a noisy image, a smooth one (patches with more
+    candidates than a patch may keep are marked and evaluated by the dense kernel), one that is half of each, a
+    patch-row shard, with filtered patches; the dense kernel's own bits where it takes every patch: 40 equal components
+    (every patch marked) and an infinite pixel (the pass falls back on the device)."""
     from jolideco_amd.data import synthetic_gmm
     from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
 
@@ -557,7 +558,8 @@ def test_gmm_logsumexp_screen_equals_the_dense_kernels(jd_option):
 
     means, covs, weights = synthetic_gmm(24, 64, seed=9)
     handle = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4)).handle(DEV)
-    for image in (noisy, smooth):
+    half = np.where(xx < shape[1] // 2, smooth, noisy).astype(np.float32)
+    for image in (noisy, smooth, half):
         for rows in ((0, -1), (5, 19)):
             for _ in range(3):  # (the record buffer of a handle grows over the first passes: all of them must be right)
                 a, b = run(handle, image, True, rows), run(handle, image, False, rows)
@@ -568,7 +570,8 @@ def test_gmm_logsumexp_screen_equals_the_dense_kernels(jd_option):
     gmm40 = GaussianMixtureModel.from_numpy(np.repeat(means, 40, axis=0), np.repeat(covs, 40, axis=0), np.full(40, 1 / 40),
                                             meta=GaussianMixtureModelMeta(stride=4))
     a, b = run(gmm40.handle(DEV), noisy, True), run(gmm40.handle(DEV), noisy, False)
-    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6)  # (the per-patch values are summed in another order)
+    assert np.array_equal(a[1], b[1])
     bad = noisy.copy()
     bad[20, 30] = np.inf
     a, b = run(handle, bad, True), run(handle, bad, False)

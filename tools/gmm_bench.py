@@ -39,4 +39,4 @@ for _ in range(n):
 e1.record(); torch.cuda.synchronize()
 prof = _hip.profile_read()
 print(f"{edge}^2 K={K} gmm={kind} image={image} lse={int(lse)}: {e0.elapsed_time(e1) / n * 1e3:.1f} us per call;",
-      {k: round(t / c * 1e3, 1) for k, (t, c) in prof.items() if c}, "value", float(v))
+      {k: round(t / c * 1e3, 1) for k, (t, c) in prof.items() if c}, "value", float(v), "stats", h.screen_stats())
