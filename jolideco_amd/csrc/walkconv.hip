@@ -1183,7 +1183,7 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
   if (!walk_setup(a, n * n_comp, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
   // Block shape.  6-8 datasets: 4 columns per lane (1 KB per row and stream), exchange groups of 6 rows: 112 KB of LDS, ONE
   // block of 6-8 waves per CU; fewer datasets: 2 columns per lane, as many blocks per CU as LDS (exchange buffer) and
-  // registers (86: 5 waves per SIMD) allow.  Rows per tile: a multiple of every exchange group size, the smallest that
+  // registers (112-127: 4 waves per SIMD) allow.  Rows per tile: a multiple of every exchange group size, the smallest that
   // leaves all blocks resident at once.  Measured inside the fit at 2048^2 x 8 (tools/ab.py): C = 4, rows 36 / 66 / 72 /
   // 84 = 98 / 77.5 / 85 / 89 us (66 rows: 8 strips x 32 tiles = one block for every CU); C = 2 (two blocks per CU), rows
   // 54 / 72 / 90 = 111 / 85 / 97 us.
@@ -1196,7 +1196,7 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
     const int C = wide ? 4 : 2;
     const int lds = (2 * xg * XW * 64 * C + XW * 128 * C) * 4;  // exchange buffer + row buffers
     int per_cu = 160 * 1024 / lds;
-    const int by_regs = (wide ? 12 : 20) / m;  // (136 registers at C = 4: 3 waves per SIMD; 86 at C = 2: 5)
+    const int by_regs = (wide ? 8 : 16) / m;  // (204 registers at C = 4: 2 waves per SIMD; 112-127 at C = 2: 4)
     if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu < 1) per_cu = 1;
     const long slots = (long)device_cus() * per_cu * (per_cu > 1 ? 15 : 16) / 16;
@@ -1279,7 +1279,7 @@ int walk_conv_adjoint_batch_all(int n, int n_comp, const SepBatchTable& table, c
   const int xw = big ? XW2 : XW;
   const int lds = (2 * xg * xw * 64 * C + xw * 128 * C) * 4;
   int per_cu = 160 * 1024 / lds;
-  const int by_regs = (big ? 16 : wide ? 12 : 20) / n;
+  const int by_regs = (big ? 16 : wide ? 8 : 16) / n;
   if (per_cu > by_regs) per_cu = by_regs;
   if (per_cu < 1) per_cu = 1;
   const long slots = (long)device_cus() * per_cu * (per_cu > 1 ? 15 : 16) / 16;
