@@ -212,7 +212,10 @@ int jd_gmm_is_triangular(const jd_gmm* gmm);
  * IdentityImageNorm, SubtractMeanPatchNorm (utils/norms.py:97-103), cycle-spin roll by
  * (shift_y, shift_x) (utils/torch.py:108-119), patch size 8, stride `stride`
  * (utils/torch.py:226-275), GaussianMixtureModel.estimate_log_prob (patches/gmm.py:262-281),
- * max over components (marginalize = 0) or logsumexp (marginalize = 1).
+ * max over components (marginalize = 0) or logsumexp (marginalize = 1).  With a gradient and upper triangular
+ * factors both modes go through the fp16 screen: the arg-max result is that of the dense fp32 kernel bit for bit; the
+ * logsumexp leaves out terms below exp(-25) of the largest one (< 2e-9 of the sum) and is held to the reference's
+ * values at 5e-5 like the dense logsumexp kernel (options JD_GMM_SCREEN=0 / JD_GMM_LSE_SCREEN=0: dense kernels).
  *   value_out       <- (accumulate_value ? += : =) value_scale * sum_{patches in shard} v_patch
  *   grad_flux_accum += grad_coef * d(sum_{patches in shard} v_patch)/d flux   (NULL: forward only)
  *   argmax_out      optional int32 per patch (global patch index order), max mode only
