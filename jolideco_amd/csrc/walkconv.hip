@@ -987,13 +987,14 @@ void walk_tiles(WalkArgs& a, int C, int rows) {
   a.tiles_y = (a.H + rows - 1) / rows;
 }
 
-// (C, rows) of a launch over `n` datasets.  Measured inside the fit (tools/ab.py, MI355X): the launch is fastest with 6-7
-// waves per CU -- all resident at once (capacity 12 at C = 4) and long enough that the 16 warm-up rows of a tile stay a
-// small part of it: forward + Poisson launch of 2048^2 x 8 at C = 4, rows 74 / 92 / 110 / 128 / 146 = 130 / 122 / 127 /
-// 138 / 152 us (5.75 waves per CU at 92); 4096^2 x 1 forward + adjoint, rows 38 / 56 / 74 = 156 / 172 / 178 us (6.75 at
-// 38).  Rows = 18 k - 16: the walk advances in rounds of WS = 18 rows.
+// (C, rows) of a launch over `n` datasets.  Measured inside the fit (tools/ab.py, MI355X): the launch is fastest with as
+// many waves as are resident at once -- 8 per CU at C = 4 (218 registers: two per SIMD) -- and no second round: forward
+// + Poisson launch of 2048^2 x 8 at C = 4 (after the packed column pass), rows 56 / 65 / 74 / 83 / 92 / 110 / 128 =
+// 137 / 118 / 119 / 128 / 122 / 123 / 125 us (9.25 / 8 / 7 / 6.25 / 5.75 / 4.75 / 4 waves per CU); 4096^2 x 1 forward,
+// rows 38 / 56 / 74 = 77 / 81 / 86 us (6.75 waves per CU at 38).  Rows = 18 k - 16: the walk advances in rounds of WS = 18
+// rows.
 void walk_shape(const WalkArgs& a, int n, bool adjoint, int* C, int* rows) {
-  const long want = (long)((n > 1 ? 6.0 : 7.25) * device_cus());
+  const long want = (long)(7.25 * device_cus());
   auto waves = [&](int c, int r) { return (long)((a.W + 64 * c - 1) / (64 * c)) * ((a.H + r - 1) / r) * n; };
   *C = waves(4, 38) >= want * 5 / 8 ? 4 : 2;
   *rows = 38;
