@@ -270,6 +270,13 @@ int jd_gmm_prior_band_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int 
  * all-gather of the per-rank bands produced; y_begin / y_end are HOST arrays of n_bands (<= 64) entries. */
 int jd_add_rolled_bands(float* grad, int H, int W, int shift_y, int shift_x, const float* bands, size_t chunk_floats,
                         int n_bands, const int* y_begin, const int* y_end, void* stream);
+/* The same sum followed at once by the optimizer step of jd_adam_step (sharded fits, where the prior's bands are the
+ * last term of the gradient): every pixel takes g = step->grad_flux[pixel] + (the band sum above, same additions in the
+ * same order) -- the gradient image itself is only read -- and the update of jd_adam_step with g: the bits of
+ * jd_add_rolled_bands followed by jd_adam_step, one launch and one pass over the gradient image less.  Needs W % 4 == 0
+ * and 16-byte aligned images (JD_ERR_INVALID otherwise: use the two calls). */
+int jd_add_rolled_bands_step(int H, int W, int shift_y, int shift_x, const float* bands, size_t chunk_floats, int n_bands,
+                             const int* y_begin, const int* y_end, const jd_step* step, void* stream);
 
 /* (Np, K) log-probabilities of explicit patches: GaussianMixtureModel.estimate_log_prob
  * (patches/gmm.py:262-281).  x: (n, 64) device, out: (n, K) device. */

@@ -82,6 +82,9 @@ EXPORTS = {
     "jd_add_rolled_bands": (
         c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_int, POINTER(c_int), POINTER(c_int), c_void_p],
     ),
+    "jd_add_rolled_bands_step": (
+        c_int, [c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_int, POINTER(c_int), POINTER(c_int), c_void_p, c_void_p],
+    ),
     "jd_gmm_estimate_log_prob": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "jd_elementwise_prior_fwd_bwd": (
         c_int,

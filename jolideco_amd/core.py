@@ -566,6 +566,17 @@ class FitSession:
             and not os.environ.get("JOLIDECO_NO_FUSED_STEP")
         )
 
+    def _fuse_band_step(self, st):
+        """Sharded fits: the bands of the prior's gradient are added and the optimizer step applied in one launch
+        (jd_add_rolled_bands_step) -- not frozen, width a multiple of 4 and 16-byte aligned images, the session's own
+        `_optimizer_step`, no JOLIDECO_NO_FUSED_STEP."""
+        import os
+
+        if st.frozen or "_optimizer_step" in vars(self.cfg) or os.environ.get("JOLIDECO_NO_FUSED_STEP"):
+            return False
+        images = [st.theta, st.flux[0], st.flux[1], st.grad, getattr(st, "exp_avg", None), getattr(st, "exp_avg_sq", None), st.mask]
+        return st.grad.shape[-1] % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in images)
+
     def _timed(self, name, fn):
         """Run fn(); with `comm_events` set, bracketed by an event pair on the current stream."""
         if self.comm_events is None:
@@ -646,8 +657,17 @@ class FitSession:
                     self._timed("all_reduce_wait", pending.wait)
                 pieces = self.band_recv.view(dist.world_size, self.band_chunk)
                 for ci, item in banded.items():
-                    add_rolled_bands(states[ci].grad, item["shifts"], self.band_recv[item["offset"] :], self.band_chunk,
-                                     item["y_ranges"])
+                    if self._fuse_band_step(states[ci]):
+                        # the bands are the last term of this component's gradient: their sum and the optimizer step in
+                        # one launch (the gradient image is read once, never written)
+                        from .ops import add_rolled_bands_step
+
+                        add_rolled_bands_step(states[ci].grad.shape, item["shifts"], self.band_recv[item["offset"] :],
+                                              self.band_chunk, item["y_ranges"], cfg._step_args(states[ci], self.step + 1))
+                        stepped.add(ci)
+                    else:
+                        add_rolled_bands(states[ci].grad, item["shifts"], self.band_recv[item["offset"] :], self.band_chunk,
+                                         item["y_ranges"])
                     # every rank sums the shard values in rank order: identical replicas
                     if dist.dry_run:
                         slot(n_d + ci).copy_(pieces[dist.rank, item["value"] : item["value"] + 1])

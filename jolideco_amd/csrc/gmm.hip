@@ -2116,6 +2116,56 @@ __global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
     if (X + i < a.W) out[wrap(X + i - a.shift_x, a.W)] += v[i];
 }
 
+// The same sum, followed at once by the optimizer step of the pixel (sharded fits: the bands of the prior's gradient are
+// its last term): g = grad[pixel] + sum over the bands, the additions of add_rolled_bands_kernel in the same order, then
+// adam_pixel -- one pass over the gradient image and one launch less per step.  A thread owns an ALIGNED group of four
+// pixels of the un-rolled image (16-byte accesses to the optimizer state; W % 4 == 0) and reads the four rolled-frame
+// band values of every band that holds its row one by one.
+__global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgs a, AdamArgs st) {
+  const int yy = blockIdx.y;
+  const int xx = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (xx >= a.W) return;
+  const int Y = wrap(yy + a.shift_y, a.H);  // rolled-frame row of this image row (shift in [0, H))
+  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+  bool any = false;
+  int X[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) X[i] = wrap(xx + i + a.shift_x, a.W);
+  for (int b = 0; b < a.n_bands; ++b) {
+    const int yb = a.y_begin[b], ye = a.y_end[b];
+    if (Y < yb || Y >= ye) continue;
+    const float* row = a.bands + (size_t)b * a.chunk + (size_t)(Y - yb) * a.W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum[i] += row[X[i]];
+    any = true;
+  }
+  const size_t idx = (size_t)yy * a.W + xx;
+  const float4 g4 = *reinterpret_cast<const float4*>(st.grad_flux + idx);
+  float g[4] = {g4.x, g4.y, g4.z, g4.w};
+  const float4 t4 = *reinterpret_cast<const float4*>(st.theta + idx), f4 = *reinterpret_cast<const float4*>(st.flux_in + idx);
+  float th[4] = {t4.x, t4.y, t4.z, t4.w}, f[4] = {f4.x, f4.y, f4.z, f4.w}, m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
+  float mk[4] = {1.f, 1.f, 1.f, 1.f};
+  if (!st.sgd) {
+    const float4 m4 = *reinterpret_cast<const float4*>(st.m + idx), v4 = *reinterpret_cast<const float4*>(st.v + idx);
+    m[0] = m4.x, m[1] = m4.y, m[2] = m4.z, m[3] = m4.w, v[0] = v4.x, v[1] = v4.y, v[2] = v4.z, v[3] = v4.w;
+  }
+  if (st.mask) {
+    const float4 k4 = *reinterpret_cast<const float4*>(st.mask + idx);
+    mk[0] = k4.x, mk[1] = k4.y, mk[2] = k4.z, mk[3] = k4.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (any) g[i] += sum[i];
+    adam_pixel(th[i], f[i], m[i], v[i], g[i], mk[i], st);
+  }
+  *reinterpret_cast<float4*>(st.theta + idx) = make_float4(th[0], th[1], th[2], th[3]);
+  *reinterpret_cast<float4*>(st.flux_out + idx) = make_float4(f[0], f[1], f[2], f[3]);
+  if (!st.sgd) {
+    *reinterpret_cast<float4*>(st.m + idx) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(st.v + idx) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 }  // namespace jd
 
 // ==========================================================================================
@@ -2975,6 +3025,37 @@ extern "C" int jd_add_rolled_bands(float* grad, int H, int W, int shift_y, int s
   if (a.y_lo >= a.y_hi) return JD_OK;
   dim3 grid((W + 1023) / 1024, a.y_hi - a.y_lo);
   add_rolled_bands_kernel<<<grid, 256, 0, as_stream(stream)>>>(a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+extern "C" int jd_add_rolled_bands_step(int H, int W, int shift_y, int shift_x, const float* bands, size_t chunk_floats,
+                                        int n_bands, const int* y_begin, const int* y_end, const jd_step* step, void* stream) {
+  JD_REQUIRE(bands && y_begin && y_end && step, "jd_add_rolled_bands_step: null argument");
+  JD_REQUIRE(step->theta && step->flux_in && step->flux_out && step->grad_flux, "jd_add_rolled_bands_step: null image");
+  JD_REQUIRE(step->sgd || (step->exp_avg && step->exp_avg_sq), "jd_add_rolled_bands_step: Adam needs its moment images");
+  JD_REQUIRE(n_bands >= 1 && n_bands <= BANDS_MAX, "jd_add_rolled_bands_step: %d bands not in [1, %d]", n_bands, BANDS_MAX);
+  auto aligned = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+  JD_REQUIRE(W % 4 == 0 && aligned(step->theta) && aligned(step->flux_in) && aligned(step->flux_out) && aligned(step->grad_flux) &&
+                 aligned(step->exp_avg) && aligned(step->exp_avg_sq) && aligned(step->mask),
+             "jd_add_rolled_bands_step: needs W %% 4 == 0 and 16-byte aligned images (use jd_add_rolled_bands + jd_adam_step)");
+  AddBandsArgs a{};
+  a.grad = nullptr, a.bands = bands, a.chunk = chunk_floats, a.H = H, a.W = W, a.n_bands = n_bands;
+  a.shift_y = ((shift_y % H) + H) % H, a.shift_x = ((shift_x % W) + W) % W;
+  for (int b = 0; b < n_bands; ++b) {
+    JD_REQUIRE(y_begin[b] >= 0 && y_begin[b] <= y_end[b] && y_end[b] <= H && (size_t)(y_end[b] - y_begin[b]) * W <= chunk_floats,
+               "jd_add_rolled_bands_step: band %d rows [%d, %d) do not fit", b, y_begin[b], y_end[b]);
+    a.y_begin[b] = y_begin[b], a.y_end[b] = y_end[b];
+  }
+  AdamArgs st{};
+  st.theta = step->theta, st.flux_in = step->flux_in, st.flux_out = step->flux_out, st.grad_flux = const_cast<float*>(step->grad_flux);
+  st.m = step->exp_avg, st.v = step->exp_avg_sq, st.mask = step->mask, st.n = (size_t)H * W;
+  st.step_size = step->step_size, st.beta1 = step->beta1, st.beta2 = step->beta2, st.one_minus_beta1 = step->one_minus_beta1;
+  st.one_minus_beta2 = step->one_minus_beta2, st.bias2_sqrt = step->bias2_sqrt, st.eps = step->eps, st.lr = step->lr;
+  st.zero_grad = 0, st.sgd = step->sgd ? 1 : 0, st.linear = step->use_log_flux ? 0 : 1;
+  dim3 grid((W + 1023) / 1024, H);
+  ProfScope prof(JD_KERNEL_ADAM, as_stream(stream));
+  add_rolled_bands_step_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, st);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

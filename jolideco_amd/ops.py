@@ -456,6 +456,21 @@ def add_rolled_bands(grad, shifts, bands, chunk, y_ranges):
     check(_hip.lib().jd_add_rolled_bands(ptr(grad), H, W, int(sy), int(sx), ptr(bands), int(chunk), n, y0, y1, stream_ptr(grad.device)))
 
 
+def add_rolled_bands_step(shape, shifts, bands, chunk, y_ranges, step):
+    """The sum of `add_rolled_bands` followed at once by the optimizer step of the image (jd_add_rolled_bands_step):
+    ``step`` is the `_hip.Step` of the component, whose gradient image is only read.  Needs W % 4 == 0."""
+    bands = require_hip_tensor(bands, "bands")
+    H, W = (int(v) for v in shape[-2:])
+    n = len(y_ranges)
+    if bands.numel() < (n - 1) * chunk + max((y1 - y0) * W for y0, y1 in y_ranges):
+        raise ValueError("bands buffer too small for n_bands pieces of `chunk` values")
+    sy, sx = (0, 0) if shifts is None else shifts
+    y0 = (c_int * n)(*[int(r[0]) for r in y_ranges])
+    y1 = (c_int * n)(*[int(r[1]) for r in y_ranges])
+    check(_hip.lib().jd_add_rolled_bands_step(H, W, int(sy), int(sx), ptr(bands), int(chunk), n, y0, y1, ctypes.byref(step),
+                                              stream_ptr(bands.device)))
+
+
 def adam_bias_terms(step, lr, beta1, beta2):
     """step_size and sqrt(bias_correction2) exactly as torch.optim.Adam computes them
     (python floats = float64), torch/optim/adam.py `_single_tensor_adam`."""

@@ -228,3 +228,38 @@ def test_every_rank_of_a_sharded_joint_step_in_one_process(world_size):
     print(f"{world_size} emulated ranks: gradient rel Linf {err:.2e}, scalars", np.abs(scalars_sum / scalars_1 - 1).max())
     assert err < 2e-6
     np.testing.assert_allclose(scalars_sum, scalars_1, rtol=2e-6)
+
+
+@pytest.mark.parametrize("optimizer", ["adam", "sgd"])
+def test_optimizer_step_inside_the_band_sum_changes_no_bit(monkeypatch, optimizer):
+    """Sharded fits add the bands of the prior's gradient and apply the optimizer step in one launch
+    (jd_add_rolled_bands_step).  Same bits as jd_add_rolled_bands followed by the optimizer kernel
+    (JOLIDECO_NO_FUSED_STEP=1): four steps of one rank of three (dry run: everything but the transport) on a width that
+    takes the fused kernel, and on one that cannot (not a multiple of 4: both runs use the two launches)."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+    from jolideco_amd.data import synthetic_gmm, synthetic_observations
+    from jolideco_amd.distributed import DistContext
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    means, covs, weights = synthetic_gmm(16, 64, seed=2)
+    for shape in ((96, 132), (80, 101)):
+        datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=3, seed=4)
+        results = {}
+        for fused in (True, False):
+            if fused:
+                monkeypatch.delenv("JOLIDECO_NO_FUSED_STEP", raising=False)
+            else:
+                monkeypatch.setenv("JOLIDECO_NO_FUSED_STEP", "1")
+            gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+            comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+            deco = MAPDeconvolver(n_epochs=4, display_progress=False, device="cuda:0", fit_mode="joint", optimizer_type=optimizer,
+                                  learning_rate=0.1 if optimizer == "adam" else 1e-3)
+            session = deco.session(datasets, components=comp, dist=DistContext(rank=1, world_size=3, dry_run=True))
+            took = session._fuse_band_step(session.states[0])
+            assert took == (fused and shape[1] % 4 == 0)
+            for _ in range(4):
+                session.epoch()
+            torch.cuda.synchronize()
+            results[fused] = session.states[0].flux_cur.cpu().numpy().copy()
+        assert np.array_equal(results[True], results[False])
+        assert not np.array_equal(results[True], flux_init.astype(np.float32))
