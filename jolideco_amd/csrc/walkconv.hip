@@ -7,17 +7,20 @@
 //   * per image row: the lanes multiply flux x exposure for their C columns, exchange the products through a
 //     (64 C + 16)-float LDS row (one store, (16 + C) / 4 reads per lane), and run the 17-tap row pass on registers;
 //   * the column pass is in SCATTER form: the finished row-pass value h[r] is added into the 17 outputs r - 8 .. r + 8
-//     it contributes to, which live in 17 C rotating accumulator registers per lane (the loop is unrolled over the 17
-//     rotation states so that every register index is static); output row r - 8 is complete after row r and leaves the
-//     wave through the epilogue (Poisson pass, or scale + accumulate for the adjoint).
+//     it contributes to, which live in 18 rotating accumulator slots of C registers per lane (the loop is unrolled over
+//     the 18 rotation states so that every register index is static and the prefetch registers, period 2 or 3, rotate
+//     with it); output row r - 8 is complete after row r and leaves the wave through the epilogue (Poisson pass, or
+//     scale + accumulate for the adjoint).  At C = 4 the column pass runs on packed FMAs (two columns per instruction).
 // No second LDS image, no block barriers, no halo rows recomputed inside a tile: 34 FMAs, 1 + (16 + C) / C LDS floats
-// and one set of streaming loads per pixel; the only overhead is the 16 warm-up rows of a tile (R = 64: 25 % more row
-// passes).  Loads of row r + P are issued P steps ahead (registers), taps live in SGPRs.
+// and one set of streaming loads per pixel; the only overhead is the 16 warm-up rows of a tile (R = 74: 22 % more row
+// passes).  Loads of row r + P are issued P steps ahead (registers), row taps live in SGPRs.  The launches follow their
+// own instruction stream, not the memory system.
 //
 // Batched adjoint (the gradient of a joint step, sum over the datasets of E_d x corr(g_d, psf_d)): a block is one wave
-// PER DATASET walking the same strip; finished rows go to an LDS exchange buffer in groups of 4, and the waves add them
-// in dataset order -- the additions of the per-dataset launches, bit for bit -- into the gradient image, which is read
-// and written once.
+// PER DATASET walking the same strip; finished rows go to an LDS exchange buffer in groups of 6, 3 or 2, and the waves
+// add them in dataset order -- the additions of the per-dataset launches, bit for bit -- into the gradient image, which
+// is read and written once.  Several flux components: walk_multi_kernel (forward, one wave per component) and the same
+// adjoint over a grid of components x tiles with up to 16 waves per block.
 #include <cmath>
 #include <utility>
 
