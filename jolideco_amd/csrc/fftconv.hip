@@ -126,7 +126,7 @@ static int conv_forward(jd_conv_plan* p, int c, const float* image, const float*
 // grad (+)= coef * scale * crop_adjoint( corr(pad[c], psf) ); pad[c] already holds the (padded) gradient g_c.
 // FFT: conv[c] <- irfft2( rfft2(pad[c]) * conj(khat) ), then the K5 epilogue; direct: one fused kernel.
 static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const float* scale, float* grad, float coef,
-                              int accumulate, hipStream_t stream);
+                              int accumulate, hipStream_t stream, const SepLossFold* fold = nullptr, int* fold_done = nullptr);
 
 static int corr_backward(jd_conv_plan* p, int c, const float* khat, hipStream_t stream) {
   int rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream);
@@ -136,13 +136,14 @@ static int corr_backward(jd_conv_plan* p, int c, const float* khat, hipStream_t 
 }
 
 static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const float* scale, float* grad, float coef,
-                              int accumulate, hipStream_t stream) {
+                              int accumulate, hipStream_t stream, const SepLossFold* fold, int* fold_done) {
+  if (fold_done) *fold_done = 0;
   if (p->method == JD_CONV_DIRECT)
     return launch_direct_conv(p->pad[c], nullptr, khat + p->nspec, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox,
                               1, coef, accumulate, p->split, stream);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(p->pad[c], nullptr, khat, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1, coef,
-                           accumulate, stream, p->allow_walk);
+                           accumulate, stream, p->allow_walk, fold, fold_done);
   int rc = corr_backward(p, c, khat, stream);
   if (rc) return rc;
   return launch_adjoint_epilogue(p->conv[c], scale, grad, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox, coef, accumulate,
@@ -384,6 +385,7 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
 
   const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   int n_partials = 0;
+  bool fold_loss = false;  // the loss of the fused single-component path is finalised by the adjoint launch (see below)
   // one component convolved on the unpadded grid (separable or MFMA direct), no up-sampling, no background norm: the
   // Poisson pass is the epilogue of the convolution
   const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
@@ -421,7 +423,11 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
                                           background, counts, npred_out, p->partials, eps, (float)(1.0 / n_pix),
                                           grad_flux ? 1 : 0, &n_partials, p->split, s);
     if (rc) return rc;
-    if ((rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
+    // the loss: by block 0 of the adjoint launch where that is the separable tile kernel (one dependent launch less),
+    // by a launch of its own otherwise
+    fold_loss = p->method == JD_CONV_SEPARABLE && grad_flux != nullptr;
+    if (!fold_loss &&
+        (rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
       return rc;
     if (!grad_flux) return JD_OK;
   } else {
@@ -461,12 +467,20 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   }
 
   // adjoint: d loss / d flux_c = [shift^T] ( E_c * corr(psf_c, g_c) )
+  const SepLossFold fold{p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out};
   for (int c = 0; c < n_comp; ++c) {
+    int folded = 0;
+    const bool ask = fold_loss && c == 0;
     if (!cal.shift_xy) {
-      if ((rc = corr_backward_into(p, c, khat[c], exposure[c], grad_flux[c], grad_scale, accumulate, s))) return rc;
-      continue;
+      rc = corr_backward_into(p, c, khat[c], exposure[c], grad_flux[c], grad_scale, accumulate, s, ask ? &fold : nullptr, &folded);
+    } else {
+      rc = corr_backward_into(p, c, khat[c], exposure[c], p->gshift[c], grad_scale, 0, s, ask ? &fold : nullptr, &folded);
     }
-    if ((rc = corr_backward_into(p, c, khat[c], exposure[c], p->gshift[c], grad_scale, 0, s))) return rc;
+    if (rc) return rc;
+    if (ask && !folded &&
+        (rc = launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s)))
+      return rc;
+    if (!cal.shift_xy) continue;
     int n_blocks = 0;
     if ((rc = launch_shift_bwd(flux[c], p->gshift[c], grad_flux[c], accumulate, p->H, p->W, cal.shift_xy,
                                cal.shift_scale, p->partials_cal, &n_blocks, s)))

@@ -92,9 +92,19 @@ int sep_factorize(const float* psf_host, int kh, int kw, double tol, std::vector
 int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op);
 // allow_walk: the strip-walk kernel may take the launch (not inside a multi-component model, whose batched form runs
 // the tile kernel: both forms must round alike)
+// fold (adjoint launches of a single dataset): block 0 also turns the `count` partial sums of the forward launch into
+// the dataset's loss, *out = scale * sum(partials) + offset, in finalize_sum_kernel's summation order -- one dependent
+// launch less per step; *fold_done <- whether this launch did (the strip-walk kernel and a forward launch of another
+// kernel's partial sums leave it to launch_finalize_sum)
+struct SepLossFold {
+  const double* partials;
+  int count;
+  double scale, offset;
+  float* out;
+};
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream,
-                    bool allow_walk = true);
+                    bool allow_walk = true, const SepLossFold* fold = nullptr, int* fold_done = nullptr);
 int sep_guard_check(int** guard_dev);
 int sep_conv_tiles(int H, int W);
 // per-dataset pointers of a batched joint step: exposure (input scale of the forward model, output scale of the

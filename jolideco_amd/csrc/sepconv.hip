@@ -73,6 +73,10 @@ struct SepArgs {
   // partial sums (fin_partials[d * n_tiles + tile]) -- finalize_rows_kernel's summation order, no launch of its own
   const double* fin_partials;
   double fin_scale;
+  // single dataset (n_batch == 0): block 0 of the adjoint launch finalises its loss the same way (finalize_sum_kernel's
+  // summation order): *fin_out = fin_scale * sum(fin_partials[0 .. n_tiles)) + fin_offset
+  float* fin_out;
+  double fin_offset;
   int interleave;  // POISSON batches: the datasets of a tile are neighbours in the launch order (else dataset-major)
   // POISSON batches: the flux images of the components.  Kernel arguments, not table entries: a fit alternates between
   // two flux buffers, and a table that changes every step would be re-uploaded (synchronously) every step.  Read with
@@ -124,13 +128,18 @@ __global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD
       dsel = in_xcd / per_xcd, t_in_xcd = in_xcd % per_xcd;  // (tuning: dataset-major order)
   }
   const int tile = (blockIdx.x % 8) * per_xcd + t_in_xcd;
-  if (!POISSON && a.fin_partials && (int)blockIdx.x < a.n_batch) {  // (block-uniform)
+  if (!POISSON && a.fin_partials && (int)blockIdx.x < (a.n_batch > 0 ? a.n_batch : 1)) {  // (block-uniform)
     __shared__ double fin_red[THREADS / 64];
     const double* row = a.fin_partials + (size_t)blockIdx.x * a.n_tiles;
     double acc = 0.0;
     for (int i = tid; i < a.n_tiles; i += THREADS) acc += row[i];
     const double total = block_sum<THREADS>(acc, fin_red);
-    if (tid == 0) a.table->loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.table->loss_offset[blockIdx.x]);
+    if (tid == 0) {
+      if (a.n_batch > 0)
+        a.table->loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.table->loss_offset[blockIdx.x]);
+      else
+        a.fin_out[0] = (float)(a.fin_scale * total + a.fin_offset);
+    }
     __syncthreads();
   }
   if (tile >= a.n_tiles) return;
@@ -584,7 +593,8 @@ int sep_conv_tiles(int H, int W) { return ((W + TX - 1) / TX) * ((H + TY - 1) / 
 // adjoint != 0: out (+)= coef * out_scale * corr_same(in * in_scale, psf)    (the transpose of the above)
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
-                    hipStream_t stream, bool allow_walk) {
+                    hipStream_t stream, bool allow_walk, const SepLossFold* fold, int* fold_done) {
+  if (fold_done) *fold_done = 0;
   if (allow_walk) {
     const int rc = walk_conv(in, in_scale, op, out, out_scale, H, W, kh, kw, oy, ox, adjoint, coef, accumulate, stream);
     if (rc != JD_WALK_NOT_TAKEN) return rc;
@@ -592,6 +602,11 @@ int launch_sep_conv(const float* in, const float* in_scale, const float* op, flo
   SepArgs a{};
   a.in = in, a.in_scale = in_scale, a.op = op, a.out = out, a.out_scale = out_scale;
   a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate;
+  // (the fold sums n_tiles partial sums: only when the forward launch was this kernel's own)
+  if (fold && adjoint && fold->partials && fold->count == sep_conv_tiles(H, W)) {
+    a.fin_partials = fold->partials, a.fin_scale = fold->scale, a.fin_out = fold->out, a.fin_offset = fold->offset;
+    if (fold_done) *fold_done = 1;
+  }
   return launch_sep(a, kh, kw, oy, ox, adjoint, false, stream, sep_operator_rank(op) == 1);
 }
 
