@@ -94,6 +94,16 @@ int jd_conv_plan_method(const jd_conv_plan* plan);
  * width a multiple of 4, enough pixels x datasets to fill the chip; option JD_SEP_WALK = 0 / 1 forces either).  Both
  * compute the same function; a benchmark uses this to name the kernel it timed. */
 int jd_conv_plan_takes_walk(const jd_conv_plan* plan, int n_datasets);
+/* The frame -- 17 or 33 taps per direction -- in which the strip-walk kernels run the operator `khat` that
+ * jd_conv_psf_spectrum built for this SEPARABLE plan, or 0 when they do not take it (rank > 1, non-zero taps wider than 33,
+ * a buffer the library did not build).  The frame follows from the NON-ZERO taps of the operator, not from the plan's
+ * (kh, kw): a 17 x 17 PSF embedded in a 33 x 33 array of zeros (datasets with different PSF sizes share one plan -- and one
+ * batched joint step -- that way) walks in the 17-tap frame. */
+int jd_conv_operator_walk_frame(const jd_conv_plan* plan, const float* khat);
+/* The library remembers, by device address, what it knows about every SEPARABLE operator buffer it built (rank, support of
+ * the taps).  A caller that frees such a buffer tells the library so: a later allocation at the same address is then an
+ * unknown buffer again (and takes the general kernels) until jd_conv_psf_spectrum fills it. */
+int jd_conv_operator_forget(const float* khat);
 /* HALF the number of floats of one per-(dataset, component) kernel operator buffer `khat`:
  * FFT: complex64 elements of the kernel spectrum, Hp * (Wp/2 + 1); DIRECT: floats of one Toeplitz
  * fragment table (the buffer holds the forward and the adjoint table); SEPARABLE: the rank and the row /

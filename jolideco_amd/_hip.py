@@ -38,6 +38,8 @@ EXPORTS = {
     "jd_conv_plan_spectrum_size": (c_size_t, [c_void_p]),
     "jd_conv_plan_method": (c_int, [c_void_p]),
     "jd_conv_plan_takes_walk": (c_int, [c_void_p, c_int]),
+    "jd_conv_operator_walk_frame": (c_int, [c_void_p, c_void_p]),
+    "jd_conv_operator_forget": (c_int, [c_void_p]),
     "jd_psf_separable_rank": (c_int, [c_void_p, c_int, c_int, c_float]),
     "jd_conv_psf_spectrum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jd_conv_same": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

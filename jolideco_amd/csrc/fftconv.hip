@@ -289,6 +289,16 @@ extern "C" int jd_conv_plan_takes_walk(const jd_conv_plan* p, int n_datasets) {
   return walk_takes_launch(p->H, p->W, n_datasets, p->kh, p->kw, p->oy, p->ox) ? 1 : 0;
 }
 
+extern "C" int jd_conv_operator_walk_frame(const jd_conv_plan* p, const float* khat) {
+  if (!p || !khat || p->method != JD_CONV_SEPARABLE) return 0;
+  return walk_operator_frame(khat, p->kh, p->kw, p->oy, p->ox);
+}
+
+extern "C" int jd_conv_operator_forget(const float* khat) {
+  if (khat) sep_forget_operator(khat);
+  return JD_OK;
+}
+
 extern "C" int jd_psf_separable_rank(const float* psf_host, int kh, int kw, float tol) {
   if (!psf_host || !sep_conv_supported(kh, kw)) return 0;
   return sep_factorize(psf_host, kh, kw, tol > 0.f ? (double)tol : SEP_DEFAULT_TOL, nullptr, nullptr);
@@ -304,12 +314,13 @@ extern "C" int jd_conv_psf_spectrum(jd_conv_plan* p, const float* psf, float* kh
     std::vector<float> host((size_t)p->kh * p->kw), op;
     JD_HIP(hipMemcpyAsync(host.data(), psf, host.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     JD_HIP(hipStreamSynchronize(s));
-    const int rank = sep_build_operator(host.data(), p->kh, p->kw, p->oy, p->ox, SEP_DEFAULT_TOL, &op);
+    SepOpInfo info;
+    const int rank = sep_build_operator(host.data(), p->kh, p->kw, p->oy, p->ox, SEP_DEFAULT_TOL, &op, &info);
     JD_REQUIRE(rank > 0, "jd_conv_psf_spectrum: the %dx%d PSF is not a sum of <= %d outer products to %.0e of its sum "
                "(ask jd_psf_separable_rank() first); use JD_CONV_MODE_AUTO", p->kh, p->kw, SEP_MAX_RANK, SEP_DEFAULT_TOL);
     JD_HIP(hipMemcpyAsync(khat, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
     JD_HIP(hipStreamSynchronize(s));
-    sep_register_operator(khat, rank);
+    sep_register_operator(khat, info);
     return JD_OK;
   }
   int rc = launch_pad_mul(psf, nullptr, p->pad[0], p->kh, p->kw, p->Hp, p->Wp, s);
@@ -557,6 +568,7 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
   for (int d = 0; d < n_datasets; ++d) table.bkg[d] = background[d], table.cnt[d] = counts[d];
   for (int i = 0; i < n_datasets * n_comp; ++i) table.scale[i] = exposure[i], table.op[i] = khat[i], table.g[i] = p->gbatch[i];
   for (int d = 0; d < n_datasets; ++d) table.loss_out[d] = loss_out[d], table.loss_offset[d] = stirling_mean[d];
+  walk_batch_order(table, n_datasets, n_comp, p->kh, p->kw, p->oy, p->ox);
   // a session passes the same pointers every step: look the table up by content, upload only a new one
   int slot = -1, victim = 0;
   for (int i = 0; i < jd_conv_plan::N_TABLES; ++i) {

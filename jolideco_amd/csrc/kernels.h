@@ -66,7 +66,7 @@ enum JdOption {
   OPT_CONV_BLOCKS_PER_CU, OPT_POISSON_ROWS, OPT_GMM_NO_HOST_STATS, OPT_GMM_BLOCK_TILES, OPT_GMM_DENSE, OPT_GMM_KSPLIT,
   OPT_GMM_SCREEN_NP, OPT_GMM_SCREEN_NO_LDS_CONSTS, OPT_GMM_SCREEN_DEBUG, OPT_GMM_SCREEN, OPT_GMM_FUSED_BWD,
   OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_SEP_JOINT, OPT_SEP_JOINT_ROWS, OPT_SEP_JOINT_CHUNK,
-  OPT_SEP_WALK_ADJ_ALL, OPT_COUNT
+  OPT_SEP_WALK_ADJ_ALL, OPT_SEP_WALK_COST33, OPT_SEP_WALK_ROWS33, OPT_SEP_NO_TRIM, OPT_COUNT
 };
 bool opt_is_set(int id);
 int opt_value(int id, int unset_value);
@@ -81,15 +81,28 @@ struct SepGeom {
   int pitch;       // window columns per row (>= TX + kwp), pitch % 4 == 2 (bank spread of the row-pair reads)
 };
 SepGeom sep_geom(int kh, int kw, int oy, int ox, bool adjoint);
-// rank of the operator buffers this process has built (jd_conv_psf_spectrum registers them by device address); 0 = a
-// buffer the library has not seen (a copy made by the caller): such a buffer never takes a path that assumes its rank
-void sep_register_operator(const void* op_dev, int rank);
+// What the library knows about an operator buffer it built (jd_conv_psf_spectrum registers it by device address, the
+// caller's jd_conv_operator_forget removes it): the rank and, per direction (0 forward, 1 adjoint), the index range
+// [lo, hi) of the NON-ZERO stored taps -- row taps u within their khp block, column taps v within their kwp block (the
+// shiftx zeros in front included), union over the ranks.  A PSF embedded in a larger array of zeros (datasets with
+// different PSF sizes share one plan that way) has a support smaller than the plan's (kh, kw): the strip-walk kernels
+// choose their frame (17 or 33 taps) per operator from it, the tile kernel trims its window per launch.
+// rank 0 = a buffer the library has not seen (a copy made by the caller): such a buffer never takes a path that
+// assumes its rank or support
+struct SepOpInfo {
+  int rank = 0;
+  int ulo[2] = {0, 0}, uhi[2] = {0, 0}, vlo[2] = {0, 0}, vhi[2] = {0, 0};
+};
+void sep_register_operator(const void* op_dev, const SepOpInfo& info);
+void sep_forget_operator(const void* op_dev);
 int sep_operator_rank(const void* op_dev);
+bool sep_operator_info(const void* op_dev, SepOpInfo* info);
 constexpr double SEP_DEFAULT_TOL = 3e-7;  // residual sum|psf - sum_r u_r v_r^T| <= tol * sum|psf|  (~5 fp32 ulps)
 bool sep_conv_supported(int kh, int kw);
 size_t sep_conv_operator_floats();
 int sep_factorize(const float* psf_host, int kh, int kw, double tol, std::vector<double>* u, std::vector<double>* v);
-int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op);
+int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op,
+                       SepOpInfo* info = nullptr);
 // allow_walk: the strip-walk kernel may take the launch (not inside a multi-component model, whose batched form runs
 // the tile kernel: both forms must round alike)
 // fold (adjoint launches of a single dataset): block 0 also turns the `count` partial sums of the forward launch into
@@ -123,7 +136,12 @@ struct SepBatchTable {
   // finalize kernel; forward-only calls use launch_finalize_rows
   float* loss_out[SEP_MAX_BATCH];
   float loss_offset[SEP_MAX_BATCH];
+  // one component: the datasets whose operators walk in the 17-tap frame (n17 of them, in dataset order), then those of
+  // the 33-tap frame -- the order of the batched forward launch of the strip-walk kernels (walk_batch_order fills it)
+  int order[SEP_MAX_BATCH];
+  int n17;
 };
+void walk_batch_order(SepBatchTable& table, int n, int n_comp, int kh, int kw, int oy, int ox);
 // *n_partials <- partial sums written per dataset: partials[d * *n_partials + i]
 int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, const SepBatchTable& table,
                                   const SepBatchTable* table_dev, int H, int W, int kh, int kw, int oy, int ox,
@@ -139,11 +157,14 @@ int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTab
 // (the batched and the per-dataset step must choose the same kernel for every dataset to stay bit-identical)
 bool sep_batch_is_mixed(int n, int n_comp, const SepBatchTable& table, int H, int W, int kh, int kw, int oy, int ox);
 
-// strip-walk form of the separable convolution (walkconv.hip; rank-1 PSFs up to 17 x 17): same contracts as the
-// launch_sep_* functions above; JD_WALK_NOT_TAKEN when the case is not theirs (nothing was launched)
+// strip-walk form of the separable convolution (walkconv.hip; rank-1 PSFs whose non-zero taps fit a frame of 17 or 33
+// taps): same contracts as the launch_sep_* functions above; JD_WALK_NOT_TAKEN when the case is not theirs (nothing was
+// launched)
 constexpr int JD_WALK_NOT_TAKEN = 1;
 // geometry, size and option JD_SEP_WALK only (rank-1 operators and aligned images assumed): forward and adjoint
 bool walk_takes_launch(int H, int W, int n_datasets, int kh, int kw, int oy, int ox);
+// frame (17 / 33 taps) a registered operator of this plan geometry walks in, 0: none
+int walk_operator_frame(const float* op, int kh, int kw, int oy, int ox);
 int walk_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H, int W,
               int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream);
 int walk_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh, int kw,

@@ -17,6 +17,7 @@
 // passes are register blocked (8 outputs x 4 taps / 4 x 4) and use packed fp32 FMAs (v_pk_fma_f32: the row pass on
 // two image rows, the column pass on two neighbouring columns), so one LDS read feeds ~5 FMAs; the taps stay
 // runtime values (no template per PSF size).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -49,7 +50,8 @@ struct SepArgs {
   float* out;
   const float* out_scale;
   int H, W, tiles_x, n_tiles;
-  int khp, kwp, oy0, ox0, rpairs, pitch, taps_off;
+  int khp, kwp, oy0, ox0, rpairs, pitch, taps_off;  // (khp, kwp, oy0, ox0: of the TRIMMED taps, see launch_sep)
+  int tap_stride, tu_off, tv_off;  // stored taps per rank (row + column block); first trimmed row / column tap within them
   float coef;
   int accumulate;
   // fused Poisson epilogue (POISSON kernels only): `out` receives g = d loss / d conv instead of the convolution
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD
   // items are computed into registers, a barrier retires the window, then they are stored -- 19 KB instead of 32 KB of
   // LDS per block
   float* hbuf = a.alias ? win : win + a.rpairs * a.pitch * 2;
-  float* taps = win + a.rpairs * a.pitch * 2 + (a.alias ? 0 : 2 * a.rpairs * TX);  // per rank: khp row taps then kwp column taps
+  float* taps = win + a.rpairs * a.pitch * 2 + (a.alias ? 0 : 2 * a.rpairs * TX);  // per rank: the stored row taps, then the column taps
   const int tid = threadIdx.x;
-  const int tap_stride = a.khp + a.kwp;
+  const int tap_stride = a.tap_stride;
   const int nrows = 2 * a.rpairs;
 
   // consecutive tiles on one XCD (blockIdx % 8) are neighbours in the image: their halos hit in that XCD's L2.
@@ -276,8 +278,8 @@ __global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD
 
     for (int r = 0; r < rank; ++r) {
       __syncthreads();  // window (r == 0) / previous column pass done with hbuf (r > 0); taps visible
-      const float* tu = taps + r * tap_stride;
-      const float* tv = tu + a.khp;
+      const float* tu = taps + r * tap_stride + a.tu_off;
+      const float* tv = taps + r * tap_stride + a.tv_off;
       // ---- row pass, two rows at once: hbuf[row][x] = sum_t tv[t] * win[row][x + t] -------------------------
       const int n_items = a.rpairs * (TX / 8);
       for (int item0 = 0; item0 < n_items; item0 += THREADS) {  // (alias: one trip)
@@ -485,19 +487,32 @@ int sep_factorize(const float* psf, int kh, int kw, double tol, std::vector<doub
 // buffers found here with rank 1 and still check op[0] on the device: a mismatch (the buffer was overwritten behind the
 // library's back) raises a host-mapped flag that the next launch reports as an error.
 static std::mutex g_rank_mutex;
-static std::unordered_map<const void*, int> g_op_rank;
+static std::unordered_map<const void*, SepOpInfo> g_op_info;
 static int* g_guard_host = nullptr;
 static int* g_guard_dev = nullptr;
 
-void sep_register_operator(const void* op_dev, int rank) {
+void sep_register_operator(const void* op_dev, const SepOpInfo& info) {
   std::lock_guard<std::mutex> lock(g_rank_mutex);
-  g_op_rank[op_dev] = rank;
+  g_op_info[op_dev] = info;
+}
+
+void sep_forget_operator(const void* op_dev) {
+  std::lock_guard<std::mutex> lock(g_rank_mutex);
+  g_op_info.erase(op_dev);
 }
 
 int sep_operator_rank(const void* op_dev) {
   std::lock_guard<std::mutex> lock(g_rank_mutex);
-  auto it = g_op_rank.find(op_dev);
-  return it == g_op_rank.end() ? 0 : it->second;
+  auto it = g_op_info.find(op_dev);
+  return it == g_op_info.end() ? 0 : it->second.rank;
+}
+
+bool sep_operator_info(const void* op_dev, SepOpInfo* info) {
+  std::lock_guard<std::mutex> lock(g_rank_mutex);
+  auto it = g_op_info.find(op_dev);
+  if (it == g_op_info.end()) return false;
+  *info = it->second;
+  return true;
 }
 
 int sep_guard_check(int** guard_dev) {
@@ -517,36 +532,72 @@ int sep_guard_check(int** guard_dev) {
   return JD_OK;
 }
 
-// Host image of the operator buffer for a factorised PSF (see sep_conv_operator_floats).
-int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op) {
+// Host image of the operator buffer for a factorised PSF (see sep_conv_operator_floats); *info <- rank and the support
+// of the stored taps
+int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op, SepOpInfo* info) {
   std::vector<double> u, v;
   const int rank = sep_factorize(psf, kh, kw, tol, &u, &v);
   if (rank == 0) return 0;
   op->assign(sep_conv_operator_floats(), 0.f);
   (*op)[0] = (float)rank;
   const size_t half = (op->size() - 4) / 2;
+  SepOpInfo oi;
+  oi.rank = rank;
   for (int adjoint = 0; adjoint < 2; ++adjoint) {
     const SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
     float* dst = op->data() + 4 + adjoint * half;
+    int ulo = g.khp, uhi = 0, vlo = g.kwp, vhi = 0;
     for (int r = 0; r < rank; ++r) {
       float* tu = dst + (size_t)r * (g.khp + g.kwp);
       float* tv = tu + g.khp;
       for (int t = 0; t < kh; ++t) tu[t] = (float)u[(size_t)r * kh + (adjoint ? t : kh - 1 - t)];
       for (int t = 0; t < kw; ++t) tv[g.shiftx + t] = (float)v[(size_t)r * kw + (adjoint ? t : kw - 1 - t)];
+      for (int t = 0; t < g.khp; ++t)
+        if (tu[t] != 0.f) ulo = t < ulo ? t : ulo, uhi = t + 1 > uhi ? t + 1 : uhi;
+      for (int t = 0; t < g.kwp; ++t)
+        if (tv[t] != 0.f) vlo = t < vlo ? t : vlo, vhi = t + 1 > vhi ? t + 1 : vhi;
     }
+    if (uhi <= ulo) ulo = 0, uhi = 1;  // (all taps rounded to zero in fp32: an empty support is still one tap)
+    if (vhi <= vlo) vlo = 0, vhi = 1;
+    oi.ulo[adjoint] = ulo, oi.uhi[adjoint] = uhi, oi.vlo[adjoint] = vlo, oi.vhi[adjoint] = vhi;
   }
+  if (info) *info = oi;
   return rank;
 }
 
 namespace {
 // rank1: every operator of the launch is registered with rank 1 (sep_operator_rank)
+// ops[0 .. n_ops): the operators the launch reads.  Their NON-ZERO taps (SepOpInfo, union over the operators; an operator
+// the library does not know: all of them) decide the window: PSFs that were embedded in a larger array of zeros cost
+// what their own size costs.  Trimmed in steps of 4 taps (the kernel reads taps and window in 16-byte pieces); skipping
+// a zero tap changes no bit (h + 0 * w = h).  Option JD_SEP_NO_TRIM: the plan's full (kh, kw).
 int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool poisson, hipStream_t stream, bool rank1,
-               bool batch_aligned = true) {
+               const float* const* ops, int n_ops, bool batch_aligned = true) {
   if (!sep_conv_supported(kh, kw))
     return fail(JD_ERR_INVALID, "separable convolution: PSF %dx%d exceeds %dx%d", kh, kw, SEP_MAX_K, SEP_MAX_K);
-  const SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
+  SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
   a.tiles_x = (a.W + TX - 1) / TX;
   a.n_tiles = a.tiles_x * ((a.H + TY - 1) / TY);
+  a.tap_stride = g.khp + g.kwp, a.tu_off = 0, a.tv_off = g.khp;
+  if (!opt_is_set(OPT_SEP_NO_TRIM)) {
+    const int dir = adjoint ? 1 : 0;
+    int ulo = g.khp, uhi = 0, vlo = g.kwp, vhi = 0;
+    bool known = n_ops > 0;
+    for (int i = 0; i < n_ops && known; ++i) {
+      SepOpInfo info;
+      known = sep_operator_info(ops[i], &info);
+      if (!known) break;
+      ulo = std::min(ulo, info.ulo[dir]), uhi = std::max(uhi, info.uhi[dir]);
+      vlo = std::min(vlo, info.vlo[dir]), vhi = std::max(vhi, info.vhi[dir]);
+    }
+    if (known && uhi > ulo && vhi > vlo && uhi <= g.khp && vhi <= g.kwp) {
+      const int au = ulo / 4 * 4, av = vlo / 4 * 4;
+      const int khp = (uhi + 3) / 4 * 4 - au, kwp = (vhi + 3) / 4 * 4 - av;
+      a.tu_off = au, a.tv_off = g.khp + av;
+      g.oy0 += au, g.ox0 += av, g.khp = khp, g.kwp = kwp;
+      g.rpairs = (TY + g.khp) / 2, g.pitch = TX + g.kwp + 2;
+    }
+  }
   a.khp = g.khp, a.kwp = g.kwp, a.oy0 = g.oy0, a.ox0 = g.ox0, a.rpairs = g.rpairs, a.pitch = g.pitch;
   a.taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
   // rank-1 operators only and at most one row-pass item per thread: the row-pass image may share the window's LDS ->
@@ -555,7 +606,7 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
   int rc = sep_guard_check(&a.guard);
   if (rc) return rc;
   a.alias = rank1 && g.rpairs * (TX / 8) <= THREADS && !opt_is_set(OPT_SEP_NO_ALIAS) ? 1 : 0;
-  size_t lds = ((size_t)2 * g.rpairs * (g.pitch + (a.alias ? 0 : TX)) + (size_t)SEP_MAX_RANK * (g.khp + g.kwp)) * sizeof(float);
+  size_t lds = ((size_t)2 * g.rpairs * (g.pitch + (a.alias ? 0 : TX)) + (size_t)SEP_MAX_RANK * a.tap_stride) * sizeof(float);
   {  // tuning: caps the blocks per CU
     const size_t want = (size_t)opt_value(poisson ? OPT_SEP_FWD_MIN_LDS : OPT_SEP_ADJ_MIN_LDS, 0);
     if (want > lds && want <= 160 * 1024) lds = want;
@@ -607,7 +658,7 @@ int launch_sep_conv(const float* in, const float* in_scale, const float* op, flo
     a.fin_partials = fold->partials, a.fin_scale = fold->scale, a.fin_out = fold->out, a.fin_offset = fold->offset;
     if (fold_done) *fold_done = 1;
   }
-  return launch_sep(a, kh, kw, oy, ox, adjoint, false, stream, sep_operator_rank(op) == 1);
+  return launch_sep(a, kh, kw, oy, ox, adjoint, false, stream, sep_operator_rank(op) == 1, &op, 1);
 }
 
 // Forward model of one component fused with the Poisson pass: conv = conv_same(in * in_scale, psf) stays in
@@ -628,7 +679,7 @@ int launch_sep_conv_poisson(const float* in, const float* in_scale, const float*
   a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = partials;
   a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
   *n_partials = sep_conv_tiles(H, W);
-  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, sep_operator_rank(op) == 1);
+  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, sep_operator_rank(op) == 1, &op, 1);
 }
 
 static bool table_aligned(const SepBatchTable& t, int n, int n_comp) {
@@ -678,7 +729,7 @@ int launch_sep_conv_poisson_batch(int n, int n_comp, const float* const* flux, c
   a.interleave = opt_is_set(OPT_SEP_INTERLEAVE) ? 1 : 0;
   bool flux_aligned = true;
   for (int c = 0; c < n_comp; ++c) flux_aligned = flux_aligned && (reinterpret_cast<uintptr_t>(flux[c]) & 15) == 0;
-  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, table_rank1(table, n * n_comp),
+  return launch_sep(a, kh, kw, oy, ox, 0, true, stream, table_rank1(table, n * n_comp), table.op, n * n_comp,
                     flux_aligned && table_aligned(table, n, n_comp));
 }
 
@@ -710,7 +761,9 @@ int launch_sep_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTab
     if (fin_done) *fin_done = 1;
   }
   a.in = table.g[comp], a.op = table.op[comp];
-  return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_rank1(table, n * n_comp), table_aligned(table, n, n_comp));
+  // (the launch reads the operators of component `comp` only, but trims by all of them: one window geometry per step)
+  return launch_sep(a, kh, kw, oy, ox, 1, false, stream, table_rank1(table, n * n_comp), table.op, n * n_comp,
+                    table_aligned(table, n, n_comp));
 }
 
 }  // namespace jd

@@ -31,9 +31,16 @@ namespace jd {
 
 namespace {
 
-constexpr int WK = 17;  // taps per direction of the walk's frame: out[y] = sum_t tu[t] h[y - 8 + t]
-constexpr int WH = 8;
-constexpr int WS = 18;  // accumulator slots (rotation period of the unrolled walk)
+// The walk's FRAME: WK taps per direction, out[y] = sum_t tu[t] h[y - WH + t], and WS accumulator slots (the rotation
+// period of the unrolled walk: > WK, and a multiple of every prefetch depth and exchange group size).  Two frames are
+// compiled: 17 taps (PSFs up to 17 x 17, the common case) and 33 taps (up to 33 x 33; twice the arithmetic per pixel, two
+// columns per lane so that its 36 accumulator rows fit the register file at two waves per SIMD).  Which frame an
+// operator takes follows from the support of ITS taps (SepOpInfo), not from the plan's (kh, kw): datasets whose PSFs
+// were embedded in a common larger array walk in the frame their own PSF needs.
+template <int WKT> struct Frame;
+template <> struct Frame<17> { static constexpr int WK = 17, WH = 8, WS = 18; };
+template <> struct Frame<33> { static constexpr int WK = 33, WH = 16, WS = 36; };
+constexpr int WK = Frame<17>::WK, WH = Frame<17>::WH, WS = Frame<17>::WS;  // (the 17-tap frame: multi-component and joint kernels)
 constexpr int XG_MAX = 6;  // rows per exchange group of the batched adjoint: 2, 3 or 6 (a divisor of WS, <= waves)
 constexpr int XW = 8;   // waves (= datasets) per block of the batched adjoint
 #ifndef JD_WALK_PREFETCH
@@ -74,7 +81,12 @@ struct WalkArgs {
   double* partials;  // POISSON: one per (dataset, tile)
   int H, W, strips, tiles_y, rows;
   int taps_u, taps_v;          // op offsets of the first row tap / first column tap of this direction
-  int kh, kw, offy, offx;      // PSF size, position of its first tap in the 17-tap frame
+  int kh, kw, oy0, ox0;        // the plan's PSF size; image offset of its first stored tap (frame position WH + oy0)
+  // batched forward launch over operators of BOTH frames: blocks < blocks17 walk the 17-tap datasets
+  // table->order[0 .. n17) with the tiling above, the others the 33-tap datasets table->order[n17 ..) with this one
+  int blocks17, n17;
+  int strips33, tiles_y33, rows33;
+  int part_stride;             // POISSON: partial sums per dataset in `partials` (>= tiles of either tiling; the rest zeroed)
   float coef;
   int accumulate;
   float eps, inv_n;
@@ -120,16 +132,21 @@ __device__ __forceinline__ v2f pk_mul_tap(v2f taps, v2f h) {
 }
 
 // XG > 0: the batched adjoint (one wave per dataset -- at most XWT of them --, rows exchanged in groups of XG, wave
-// w < XG adds up row w of a group); with a.comp_blocks > 0 the grid covers all flux components, comp_blocks blocks each
-template <int C, int P, bool POISSON, bool IN_SCALE, int XG, int XWT = XW>
-__global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
+// w < XG adds up row w of a group); with a.comp_blocks > 0 the grid covers all flux components, comp_blocks blocks each.
+// `bid`: the block's index within the blocks of its frame; (strips, tiles_y, rows): their tiling; `slot0`: position of
+// the frame's first dataset in table->order (batched forward launches).
+template <int WKT, int C, int P, bool POISSON, bool IN_SCALE, int XG, int XWT>
+__device__ __forceinline__ void walk_body(const WalkArgs& a, int bid, const int strips, const int tiles_y, const int rows,
+                                          const int slot0) {
 #pragma clang fp contract(off)  // every fused multiply-add below is an explicit fmaf: batched and per-dataset paths round alike
+  constexpr int WK = Frame<WKT>::WK, WH = Frame<WKT>::WH, WS = Frame<WKT>::WS;
   constexpr bool XCHG = XG > 0;
   static_assert(!XCHG || (WS % XG == 0 && XG <= XG_MAX), "the exchange group must divide the rotation period");
   typedef typename Vec<C>::T vC;
   constexpr int NX = 2 * WH / C;       // lanes that also load the right-hand halo piece
   constexpr int NWIN = 2 * WH + C;     // window floats per lane
-  __shared__ __attribute__((aligned(16))) float rowbuf[XCHG ? XWT : 1][2 * 64 * C];  // 64 C + 16 floats used, the rest is a dump
+  static_assert(64 * C + C * 64 <= 2 * 64 * C && NX <= 64, "row buffer");
+  __shared__ __attribute__((aligned(16))) float rowbuf[XCHG ? XWT : 1][2 * 64 * C];  // 64 C + 2 WH floats used, the rest is a dump
   __shared__ __attribute__((aligned(16))) float xbuf[XCHG ? 2 * XG * XWT * 64 * C : 4];
   vC oprev;  // XCHG: the row of the gradient image this wave adds a group's row to, requested at the group's start
   __shared__ double fin_red[4];
@@ -157,15 +174,16 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
   }
 
   // consecutive tiles of one XCD (blockIdx % 8) are vertical neighbours in a strip: their halo rows hit in that L2
-  const int n_tiles = a.strips * a.tiles_y;
+  const int n_tiles = strips * tiles_y;
   const int per_xcd = (n_tiles + 7) / 8;
-  int bid = blockIdx.x, comp = a.comp;
+  int comp = a.comp;
   if (XCHG && a.comp_blocks) comp = bid / a.comp_blocks, bid -= comp * a.comp_blocks;  // (comp_blocks: a multiple of 8)
   const int q = bid / 8;
-  const int dsel = (!XCHG && a.n_batch > 0) ? q / per_xcd : 0;  // batched forward launch: dataset-major
+  // batched forward launch: dataset-major, the datasets of this frame in the table's order
+  const int dsel = (!XCHG && a.n_batch > 0) ? a.table->order[slot0 + q / per_xcd] : 0;
   const int tile = (bid % 8) * per_xcd + q % per_xcd;
   if (tile >= n_tiles) return;  // (block-uniform)
-  const int sx = tile / a.tiles_y, ty = tile - sx * a.tiles_y;
+  const int sx = tile / tiles_y, ty = tile - sx * tiles_y;
 
   // (global address space stated: pointers that come out of the table are generic to the compiler, and generic loads are
   // `flat_` instructions, which complete out of order and force a full s_waitcnt at every step)
@@ -189,8 +207,10 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
   float tu[WK], tv[WK];
   {
     if ((int)op[0] != 1 && lane == 0) *a.guard = 1;  // not a rank-1 operator: the host reports it at its next call
+    // (frame position t holds the stored tap t - WH - oy0: an operator whose PSF was embedded in a larger array of
+    // zeros has its non-zero taps inside the frame the host chose for it, the taps outside are the zeros)
     float mu = 0.f, mv = 0.f;
-    const int iu = lane - a.offy, iv = lane - a.offx;
+    const int iu = lane - (WH + a.oy0), iv = lane - (WH + a.ox0);
     if (iu >= 0 && iu < a.kh) mu = op[a.taps_u + iu];
     if (iv >= 0 && iv < a.kw) mv = op[a.taps_v + iv];
 #pragma unroll
@@ -201,9 +221,10 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
   }
 
   // the column taps once more, two per VGPR pair, for the packed FMAs of the column pass at 4 columns per lane (two
-  // columns per lane: scalar FMAs on the SGPR taps -- those kernels live on 128 registers); the empty asm keeps the
-  // compiler from moving the (uniform) values back to SGPRs
-  constexpr bool PK = C == 4;
+  // columns per lane in the 17-tap frame: scalar FMAs on the SGPR taps -- those kernels live on 128 registers; the
+  // 33-tap frame has the registers of two waves per SIMD anyway); the empty asm keeps the compiler from moving the
+  // (uniform) values back to SGPRs
+  constexpr bool PK = C == 4 || WKT == 33;
   v2f tup[PK ? (WK + 1) / 2 : 1];
   if constexpr (PK) {
 #pragma unroll
@@ -224,7 +245,7 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
   // flight exactly (s_waitcnt vmcnt(n)) instead of draining them at every merge point
   const int xd = X0 - WH + 64 * C + C * (lane % NX);
   const unsigned om = vm ? xm : 0, oe = ve ? xe : (xd < a.W ? xd : 0), oo = vo ? xo : 0;
-  const int Y0 = ty * a.rows, y_end = min(Y0 + a.rows, a.H);
+  const int Y0 = ty * rows, y_end = min(Y0 + rows, a.H);
   const int r_begin = Y0 - WH, r_end = min(y_end + WH, a.H);  // image rows >= H contribute nothing
   float* rb = rowbuf[wv];
 
@@ -413,8 +434,31 @@ __global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
   }
   if (POISSON) {
     loss = wave_sum(loss);
-    if (lane == 0) a.partials[(size_t)d * n_tiles + tile] = loss;
+    // (a launch over both frames has two tilings: every dataset's row of partial sums is `part_stride` long, and the
+    // entries beyond its own tile count are zeroed by its own waves -- exact in any summation order)
+    const int stride = a.part_stride ? a.part_stride : n_tiles;
+    if (lane == 0) {
+      double* row = a.partials + (size_t)d * stride;
+      row[tile] = loss;
+      for (int t = tile + n_tiles; t < stride; t += n_tiles) row[t] = 0.0;
+    }
   }
+}
+
+template <int WKT, int C, int P, bool POISSON, bool IN_SCALE, int XG, int XWT = XW>
+__global__ __launch_bounds__(XG ? 64 * XWT : 64) void walk_kernel(WalkArgs a) {
+  walk_body<WKT, C, P, POISSON, IN_SCALE, XG, XWT>(a, (int)blockIdx.x, a.strips, a.tiles_y, a.rows, 0);
+}
+
+// Batched forward launch over operators of both frames: the 17-tap datasets at C17 columns per lane, the 33-tap
+// datasets behind them at two (every wave of the launch resident at once; the host sizes the two tilings so that the
+// waves of both kinds take about as long).
+template <int C17, int P>
+__global__ __launch_bounds__(64) void walk_mixed_kernel(WalkArgs a) {
+  if ((int)blockIdx.x < a.blocks17)  // (block-uniform)
+    walk_body<17, C17, P, true, true, 0, XW>(a, (int)blockIdx.x, a.strips, a.tiles_y, a.rows, 0);
+  else
+    walk_body<33, 2, P, true, true, 0, XW>(a, (int)blockIdx.x - a.blocks17, a.strips33, a.tiles_y33, a.rows33, a.n17);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -950,19 +994,48 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Does the walk kernel take a launch over n datasets of (H, W) pixels with this PSF geometry?  Option JD_SEP_WALK: 0
-// never, 1 whenever the geometry allows (then independent of n: a batched step and the per-dataset calls it stands for
-// choose alike and agree bit for bit), unset: where it is the faster kernel -- which depends on n, so that by default
-// a batched step at a large size and its per-dataset form agree to fp32 rounding only.
-bool walk_geometry(int H, int W, int n, int kh, int kw, int oy, int ox, int adjoint, int* offy, int* offx) {
+// Do the walk kernels take a launch over n datasets of (H, W) pixels at all?  Option JD_SEP_WALK: 0 never, 1 whenever
+// the operators allow (then independent of n: a batched step and the per-dataset calls it stands for choose alike and
+// agree bit for bit), unset: where they are the faster kernels -- which depends on n, so that by default a batched step
+// at a large size and its per-dataset form agree to fp32 rounding only.
+bool walk_enabled(int H, int W, int n) {
   const int mode = opt_value(OPT_SEP_WALK, -1);
-  if (mode == 0) return false;
-  if (kh > WK || kw > WK || W % 4 != 0) return false;
-  const int oy0 = adjoint ? -oy : oy - (kh - 1), ox0 = adjoint ? -ox : ox - (kw - 1);
-  *offy = WH + oy0, *offx = WH + ox0;
-  if (*offy < 0 || *offy + kh > WK || *offx < 0 || *offx + kw > WK) return false;
+  if (mode == 0 || W % 4 != 0) return false;
   if (mode < 0 && (size_t)H * W * n < WALK_MIN_PIXELS) return false;
   return true;
+}
+
+// Do taps with the support `info` of a plan (kh, kw, oy, ox) fit a frame of WKf taps around position WHf, in both
+// directions?  (Frame position of the stored row tap i: WHf + oy0 + i, of the stored column tap j: WHf + ox0 + j.)
+bool frame_fits(const SepOpInfo& info, int kh, int kw, int oy, int ox, int WHf, int WKf) {
+  for (int adj = 0; adj < 2; ++adj) {
+    const SepGeom g = sep_geom(kh, kw, oy, ox, adj != 0);
+    if (WHf + g.oy0 + info.ulo[adj] < 0 || WHf + g.oy0 + info.uhi[adj] > WKf) return false;
+    if (WHf + g.ox0 + info.vlo[adj] < 0 || WHf + g.ox0 + info.vhi[adj] > WKf) return false;
+  }
+  return true;
+}
+
+// The frame (17 or 33 taps) the walk kernels run a REGISTERED rank-1 operator of the plan geometry in, 0: none
+int walk_frame(const void* op, int kh, int kw, int oy, int ox) {
+  SepOpInfo info;
+  if (!sep_operator_info(op, &info) || info.rank != 1) return 0;
+  if (frame_fits(info, kh, kw, oy, ox, Frame<17>::WH, Frame<17>::WK)) return 17;
+  if (frame_fits(info, kh, kw, oy, ox, Frame<33>::WH, Frame<33>::WK)) return 33;
+  return 0;
+}
+
+// the widest support a plan of this geometry can hold (a full kh x kw PSF)
+int plan_frame(int kh, int kw, int oy, int ox) {
+  SepOpInfo full;
+  full.rank = 1;
+  for (int adj = 0; adj < 2; ++adj) {
+    const SepGeom g = sep_geom(kh, kw, oy, ox, adj != 0);
+    full.ulo[adj] = 0, full.uhi[adj] = kh, full.vlo[adj] = g.shiftx, full.vhi[adj] = g.shiftx + kw;
+  }
+  if (frame_fits(full, kh, kw, oy, ox, Frame<17>::WH, Frame<17>::WK)) return 17;
+  if (frame_fits(full, kh, kw, oy, ox, Frame<33>::WH, Frame<33>::WK)) return 33;
+  return 0;
 }
 
 int device_cus() {
@@ -975,13 +1048,13 @@ int device_cus() {
   return n_cu;
 }
 
-bool walk_setup(WalkArgs& a, int n, int kh, int kw, int oy, int ox, int adjoint) {
-  if (!walk_geometry(a.H, a.W, n, kh, kw, oy, ox, adjoint, &a.offy, &a.offx)) return false;
+// tap addressing of one direction (frame independent: the kernels place the taps in their frame themselves)
+void walk_setup(WalkArgs& a, int kh, int kw, int oy, int ox, int adjoint) {
   const SepGeom g = sep_geom(kh, kw, oy, ox, adjoint != 0);
   const int taps_off = 4 + (adjoint ? (int)((sep_conv_operator_floats() - 4) / 2) : 0);
   a.kh = kh, a.kw = kw;
+  a.oy0 = g.oy0, a.ox0 = g.ox0 + g.shiftx;
   a.taps_u = taps_off, a.taps_v = taps_off + g.khp + g.shiftx;
-  return true;
 }
 
 void walk_tiles(WalkArgs& a, int C, int rows) {
@@ -994,80 +1067,106 @@ void walk_tiles(WalkArgs& a, int C, int rows) {
 // many waves as are resident at once -- 8 per CU at C = 4 (218 registers: two per SIMD) -- and no second round: forward
 // + Poisson launch of 2048^2 x 8 at C = 4 (after the packed column pass), rows 56 / 65 / 74 / 83 / 92 / 110 / 128 =
 // 137 / 118 / 119 / 128 / 122 / 123 / 125 us (9.25 / 8 / 7 / 6.25 / 5.75 / 4.75 / 4 waves per CU); 4096^2 x 1 forward,
-// rows 38 / 56 / 74 = 77 / 81 / 86 us (6.75 waves per CU at 38).  Rows = 18 k - 16: the walk advances in rounds of WS = 18
-// rows.
-void walk_shape(const WalkArgs& a, int n, bool adjoint, int* C, int* rows) {
+// rows 38 / 56 / 74 = 77 / 81 / 86 us (6.75 waves per CU at 38).  Rows = k WS - 2 WH: the walk advances in rounds of WS
+// rows (18 k - 16 in the 17-tap frame, 36 k - 32 in the 33-tap frame, which always runs two columns per lane).
+void walk_shape(const WalkArgs& a, int n, bool adjoint, int frame, int* C, int* rows) {
   const long want = (long)(7.25 * device_cus());
   auto waves = [&](int c, int r) { return (long)((a.W + 64 * c - 1) / (64 * c)) * ((a.H + r - 1) / r) * n; };
-  *C = waves(4, 38) >= want * 5 / 8 ? 4 : 2;
-  *rows = 38;
-  while (*rows < 4096 && waves(*C, *rows) > want) *rows += WS;
+  const int ws = frame == 33 ? Frame<33>::WS : Frame<17>::WS;
+  if (frame == 33) {
+    *C = 2, *rows = 2 * ws - 2 * Frame<33>::WH;
+  } else {
+    *C = waves(4, 38) >= want * 5 / 8 ? 4 : 2;
+    *rows = 38;
+  }
+  while (*rows < 4096 && waves(*C, *rows) > want) *rows += ws;
   const int oc = opt_value(adjoint ? OPT_SEP_WALK_ADJ_COLS : OPT_SEP_WALK_COLS, 0);
   const int orows = opt_value(adjoint ? OPT_SEP_WALK_ADJ_ROWS : OPT_SEP_WALK_ROWS, 0);
-  if (oc == 2 || oc == 4) *C = oc;
+  if ((oc == 2 || oc == 4) && frame != 33) *C = oc;
   if (orows >= 20 && orows <= 4096) *rows = orows;
 }
 
 template <bool POISSON, bool IN_SCALE>
-int launch_walk(WalkArgs a, int C, int n_grid, hipStream_t stream) {
+int launch_walk(WalkArgs a, int frame, int C, int n_grid, hipStream_t stream) {
   int rc = sep_guard_check(&a.guard);
   if (rc) return rc;
   const int n_tiles = a.strips * a.tiles_y;
   const unsigned blocks = (unsigned)(((n_tiles + 7) / 8) * 8 * n_grid);
   ProfScope prof(POISSON ? JD_KERNEL_POISSON_FUSED : JD_KERNEL_SEP_CONV, stream);
-  if (C == 4)
-    hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH, POISSON, IN_SCALE, 0>), dim3(blocks), dim3(64), 0, stream, a);
+  if (frame == 33)
+    hipLaunchKernelGGL((walk_kernel<33, 2, WALK_PREFETCH, POISSON, IN_SCALE, 0>), dim3(blocks), dim3(64), 0, stream, a);
+  else if (C == 4)
+    hipLaunchKernelGGL((walk_kernel<17, 4, WALK_PREFETCH, POISSON, IN_SCALE, 0>), dim3(blocks), dim3(64), 0, stream, a);
   else
-    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, POISSON, IN_SCALE, 0>), dim3(blocks), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, POISSON, IN_SCALE, 0>), dim3(blocks), dim3(64), 0, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
 
-// one dataset of a batch: operator registered with rank 1, every image 16-byte aligned
-bool dataset_walkable(const SepBatchTable& t, int i, int d) {
-  return sep_operator_rank(t.op[i]) == 1 && aligned16(t.scale[i]) && aligned16(t.g[i]) && aligned16(t.bkg[d]) &&
-         aligned16(t.cnt[d]);
+// frame of one (dataset, component) entry of a batch: operator registered with rank 1 and a support that fits a frame,
+// every image 16-byte aligned; 0: not a walk case
+int dataset_frame(const SepBatchTable& t, int i, int d, int kh, int kw, int oy, int ox) {
+  if (!(aligned16(t.scale[i]) && aligned16(t.g[i]) && aligned16(t.bkg[d]) && aligned16(t.cnt[d]))) return 0;
+  return walk_frame(t.op[i], kh, kw, oy, ox);
 }
 
 }  // namespace
 
 bool walk_takes_launch(int H, int W, int n_datasets, int kh, int kw, int oy, int ox) {
-  int offy, offx;
-  return walk_geometry(H, W, n_datasets, kh, kw, oy, ox, 0, &offy, &offx) && walk_geometry(H, W, n_datasets, kh, kw, oy, ox, 1, &offy, &offx);
+  return walk_enabled(H, W, n_datasets) && plan_frame(kh, kw, oy, ox) != 0;
+}
+
+int walk_operator_frame(const float* op, int kh, int kw, int oy, int ox) { return walk_frame(op, kh, kw, oy, ox); }
+
+// order <- the datasets with the 17-tap operators first (in dataset order), then the others; *n17 <- how many
+void walk_batch_order(SepBatchTable& table, int n, int n_comp, int kh, int kw, int oy, int ox) {
+  int k = 0;
+  table.n17 = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int d = 0; d < n; ++d) {
+      const bool is17 = n_comp != 1 || walk_frame(table.op[d], kh, kw, oy, ox) != 33;
+      if (is17 == (pass == 0)) table.order[k++] = d;
+      if (is17 && pass == 0) ++table.n17;
+    }
+  for (; k < SEP_MAX_BATCH; ++k) table.order[k] = 0;
 }
 
 bool sep_batch_is_mixed(int n, int n_comp, const SepBatchTable& table, int H, int W, int kh, int kw, int oy, int ox) {
-  int offy, offx;
   // (the per-dataset calls a mixed batch falls back to decide with n = 1)
-  if (n_comp > MULTI_MAX || !walk_geometry(H, W, n * n_comp, kh, kw, oy, ox, 0, &offy, &offx) ||
-      !walk_geometry(H, W, n * n_comp, kh, kw, oy, ox, 1, &offy, &offx))
-    return false;  // no dataset takes the walk kernels
+  if (n_comp > MULTI_MAX || !walk_enabled(H, W, n * n_comp)) return false;  // no dataset takes the walk kernels
   int yes = 0;
   for (int d = 0; d < n; ++d)
-    for (int c = 0; c < n_comp; ++c) yes += dataset_walkable(table, d * n_comp + c, d) ? 1 : 0;
+    for (int c = 0; c < n_comp; ++c) {
+      const int f = dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox);
+      yes += (n_comp == 1 ? f != 0 : f == 17) ? 1 : 0;  // (several components: the 17-tap frame only)
+    }
   return yes != 0 && yes != n * n_comp;
 }
 
 // out (+)= coef * out_scale * conv/corr_same(in * in_scale, psf)      [launch_sep_conv's contract]
 int walk_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H, int W,
               int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream) {
-  if (sep_operator_rank(op) != 1) return JD_WALK_NOT_TAKEN;
+  if (!walk_enabled(H, W, 1)) return JD_WALK_NOT_TAKEN;
+  const int frame = walk_frame(op, kh, kw, oy, ox);
+  if (!frame) return JD_WALK_NOT_TAKEN;
   if (!aligned16(in) || !aligned16(in_scale) || !aligned16(out) || !aligned16(out_scale)) return JD_WALK_NOT_TAKEN;
   WalkArgs a{};
   a.in = in, a.in_scale = in_scale, a.op = op, a.out = out, a.out_scale = out_scale;
   a.H = H, a.W = W, a.coef = coef, a.accumulate = accumulate;
-  if (!walk_setup(a, 1, kh, kw, oy, ox, adjoint)) return JD_WALK_NOT_TAKEN;
+  walk_setup(a, kh, kw, oy, ox, adjoint);
   int C, rows;
-  walk_shape(a, 1, adjoint != 0, &C, &rows);
+  walk_shape(a, 1, adjoint != 0, frame, &C, &rows);
   walk_tiles(a, C, rows);
-  return in_scale ? launch_walk<false, true>(a, C, 1, stream) : launch_walk<false, false>(a, C, 1, stream);
+  return in_scale ? launch_walk<false, true>(a, frame, C, 1, stream) : launch_walk<false, false>(a, frame, C, 1, stream);
 }
 
 // launch_sep_conv_poisson's contract; *n_partials = partial sums written
 int walk_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh, int kw,
                       int oy, int ox, const float* background, const float* counts, float* npred_out, double* partials,
                       float eps, float inv_n, int write_grad, int* n_partials, hipStream_t stream) {
-  if (sep_operator_rank(op) != 1 || !in_scale) return JD_WALK_NOT_TAKEN;
+  if (!walk_enabled(H, W, 1) || !in_scale) return JD_WALK_NOT_TAKEN;
+  const int frame = walk_frame(op, kh, kw, oy, ox);
+  if (!frame) return JD_WALK_NOT_TAKEN;
   if (!aligned16(in) || !aligned16(in_scale) || !aligned16(g_out) || !aligned16(background) || !aligned16(counts) ||
       !aligned16(npred_out))
     return JD_WALK_NOT_TAKEN;
@@ -1076,31 +1175,82 @@ int walk_conv_poisson(const float* in, const float* in_scale, const float* op, f
   a.H = H, a.W = W, a.coef = 1.f;
   a.background = background, a.counts = counts, a.npred_out = npred_out, a.partials = partials;
   a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad;
-  if (!walk_setup(a, 1, kh, kw, oy, ox, 0)) return JD_WALK_NOT_TAKEN;
+  walk_setup(a, kh, kw, oy, ox, 0);
   int C, rows;
-  walk_shape(a, 1, false, &C, &rows);
+  walk_shape(a, 1, false, frame, &C, &rows);
   walk_tiles(a, C, rows);
   *n_partials = a.strips * a.tiles_y;
-  return launch_walk<true, true>(a, C, 1, stream);
+  return launch_walk<true, true>(a, frame, C, 1, stream);
 }
 
-// One flux component: all forward models + Poisson passes of a joint step in one launch (dataset-major grid);
-// *n_partials = partial sums per dataset, partials[d * *n_partials + tile]
+// One flux component: all forward models + Poisson passes of a joint step in one launch (dataset-major grid, the
+// datasets in table.order: 17-tap operators first); *n_partials = partial sums per dataset,
+// partials[d * *n_partials + tile]
 int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table, const SepBatchTable* table_dev, int H,
                             int W, int kh, int kw, int oy, int ox, double* partials, float eps, float inv_n,
                             int write_grad, int* n_partials, hipStream_t stream) {
-  if (!aligned16(flux)) return JD_WALK_NOT_TAKEN;
-  for (int d = 0; d < n; ++d)
-    if (!dataset_walkable(table, d, d)) return JD_WALK_NOT_TAKEN;
+  if (!walk_enabled(H, W, n) || !aligned16(flux)) return JD_WALK_NOT_TAKEN;
+  int n17 = 0, n33 = 0;
+  for (int d = 0; d < n; ++d) {
+    const int f = dataset_frame(table, d, d, kh, kw, oy, ox);
+    if (!f) return JD_WALK_NOT_TAKEN;
+    (f == 17 ? n17 : n33)++;
+  }
+  if (n17 != table.n17) return fail(JD_ERR_INVALID, "walk_conv_poisson_batch: the table's dataset order is stale");
   WalkArgs a{};
   a.in = flux, a.H = H, a.W = W, a.coef = 1.f, a.partials = partials;
   a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_batch = n, a.table = table_dev;
-  if (!walk_setup(a, n, kh, kw, oy, ox, 0)) return JD_WALK_NOT_TAKEN;
+  walk_setup(a, kh, kw, oy, ox, 0);
   int C, rows;
-  walk_shape(a, n, false, &C, &rows);
+  if (n17 == 0 || n33 == 0) {
+    const int frame = n33 ? 33 : 17;
+    walk_shape(a, n, false, frame, &C, &rows);
+    walk_tiles(a, C, rows);
+    *n_partials = a.strips * a.tiles_y;
+    return launch_walk<true, true>(a, frame, C, n, stream);
+  }
+  // Both frames in one launch, all waves resident at once.  A 17-tap wave at 4 columns per lane issues ~226 vector
+  // instructions per row of 256 pixels, a 33-tap wave at 2 columns ~COST33 per row of 128; the two tilings are chosen so
+  // that tile time (cost per row x (rows + warm-up rows)) is about equal and the waves fill the chip once.
+  const double cost17_4 = 226.0, cost17_2 = 150.0;
+  const double cost33 = (double)opt_value(OPT_SEP_WALK_COST33, 190);
+  const long want = (long)(7.25 * device_cus());
+  auto tiles = [&](int c, int r) { return (long)((W + 64 * c - 1) / (64 * c)) * ((H + r - 1) / r); };
+  C = tiles(4, 38) * n17 + tiles(2, 40) * n33 >= want * 5 / 8 ? 4 : 2;
+  const int oc = opt_value(OPT_SEP_WALK_COLS, 0);
+  if (oc == 2 || oc == 4) C = oc;
+  const double cost17 = C == 4 ? cost17_4 : cost17_2;
+  int rows33 = 40;
+  rows = 38;
+  for (int r17 = 38; r17 < 4096; r17 += Frame<17>::WS) {
+    // the 33-tap tile height (36 k - 32) whose tile time is nearest that of the 17-tap tile
+    const double t17 = cost17 * (r17 + 2 * Frame<17>::WH);
+    int k = (int)std::lround(t17 / cost33 / Frame<33>::WS);  // (rows + 2 WH = k WS)
+    if (k < 2) k = 2;
+    const int r33 = k * Frame<33>::WS - 2 * Frame<33>::WH;
+    rows = r17, rows33 = r33;
+    if (tiles(C, r17) * n17 + tiles(2, r33) * n33 <= want) break;
+  }
+  const int orows = opt_value(OPT_SEP_WALK_ROWS, 0), orows33 = opt_value(OPT_SEP_WALK_ROWS33, 0);
+  if (orows >= 20 && orows <= 4096) rows = orows;
+  if (orows33 >= 20 && orows33 <= 4096) rows33 = orows33;
   walk_tiles(a, C, rows);
-  *n_partials = a.strips * a.tiles_y;
-  return launch_walk<true, true>(a, C, n, stream);
+  a.rows33 = rows33, a.strips33 = (W + 127) / 128, a.tiles_y33 = (H + rows33 - 1) / rows33;
+  const int t17 = a.strips * a.tiles_y, t33 = a.strips33 * a.tiles_y33;
+  a.n17 = n17;
+  a.blocks17 = ((t17 + 7) / 8) * 8 * n17;
+  a.part_stride = t17 > t33 ? t17 : t33;
+  *n_partials = a.part_stride;
+  int rc = sep_guard_check(&a.guard);
+  if (rc) return rc;
+  const unsigned blocks = (unsigned)(a.blocks17 + ((t33 + 7) / 8) * 8 * n33);
+  ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
+  if (C == 4)
+    hipLaunchKernelGGL((walk_mixed_kernel<4, WALK_PREFETCH>), dim3(blocks), dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((walk_mixed_kernel<2, WALK_PREFETCH>), dim3(blocks), dim3(64), 0, stream, a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
 }
 
 // Several flux components: forward models + Poisson passes of all datasets in one launch, one wave per component
@@ -1112,15 +1262,16 @@ int walk_conv_poisson_batch_multi(int n, int n_comp, const float* const* flux, c
   if (n_comp < 2 || n_comp > MULTI_MAX) return JD_WALK_NOT_TAKEN;
   for (int c = 0; c < n_comp; ++c)
     if (!aligned16(flux[c])) return JD_WALK_NOT_TAKEN;
+  if (!walk_enabled(H, W, n * n_comp)) return JD_WALK_NOT_TAKEN;
   for (int d = 0; d < n; ++d)
-    for (int c = 0; c < n_comp; ++c)
-      if (!dataset_walkable(table, d * n_comp + c, d)) return JD_WALK_NOT_TAKEN;
+    for (int c = 0; c < n_comp; ++c)  // (this kernel walks in the 17-tap frame only)
+      if (dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox) != 17) return JD_WALK_NOT_TAKEN;
   MultiArgs a{};
   for (int c = 0; c < n_comp; ++c) a.flux[c] = flux[c];
   a.partials = partials, a.H = H, a.W = W, a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_comp = n_comp;
   a.table = table_dev;
-  if (!walk_geometry(H, W, n * n_comp, kh, kw, oy, ox, 0, &a.offy, &a.offx)) return JD_WALK_NOT_TAKEN;
   const SepGeom g = sep_geom(kh, kw, oy, ox, false);
+  a.offy = WH + g.oy0, a.offx = WH + g.ox0 + g.shiftx;
   a.kh = kh, a.kw = kw, a.taps_u = 4, a.taps_v = 4 + g.khp + g.shiftx;
   // 4 columns per lane (184 registers: 2 waves per SIMD) unless that leaves CUs without a block
   int C = opt_value(OPT_SEP_WALK_COLS, 0);
@@ -1172,35 +1323,44 @@ int walk_conv_poisson_batch_multi(int n, int n_comp, const float* const* flux, c
 }
 
 // grad (+)= coef * sum_d scale[d] * corr_same(g[d], psf_d), the datasets added in order: one wave per dataset, up to 8
-// datasets per launch, later chunks accumulate (the same additions in the same order).  With fin_partials, blocks
-// d < n of the first launch also turn the fin_count partial sums of dataset d into its loss (*fin_done <- 1)
+// datasets per launch, later chunks accumulate (the same additions in the same order).  Datasets whose operators walk
+// in different frames go to different launches: the batch is cut into runs of consecutive datasets of one frame (the
+// benchmark's 6 + 2), so the order of the additions stays the dataset order.  With fin_partials, blocks d < n of the
+// first launch also turn the fin_count partial sums of dataset d into its loss (*fin_done <- 1)
 int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& table, const SepBatchTable* table_dev,
                             float* grad, int H, int W, int kh, int kw, int oy, int ox, float coef, int accumulate,
                             hipStream_t stream, const double* fin_partials, double fin_scale, int fin_count, int* fin_done) {
   *fin_done = 0;
-  if (!aligned16(grad)) return JD_WALK_NOT_TAKEN;
+  if (!walk_enabled(H, W, n * n_comp) || !aligned16(grad)) return JD_WALK_NOT_TAKEN;
+  int frames[SEP_MAX_BATCH];
   for (int d = 0; d < n; ++d)
-    for (int c = 0; c < n_comp; ++c)  // (all components: the forward launch of the step must have been a walk launch too)
-      if (!dataset_walkable(table, d * n_comp + c, d)) return JD_WALK_NOT_TAKEN;
+    for (int c = 0; c < n_comp; ++c) {  // (all components: the forward launch of the step must have been a walk launch too)
+      const int f = dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox);
+      if (!f || (n_comp > 1 && f != 17)) return JD_WALK_NOT_TAKEN;
+      if (c == comp) frames[d] = f;
+    }
   WalkArgs a{};
   a.out = grad, a.H = H, a.W = W, a.coef = coef, a.table = table_dev, a.n_comp = n_comp, a.comp = comp;
-  if (!walk_setup(a, n * n_comp, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
+  walk_setup(a, kh, kw, oy, ox, 1);
   // Block shape.  6-8 datasets: 4 columns per lane (1 KB per row and stream), exchange groups of 6 rows: 112 KB of LDS, ONE
   // block of 6-8 waves per CU; fewer datasets: 2 columns per lane, as many blocks per CU as LDS (exchange buffer) and
   // registers (112-127: 4 waves per SIMD) allow.  Rows per tile: a multiple of every exchange group size, the smallest that
   // leaves all blocks resident at once.  Measured inside the fit at 2048^2 x 8 (tools/ab.py): C = 4, rows 36 / 66 / 72 /
   // 84 = 98 / 77.5 / 85 / 89 us (66 rows: 8 strips x 32 tiles = one block for every CU); C = 2 (two blocks per CU), rows
-  // 54 / 72 / 90 = 111 / 85 / 97 us.
+  // 54 / 72 / 90 = 111 / 85 / 97 us.  The 33-tap frame: two columns per lane, two waves per SIMD.
   int rc = sep_guard_check(&a.guard);
   if (rc) return rc;
-  for (int d0 = 0; d0 < n; d0 += XW) {
-    const int m = n - d0 < XW ? n - d0 : XW;  // datasets (= waves) of this launch: its block shape follows from it
+  for (int d0 = 0; d0 < n;) {
+    const int frame = frames[d0];
+    int m = 1;
+    while (d0 + m < n && m < XW && frames[d0 + m] == frame) ++m;  // datasets (= waves) of this launch: its block shape follows
     const int xg = m >= 6 ? 6 : m >= 3 ? 3 : 2;
-    const bool wide = m >= 6 && opt_value(OPT_SEP_WALK_ADJ_COLS, 4) != 2;
+    const bool wide = frame == 17 && m >= 6 && opt_value(OPT_SEP_WALK_ADJ_COLS, 4) != 2;
     const int C = wide ? 4 : 2;
     const int lds = (2 * xg * XW * 64 * C + XW * 128 * C) * 4;  // exchange buffer + row buffers
     int per_cu = 160 * 1024 / lds;
-    const int by_regs = (wide ? 8 : 16) / m;  // (204 registers at C = 4: 2 waves per SIMD; 112-127 at C = 2: 4)
+    // (204 registers at C = 4 and in the 33-tap frame: 2 waves per SIMD; 112-127 at C = 2 in the 17-tap frame: 4)
+    const int by_regs = (wide || frame == 33 ? 8 : 16) / m;
     if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu < 1) per_cu = 1;
     const long slots = (long)device_cus() * per_cu * (per_cu > 1 ? 15 : 16) / 16;
@@ -1220,28 +1380,37 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
       *fin_done = 1;
     }
     ProfScope prof(JD_KERNEL_SEP_CONV, stream);
-    if (m >= 6 && wide)
-      hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH_ADJ, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    if (frame == 33 && m >= 6)
+      hipLaunchKernelGGL((walk_kernel<33, 2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (frame == 33 && m >= 3)
+      hipLaunchKernelGGL((walk_kernel<33, 2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (frame == 33 && m == 2)
+      hipLaunchKernelGGL((walk_kernel<33, 2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
+    else if (m >= 6 && wide)
+      hipLaunchKernelGGL((walk_kernel<17, 4, WALK_PREFETCH_ADJ, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m >= 6)
-      hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
+      hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m >= 3)
-      hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
+      hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else if (m == 2)
-      hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
+      hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * m), 0, stream, a);
     else {  // a single dataset: the plain walk (same arithmetic: out (+)= (coef * corr) * scale)
       WalkArgs b = a;
       const int slot = d0 * n_comp + comp;
       b.n_batch = 0, b.table = nullptr, b.in = table.g[slot], b.op = table.op[slot], b.out_scale = table.scale[slot];
-      int C, r1;
-      walk_shape(b, 1, true, &C, &r1);
-      walk_tiles(b, C, r1);
+      int C1, r1;
+      walk_shape(b, 1, true, frame, &C1, &r1);
+      walk_tiles(b, C1, r1);
       const unsigned blocks1 = (unsigned)(((b.strips * b.tiles_y + 7) / 8) * 8);
-      if (C == 4)
-        hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
+      if (frame == 33)
+        hipLaunchKernelGGL((walk_kernel<33, 2, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
+      else if (C1 == 4)
+        hipLaunchKernelGGL((walk_kernel<17, 4, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
       else
-        hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
+        hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 0>), dim3(blocks1), dim3(64), 0, stream, b);
     }
     JD_LAUNCH_CHECK();
+    d0 += m;
   }
   return JD_OK;
 }
@@ -1269,11 +1438,12 @@ int walk_conv_adjoint_batch_all(int n, int n_comp, const SepBatchTable& table, c
     if (!aligned16(grads[c])) return JD_WALK_NOT_TAKEN;
     a.out_comp[c] = grads[c];
   }
+  if (!walk_enabled(H, W, n * n_comp)) return JD_WALK_NOT_TAKEN;
   for (int d = 0; d < n; ++d)
-    for (int c = 0; c < n_comp; ++c)
-      if (!dataset_walkable(table, d * n_comp + c, d)) return JD_WALK_NOT_TAKEN;
+    for (int c = 0; c < n_comp; ++c)  // (one launch = one frame: the 17-tap one)
+      if (dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox) != 17) return JD_WALK_NOT_TAKEN;
   a.out = grads[0], a.H = H, a.W = W, a.coef = coef, a.table = table_dev, a.n_comp = n_comp, a.comp = 0;
-  if (!walk_setup(a, n * n_comp, kh, kw, oy, ox, 1)) return JD_WALK_NOT_TAKEN;
+  walk_setup(a, kh, kw, oy, ox, 1);
   int rc = sep_guard_check(&a.guard);
   if (rc) return rc;
   const bool big = n > XW;
@@ -1304,15 +1474,15 @@ int walk_conv_adjoint_batch_all(int n, int n_comp, const SepBatchTable& table, c
   }
   ProfScope prof(JD_KERNEL_SEP_CONV, stream);
   if (big)
-    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6, XW2>), dim3(blocks), dim3(64 * n), 0, stream, a);
+    hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 6, XW2>), dim3(blocks), dim3(64 * n), 0, stream, a);
   else if (wide)
-    hipLaunchKernelGGL((walk_kernel<4, WALK_PREFETCH_ADJ, false, false, 6>), dim3(blocks), dim3(64 * n), 0, stream, a);
+    hipLaunchKernelGGL((walk_kernel<17, 4, WALK_PREFETCH_ADJ, false, false, 6>), dim3(blocks), dim3(64 * n), 0, stream, a);
   else if (n >= 6)
-    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * n), 0, stream, a);
+    hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 6>), dim3(blocks), dim3(64 * n), 0, stream, a);
   else if (n >= 3)
-    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * n), 0, stream, a);
+    hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 3>), dim3(blocks), dim3(64 * n), 0, stream, a);
   else
-    hipLaunchKernelGGL((walk_kernel<2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * n), 0, stream, a);
+    hipLaunchKernelGGL((walk_kernel<17, 2, WALK_PREFETCH, false, false, 2>), dim3(blocks), dim3(64 * n), 0, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -1331,15 +1501,14 @@ int walk_joint_step(int n, const float* flux, const SepBatchTable& table, const 
   // are those of the two-launch path bit for bit.
   const int mode = opt_value(OPT_SEP_JOINT, 0);
   if (mode != 1 || !aligned16(flux) || !aligned16(grad)) return JD_WALK_NOT_TAKEN;
+  if (!walk_enabled(H, W, n)) return JD_WALK_NOT_TAKEN;
   for (int d = 0; d < n; ++d)
-    if (!dataset_walkable(table, d, d)) return JD_WALK_NOT_TAKEN;
+    if (dataset_frame(table, d, d, kh, kw, oy, ox) != 17) return JD_WALK_NOT_TAKEN;
   if (!table_dev && n != 1) return JD_WALK_NOT_TAKEN;  // (without a device table: one dataset, pointers by value)
   JointArgs a{};
   a.flux = flux, a.grad = grad, a.partials = partials, a.H = H, a.W = W, a.coef = coef, a.eps = eps, a.inv_n = inv_n;
-  int offy_adj, offx_adj;
-  if (!walk_geometry(H, W, n, kh, kw, oy, ox, 0, &a.offy, &a.offx) || !walk_geometry(H, W, n, kh, kw, oy, ox, 1, &offy_adj, &offx_adj))
-    return JD_WALK_NOT_TAKEN;
   const SepGeom g = sep_geom(kh, kw, oy, ox, false);
+  a.offy = WH + g.oy0, a.offx = WH + g.ox0 + g.shiftx;
   a.kh = kh, a.kw = kw, a.taps_u = 4, a.taps_v = 4 + g.khp + g.shiftx;
   constexpr int C = 2;
   a.strips = (W + (64 * C - 2 * WH) - 1) / (64 * C - 2 * WH);

@@ -156,11 +156,17 @@ def image_like_gmm(n_components=128, patch=8, seed=0, ridge=1e-4):
     return np.zeros((n_components, d)), covs, weights
 
 
+def psf_shape(sigma):
+    """PSF array size of the synthetic observations: 17x17, 33x33 for sigma >= 3."""
+    return (33, 33) if sigma >= 3 else (17, 17)
+
+
 def synthetic_observations(shape=(2048, 2048), n_obs=8, seed=0, n_points=64, dtype=np.float32):
     """`n_obs` observations of one sky (smooth blobs + point sources) with varying PSF width,
     exposure and background (BASELINE config 3):
-    PSF sigma_i = 1.5 + 0.25 i on a 17x17 grid, E_i = (1 + 0.1 i) * (1 +- 0.5 row gradient),
-    bkg_i = 0.5 + 0.1 i.  Returns (datasets dict, truth image, flux_init)."""
+    PSF sigma_i = 1.5 + 0.25 i on a 17x17 grid -- 33x33 for sigma >= 3 (observations 6 and 7 of 8) --,
+    E_i = (1 + 0.1 i) * (1 +- 0.5 row gradient), bkg_i = 0.5 + 0.1 i.
+    Returns (datasets dict, truth image, flux_init)."""
     rs = np.random.RandomState(seed)
     h, w = shape
     y, x = np.mgrid[0:h, 0:w].astype(np.float32)
@@ -174,7 +180,8 @@ def synthetic_observations(shape=(2048, 2048), n_obs=8, seed=0, n_points=64, dty
     datasets = {}
     gradient = np.linspace(-1, 1, h).reshape(-1, 1)
     for i in range(n_obs):
-        psf = gaussian_kernel(1.5 + 0.25 * i, (17, 17))
+        sigma = 1.5 + 0.25 * i
+        psf = gaussian_kernel(sigma, psf_shape(sigma))
         sign = 1.0 if i % 2 == 0 else -1.0
         exposure = (1 + 0.1 * i) * (1 + sign * 0.5 * gradient) * np.ones(shape)
         background = (0.5 + 0.1 * i) * np.ones(shape)

@@ -9,6 +9,7 @@ import numpy as np
 import torch
 
 from .models import NPredModels
+from .models.npred import common_kernel_shape
 from .ops import PoissonNLLFunction, stirling_mean
 from .utils.table import TraceTable
 from .utils.torch import TORCH_DEFAULT_DEVICE
@@ -117,10 +118,11 @@ class PoissonLoss:
     @classmethod
     def from_datasets(cls, datasets, components, calibrations=None, device=TORCH_DEFAULT_DEVICE):
         npred_models_all, counts_all = [], []
+        kernel_shape = common_kernel_shape(datasets, components, calibrations)
         for name, dataset in datasets.items():
             calibration = calibrations[name] if calibrations else None  # KeyError for an unknown name, like the reference
             models = NPredModels.from_dataset_numpy(
-                dataset=dataset, components=components, calibration=calibration, device=device
+                dataset=dataset, components=components, calibration=calibration, device=device, kernel_shape=kernel_shape
             )
             npred_models_all.append(models)
             counts = torch.from_numpy(np.ascontiguousarray(dataset["counts"], dtype=np.float32)[None, None])

@@ -137,6 +137,38 @@ class NPredModel(nn.Module):
         return torch.clip(conv, 0, torch.inf)
 
 
+def dataset_psfs(dataset, components):
+    """{component name: PSF array} of one dataset (`psf`: one array, or a dict by component, models/npred.py:281-295)."""
+    psf = dataset["psf"]
+    return {name: np.asarray(psf[name] if isinstance(psf, dict) else psf) for name in components.keys()}
+
+
+WALK_MAX_EDGE = 33  # widest frame of the strip-walk kernels (csrc/walkconv.hip)
+
+
+def common_kernel_shape(datasets, components, calibrations=None):
+    """PSF array shape to embed every PSF of every dataset in, or None to leave each dataset its own.
+
+    Datasets whose PSF arrays differ in size have different plans, and the batched joint step needs one.  When that is
+    all that keeps them apart -- convolution method "auto", every PSF a single outer product (every sampled Gaussian
+    is), no calibration, no up-sampling, at most 4 components, nothing wider than 33 taps -- the PSFs are embedded in
+    zeros up to the largest array shape: the same 'same' convolution (`embed_kernel`), one separable plan, and the
+    kernels work on the non-zero taps of each operator, not on the array size (include/jolideco_hip.h,
+    jd_conv_operator_walk_frame)."""
+    if default_conv_method() != "auto" or calibrations or len(datasets) < 2 or not 1 <= len(components) <= 4:
+        return None
+    if any((c.upsampling_factor or 1) != 1 for c in components.values()):
+        return None
+    psfs = [p for dataset in datasets.values() for p in dataset_psfs(dataset, components).values()]
+    shapes = {p.shape for p in psfs}
+    if len(shapes) < 2:
+        return None
+    shape = (max(s[0] for s in shapes), max(s[1] for s in shapes))
+    if max(shape) > WALK_MAX_EDGE or any(p.ndim != 2 or psf_separable_rank(p) != 1 for p in psfs):
+        return None
+    return shape
+
+
 def rescale_psf(psf, factor):
     """Setup-time `rescale_image_torch` (jolideco/utils/torch.py:172-193) of a (kh, kw) PSF on the host:
     the PSF scale of a calibration is not trainable (npred.py:333-334), so the rescaled PSF is a
@@ -262,16 +294,17 @@ class NPredModels(nn.ModuleDict):
         return total
 
     @classmethod
-    def from_dataset_numpy(cls, dataset, components, calibration=None, device="cuda"):
+    def from_dataset_numpy(cls, dataset, components, calibration=None, device="cuda", kernel_shape=None):
+        """``kernel_shape``: a PSF array shape (before up-sampling) shared with OTHER datasets -- every component PSF is
+        embedded in zeros up to it (same 'same' convolution), so that datasets with different PSF sizes share one plan
+        and the batched joint step (`common_kernel_shape`)."""
         values = []
-        psfs = {}
-        for name in components.keys():
-            psf = dataset["psf"]
-            psfs[name] = np.asarray(psf[name] if isinstance(psf, dict) else psf)
+        psfs = dataset_psfs(dataset, components)
         factors = {c.upsampling_factor or 1 for c in components.values()}
         if len(factors) != 1:
             raise NotImplementedError("all components of a fit must share one upsampling_factor in jolideco_amd")
-        kernel_shape = (max(p.shape[0] for p in psfs.values()), max(p.shape[1] for p in psfs.values()))
+        own = (max(p.shape[0] for p in psfs.values()), max(p.shape[1] for p in psfs.values()))
+        kernel_shape = own if kernel_shape is None else (max(own[0], kernel_shape[0]), max(own[1], kernel_shape[1]))
         psf_scale = None if calibration is None else float(calibration.psf_scale.detach().cpu())
         for allow_separable in (True, False):
             values = []

@@ -7,6 +7,7 @@ tensors and raises RuntimeError otherwise.
 """
 import ctypes
 import math
+import weakref
 from ctypes import c_float, c_int, c_void_p
 
 import numpy as np
@@ -76,6 +77,13 @@ def default_conv_method():
     return method
 
 
+def _forget_operator(address):
+    try:
+        _hip.lib().jd_conv_operator_forget(address)
+    except Exception:  # interpreter shutdown: the library may be gone
+        pass
+
+
 class ConvPlan:
     """'same'-convolution plan for one (H, W, kh, kw) geometry (jd_conv_plan).
 
@@ -138,7 +146,16 @@ class ConvPlan:
             raise ValueError(f"psf shape {tuple(psf.shape)} does not match the plan ({self.kh}, {self.kw})")
         khat = torch.empty(2 * self.spectrum_size, dtype=torch.float32, device=psf.device)
         check(_hip.lib().jd_conv_psf_spectrum(self._handle, ptr(psf), ptr(khat), stream_ptr(psf.device)))
+        if self.method == "separable":
+            # the library keeps what it knows about the operator (rank, support of its taps) by device address: the entry
+            # goes with this tensor, so that a later allocation at the same address is an unknown buffer again (a view
+            # that outlives the tensor is then unknown too: it takes the general kernels, never a wrong one)
+            weakref.finalize(khat, _forget_operator, khat.data_ptr())
         return khat
+
+    def walk_frame(self, khat):
+        """17 / 33: the frame the strip-walk kernels run this operator in, 0: not theirs (jd_conv_operator_walk_frame)."""
+        return int(_hip.lib().jd_conv_operator_walk_frame(self._handle, ptr(khat)))
 
     def _check_image(self, image, name):
         image = require_hip_tensor(image, name)
