@@ -89,7 +89,7 @@ def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
     return deconvolver.session(datasets, components=comp, dist=dist)
 
 
-PMC_TRAFFIC_FILES = ("profiles/r03/pmc_hbm_traffic.csv", "profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
+PMC_TRAFFIC_FILES = ("profiles/r04/pmc_hbm_traffic.csv", "profiles/r03/pmc_hbm_traffic.csv", "profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
 _TRAFFIC_USED = {}  # kernel -> file its traffic figure came from
 
 
@@ -228,10 +228,13 @@ def settle(session, device, dist_ctx, seconds=SETTLE_SECONDS, chunk=20):
     return {"seconds": time.perf_counter() - t0, "steps": n}
 
 
+HOST_ENQUEUE = []  # per call of timed_regions: seconds the host took to enqueue each region (MAX over the ranks)
+
+
 def timed_regions(session, steps, repeats, device, dist_ctx):
     """`repeats` regions of exactly `steps` steps, each bracketed by barrier + synchronize; per region the MAX over the
     ranks.  Returns the list of region times in seconds."""
-    times = []
+    times, enqueue = [], []
     # Python's cycle collector stays out of the timed steps: when it frees the device buffers of an earlier session
     # (set-up objects, a side run) inside the loop, every hipFree synchronises the device
     gc.collect()
@@ -244,16 +247,19 @@ def timed_regions(session, steps, repeats, device, dist_ctx):
             t0 = time.perf_counter()
             for _ in range(steps):
                 session.epoch()
+            t_enqueued = time.perf_counter()  # the host has issued every launch and collective of the region
             torch.cuda.synchronize(device)
             dist_ctx.barrier()
             torch.cuda.synchronize(device)
             times.append(time.perf_counter() - t0)
+            enqueue.append(t_enqueued - t0)
     finally:
         gc.enable()
     if dist_ctx.world_size > 1:
-        t = torch.tensor(times, dtype=torch.float64, device=device)
+        t = torch.tensor([times, enqueue], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        times = [float(v) for v in t.cpu()]
+        times, enqueue = [float(v) for v in t[0].cpu()], [float(v) for v in t[1].cpu()]
+    HOST_ENQUEUE.append(enqueue)
     return times
 
 
@@ -329,6 +335,7 @@ def main():
     log(f"settled: {settled['steps']} steps in {settled['seconds']:.3f} s; timed regions")
     times = timed_regions(session, args.steps, max(args.repeats, 1), device, dist_ctx)
     stats = region_stats(times, args.steps)
+    host_enqueue_ms = 1e3 * float(np.median(HOST_ENQUEUE[-1])) / args.steps
     elapsed = args.steps / stats["value"]  # the median region
     log(f"timed regions done: {stats['ms_per_step']:.4f} ms/step (median of {len(times)}; "
         f"{stats['ms_per_step_min']:.4f} .. {stats['ms_per_step_max']:.4f})")
@@ -429,10 +436,16 @@ def main():
     # (the strip-walk kernels take launches of >= 2^24 (pixel, dataset, component) triples; several components: batched only)
     walk = (methods == ["separable"] and (n_comp == 1 or (batched and n_comp <= 4))
             and models_all[0].plan.takes_walk(per_launch * n_comp))
+    # frames of the local operators in the strip-walk kernels (17 / 33 taps; jd_conv_operator_walk_frame)
+    frames = [models.plan.walk_frame(next(iter(models.values())).khat) for models in models_all] if walk and n_comp == 1 else []
+    frame_runs = 1 + sum(1 for a, b in zip(frames, frames[1:]) if a != b) if frames else 1
     if fused_one:
         poi_px_bytes = 20
+        walk_name = ("walk_mixed_kernel<4, 2>" if batched and len(set(frames)) == 2 else
+                     "walk_kernel<33, 2, 2, true, true, 0, 8>" if set(frames) == {33} else
+                     "walk_kernel<17, 4, 2, true, true, 0, 8>")
         poi_kernel = ("direct_conv_kernel<" if methods == ["direct"] else
-                      "walk_kernel<4, 2, true, true, 0, 8>" if walk else "sep_conv_kernel<true, true, true, false>")
+                      walk_name if walk else "sep_conv_kernel<true, true, true, false>")
         poi_what = "forward convolution + Poisson pass"
     elif fused_multi:
         poi_px_bytes = 12 * n_comp + 8
@@ -441,7 +454,10 @@ def main():
     else:
         poi_px_bytes = 8 * n_comp + 8
         poi_kernel, poi_what = "poisson_fused_kernel", "stand-alone Poisson pass"
-    poi_bytes = poi_px_bytes * H * W * per_launch
+    # MINIMUM traffic of one launch: a batched launch reads the flux image(s) it shares between its datasets ONCE
+    # (round-3 verdict: 8 x (exposure + counts + background + g) + flux = 553.6 MB at config 3, not 8 x 20 B = 671 MB)
+    shared_bytes = 4 * n_comp * (per_launch - 1) if (fused_one or fused_multi) and per_launch > 1 else 0
+    poi_bytes = (poi_px_bytes * per_launch - shared_bytes) * H * W
     roof_poi = None
     if poi_ms:
         achieved = poi_bytes / (poi_ms * 1e-3) / 1e9
@@ -452,6 +468,8 @@ def main():
             "traffic_source": pmc_traffic_source(poi_kernel),
             "avg_launch_ms": poi_ms, "launches": poi_n, "bytes_per_launch": poi_bytes, "datasets_per_launch": per_launch,
             "bytes_per_pixel_and_dataset": poi_px_bytes,
+            "bytes_note": "minimum traffic: the flux image shared by the datasets of a launch counted once",
+            "frames": {str(f): frames.count(f) for f in sorted(set(frames))} if frames else None,
         }
     poisson_in_conv = fused_one
     n_profiled = PROFILE_STEPS
@@ -460,6 +478,17 @@ def main():
     dominant = max(kernel_ms_per_step, key=kernel_ms_per_step.get) if kernel_ms_per_step else None
     roofline = roof_poi if dominant == "poisson_fused" else roof_gmm
 
+    # PSF array sizes of the observations as SURVEY.md section 8(d) gives them (17x17; 33x33 for sigma >= 3)
+    from jolideco_amd.data import psf_shape
+
+    psf_shapes = ["%dx%d" % psf_shape(1.5 + 0.25 * i) for i in range(n_obs)]
+    runs = []
+    for shp in psf_shapes:
+        if runs and runs[-1][0] == shp:
+            runs[-1][1] += 1
+        else:
+            runs.append([shp, 1])
+    psf_sizes = " + ".join(f"{n} x {shp}" for shp, n in runs)
     out = {
         "metric": ("MAP iters/sec at 2048x2048, 8-obs joint fit" if args.config == "c3" else f"MAP iters/sec ({args.config})")
         + (f" [TUNING: rank 0 of {args.shard_of}, no collective]" if args.shard_of > 1 else ""),
@@ -471,6 +500,11 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "ms_per_step_min": stats["ms_per_step_min"], "ms_per_step_max": stats["ms_per_step_max"],
+        # time the HOST needs to issue one step (python + ctypes + hipLaunch, and at N > 1 the torch.distributed calls):
+        # from the start of a timed region until its last step has been enqueued, before the synchronisation; median
+        # region, MAX over the ranks.  A step cannot be faster than this: where it approaches ms_per_step the run is
+        # host bound (tools/hosttime.py's method)
+        "host_enqueue_ms_per_step": host_enqueue_ms,
         "repeats": len(times), "timing": "median of `repeats` regions of `steps` steps, each bracketed by barrier + synchronize",
         "settle": settled,
         "clock_mhz": clock_mhz,
@@ -481,8 +515,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.config}: {H}x{W}, {n_obs} observations (17x17 Gaussian PSFs, varying exposure/"
-                        f"background), GMM patch prior 8x8 stride 4 K={K}, joint fit, Adam lr 0.1",
+            "workload": f"{args.config}: {H}x{W}, {n_obs} observations (Gaussian PSFs sigma = 1.5 + 0.25 i on {psf_sizes}, "
+                        f"varying exposure/background), GMM patch prior 8x8 stride 4 K={K}, joint fit, Adam lr 0.1",
+            "psf_shapes": psf_shapes,
             "global_observations": n_obs,
             "sharding": (f"observations round-robin over {world} rank(s), prior by patch rows; per step 1 all-reduce of the "
                          "likelihood gradient started before the prior and overlapped with it + 1 all-gather of the prior "
@@ -523,6 +558,12 @@ def main():
         # (with the Poisson pass fused into the forward launch only the adjoint carries this timer: 16 B/pixel)
         # a batched adjoint reads g + exposure per dataset and reads / writes the gradient once: (8 n + 8) B/pixel
         conv_bytes = ((8 * per_launch + 8) if ((poisson_in_conv or fused_multi) and per_launch > 1) else 16 if poisson_in_conv else 14) * H * W
+        batched_adjoint_runs = frame_runs if poisson_in_conv and walk and batched and per_launch > 1 else 1
+        if batched_adjoint_runs > 1:
+            # operators of both frames: one launch per run of consecutive datasets of one frame, each reads and writes the
+            # gradient image; `avg_launch_ms` is then the time of ALL the step's adjoint launches
+            conv_bytes += 8 * (batched_adjoint_runs - 1) * H * W
+            conv_ms = conv_ms * batched_adjoint_runs
         # several components, strip-walk kernels: ONE launch adds up the datasets of every component (blocks of one wave
         # per dataset, up to 16; walk_conv_adjoint_batch_all)
         adjoint_all = fused_multi and walk and 2 <= per_launch <= 16
@@ -534,10 +575,12 @@ def main():
             if conv_key != "sep_conv":
                 names = ("direct_conv_kernel",)
             elif adjoint_all:
-                names = ("walk_kernel<2, 2, false, false, 6, 16>",) if per_launch > 8 else ()
+                names = ("walk_kernel<17, 2, 2, false, false, 6, 16>",) if per_launch > 8 else ()
+            elif poisson_in_conv and walk and batched_adjoint_runs > 1:
+                names = ()  # (several kernels per step: see profiles/<round>/pmc_hbm_traffic.csv)
             elif poisson_in_conv and walk:
-                names = (("walk_kernel<4, 3, false, false, 6, 8>",) if per_launch >= 6 else
-                         ("walk_kernel<4, 2, false, false, 0, 8>",))
+                names = (("walk_kernel<17, 4, 3, false, false, 6, 8>",) if per_launch >= 6 else
+                         ("walk_kernel<17, 4, 2, false, false, 0, 8>",))
             elif poisson_in_conv:
                 names = ("sep_conv_kernel<true, false, false",)
             else:
@@ -549,7 +592,7 @@ def main():
                        _hip.lib().jd_kernel_name(_hip.KERNEL_IDS[conv_key]).decode()), "bound": "hbm",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": conv_traffic, "avg_launch_ms": conv_ms, "launches": conv_n, "bytes_per_launch": conv_bytes,
-            "datasets_per_launch": per_launch,
+            "datasets_per_launch": per_launch, "launches_per_step": batched_adjoint_runs,
         }
     # The same fit with the PSFs treated as general (not low-rank) kernels -- what an instrument PSF that is not a sum of
     # <= 3 outer products gets: the MFMA Toeplitz convolution -- and through rocFFT (R2C, k-space multiply, C2R: the
@@ -584,7 +627,7 @@ def main():
 
     if world == 1 and fake is None and "separable" in methods and not args.no_general_psf:
         out["general_psf"], _ = conv_method_run(
-            "direct", "same workload with the PSFs convolved as general 17x17 kernels (MFMA Toeplitz convolution, "
+            "direct", "same workload with the PSFs convolved as general 17x17 / 33x33 kernels (MFMA Toeplitz convolution, "
                       "fp16 x 3 split operands; Poisson pass in the forward launch's epilogue)")
         out["fft_psf"], prof_fft = conv_method_run(
             "fft", "same workload through rocFFT: pad+scale, R2C, k-space multiply, C2R, stand-alone Poisson pass, "

@@ -110,14 +110,14 @@ class MAPDeconvolver:
     optimizer_kwargs : dict
         ``lr``, and for Adam ``betas`` and ``eps``.
     checkpoint_path : str
-        Directory for per-epoch checkpoints (``checkpoint-epoch-<n>.fits``; the reference writes the
-        same content as ASDF, which is not available here).  Forces one device->host copy per epoch.
+        Directory for per-epoch checkpoints (``checkpoint-epoch-<n>.asdf``, the reference's name and format,
+        core.py:77,234-245).  Forces one device->host copy per epoch.
     fit_mode : {"sequential", "joint"}
         See the module docstring.
     """
 
     _default_flux_component = "flux"
-    _default_checkpoint_filename = "checkpoint-epoch-{epoch}.fits"
+    _default_checkpoint_filename = "checkpoint-epoch-{epoch}.asdf"
 
     def __init__(
         self,
@@ -392,7 +392,7 @@ class FitSession:
         self.joint = deconvolver.fit_mode == "joint"
         names_all = list(datasets)
         # joint mode shards the datasets over the ranks; sequential mode runs full replicas
-        if self.joint and dist.world_size > 1:
+        if self.joint and dist.sharded:
             local_names = dist.shard_items(names_all)
         else:
             local_names = names_all
@@ -458,7 +458,7 @@ class FitSession:
         own (one small all-reduce: each owner contributes its (shift_x, shift_y, log background norm), the others
         zeros).  A collective: every rank must call it.  No-op for a single process or without calibrations."""
         cals, dist = self.calibrations, self.dist
-        if cals is None or not (self.joint and dist.world_size > 1) or dist.dry_run:
+        if cals is None or not (self.joint and dist.sharded) or dist.dry_run:
             return
         names = self.total_loss.poisson_loss.names_all_global
         mine = {names[gslot] for gslot, _ in self.local_idx}
@@ -486,7 +486,7 @@ class FitSession:
 
         self.band_plan = None
         dist = self.dist
-        if not (self.joint and dist.world_size > 1):
+        if not (self.joint and dist.sharded):
             return
         # ranks must draw identical cycle-spin shifts: identical generator states at the start
         state = []
@@ -542,7 +542,7 @@ class FitSession:
             opt.step()
 
     def _prior_rows(self, prior, state):
-        if self.joint and self.dist.world_size > 1 and prior.shardable:
+        if self.joint and self.dist.sharded and prior.shardable:
             return self.dist.shard_range(prior.n_patch_rows(state.shape))
         return None
 
@@ -561,7 +561,7 @@ class FitSession:
         import os
 
         return (
-            self.dist.world_size == 1 and not st.frozen and getattr(prior, "supports_fused_step", False)
+            not self.dist.sharded and not st.frozen and getattr(prior, "supports_fused_step", False)
             and getattr(prior, "stride", 0) >= 4 and "_optimizer_step" not in vars(self.cfg)
             and not os.environ.get("JOLIDECO_NO_FUSED_STEP")
         )
@@ -605,7 +605,7 @@ class FitSession:
             # ---- one step on sum_d L_d - beta * logprior ------------------------------------
             fluxes = [st.flux_cur for st in states]
             grads = [st.grad for st in states]
-            if dist.world_size > 1:
+            if dist.sharded:
                 self.scalars.zero_()
             first = True
             if self.batch_joint:
@@ -628,7 +628,7 @@ class FitSession:
             for ci, (st, prior) in enumerate(zip(states, priors)):
                 if ci in banded:
                     continue
-                if dist.world_size > 1 and not prior.shardable and dist.rank != 0:
+                if dist.sharded and not prior.shardable and dist.rank != 0:
                     continue  # cheap element-wise priors: rank 0 only, summed by the all-reduce
                 if self._fuse_step(st, prior):
                     # single process: the prior is the last gradient term of its component -- its gather kernel applies
@@ -673,7 +673,7 @@ class FitSession:
                         slot(n_d + ci).copy_(pieces[dist.rank, item["value"] : item["value"] + 1])
                     else:
                         torch.sum(pieces[:, item["value"]], dim=0, keepdim=True, out=slot(n_d + ci))
-            elif dist.world_size > 1:
+            elif dist.sharded:
                 self._timed("all_reduce_blocking", lambda: dist.all_reduce_sum(self.comm))
             self.step += 1
             self._apply_step(states, stepped)
@@ -779,10 +779,10 @@ class MAPDeconvolverResult:
     def write(self, filename, overwrite=False, format=None):
         """Write the result to file.
 
-        format : {"fits", "npz"}
-            "fits" is the reference's layout (jolideco/utils/io/fits.py:421-459), readable by the
-            reference; "npz" a compact numpy archive (fluxes, trace, calibrations).  Default: from the
-            file suffix.  "asdf" raises (package not available).
+        format : {"fits", "asdf", "npz"}
+            "fits" and "asdf" are the reference's layouts (jolideco/utils/io/fits.py:421-459,
+            asdf.py:112-142); "npz" a compact numpy archive (fluxes, trace, calibrations).  Default: from the
+            file suffix.
         """
         from .utils.io import IO_FORMATS_MAP_RESULT_WRITE, get_writer
 

@@ -28,7 +28,8 @@ OptionSlot g_options[OPT_COUNT] = {
     {"JD_GMM_FUSED_BWD", {INT_MIN}},     {"JD_GMM_GATHER_TILED", {INT_MIN}}, {"JD_GMM_LSE_SCREEN", {INT_MIN}},
     {"JD_GMM_WINNER_ROWS", {INT_MIN}},   {"JD_SEP_JOINT", {INT_MIN}},        {"JD_SEP_JOINT_ROWS", {INT_MIN}},
     {"JD_SEP_JOINT_CHUNK", {INT_MIN}},   {"JD_SEP_WALK_ADJ_ALL", {INT_MIN}}, {"JD_SEP_WALK_COST33", {INT_MIN}},
-    {"JD_SEP_WALK_ROWS33", {INT_MIN}},   {"JD_SEP_NO_TRIM", {INT_MIN}},
+    {"JD_SEP_WALK_ROWS33", {INT_MIN}},   {"JD_SEP_NO_TRIM", {INT_MIN}},      {"JD_SEP_WALK_ADJ_ROWS33", {INT_MIN}},
+    {"JD_SEP_WALK_ADJ33", {INT_MIN}},
 };
 
 int parse(const char* text) {

@@ -1354,6 +1354,7 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
     const int frame = frames[d0];
     int m = 1;
     while (d0 + m < n && m < XW && frames[d0 + m] == frame) ++m;  // datasets (= waves) of this launch: its block shape follows
+    if (frame == 33 && opt_value(OPT_SEP_WALK_ADJ33, 0) == 1) m = 1;  // (tuning: one plain accumulating launch per dataset)
     const int xg = m >= 6 ? 6 : m >= 3 ? 3 : 2;
     const bool wide = frame == 17 && m >= 6 && opt_value(OPT_SEP_WALK_ADJ_COLS, 4) != 2;
     const int C = wide ? 4 : 2;
@@ -1367,7 +1368,7 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
     const int strips = (W + 64 * C - 1) / (64 * C);
     int rows = 36;
     while (rows < 4096 && (long)strips * ((H + rows - 1) / rows) > slots) rows += 6;
-    const int orows = opt_value(OPT_SEP_WALK_ADJ_ROWS, 0);
+    const int orows = opt_value(frame == 33 ? OPT_SEP_WALK_ADJ_ROWS33 : OPT_SEP_WALK_ADJ_ROWS, 0);
     if (orows >= 18) rows = orows;
     rows = (rows + 5) / 6 * 6;
     walk_tiles(a, C, rows);
@@ -1400,6 +1401,7 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
       b.n_batch = 0, b.table = nullptr, b.in = table.g[slot], b.op = table.op[slot], b.out_scale = table.scale[slot];
       int C1, r1;
       walk_shape(b, 1, true, frame, &C1, &r1);
+      if (frame == 33 && orows >= 18) r1 = orows;
       walk_tiles(b, C1, r1);
       const unsigned blocks1 = (unsigned)(((b.strips * b.tiles_y + 7) / 8) * 8);
       if (frame == 33)

@@ -21,18 +21,27 @@ __all__ = ["DistContext", "init_from_env"]
 class DistContext:
     """Rank / world size and the two sharding rules + the gradient all-reduce."""
 
-    def __init__(self, rank=0, world_size=1, group=None, dry_run=False):
+    def __init__(self, rank=0, world_size=1, group=None, dry_run=False, force_collectives=False):
         self.rank = rank
         self.world_size = world_size
         self.group = group
         # dry_run: shard like rank `rank` of `world_size` but skip the collectives (single-process
         # timing of one rank's share of the step, bench.py --shard-of)
         self.dry_run = dry_run
+        # force_collectives: take the sharded code path -- async all-reduce of the flat buffer, all-gather of the prior
+        # bands, band sum + optimizer step -- even with ONE rank, through an initialised process group: how RCCL is
+        # exercised on a single-GPU box (tests/test_gpu_distributed.py; the result is the un-sharded step's bit for bit)
+        self.force_collectives = force_collectives
+
+    @property
+    def sharded(self):
+        """The joint step goes through the collectives (more than one rank, or forced)."""
+        return self.world_size > 1 or self.force_collectives
 
     @classmethod
     def current(cls):
         if dist.is_available() and dist.is_initialized():
-            return cls(rank=dist.get_rank(), world_size=dist.get_world_size())
+            return cls(rank=dist.get_rank(), world_size=dist.get_world_size(), force_collectives=force_collectives_requested())
         return cls()
 
     def shard_items(self, items):
@@ -48,7 +57,7 @@ class DistContext:
 
     def all_reduce_sum(self, buffer):
         """In-place sum all-reduce of one flat tensor (a no-op for a single process)."""
-        if self.world_size > 1 and not self.dry_run:
+        if self.sharded and not self.dry_run:
             dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=self.group)
         return buffer
 
@@ -56,7 +65,7 @@ class DistContext:
         """Start the in-place sum all-reduce of one flat tensor and return a handle whose ``wait()`` orders the
         current stream behind it (None for a single process).  RCCL runs the collective on its own stream, so kernels
         enqueued on the current stream after this call overlap with it."""
-        if self.world_size > 1 and not self.dry_run:
+        if self.sharded and not self.dry_run:
             return dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return None
 
@@ -66,7 +75,7 @@ class DistContext:
         n = piece.numel()
         if out.numel() != n * self.world_size:
             raise ValueError("all_gather_flat: out must hold world_size pieces")
-        if self.world_size == 1 or self.dry_run:
+        if not self.sharded or self.dry_run:
             out[self.rank * n : (self.rank + 1) * n].copy_(piece)
             return out
         if dist.get_backend(self.group) == "gloo" and piece.is_cuda:
@@ -80,7 +89,7 @@ class DistContext:
     def assert_same_on_all_ranks(self, values, what):
         """Raise on every rank if the int64 vector ``values`` (host) differs between ranks (one synchronising
         exchange at set-up time, e.g. the state of the cycle-spin generators that must draw identical shifts)."""
-        if self.world_size == 1 or self.dry_run:
+        if not self.sharded or self.dry_run:
             return
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(self.group) == "nccl" else "cpu"
         mine = torch.as_tensor(values, dtype=torch.int64).to(device)
@@ -90,17 +99,25 @@ class DistContext:
             raise RuntimeError(f"{what} differs between the ranks of the sharded fit")
 
     def barrier(self):
-        if self.world_size > 1 and not self.dry_run:
+        if self.sharded and not self.dry_run:
             dist.barrier(group=self.group)
+
+
+def force_collectives_requested():
+    """JOLIDECO_FORCE_COLLECTIVES=1: a ONE-rank process group still runs the sharded joint step with its collectives
+    (`DistContext.force_collectives`) -- RCCL on a single-GPU box."""
+    return os.environ.get("JOLIDECO_FORCE_COLLECTIVES", "0") not in ("", "0")
 
 
 def init_from_env(backend=None):
     """Initialise the default process group from the torchrun environment (RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR, MASTER_PORT) and bind this process to its GPU.  Returns a DistContext;
-    a single-process run (no WORLD_SIZE or WORLD_SIZE=1) initialises nothing."""
+    a single-process run (no WORLD_SIZE or WORLD_SIZE=1) initialises nothing -- unless
+    JOLIDECO_FORCE_COLLECTIVES=1 asks for a one-rank group whose collectives really run."""
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size <= 1:
+    if world_size <= 1 and not force_collectives_requested():
         return DistContext()
+    os.environ.setdefault("RANK", "0"), os.environ.setdefault("WORLD_SIZE", "1"), os.environ.setdefault("MASTER_PORT", "29533")
     # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer registration fails with
     # "hipIpcGetMemHandle: invalid argument" (read by the HSA runtime when the first GPU call initialises it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

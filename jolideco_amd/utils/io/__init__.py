@@ -1,10 +1,18 @@
 """File formats either side of the hot path (reference: jolideco/utils/io/__init__.py).
 
-FITS (self-contained codec, `_fitsfile`) and YAML are implemented; ASDF needs the ``asdf`` package
-and its astropy converters, which this image does not have -- asking for it raises.
+FITS (`_fitsfile`), ASDF (`_asdffile`) and YAML, each on a self-contained codec: the reference uses astropy, the
+``asdf`` package and ruamel.yaml, none of which this image has.
 """
 from pathlib import Path
 
+from .asdf import (
+    read_flux_component_from_asdf,
+    read_flux_components_from_asdf,
+    read_map_result_from_asdf,
+    write_flux_component_to_asdf,
+    write_flux_components_to_asdf,
+    write_map_result_to_asdf,
+)
 from .fits import (
     read_flux_component_from_fits,
     read_flux_components_from_fits,
@@ -39,13 +47,6 @@ __all__ = [
 ]
 
 
-def _asdf_unavailable(*args, **kwargs):
-    raise NotImplementedError(
-        "the ASDF format needs the 'asdf' package (and asdf-astropy for the loss trace), which is not "
-        "available to jolideco_amd; use format='fits'"
-    )
-
-
 def guess_format_from_filename(filename):
     """{"fits", "yaml", "asdf"} from the file suffix."""
     suffix = Path(filename).suffix
@@ -71,28 +72,28 @@ def get_reader(filename, format, registry):
     return _dispatch(filename, format, registry)
 
 
-IO_FORMATS_MAP_RESULT_READ = {"fits": read_map_result_from_fits, "asdf": _asdf_unavailable}
-IO_FORMATS_MAP_RESULT_WRITE = {"fits": write_map_result_to_fits, "asdf": _asdf_unavailable}
+IO_FORMATS_MAP_RESULT_READ = {"fits": read_map_result_from_fits, "asdf": read_map_result_from_asdf}
+IO_FORMATS_MAP_RESULT_WRITE = {"fits": write_map_result_to_fits, "asdf": write_map_result_to_asdf}
 
 IO_FORMATS_FLUX_COMPONENT_READ = {
     "fits": read_flux_component_from_fits,
     "yaml": read_flux_component_from_yaml,
-    "asdf": _asdf_unavailable,
+    "asdf": read_flux_component_from_asdf,
 }
 IO_FORMATS_FLUX_COMPONENT_WRITE = {
     "yaml": write_flux_component_to_yaml,
     "fits": write_flux_component_to_fits,
-    "asdf": _asdf_unavailable,
+    "asdf": write_flux_component_to_asdf,
 }
 
 IO_FORMATS_FLUX_COMPONENTS_READ = {
     "fits": read_flux_components_from_fits,
-    "asdf": _asdf_unavailable,
+    "asdf": read_flux_components_from_asdf,
     "yaml": read_flux_components_from_yaml,
 }
 IO_FORMATS_FLUX_COMPONENTS_WRITE = {
     "fits": write_flux_components_to_fits,
-    "asdf": _asdf_unavailable,
+    "asdf": write_flux_components_to_asdf,
     "yaml": write_flux_components_to_yaml,
 }
 

@@ -263,3 +263,71 @@ def test_optimizer_step_inside_the_band_sum_changes_no_bit(monkeypatch, optimize
             results[fused] = session.states[0].flux_cur.cpu().numpy().copy()
         assert np.array_equal(results[True], results[False])
         assert not np.array_equal(results[True], flux_init.astype(np.float32))
+
+
+def _worker_rccl_one_rank(rank, port, out_dir):
+    """Child process: a ONE-rank "nccl" (= RCCL) process group on cuda:0, the sharded joint step forced through its
+    collectives (JOLIDECO_FORCE_COLLECTIVES=1), then the same fit un-sharded in the same process."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      JOLIDECO_FORCE_COLLECTIVES="1", JOLIDECO_DIST_OVERLAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("JOLIDECO_DIST_BACKEND", None)
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
+    from jolideco_amd.data import synthetic_gmm, synthetic_observations
+    from jolideco_amd.distributed import DistContext, init_from_env
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    ctx = init_from_env()
+    backend = torch.distributed.get_backend()
+    assert backend == "nccl" and torch.distributed.get_world_size() == 1
+    assert ctx.world_size == 1 and ctx.rank == 0 and ctx.sharded and ctx.force_collectives and not ctx.dry_run
+    shape, n_obs, n_epochs = (328, 512), 8, 6  # config 3 in small: 17x17 and 33x33 PSFs, 81 patch rows
+    datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=n_obs, seed=0)
+    means, covs, weights = synthetic_gmm(32, 64, seed=0)
+
+    def fit(dist, events):
+        gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+        comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+        deco = MAPDeconvolver(n_epochs=n_epochs, display_progress=False, device="cuda:0", fit_mode="joint")
+        session = deco.session(datasets, components=comp, dist=dist)
+        if events:
+            session.comm_events = []
+        scalars = []
+        for _ in range(n_epochs):
+            session.epoch()
+            scalars.append(session.scalars.clone())
+        torch.cuda.synchronize()
+        comm = session.comm_times_ms() if events else {}
+        return session, session.states[0].flux_cur.cpu().numpy().copy(), torch.stack(scalars).cpu().numpy(), comm
+
+    sharded, flux_s, scalars_s, comm = fit(ctx, True)
+    # the sharded schedule really ran: band plan over one rank, band sum + optimizer step in one launch, both collectives
+    assert sharded.band_plan and len(sharded.band_plan[0]["y_ranges"]) == 1 and sharded._fuse_band_step(sharded.states[0])
+    assert not sharded._fuse_step(sharded.states[0], sharded.priors[0])
+    assert set(comm) == {"all_gather_bands", "all_reduce_wait"}
+    plain, flux_p, scalars_p, _ = fit(DistContext(), False)
+    assert plain.band_plan is None and plain._fuse_step(plain.states[0], plain.priors[0])
+    # MAPDeconvolver.run picks the forced context up from the process group + environment
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
+    comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
+    res = MAPDeconvolver(n_epochs=n_epochs, display_progress=False, device="cuda:0", fit_mode="joint").run(datasets, components=comp)
+    np.savez(Path(out_dir) / "rccl.npz", flux_sharded=flux_s, flux_plain=flux_p, scalars_sharded=scalars_s,
+             scalars_plain=scalars_p, flux_run=res.flux_total, flux_init=flux_init.astype(np.float32),
+             comm=np.array([comm["all_gather_bands"], comm["all_reduce_wait"]]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_rccl_one_rank_sharded_step_equals_the_unsharded_step_bit_for_bit(tmp_path):
+    """RCCL on the hardware there is: `init_process_group("nccl", world_size=1, device_id=cuda:0)` in a child process, and
+    `FitSession`'s SHARDED joint step forced through the collectives (no `world_size == 1` short-cut): the asynchronous
+    all-reduce of the flat [gradient | scalars] buffer on RCCL's stream with `wait()` ordering the compute stream behind
+    it, `all_gather_into_tensor` on the device bands of the prior, the band sum + optimizer step, the set-up exchanges
+    (`assert_same_on_all_ranks` on device tensors), HSA_ENABLE_IPC_MODE_LEGACY=0.  With one rank the collectives are
+    identities, so six steps must give the un-sharded fit BIT FOR BIT: fluxes and every loss scalar of every step."""
+    mp.spawn(_worker_rccl_one_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = dict(np.load(tmp_path / "rccl.npz"))
+    assert np.array_equal(r["flux_sharded"], r["flux_plain"])
+    assert np.array_equal(r["scalars_sharded"], r["scalars_plain"])
+    assert np.array_equal(r["flux_run"], r["flux_sharded"])
+    assert not np.array_equal(r["flux_sharded"], r["flux_init"]) and np.all(np.isfinite(r["scalars_sharded"]))
+    assert np.all(r["comm"] >= 0)

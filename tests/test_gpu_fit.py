@@ -492,7 +492,7 @@ def test_fit_writes_the_file_the_reference_writes(tmp_path):
 
     # checkpoints: one per epoch, each holding the flux after that epoch and the trace rows before it
     names = list(result.trace_loss["filename"])
-    assert names == [f"checkpoint-epoch-{i}.fits" for i in range(4)]
+    assert names == [f"checkpoint-epoch-{i}.asdf" for i in range(4)]  # the reference's name (core.py:77)
     last = result.read_checkpoint(3)
     # (a component read back stores log(flux) again: exp(log(x)) is x to 1 ulp)
     assert rel_linf(last.flux_total, result.flux_total) < 1e-6 and len(last.trace_loss) == 3

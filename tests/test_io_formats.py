@@ -403,8 +403,6 @@ def test_formats_and_errors(tmp_path):
     with pytest.raises(ValueError):
         guess_format_from_filename("b.txt")
     result = make_result()
-    with pytest.raises(NotImplementedError, match="asdf"):
-        result.write(tmp_path / "result.asdf")
     with pytest.raises(ValueError, match="Not a valid format"):
         result.write(tmp_path / "result.fits", format="hdf5")
     with pytest.raises(ValueError, match="Not a valid format"):
