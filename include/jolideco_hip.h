@@ -63,8 +63,11 @@ int jd_get_option(const char* key, int* is_set, int* value);
  *   FFT    rocFFT R2C / k-space multiply / C2R on a zero padded (Hp, Wp) grid, Hp >= H+kh-1,
  *          Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5-smooth, Wp % 4 == 0) sizes
  *          (JD_CONV_MODE_FFT_EXACT forces the reference's own grid (H+kh-1, W+kw-1));
- *   DIRECT the sum over PSF taps on the fp32 matrix cores (exact fmaf chain), PSFs up to 33x33;
- *          padding, exposure scaling and crop are folded into the kernel (csrc/directconv.hip).
+ *   DIRECT the sum over PSF taps as Toeplitz products on the matrix cores, PSFs up to 33x33; padding, exposure
+ *          scaling and crop are folded into the kernel (csrc/directconv.hip).  Default where the operands fit in LDS
+ *          (up to ~25x33): both operands split into two fp16 terms (22 significant bits, three fp16 MFMAs per
+ *          product, fp32 accumulation; relative error of a convolution ~1e-6 of its maximum); otherwise, or with
+ *          option JD_DIRECT_FP32=1, the fp32-input MFMA kernel (an exact fmaf chain).
  *   SEPARABLE for a PSF that is a sum of at most 3 outer products u_r v_r^T (a sampled Gaussian is 1, a
  *          double Gaussian 2): a row pass and a column pass of kh + kw taps per rank instead of kh * kw,
  *          PSFs up to 68x68 (csrc/sepconv.hip).  Whether a PSF qualifies is decided by
@@ -226,6 +229,11 @@ int jd_gmm_is_triangular(const jd_gmm* gmm);
  * factors both modes go through the fp16 screen: the arg-max result is that of the dense fp32 kernel bit for bit; the
  * logsumexp leaves out terms below exp(-25) of the largest one (< 2e-9 of the sum) and is held to the reference's
  * values at 5e-5 like the dense logsumexp kernel (options JD_GMM_SCREEN=0 / JD_GMM_LSE_SCREEN=0: dense kernels).
+ * Reproducibility: the arg-max mode is bit-reproducible from run to run.  The logsumexp mode with a gradient is
+ * reproducible with JD_GMM_LSE_SCREEN=0 (always the dense kernels) or =2 (always the screen); by DEFAULT the library
+ * decides per pass, from host-mapped statistics of earlier passes that it reads without synchronising, whether the
+ * screen is worth running -- on images where it keeps overflowing, WHICH pass first skips it depends on host / GPU
+ * timing, and the two paths differ at the rounding level (both within 5e-5 of the reference).
  *   value_out       <- (accumulate_value ? += : =) value_scale * sum_{patches in shard} v_patch
  *   grad_flux_accum += grad_coef * d(sum_{patches in shard} v_patch)/d flux   (NULL: forward only)
  *   argmax_out      optional int32 per patch (global patch index order), max mode only

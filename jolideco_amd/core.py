@@ -445,6 +445,16 @@ class FitSession:
         self.comm_events = None
         import os
 
+        # The optimizer step inside the last kernel of a component's gradient (the prior's gather kernel, or the band sum of
+        # a sharded prior): decided ONCE here -- the deconvolver's own `_optimizer_step` (a subclass or an instance that
+        # overrides it is stepped through its hook and sees every gradient), no JOLIDECO_NO_FUSED_STEP, and the tiled
+        # gather kernel the fused form lives in (option JD_GMM_GATHER_TILED=0 selects the per-pixel kernel: two calls).
+        from . import _hip as _hip_mod
+
+        own_step = getattr(type(deconvolver), "_optimizer_step", None) is MAPDeconvolver._optimizer_step
+        tiled = _hip_mod.get_option("JD_GMM_GATHER_TILED") in (None, 1)
+        self.fuse_optimizer_step = bool(own_step and "_optimizer_step" not in vars(deconvolver) and tiled
+                                        and not os.environ.get("JOLIDECO_NO_FUSED_STEP"))
         self._setup_sharded_prior(os.environ.get("JOLIDECO_DIST_OVERLAP", "1") != "0")
         batchable = not os.environ.get("JOLIDECO_NO_BATCH") and self.total_loss.poisson_loss.batchable(
             [li for _, li in self.local_idx]
@@ -558,21 +568,17 @@ class FitSession:
         """The prior of this component applies the optimizer step itself (`device_fwd_bwd_step`): single process (the
         gradient buffer is complete when the prior runs), not frozen, a prior that supports it, stride >= 4, and the
         session's own `_optimizer_step` (tests that replace it to record or suppress the step see every gradient)."""
-        import os
-
         return (
-            not self.dist.sharded and not st.frozen and getattr(prior, "supports_fused_step", False)
-            and getattr(prior, "stride", 0) >= 4 and "_optimizer_step" not in vars(self.cfg)
-            and not os.environ.get("JOLIDECO_NO_FUSED_STEP")
+            self.fuse_optimizer_step and not self.dist.sharded and not st.frozen
+            and getattr(prior, "supports_fused_step", False) and getattr(prior, "stride", 0) >= 4
+            and "_optimizer_step" not in vars(self.cfg)  # (a hook installed on the instance AFTER the session was built)
         )
 
     def _fuse_band_step(self, st):
         """Sharded fits: the bands of the prior's gradient are added and the optimizer step applied in one launch
         (jd_add_rolled_bands_step) -- not frozen, width a multiple of 4 and 16-byte aligned images, the session's own
         `_optimizer_step`, no JOLIDECO_NO_FUSED_STEP."""
-        import os
-
-        if st.frozen or "_optimizer_step" in vars(self.cfg) or os.environ.get("JOLIDECO_NO_FUSED_STEP"):
+        if st.frozen or not self.fuse_optimizer_step or "_optimizer_step" in vars(self.cfg):
             return False
         images = [st.theta, st.flux[0], st.flux[1], st.grad, getattr(st, "exp_avg", None), getattr(st, "exp_avg_sq", None), st.mask]
         return st.grad.shape[-1] % 4 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in images)

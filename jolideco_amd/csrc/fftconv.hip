@@ -26,7 +26,6 @@ struct jd_conv_plan {
   int py = 0, px = 0;        // offset of the (H, W) image inside the conv / pad buffers (FFT: oy, ox; direct: 0)
   size_t nspec = 0;  // complex elements of one spectrum (direct: floats of one Toeplitz fragment table)
   int split = 0;     // direct: the split-fp16 kernel (default where it fits; JD_DIRECT_FP32=1: the fp32 MFMA kernel)
-  bool allow_walk = true;  // separable: the strip-walk kernel may take plain launches (false inside multi-component models)
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   void* work = nullptr;
@@ -115,7 +114,7 @@ static int conv_forward(jd_conv_plan* p, int c, const float* image, const float*
                               1.f, 0, p->split, stream);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0,
-                           stream, p->allow_walk);
+                           stream);
   int rc = launch_pad_mul(image, scale, p->pad[c], p->H, p->W, p->Hp, p->Wp, stream);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream))) return rc;
@@ -143,7 +142,7 @@ static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const f
                               1, coef, accumulate, p->split, stream);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(p->pad[c], nullptr, khat, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1, coef,
-                           accumulate, stream, p->allow_walk, fold, fold_done);
+                           accumulate, stream, fold, fold_done);
   int rc = corr_backward(p, c, khat, stream);
   if (rc) return rc;
   return launch_adjoint_epilogue(p->conv[c], scale, grad, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox, coef, accumulate,
@@ -401,7 +400,6 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   // Poisson pass is the epilogue of the convolution
   const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
                      upsampling == 1 && !cal.log_bkg_norm && !opt_is_set(OPT_SEP_NO_FUSION);
-  p->allow_walk = true;  // (the batched multi-component step has a walk form too: both round alike)
   if (fused) {
     const float* in = flux[0];
     if (cal.shift_xy) {

@@ -1890,6 +1890,7 @@ struct GmmGatherArgs {
 };
 
 __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
+#pragma clang fp contract(off)
   const int Y = a.y_begin + blockIdx.y;
   const int X = blockIdx.x * 256 + threadIdx.x;
   if (X >= a.W || Y >= a.y_end) return;
@@ -1932,6 +1933,10 @@ __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
 // The same overlap-add, one 32 x 32 pixel tile of the rolled frame per block (stride >= 4: at most 10 x 10 patches touch a
 // tile): the gradient rows of those patches are fetched ONCE, as whole 256-byte rows, into LDS and every pixel sums its
 // contributions from there in the order of gmm_gather_kernel (patch rows ascending, then patch columns: the same bits).
+// Every gather kernel adds the ROUNDED product coef * sum (`fp contract(off)`: no fused multiply-add -- hipcc's __fmul_rn
+// is a plain product that the compiler contracts all the same): the band
+// form stores that product and jd_add_rolled_bands adds it later, so a sharded step -- with one rank: RCCL's identity
+// collectives -- gives the bits of the un-sharded one (tests/test_gpu_distributed.py).
 // The per-pixel kernel reads 4 bytes from each of up to four different rows per thread -- 4x the memory instructions,
 // none of them a full line; at 4096^2, where the rows no longer sit in the Infinity Cache, it took 5x the 2048^2 time.
 #ifndef JD_GATHER_MAX_P
@@ -1943,6 +1948,7 @@ __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
 constexpr int GATHER_T = 32, GATHER_MAX_P = JD_GATHER_MAX_P, GATHER_MAX_PX = JD_GATHER_MAX_P + 1;
 
 __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
+#pragma clang fp contract(off)
   __shared__ __attribute__((aligned(16))) float rows[GATHER_MAX_P * GATHER_MAX_PX][D];
   const int tid = threadIdx.x;
   const int xoff = a.vec ? ((a.shift_x % 4) + 4) & 3 : 0;

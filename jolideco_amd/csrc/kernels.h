@@ -104,8 +104,9 @@ size_t sep_conv_operator_floats();
 int sep_factorize(const float* psf_host, int kh, int kw, double tol, std::vector<double>* u, std::vector<double>* v);
 int sep_build_operator(const float* psf_host, int kh, int kw, int oy, int ox, double tol, std::vector<float>* op,
                        SepOpInfo* info = nullptr);
-// allow_walk: the strip-walk kernel may take the launch (not inside a multi-component model, whose batched form runs
-// the tile kernel: both forms must round alike)
+// (The strip-walk kernels take a launch wherever walk_conv() accepts it.  With option JD_SEP_WALK unset that depends on
+// the number of (pixel, dataset, component) triples of the LAUNCH, so a batched step and the per-dataset calls it
+// stands for may run different kernels and then agree to rounding only; JD_SEP_WALK = 0 / 1 makes both choose alike.)
 // fold (adjoint launches of a single dataset): block 0 also turns the `count` partial sums of the forward launch into
 // the dataset's loss, *out = scale * sum(partials) + offset, in finalize_sum_kernel's summation order -- one dependent
 // launch less per step; *fold_done <- whether this launch did (the strip-walk kernel and a forward launch of another
@@ -118,7 +119,7 @@ struct SepLossFold {
 };
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream,
-                    bool allow_walk = true, const SepLossFold* fold = nullptr, int* fold_done = nullptr);
+                    const SepLossFold* fold = nullptr, int* fold_done = nullptr);
 int sep_guard_check(int** guard_dev);
 int sep_conv_tiles(int H, int W);
 // per-dataset pointers of a batched joint step: exposure (input scale of the forward model, output scale of the

@@ -644,9 +644,9 @@ int sep_conv_tiles(int H, int W) { return ((W + TX - 1) / TX) * ((H + TY - 1) / 
 // adjoint != 0: out (+)= coef * out_scale * corr_same(in * in_scale, psf)    (the transpose of the above)
 int launch_sep_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H,
                     int W, int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate,
-                    hipStream_t stream, bool allow_walk, const SepLossFold* fold, int* fold_done) {
+                    hipStream_t stream, const SepLossFold* fold, int* fold_done) {
   if (fold_done) *fold_done = 0;
-  if (allow_walk) {
+  {
     const int rc = walk_conv(in, in_scale, op, out, out_scale, H, W, kh, kw, oy, ox, adjoint, coef, accumulate, stream);
     if (rc != JD_WALK_NOT_TAKEN) return rc;
   }

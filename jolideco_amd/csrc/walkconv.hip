@@ -131,6 +131,29 @@ __device__ __forceinline__ v2f pk_mul_tap(v2f taps, v2f h) {
   return r;
 }
 
+// The same with the tap pair in SGPRs (uniform values: the row taps): no vector registers for the taps at all.
+template <int SEL>
+__device__ __forceinline__ v2f pk_fma_stap(v2f taps, v2f h, v2f acc) {
+  if constexpr (SEL == 0)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(taps), "v"(h));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(taps), "v"(h));
+  return acc;
+}
+template <int SEL>
+__device__ __forceinline__ v2f pk_mul_stap(v2f taps, v2f h) {
+  v2f r;
+  if constexpr (SEL == 0)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "s"(taps), "v"(h));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "s"(taps), "v"(h));
+  return r;
+}
+
+#ifndef JD_WALK_PKROW
+#define JD_WALK_PKROW 0  // 1: the row pass on packed FMAs (measured: no gain, see DESIGN_LOG.md); 0: the scalar row pass
+#endif
+
 // XG > 0: the batched adjoint (one wave per dataset -- at most XWT of them --, rows exchanged in groups of XG, wave
 // w < XG adds up row w of a group); with a.comp_blocks > 0 the grid covers all flux components, comp_blocks blocks each.
 // `bid`: the block's index within the blocks of its frame; (strips, tiles_y, rows): their tiling; `slot0`: position of
@@ -296,6 +319,55 @@ __device__ __forceinline__ void walk_body(const WalkArgs& a, int bid, const int 
     load_epi(r_begin + p - WH, ep[p]);
   }
 
+#if JD_WALK_PKROW
+  // The ROW PASS on packed FMAs (round 4): two neighbouring outputs per instruction.  The operand pair of outputs
+  // (c, c + 1) and tap t is (w[c + t], w[c + t + 1]): an ALIGNED register pair of the window for even c + t, a pair that
+  // straddles two of them for odd.  So the window is read from LDS twice, at both alignments -- Wp[k] = (w[2k], w[2k+1])
+  // and Wq[k] = (w[2k+1], w[2k+2]) -- which costs LDS reads (cheap: the launches follow their vector instructions, DESIGN
+  // section 5) and no registers: the two alignments take the place of the two window sets of the round-3 software pipeline.
+  // The taps are SGPR pairs, broadcast through the operand-select bits (pk_fma_stap).  Per element the same chain
+  // tv[0] w[c], fma(tv[1], w[c + 1], .), ... as before: same bits.  17 taps, 4 columns: 34 instead of 68 instructions.
+  // The pipeline: the window of row rr + 1 is requested right after the row pass of row rr has consumed the registers, and
+  // arrives behind the column pass of row rr.
+  constexpr int NP = NWIN / 2, NQ = NWIN / 2 - 1;
+  typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
+  v2f Wp[NP], Wq[NQ];
+  // (the address of the shifted pairs goes through an empty asm: otherwise the compiler, which sees that they overlap the
+  // aligned reads, builds most of them from those registers with two v_mov each -- ten vector instructions per row)
+  int qoff = C * lane + 1;
+  asm volatile("" : "+v"(qoff));
+  const float* rbq = rb + qoff;
+  v2f tvp[(WK + 1) / 2];
+#pragma unroll
+  for (int j = 0; j < (WK + 1) / 2; ++j) tvp[j] = v2f{tv[2 * j], 2 * j + 1 < WK ? tv[2 * j + 1] : 0.f};
+  // (rows outside the image go through the exchange too -- clamped loads, never used: every step issues the same LDS
+  // operations, so the compiler counts the ones in flight exactly instead of waiting for all of them at a join)
+  auto produce = [&](int rr1, Row& nx) {
+    // ---- products of the row -> LDS ----------------------------------------------------------------------------
+    vC prod = nx.a;
+    if (IN_SCALE) prod = prod * nx.s;
+#pragma unroll
+    for (int c = 0; c < C; ++c) prod[c] = vm ? prod[c] : 0.f;
+    *reinterpret_cast<vC*>(rb + C * lane) = prod;
+    vC px = nx.xa;
+    if (IN_SCALE) px = px * nx.xs;
+#pragma unroll
+    for (int c = 0; c < C; ++c) px[c] = ve ? px[c] : 0.f;
+    *reinterpret_cast<vC*>(rb + 64 * C + C * lane) = px;  // (lanes >= NX: behind the window, never read)
+    load_row(rr1 + P, nx);  // the row P steps ahead takes this row's registers
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NWIN / C; ++k) {
+      const vC t = *reinterpret_cast<const vC*>(rb + C * lane + C * k);
+#pragma unroll
+      for (int c = 0; c < C; ++c) Wp[(C * k + c) / 2][c % 2] = t[c];
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) Wq[k] = *reinterpret_cast<const v2u*>(rbq + 2 * k);
+    wave_lds_fence();
+  };
+  produce(r_begin, pf[0]);
+#else
   // The row exchange is software-pipelined: in step i the products of row rr + 1 go to LDS and its window is READ BACK
   // at once into the other of two window register sets, and only then the FMAs of row rr run on the window that was
   // requested one step earlier -- the LDS round trip (write, read, ~200 cycles that two waves per SIMD do not hide)
@@ -329,12 +401,40 @@ __device__ __forceinline__ void walk_body(const WalkArgs& a, int bid, const int 
   };
   produce(r_begin, pf[0], W[0]);
 
+#endif
+
   for (int r0 = r_begin; r0 < y_end + WH + (XCHG ? XG - 1 : 0); r0 += WS) {  // (+: the last group's flush step)
     static_for<WS>([&](auto ic) {  // (the 18 rotation states as compile-time constants: see walk_multi_kernel)
       constexpr int i = decltype(ic)::value;
       const int rr = r0 + i;
       Epi& ce = ep[i % P];
       const bool live = row_ok(rr);
+#if JD_WALK_PKROW
+      // ---- row pass: h[c] = sum_t tv[t] w[c + t], outputs in pairs ---------------------------------------------------
+      v2f hp[C / 2];
+      if (live) {
+        // (two chains per output pair -- the even taps on the aligned window, the odd taps on the shifted one -- added
+        // at the end: dependent packed FMAs issue a wait state apart, and one chain of 33 of them is latency, not work)
+        v2f ho[C / 2];
+        static_for<WK>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          static_for<C / 2>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, e = 2 * j + t;  // c + t of the pair's first output
+            if constexpr (t == 0) hp[j] = pk_mul_stap<0>(tvp[0], Wp[e / 2]);
+            else if constexpr (t == 1) ho[j] = pk_mul_stap<1>(tvp[0], Wq[e / 2]);
+            else if constexpr (t % 2 == 0) hp[j] = pk_fma_stap<0>(tvp[t / 2], Wp[e / 2], hp[j]);
+            else ho[j] = pk_fma_stap<1>(tvp[t / 2], Wq[e / 2], ho[j]);
+          });
+        });
+#pragma unroll
+        for (int j = 0; j < C / 2; ++j) hp[j] = hp[j] + ho[j];
+      }
+      produce(rr + 1, pf[(i + 1) % P]);
+      if (live) {
+        float h[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) h[c] = hp[c / 2][c % 2];
+#else
       produce(rr + 1, pf[(i + 1) % P], W[(i + 1) & 1]);
       if (live) {
         const float (&w)[NWIN] = W[i & 1];
@@ -346,11 +446,12 @@ __device__ __forceinline__ void walk_body(const WalkArgs& a, int bid, const int 
         for (int t = 1; t < WK; ++t)
 #pragma unroll
           for (int c = 0; c < C; ++c) h[c] = fmaf(tv[t], w[c + t], h[c]);
-        // ---- column pass, scatter form: out[rr + 8 - t] += tu[t] h; 4 columns per lane: on packed FMAs (the same fused
-        // operation per element; with one or two waves per SIMD a packed FMA costs well under two scalar ones)
         v2f hp[C / 2];
 #pragma unroll
         for (int c = 0; c < C; ++c) hp[c / 2][c % 2] = h[c];
+#endif
+        // ---- column pass, scatter form: out[rr + 8 - t] += tu[t] h; 4 columns per lane: on packed FMAs (the same fused
+        // operation per element; with one or two waves per SIMD a packed FMA costs well under two scalar ones)
         static_for<WK>([&](auto tc) {
           constexpr int t = decltype(tc)::value, s = (i + WH - t + WS) % WS;
           if constexpr (PK) {
@@ -1211,9 +1312,11 @@ int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table
   }
   // Both frames in one launch, all waves resident at once.  A 17-tap wave at 4 columns per lane issues ~226 vector
   // instructions per row of 256 pixels, a 33-tap wave at 2 columns ~COST33 per row of 128; the two tilings are chosen so
-  // that tile time (cost per row x (rows + warm-up rows)) is about equal and the waves fill the chip once.
+  // that tile time (cost per row x (rows + warm-up rows)) is about equal and the waves fill the chip once.  Measured
+  // inside the fit (tools/ab.py, 2048^2, 6 + 2 datasets): COST33 = 150 / 190 / 230 / 260 / 280 -> 139.5 / 124.4-126.9 /
+  // 123.0-124.9 / 122.8-124.4 / 125.0 us.
   const double cost17_4 = 226.0, cost17_2 = 150.0;
-  const double cost33 = (double)opt_value(OPT_SEP_WALK_COST33, 190);
+  const double cost33 = (double)opt_value(OPT_SEP_WALK_COST33, 230);
   const long want = (long)(7.25 * device_cus());
   auto tiles = [&](int c, int r) { return (long)((W + 64 * c - 1) / (64 * c)) * ((H + r - 1) / r); };
   C = tiles(4, 38) * n17 + tiles(2, 40) * n33 >= want * 5 / 8 ? 4 : 2;

@@ -9,7 +9,8 @@ all gradients) so that it (a) reproduces the reference bit-for-bit on the same t
 (b) is a fair stand-in when timed as the "reference CPU path".
 
 Parity pinning: checked in the build container against the imported reference
-(oracle/refload/make_golden.py, tests/test_oracle_vs_reference.py) and against the golden
+(oracle/refload/make_golden.py asserts np.array_equal(oracle, reference) on every case it writes) and,
+on every run of the CPU suite (tests/test_oracle_golden.py), against the golden
 fixtures in tests/golden/ (generated from the reference, incl. the reference's own known-answer
 numbers from jolideco/tests/test_core.py:72-79,144-153,181-188).
 """

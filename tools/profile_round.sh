@@ -2,7 +2,8 @@
 # Everything profiles/<round>/ is made of, in one call on a GPU box (run from the repository root):
 #   tools/profile_round.sh r03      ->  gpurun_out/profile_r03/{c3,c2,c4,c5}_n1_bench.json, *_kernel_stats.csv, pmc_*/
 # The PMC passes collect FETCH_SIZE and WRITE_SIZE in SEPARATE runs (MI355X_MICROARCH.md: they do not fit one pass).
-R=${1:-r03}
+set -euo pipefail  # a failed bench or profiler run stops the script: no partial profile round gets copied
+R=${1:-r04}
 OUT=gpurun_out/profile_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -14,8 +15,10 @@ done
 for cfg in c3 c4 c5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$cfg -o $cfg -- \
       python3 bench.py --config $cfg --steps 20 --warmup 5 --no-cpu-baseline --no-general-psf > $OUT/prof_$cfg.log 2>&1
-  cp $(find $OUT/prof_$cfg -name "*kernel_stats.csv" | head -1) $OUT/${cfg}_n1_kernel_stats.csv
-  [ $cfg = c5 ] && continue  # (counters: the two configurations the roofline objects quote)
+  stats=$(find $OUT/prof_$cfg -name "*kernel_stats.csv" | sort | sed -n 1p)
+  [ -n "$stats" ] && [ -s "$stats" ] || { echo "no kernel_stats.csv for $cfg" >&2; exit 1; }
+  cp "$stats" $OUT/${cfg}_n1_kernel_stats.csv
+  if [ $cfg = c5 ]; then continue; fi  # (counters: the two configurations the roofline objects quote)
   for counter in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $counter --output-format csv -d $OUT/pmc_${cfg}_$counter -o pmc -- \
         python3 bench.py --config $cfg --steps 5 --warmup 2 --repeats 1 --settle-seconds 0 --no-cpu-baseline --no-general-psf \
