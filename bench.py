@@ -89,6 +89,58 @@ def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
     return deconvolver.session(datasets, components=comp, dist=dist)
 
 
+def build_session_c6(device, shape=(2048, 2048), n_obs=8, seed=0, K=128):
+    """Config "c6" (round-3 verdict): the fit the reference's Chandra example runs (examples/chandra-e0102-filament.py:
+    91-93,178-203) at the benchmark's size -- 2048^2 counts grid, 8 observations, ``upsampling_factor=2`` (flux, exposure,
+    PSF and the GMM prior live on the 4096^2 grid), general 65x65 PSFs (130x130 after up-sampling: rocFFT), one
+    `NPredCalibration` per observation (trained sub-pixel shift + background norm), joint fit."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent
+    from jolideco_amd.data import instrument_observations, synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    datasets, _, flux_init, cal = instrument_observations(shape=shape, n_obs=n_obs, seed=seed)
+    means, covs, weights = synthetic_gmm(K, D, seed=0)
+    gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=STRIDE))
+    comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm), upsampling_factor=2)
+    calibrations = NPredCalibrations()
+    for name, (sx, sy, norm) in cal.items():
+        calibrations[name] = NPredCalibration(shift_x=sx, shift_y=sy, background_norm=norm)
+    deconvolver = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="joint")
+    return deconvolver.session(datasets, components=comp, calibrations=calibrations)
+
+
+def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), n_obs=8):
+    """Time config c6 (see `build_session_c6`): it/s and the per-kernel table.  No roofline object: the step is a chain of
+    rocFFT transforms, shift kernels and the 4096^2 prior -- the table says where the time goes."""
+    session = build_session_c6(device, shape=shape, n_obs=n_obs)
+    for _ in range(warmup):
+        session.epoch()
+    torch.cuda.synchronize(device)
+    stats = region_stats(timed_regions(session, steps, repeats, device, dist_ctx), steps)
+    host_ms = 1e3 * float(np.median(HOST_ENQUEUE[-1])) / steps
+    prof = profile_phase(session, device, n_obs, steps=4)
+    nested = ("gmm_stage", "gmm_screen", "gmm_sort", "gmm_exact")
+    models = session.total_loss.poisson_loss.npred_models_all
+    plan = models[0].plan
+    scal = session.scalars.detach().cpu().numpy()
+    if not np.all(np.isfinite(scal)):
+        raise SystemExit(f"c6: non-finite losses {scal}")
+    out = {
+        "value": stats["value"], "unit": "iters/s", "ms_per_step": stats["ms_per_step"], "steps": steps, "repeats": repeats,
+        "host_enqueue_ms_per_step": host_ms,
+        "workload": f"c6: {shape[0]}x{shape[1]} counts grid, {n_obs} observations, upsampling_factor 2 (flux grid "
+                    f"{2 * shape[0]}x{2 * shape[1]}), general 65x65 PSFs ({plan.kh}x{plan.kw} up-sampled), one NPredCalibration "
+                    "(shift + background norm, trained) per observation, GMM patch prior K=128 on the flux grid, joint fit",
+        "conv_method": "+".join(sorted({m.plan.method for m in models})),
+        "padded_grid": [plan.Hp, plan.Wp],
+        "batched": bool(getattr(session, "batch_joint", False)),
+        "kernel_ms_per_step": {k: v[0] / 4 for k, v in prof.items() if v[1] and k not in nested},
+        "launches_per_step": {k: v[1] / 4 for k, v in prof.items() if v[1] and k not in nested},
+    }
+    del session
+    return out
+
+
 PMC_TRAFFIC_FILES = ("profiles/r04/pmc_hbm_traffic.csv", "profiles/r03/pmc_hbm_traffic.csv", "profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
 _TRAFFIC_USED = {}  # kernel -> file its traffic figure came from
 
@@ -288,7 +340,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--settle-seconds", type=float, default=SETTLE_SECONDS,
                     help="steps run for at least this long between the warm-up and the timed regions (0: none)")
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c6"])
+    ap.add_argument("--no-c6", action="store_true", help="skip the c6 side run (calibrations + up-sampling + general 65x65 PSFs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-psf", action="store_true",
                     help="skip the extra run that convolves the PSFs as general (not separable) kernels")
@@ -317,6 +370,15 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    if args.config == "c6":
+        if world != 1:
+            raise SystemExit("--config c6 is a single-GPU side run")
+        log("c6: calibrations + up-sampling x2 + general 65x65 PSFs")
+        out = c6_run(device, dist_ctx, steps=max(args.steps // 10, 5), warmup=max(args.warmup // 5, 2), repeats=min(args.repeats, 3))
+        out = dict({"metric": "MAP iters/sec (c6)", "n_gpus": 1, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                    "scaling": "strong", "vs_baseline": None, "warmup": max(args.warmup // 5, 2), "config": {"workload": out.pop("workload")}}, **out)
+        print(json.dumps(out))
+        return
     H, W, n_obs, K = CONFIGS[args.config]
     log(f"building {args.config}: {H}x{W}, {n_obs} obs, K={K} on {device}")
     fake = None
@@ -679,6 +741,12 @@ def main():
                     "evaluation of every observation per epoch",
         }
         del seq
+    if world == 1 and fake is None and args.config == "c3" and not args.no_general_psf and not args.no_c6:
+        log("c6 side run (calibrations + up-sampling x2 + general 65x65 PSFs)")
+        del session
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["c6_chandra_like"] = c6_run(device, dist_ctx)
     log("gpu result: " + json.dumps(out))
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.config)

@@ -26,6 +26,9 @@ struct jd_conv_plan {
   int py = 0, px = 0;        // offset of the (H, W) image inside the conv / pad buffers (FFT: oy, ox; direct: 0)
   size_t nspec = 0;  // complex elements of one spectrum (direct: floats of one Toeplitz fragment table)
   int split = 0;     // direct: the split-fp16 kernel (default where it fits; JD_DIRECT_FP32=1: the fp32 MFMA kernel)
+  // FFT method on sizes the hand-written transforms cover (fftnative.hip): no rocFFT plans, no padded buffers
+  bool native = false;
+  jd::FftNative fftn;
   rocfft_plan fwd = nullptr, inv = nullptr;
   rocfft_execution_info info = nullptr;
   void* work = nullptr;
@@ -115,6 +118,8 @@ static int conv_forward(jd_conv_plan* p, int c, const float* image, const float*
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(image, scale, khat, p->conv[c], nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0,
                            stream);
+  if (p->native)
+    return fftn_conv(p->fftn, image, scale, reinterpret_cast<const float2*>(khat), p->conv[c], nullptr, 0, 1.f, 0, stream);
   int rc = launch_pad_mul(image, scale, p->pad[c], p->H, p->W, p->Hp, p->Wp, stream);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[c], p->spec, stream))) return rc;
@@ -143,6 +148,8 @@ static int corr_backward_into(jd_conv_plan* p, int c, const float* khat, const f
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(p->pad[c], nullptr, khat, grad, scale, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1, coef,
                            accumulate, stream, fold, fold_done);
+  if (p->native)
+    return fftn_conv(p->fftn, p->pad[c], nullptr, reinterpret_cast<const float2*>(khat), grad, scale, 1, coef, accumulate, stream);
   int rc = corr_backward(p, c, khat, stream);
   if (rc) return rc;
   return launch_adjoint_epilogue(p->conv[c], scale, grad, p->H, p->W, p->Hp, p->Wp, p->oy, p->ox, coef, accumulate,
@@ -184,6 +191,26 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
     p->partials_cap = std::max(std::max(poisson_fused_max_partials(H, W), sep_conv_tiles(H, W)), direct_conv_tiles(H, W));
     int rc = JD_OK;
     if (hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
+      rc = fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc of the partial sums failed");
+    if (!rc) rc = ensure_component_buffers(p, 1);
+    if (rc) {
+      jd_conv_plan_destroy(p);
+      return rc;
+    }
+    *plan_out = p;
+    return JD_OK;
+  }
+  if (!exact_shape && opt_value(OPT_FFT_NATIVE, 1) != 0 && fftn_supported(H, W, kh, kw)) {
+    // FFT method on the hand-written transforms: works on the un-padded (H, W) grid like the direct kernels
+    jd_conv_plan* p = new (std::nothrow) jd_conv_plan();
+    if (!p) return fail(JD_ERR_ALLOC, "jd_conv_plan_create: out of host memory");
+    p->method = JD_CONV_FFT, p->native = true;
+    p->H = H, p->W = W, p->kh = kh, p->kw = kw, p->Hp = H, p->Wp = W;
+    p->oy = (kh - 1) / 2, p->ox = (kw - 1) / 2, p->py = 0, p->px = 0;
+    int rc = fftn_create(&p->fftn, H, W, kh, kw);
+    p->nspec = fftn_spectrum_elements(p->fftn);
+    p->partials_cap = poisson_fused_max_partials(H, W);
+    if (!rc && hipMalloc(&p->partials, (size_t)p->partials_cap * sizeof(double)) != hipSuccess)
       rc = fail(JD_ERR_ALLOC, "jd_conv_plan_create: hipMalloc of the partial sums failed");
     if (!rc) rc = ensure_component_buffers(p, 1);
     if (rc) {
@@ -251,6 +278,7 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
 extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
   if (!p) return JD_OK;
   (void)hipDeviceSynchronize();
+  if (p->native) fftn_destroy(&p->fftn);
   if (p->fwd) rocfft_plan_destroy(p->fwd);
   if (p->inv) rocfft_plan_destroy(p->inv);
   if (p->info) rocfft_execution_info_destroy(p->info);
@@ -322,6 +350,7 @@ extern "C" int jd_conv_psf_spectrum(jd_conv_plan* p, const float* psf, float* kh
     sep_register_operator(khat, info);
     return JD_OK;
   }
+  if (p->native) return fftn_spectrum(p->fftn, psf, reinterpret_cast<float2*>(khat), s);
   int rc = launch_pad_mul(psf, nullptr, p->pad[0], p->kh, p->kw, p->Hp, p->Wp, s);
   if (rc) return rc;
   if ((rc = exec_fft(p, p->fwd, p->pad[0], p->spec, s))) return rc;
@@ -343,6 +372,8 @@ extern "C" int jd_conv_same(jd_conv_plan* p, const float* image, const float* sc
                               p->split, s);
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(image, scale_image, khat, out, nullptr, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 0, 1.f, 0, s);
+  if (p->native)
+    return fftn_conv(p->fftn, image, scale_image, reinterpret_cast<const float2*>(khat), out, nullptr, 0, 1.f, 0, s);
   int rc = conv_forward(p, 0, image, scale_image, khat, s);
   if (rc) return rc;
   return launch_crop(p->conv[0], out, p->H, p->W, p->Wp, p->oy, p->ox, s);
@@ -358,6 +389,8 @@ extern "C" int jd_conv_same_adjoint(jd_conv_plan* p, const float* grad_out, cons
   if (p->method == JD_CONV_SEPARABLE)
     return launch_sep_conv(grad_out, nullptr, khat, grad_image, scale_image, p->H, p->W, p->kh, p->kw, p->oy, p->ox, 1,
                            1.f, accumulate, s);
+  if (p->native)
+    return fftn_conv(p->fftn, grad_out, nullptr, reinterpret_cast<const float2*>(khat), grad_image, scale_image, 1, 1.f, accumulate, s);
   int rc = launch_pad_mul(grad_out, nullptr, p->pad[0], p->H, p->W, p->Hp, p->Wp, s);
   if (rc) return rc;
   return corr_backward_into(p, 0, khat, scale_image, grad_image, 1.f, accumulate, s);
@@ -398,6 +431,14 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   bool fold_loss = false;  // the loss of the fused single-component path is finalised by the adjoint launch (see below)
   // one component convolved on the unpadded grid (separable or MFMA direct), no up-sampling, no background norm: the
   // Poisson pass is the epilogue of the convolution
+  if (p->native && n_comp == 1 && upsampling == 1 && !calibrated && grad_flux && !npred_out && !opt_is_set(OPT_SEP_NO_FUSION) &&
+      p->partials_cap >= p->fftn.Hh) {
+    // native FFT path, one component: rows, columns, rows^-1 + Poisson pass + rows of g, columns, rows^-1 + adjoint epilogue
+    if ((rc = fftn_poisson_step(p->fftn, flux[0], exposure[0], reinterpret_cast<const float2*>(khat[0]), background, counts,
+                                p->partials, &n_partials, eps, (float)(1.0 / n_pix), grad_flux[0], grad_scale, accumulate, s)))
+      return rc;
+    return launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s);
+  }
   const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
                      upsampling == 1 && !cal.log_bkg_norm && !opt_is_set(OPT_SEP_NO_FUSION);
   if (fused) {

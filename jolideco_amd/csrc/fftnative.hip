@@ -1,0 +1,623 @@
+// Native FFT convolution: the 'same' convolution of jolideco/utils/torch.py:347-370 (rfft2 -> k-space product -> irfft2 ->
+// centre crop) as THREE launches of hand-written CDNA4 kernels instead of rocFFT's ~12 (2 x 6) + pad + product + crop:
+//
+//   rows    one block per PAIR of image rows: z = (a * scale)[y] + i (a * scale)[y + H/2] -- the image is split into its
+//           upper and lower half, one in the real and one in the imaginary part; a convolution with a REAL kernel acts on
+//           both independently -- zero padded to Nx, complex FFT of length Nx in LDS, spectrum row to HBM.  No padded
+//           real image, no Hermitian bookkeeping: every transform of the path is a plain complex FFT.
+//   columns one wave per column (four columns per block): the H/2 spectrum rows of the column, zero extended to Ny, FFT of
+//           length Ny in LDS, times the kernel spectrum K^ (stored column-major: a contiguous read), inverse FFT, back.
+//   rows^-1 one block per row pair: inverse FFT of length Nx, then the epilogue on the un-padded image: Re -> row y, Im ->
+//           row y + H/2, plus the few rows where the convolution of one half spills into the other (the halves are
+//           convolved as separate images: overlap-add across the seam).  Epilogues: plain store, or the adjoint's
+//           grad (+)= coef * exposure * corr.
+//
+// HBM traffic of one forward convolution at 2048^2 with a 33 x 33 PSF (Nx = 2304, Ny = 1152): 33.6 MB in, 18.9 MB
+// spectrum out, 18.9 + 21.2 (K^) in, 21.2 out, 21.2 in, 16.8 out = 152 MB against rocFFT's ~6 passes over a 2100 x 2100
+// grid per transform (profiles/r01).  Lengths 2^a * {1, 3, 9} (jd_fftcore.h); everything else stays with rocFFT.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "jd_common.h"
+#include "jd_fftcore.h"
+#include "kernels.h"
+
+namespace jd {
+
+namespace {
+
+using namespace jdfft;
+
+constexpr int ROW_THREADS = 256;
+
+struct FftPasses {
+  int n, r[MAX_PASSES];
+};
+
+__device__ __forceinline__ void lds_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int DIR>
+__device__ __forceinline__ void pass_dispatch(int R, const float2* x, float2* y, int N, int p, const float2* tw, int b) {
+  switch (R) {
+    case 16: pass_one<16, DIR>(x, y, N, p, tw, b); break;
+    case 8: pass_one<8, DIR>(x, y, N, p, tw, b); break;
+    case 4: pass_one<4, DIR>(x, y, N, p, tw, b); break;
+    case 2: pass_one<2, DIR>(x, y, N, p, tw, b); break;
+    case 9: pass_one<9, DIR>(x, y, N, p, tw, b); break;
+    default: pass_one<3, DIR>(x, y, N, p, tw, b); break;
+  }
+}
+
+// FFT of one sequence by `nthreads` threads (a block: BLOCK_SYNC, or one wave); the result is in the returned buffer
+template <int DIR, bool BLOCK_SYNC>
+__device__ __forceinline__ float2* fft_lds(float2* a, float2* b, int N, const FftPasses& f, const float2* tw, int tid, int nthreads) {
+  int p = 1;
+  for (int s = 0; s < f.n; ++s) {
+    const int R = f.r[s], nb = N / R;
+    for (int i = tid; i < nb; i += nthreads) pass_dispatch<DIR>(R, a, b, N, p, tw, i);
+    if (BLOCK_SYNC) __syncthreads();
+    else lds_wave_fence();
+    p *= R;
+    float2* t = a;
+    a = b, b = t;
+  }
+  return a;
+}
+
+// The same transform IN PLACE by ONE WAVE (the column kernel: one buffer per column instead of two, twice the columns
+// in flight per CU): in every pass a lane first reads the inputs of all its butterflies (at most MAXB of them) into
+// registers, then writes their outputs.  LDS operations of one wave execute in program order, so all reads of a pass
+// are done before its first write lands; the fence only keeps the compiler from reordering them.
+template <int R, int DIR, int MAXB>
+__device__ __forceinline__ void wave_pass_inplace(float2* x, int N, int p, const float2* tw, int lane) {
+  const int nb = N / R;
+  float2 u[MAXB][R];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int b = lane + 64 * q;
+    if (b < nb) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) u[q][t] = x[lp(b + t * nb)];
+    }
+  }
+  lds_wave_fence();
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int b = lane + 64 * q;
+    if (b < nb) {
+      const int k = b & (p - 1);
+      if (p > 1) {
+        float2 w[R];
+        w[1] = tw[k * (nb / p)];
+        if (DIR > 0) w[1].y = -w[1].y;
+#pragma unroll
+        for (int t = 2; t < R; ++t) w[t] = cmul(w[t / 2], w[t - t / 2]);
+#pragma unroll
+        for (int t = 1; t < R; ++t) u[q][t] = cmul(u[q][t], w[t]);
+      }
+      Dft<R, DIR>::run(u[q]);
+      const int j = (b - k) * R + k;
+#pragma unroll
+      for (int t = 0; t < R; ++t) x[lp(j + t * p)] = u[q][t];
+    }
+  }
+  lds_wave_fence();
+}
+
+// butterflies per lane (N / R / 64 rounded up) the instantiations below hold: column lengths 2^a * {1, 9} up to 2304
+// (16: 144 butterflies -> 3; 8: 256 at N = 2048 -> 4; 9: 256 at N = 2304 -> 4; 4: only N = 32, 288 -> 2)
+__host__ __device__ inline bool wave_fft_fits(int N, const FftPasses& f) {
+  for (int s = 0; s < f.n; ++s) {
+    const int R = f.r[s], per_lane = (N / R + 63) / 64;
+    if ((R == 16 && per_lane > 3) || (R == 8 && per_lane > 4) || (R == 9 && per_lane > 4) || (R == 4 && per_lane > 2) || R == 2 || R == 3)
+      return false;
+  }
+  return true;
+}
+
+// BIG = false: at most 2 / 3 / 2 butterflies per lane at radix 16 / 8 / 9 (column lengths up to 1152 -- a 2048-row image),
+// fewer registers and twice the waves per SIMD; BIG = true: 3 / 4 / 4 (up to 2304)
+__host__ __device__ inline bool wave_fft_is_big(int N, const FftPasses& f) {
+  for (int s = 0; s < f.n; ++s) {
+    const int R = f.r[s], per_lane = (N / R + 63) / 64;
+    if ((R == 16 && per_lane > 2) || (R == 8 && per_lane > 3) || (R == 9 && per_lane > 2)) return true;
+  }
+  return false;
+}
+
+template <int DIR, bool BIG>
+__device__ __forceinline__ void wave_fft_inplace(float2* x, int N, const FftPasses& f, const float2* tw, int lane) {
+  int p = 1;
+  for (int s = 0; s < f.n; ++s) {
+    const int R = f.r[s];
+    switch (R) {
+      case 16: wave_pass_inplace<16, DIR, BIG ? 3 : 2>(x, N, p, tw, lane); break;
+      case 8: wave_pass_inplace<8, DIR, BIG ? 4 : 3>(x, N, p, tw, lane); break;
+      case 9: wave_pass_inplace<9, DIR, BIG ? 4 : 2>(x, N, p, tw, lane); break;
+      default: wave_pass_inplace<4, DIR, 2>(x, N, p, tw, lane); break;
+    }
+    p *= R;
+  }
+}
+
+struct RowsFwdArgs {
+  const float* in;
+  const float* scale;  // nullable
+  float2* spec;        // [Hh][Nx]
+  const float2* tw;
+  int H, W, Hh, Nx;
+  FftPasses f;
+};
+
+// rows: z[x] = in[y][x] s[y][x] + i in[y + Hh][x] s[y + Hh][x], zero beyond W -> FFT -> spec[y][.]
+__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs a) {
+  extern __shared__ float2 lds[];
+  const int tid = threadIdx.x, y = blockIdx.x;
+  float2* bufa = lds;
+  float2* bufb = lds + lp_size(a.Nx);
+  const size_t ra = (size_t)y * a.W, rb = (size_t)(y + a.Hh) * a.W;
+  for (int x = 4 * tid; x < a.Nx; x += 4 * ROW_THREADS) {
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+    if (x < a.W) {
+      u = *reinterpret_cast<const float4*>(a.in + ra + x);
+      v = *reinterpret_cast<const float4*>(a.in + rb + x);
+      if (a.scale) {
+        const float4 su = *reinterpret_cast<const float4*>(a.scale + ra + x), sv = *reinterpret_cast<const float4*>(a.scale + rb + x);
+        u.x *= su.x, u.y *= su.y, u.z *= su.z, u.w *= su.w;
+        v.x *= sv.x, v.y *= sv.y, v.z *= sv.z, v.w *= sv.w;
+      }
+    }
+    const int e = lp(x);  // (x % 4 == 0: the four elements share a group of 16, consecutive in the padded layout)
+    bufa[e] = float2{u.x, v.x}, bufa[e + 1] = float2{u.y, v.y}, bufa[e + 2] = float2{u.z, v.z}, bufa[e + 3] = float2{u.w, v.w};
+  }
+  __syncthreads();
+  const float2* res = fft_lds<-1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+  float2* out = a.spec + (size_t)y * a.Nx;
+  for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+    const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
+    *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
+  }
+}
+
+struct ColsArgs {
+  const float2* spec;  // [Hh][Nx]
+  float2* work;        // [Ny][Nx]
+  const float2* khat;  // [Nx][Ny] (column-major), normalisation folded in
+  const float2* tw;
+  int Hh, Nx, Ny, conj, groups;
+  int debug;  // (timing experiments only, option JD_FFT_DEBUG: bit 0 skips the transforms, bit 1 the kernel spectrum)
+  int keep_lo, keep_hi;  // rows [0, keep_lo) and [keep_hi, Ny) of the result are written (the others are never read)
+  FftPasses f;
+};
+
+// columns: one wave per column, CB = blockDim / 64 columns per block, transforms in place (one padded sequence per column)
+template <bool BIG>
+__global__ __launch_bounds__(512, BIG ? 2 : 3) void fftn_cols_kernel(ColsArgs a) {
+  extern __shared__ float2 lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, CB = blockDim.x >> 6;
+  // neighbouring column groups (the same 128-byte lines of every spectrum row) go to the same XCD (blockIdx % 8), one
+  // after the other: the partial lines they read and write meet in that XCD's L2
+  const int per_xcd = (a.groups + 7) / 8;
+  const int g = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (g >= a.groups) return;
+  const int x0 = g * CB;
+  const int stride = lp_size(a.Ny);
+  float2* col = lds + (size_t)wv * stride;
+  // ---- load: row-major pieces of CB columns, two columns (16 bytes) per thread ---------------------------------------
+  const int half = CB / 2;  // float4 pieces per row
+  for (int i = tid; i < a.Ny * half; i += blockDim.x) {
+    const int row = i / half, piece = i - row * half;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < a.Hh) v = *reinterpret_cast<const float4*>(a.spec + (size_t)row * a.Nx + x0 + 2 * piece);
+    float2* c0 = lds + (size_t)(2 * piece) * stride;
+    c0[lp(row)] = float2{v.x, v.y};
+    c0[stride + lp(row)] = float2{v.z, v.w};
+  }
+  __syncthreads();
+  // ---- per wave: FFT, product with the kernel spectrum, inverse FFT --------------------------------------------------
+  if (!(a.debug & 1)) wave_fft_inplace<-1, BIG>(col, a.Ny, a.f, a.tw, lane);
+  const float2* kcol = a.khat + (size_t)(x0 + wv) * a.Ny;
+  if (!(a.debug & 2))
+    for (int v = lane; v < a.Ny; v += 64) {
+      float2 k = kcol[v];
+      if (a.conj) k.y = -k.y;
+      col[lp(v)] = cmul(col[lp(v)], k);
+    }
+  lds_wave_fence();
+  if (!(a.debug & 1)) wave_fft_inplace<1, BIG>(col, a.Ny, a.f, a.tw, lane);
+  __syncthreads();
+  // ---- store: rows [0, keep_lo) and [keep_hi, Ny), row-major pieces --------------------------------------------------
+  for (int i = tid; i < a.Ny * half; i += blockDim.x) {
+    const int row = i / half, piece = i - row * half;
+    if (row >= a.keep_lo && row < a.keep_hi) continue;
+    const float2* c0 = lds + (size_t)(2 * piece) * stride;
+    const float2 p = c0[lp(row)], q = c0[stride + lp(row)];
+    *reinterpret_cast<float4*>(a.work + (size_t)row * a.Nx + x0 + 2 * piece) = make_float4(p.x, p.y, q.x, q.y);
+  }
+}
+
+struct RowsInvArgs {
+  const float2* work;  // [Ny][Nx]
+  const float2* tw;
+  float* out;          // (H, W)
+  const float* scale;  // adjoint: nullable
+  int H, W, Hh, Nx, Ny, ra, rb;  // the convolution of a half spills ra rows above and rb rows below it
+  float coef;
+  int accumulate;
+  FftPasses f;
+};
+
+// rows^-1 + epilogue.  ADJ = false: out = conv;  ADJ = true: out (+)= (coef * corr) * scale
+template <bool ADJ>
+__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs a) {
+  extern __shared__ float2 lds[];
+  const int tid = threadIdx.x, y = blockIdx.x;
+  float2* bufa = lds;
+  float2* bufb = lds + lp_size(a.Nx);
+  constexpr int MAXQ = 5;  // float4 pieces of a row per thread: W <= 4 * 256 * 5
+  // the spill of the OTHER half into this block's two output rows: at most one of them has one (Hh >= ra + rb + 1)
+  //   row y      (upper half) receives Im C[Ny - Hh + y] when y >= Hh - ra   (the lower half's rows above its top)
+  //   row y + Hh (lower half) receives Re C[Hh + y]      when y <  rb        (the upper half's rows below its bottom)
+  const bool spill_up = y >= a.Hh - a.ra, spill_down = y < a.rb;
+  float4 extra[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) extra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_row = [&](int row) {
+    const float2* src = a.work + (size_t)row * a.Nx;
+    for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+      const float4 v = *reinterpret_cast<const float4*>(src + x);
+      bufa[lp(x)] = float2{v.x, v.y}, bufa[lp(x + 1)] = float2{v.z, v.w};
+    }
+    __syncthreads();
+  };
+  if (spill_up || spill_down) {  // (block-uniform)
+    load_row(spill_up ? a.Ny - a.Hh + y : a.Hh + y);
+    const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int x = 4 * (tid + q * ROW_THREADS);
+      if (x >= a.W) continue;
+      const int e = lp(x);
+      const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
+      extra[q] = spill_up ? make_float4(c0.y, c1.y, c2.y, c3.y) : make_float4(c0.x, c1.x, c2.x, c3.x);
+    }
+    __syncthreads();
+  }
+  load_row(y);
+  const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+  const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int x = 4 * (tid + q * ROW_THREADS);
+    if (x >= a.W) continue;
+    const int e = lp(x);
+    const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
+    float4 up = make_float4(c0.x, c1.x, c2.x, c3.x), dn = make_float4(c0.y, c1.y, c2.y, c3.y);
+    if (spill_up) up.x += extra[q].x, up.y += extra[q].y, up.z += extra[q].z, up.w += extra[q].w;
+    if (spill_down) dn.x += extra[q].x, dn.y += extra[q].y, dn.z += extra[q].z, dn.w += extra[q].w;
+    if (ADJ) {
+      up.x *= a.coef, up.y *= a.coef, up.z *= a.coef, up.w *= a.coef;
+      dn.x *= a.coef, dn.y *= a.coef, dn.z *= a.coef, dn.w *= a.coef;
+      if (a.scale) {
+        const float4 s1 = *reinterpret_cast<const float4*>(a.scale + o1 + x), s2 = *reinterpret_cast<const float4*>(a.scale + o2 + x);
+        up.x *= s1.x, up.y *= s1.y, up.z *= s1.z, up.w *= s1.w;
+        dn.x *= s2.x, dn.y *= s2.y, dn.z *= s2.z, dn.w *= s2.w;
+      }
+      if (a.accumulate) {
+        const float4 g1 = *reinterpret_cast<const float4*>(a.out + o1 + x), g2 = *reinterpret_cast<const float4*>(a.out + o2 + x);
+        up.x += g1.x, up.y += g1.y, up.z += g1.z, up.w += g1.w;
+        dn.x += g2.x, dn.y += g2.y, dn.z += g2.z, dn.w += g2.w;
+      }
+    }
+    *reinterpret_cast<float4*>(a.out + o1 + x) = up;
+    *reinterpret_cast<float4*>(a.out + o2 + x) = dn;
+  }
+}
+
+struct RowsPoissonArgs {
+  const float2* work;  // [Ny][Nx]: the forward convolution after the column pass
+  float2* spec;        // [Hh][Nx]: <- row spectra of g (the input of the adjoint's column pass)
+  const float2* tw;
+  const float* background;
+  const float* counts;
+  double* partials;    // [Hh]
+  int H, W, Hh, Nx, Ny, ra, rb;
+  float eps, inv_n;
+  FftPasses f;
+};
+
+// The middle of a likelihood step in ONE launch: rows^-1 of the forward convolution, the Poisson pass on the two
+// finished image rows (clip, + background, NLL term, g = d loss / d conv where conv >= 0: `poisson_point`, the
+// arithmetic of every Poisson pass of the library), and at once the forward row transform of the g rows -- they ARE the
+// row pair the adjoint's first launch would read.  The convolution image and the g image never exist.
+__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPoissonArgs a) {
+  extern __shared__ float2 lds[];
+  __shared__ double red[ROW_THREADS / 64];
+  const int tid = threadIdx.x, y = blockIdx.x;
+  float2* bufa = lds;
+  float2* bufb = lds + lp_size(a.Nx);
+  constexpr int MAXQ = 5;
+  const bool spill_up = y >= a.Hh - a.ra, spill_down = y < a.rb;
+  float4 extra[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) extra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_row = [&](int row) {
+    const float2* src = a.work + (size_t)row * a.Nx;
+    for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+      const float4 v = *reinterpret_cast<const float4*>(src + x);
+      bufa[lp(x)] = float2{v.x, v.y}, bufa[lp(x + 1)] = float2{v.z, v.w};
+    }
+    __syncthreads();
+  };
+  if (spill_up || spill_down) {  // (block-uniform)
+    load_row(spill_up ? a.Ny - a.Hh + y : a.Hh + y);
+    const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int x = 4 * (tid + q * ROW_THREADS);
+      if (x >= a.W) continue;
+      const int e = lp(x);
+      const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
+      extra[q] = spill_up ? make_float4(c0.y, c1.y, c2.y, c3.y) : make_float4(c0.x, c1.x, c2.x, c3.x);
+    }
+    __syncthreads();
+  }
+  load_row(y);
+  const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+  const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
+  float4 gu[MAXQ], gd[MAXQ];
+  float local = 0.f;
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int x = 4 * (tid + q * ROW_THREADS);
+    gu[q] = gd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (x >= a.W) continue;
+    const int e = lp(x);
+    const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
+    float up[4] = {c0.x, c1.x, c2.x, c3.x}, dn[4] = {c0.y, c1.y, c2.y, c3.y};
+    const float ex[4] = {extra[q].x, extra[q].y, extra[q].z, extra[q].w};
+    const float4 b1 = *reinterpret_cast<const float4*>(a.background + o1 + x), b2 = *reinterpret_cast<const float4*>(a.background + o2 + x);
+    const float4 n1 = *reinterpret_cast<const float4*>(a.counts + o1 + x), n2 = *reinterpret_cast<const float4*>(a.counts + o2 + x);
+    const float bu[4] = {b1.x, b1.y, b1.z, b1.w}, bd[4] = {b2.x, b2.y, b2.z, b2.w};
+    const float cu[4] = {n1.x, n1.y, n1.z, n1.w}, cd[4] = {n2.x, n2.y, n2.z, n2.w};
+    float g1[4], g2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (spill_up) up[i] += ex[i];
+      if (spill_down) dn[i] += ex[i];
+      float term, g;
+      poisson_point(fmaxf(up[i], 0.f) + bu[i], cu[i], a.eps, a.inv_n, term, g);
+      local += term;
+      g1[i] = up[i] >= 0.f ? g : 0.f;  // clamp backward
+      poisson_point(fmaxf(dn[i], 0.f) + bd[i], cd[i], a.eps, a.inv_n, term, g);
+      local += term;
+      g2[i] = dn[i] >= 0.f ? g : 0.f;
+    }
+    gu[q] = make_float4(g1[0], g1[1], g1[2], g1[3]), gd[q] = make_float4(g2[0], g2[1], g2[2], g2[3]);
+  }
+  const double total = block_sum<ROW_THREADS>((double)local, red);
+  if (tid == 0) a.partials[y] = total;
+  __syncthreads();  // every thread has read its part of the convolution row: the buffers are free
+  // ---- z = g[y] + i g[y + Hh], zero padded: the adjoint's row transform ---------------------------------------------
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {  // (Nx <= 4608 < 4 * 256 * MAXQ)
+    const int x = 4 * (tid + q * ROW_THREADS), e = lp(x);
+    if (x >= a.Nx) continue;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
+    if (x < a.W) u = gu[q], v = gd[q];
+    bufa[e] = float2{u.x, v.x}, bufa[e + 1] = float2{u.y, v.y}, bufa[e + 2] = float2{u.z, v.z}, bufa[e + 3] = float2{u.w, v.w};
+  }
+  __syncthreads();
+  const float2* res = fft_lds<-1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+  float2* out = a.spec + (size_t)y * a.Nx;
+  for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+    const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
+    *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
+  }
+}
+
+// Kernel spectrum, column-major and normalised: khat[x][v] = 1 / (Ny Nx) sum_j sum_i psf[j][i] exp(-2 pi i (v (j - oy) / Ny +
+// x (i - ox) / Nx)) -- the PSF placed on the (Ny, Nx) torus with its centre tap at the origin, so that the circular
+// convolution IS the 'same' crop of utils/torch.py:337-344.  Two small DFT stages in double precision (set-up time only).
+__global__ __launch_bounds__(256) void fftn_spectrum_rows_kernel(const float* psf, double2* tmp, int kh, int kw, int ox, int Nx) {
+  const int x = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  if (x >= Nx) return;
+  double re = 0.0, im = 0.0;
+  for (int i = 0; i < kw; ++i) {
+    const long m = ((long)x * (i - ox)) % Nx;
+    double s, c;
+    sincospi(-2.0 * (double)m / (double)Nx, &s, &c);
+    const double p = (double)psf[j * kw + i];
+    re += p * c, im += p * s;
+  }
+  tmp[(size_t)j * Nx + x] = double2{re, im};
+}
+
+__global__ __launch_bounds__(256) void fftn_spectrum_cols_kernel(const double2* tmp, float2* khat, int kh, int oy, int Nx, int Ny) {
+  const int v = blockIdx.x * 256 + threadIdx.x, x = blockIdx.y;
+  if (v >= Ny) return;
+  double re = 0.0, im = 0.0;
+  for (int j = 0; j < kh; ++j) {
+    const long m = ((long)v * (j - oy)) % Ny;
+    double s, c;
+    sincospi(-2.0 * (double)m / (double)Ny, &s, &c);
+    const double2 t = tmp[(size_t)j * Nx + x];
+    re += t.x * c - t.y * s, im += t.x * s + t.y * c;
+  }
+  const double norm = 1.0 / ((double)Nx * (double)Ny);
+  khat[(size_t)x * Ny + v] = float2{(float)(re * norm), (float)(im * norm)};
+}
+
+FftPasses passes_of(int N) {
+  const Radices r = factorize(N);
+  FftPasses f{};
+  f.n = r.n;
+  for (int i = 0; i < r.n; ++i) f.r[i] = r.r[i];
+  return f;
+}
+
+}  // namespace
+
+bool fftn_supported(int H, int W, int kh, int kw) {
+  if (H % 2 != 0 || W % 4 != 0 || H / 2 < kh || kh < 1 || kw < 1) return false;
+  if (W > 4 * ROW_THREADS * 5) return false;
+  const int ox = (kw - 1) / 2;
+  const int nx = next_length(W + std::max(ox, kw - 1 - ox)), ny = next_length(H / 2 + kh - 1, false);
+  // LDS: two padded sequences per row block, one per wave of a column block
+  if (!(nx > 0 && ny > 0 && nx <= 4608 && ny <= 2304 && ny >= 2 * kh)) return false;
+  return factorize(nx).n > 0 && wave_fft_fits(ny, passes_of(ny));
+}
+
+int fftn_create(FftNative* n, int H, int W, int kh, int kw) {
+  *n = FftNative{};
+  n->H = H, n->W = W, n->kh = kh, n->kw = kw, n->oy = (kh - 1) / 2, n->ox = (kw - 1) / 2;
+  n->Hh = H / 2;
+  n->Nx = next_length(W + std::max(n->ox, kw - 1 - n->ox));
+  n->Ny = next_length(n->Hh + kh - 1, false);
+  JD_HIP(hipMalloc(&n->spec, (size_t)n->Hh * n->Nx * sizeof(float2)));
+  JD_HIP(hipMalloc(&n->work, (size_t)n->Ny * n->Nx * sizeof(float2)));
+  std::vector<float2> tw;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int N = pass ? n->Ny : n->Nx;
+    tw.resize(N);
+    for (int m = 0; m < N; ++m) {
+      const double ang = -2.0 * M_PI * (double)m / (double)N;
+      tw[m] = float2{(float)std::cos(ang), (float)std::sin(ang)};
+    }
+    float2** dst = pass ? &n->tw_y : &n->tw_x;
+    JD_HIP(hipMalloc(dst, (size_t)N * sizeof(float2)));
+    JD_HIP(hipMemcpy(*dst, tw.data(), (size_t)N * sizeof(float2), hipMemcpyHostToDevice));
+  }
+  return JD_OK;
+}
+
+void fftn_destroy(FftNative* n) {
+  if (n->spec) (void)hipFree(n->spec);
+  if (n->work) (void)hipFree(n->work);
+  if (n->tw_x) (void)hipFree(n->tw_x);
+  if (n->tw_y) (void)hipFree(n->tw_y);
+  *n = FftNative{};
+}
+
+size_t fftn_spectrum_elements(const FftNative& n) { return (size_t)n.Nx * n.Ny; }
+
+int fftn_spectrum(const FftNative& n, const float* psf, float2* khat, hipStream_t stream) {
+  // (the double-precision row stage borrows the column work buffer: kh * Nx * 16 bytes <= Ny * Nx * 8)
+  double2* tmp = reinterpret_cast<double2*>(n.work);
+  fftn_spectrum_rows_kernel<<<dim3((n.Nx + 255) / 256, n.kh), 256, 0, stream>>>(psf, tmp, n.kh, n.kw, n.ox, n.Nx);
+  JD_LAUNCH_CHECK();
+  fftn_spectrum_cols_kernel<<<dim3((n.Ny + 255) / 256, n.Nx), 256, 0, stream>>>(tmp, khat, n.kh, n.oy, n.Nx, n.Ny);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+namespace {
+int lds_attr(const void* kernel, size_t bytes, size_t* set) {
+  if (bytes > 64 * 1024 && bytes > *set) {
+    JD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    *set = bytes;
+  }
+  return JD_OK;
+}
+
+int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream) {
+  const FftPasses fy = passes_of(n.Ny);
+  const int ra = adjoint ? n.kh - 1 - n.oy : n.oy, rb = adjoint ? n.oy : n.kh - 1 - n.oy;
+  ColsArgs a{};
+  a.spec = n.spec, a.work = n.work, a.khat = khat, a.tw = n.tw_y, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.conj = adjoint ? 1 : 0;
+  a.keep_lo = n.Hh + rb, a.keep_hi = n.Ny - ra, a.f = fy;
+  a.debug = opt_value(OPT_FFT_DEBUG, 0);
+  const size_t per_wave = (size_t)lp_size(n.Ny) * sizeof(float2);
+  // columns per block: 4 (32 contiguous bytes of every spectrum row; three blocks per CU), 2 for the long columns
+  // (measured at 2048^2, Ny = 1152: 8 columns per block 45 us -- one block per CU --, 4: 33 us, 2: 35 us)
+  int cb = 4 * per_wave <= 80 * 1024 ? 4 : 2;
+  const int ocb = opt_value(OPT_FFT_NATIVE, 1);  // (tuning: JD_FFT_NATIVE = 2 / 4 / 8 forces the columns per block)
+  if ((ocb == 2 || ocb == 4 || ocb == 8) && (size_t)ocb * per_wave <= 160 * 1024 && n.Nx % ocb == 0) cb = ocb;
+  a.groups = n.Nx / cb;
+  static size_t lds_cols_set[2] = {0, 0};
+  const bool big = wave_fft_is_big(n.Ny, fy);
+  const void* kernel = big ? reinterpret_cast<const void*>(fftn_cols_kernel<true>) : reinterpret_cast<const void*>(fftn_cols_kernel<false>);
+  int rc = lds_attr(kernel, cb * per_wave, &lds_cols_set[big ? 1 : 0]);
+  if (rc) return rc;
+  ProfScope prof(JD_KERNEL_CMUL, stream);
+  if (big) hipLaunchKernelGGL(fftn_cols_kernel<true>, dim3(((a.groups + 7) / 8) * 8), dim3(64 * cb), cb * per_wave, stream, a);
+  else hipLaunchKernelGGL(fftn_cols_kernel<false>, dim3(((a.groups + 7) / 8) * 8), dim3(64 * cb), cb * per_wave, stream, a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream) {
+  static size_t set = 0;
+  const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
+  RowsFwdArgs a{};
+  a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
+  int rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_fwd_kernel), lds_rows, &set);
+  if (rc) return rc;
+  ProfScope prof(JD_KERNEL_FFT_R2C, stream);
+  hipLaunchKernelGGL(fftn_rows_fwd_kernel, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream) {
+  static size_t set[2] = {0, 0};
+  const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
+  RowsInvArgs a{};
+  a.work = n.work, a.tw = n.tw_x, a.out = out, a.scale = out_scale, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
+  a.ra = adjoint ? n.kh - 1 - n.oy : n.oy, a.rb = adjoint ? n.oy : n.kh - 1 - n.oy;
+  a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx);
+  ProfScope prof(JD_KERNEL_FFT_C2R, stream);
+  int rc;
+  if (adjoint) {
+    if ((rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_inv_kernel<true>), lds_rows, &set[1]))) return rc;
+    hipLaunchKernelGGL(fftn_rows_inv_kernel<true>, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
+  } else {
+    if ((rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_inv_kernel<false>), lds_rows, &set[0]))) return rc;
+    hipLaunchKernelGGL(fftn_rows_inv_kernel<false>, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
+  }
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+}  // namespace
+
+// out = conv_same(in * in_scale, psf)                       (adjoint == 0)
+// out (+)= coef * out_scale * corr_same(in, psf)            (adjoint != 0; the transpose of the above)
+int fftn_conv(const FftNative& n, const float* in, const float* in_scale, const float2* khat, float* out, const float* out_scale,
+              int adjoint, float coef, int accumulate, hipStream_t stream) {
+  int rc = launch_rows_fwd(n, in, in_scale, stream);
+  if (rc) return rc;
+  if ((rc = launch_cols(n, khat, adjoint, stream))) return rc;
+  return launch_rows_inv(n, out, out_scale, adjoint, coef, accumulate, stream);
+}
+
+// The likelihood step of one dataset and one flux component in FIVE launches: rows(flux x exposure), columns(K^),
+// rows^-1 + Poisson pass + rows(g), columns(conj K^), rows^-1 + adjoint epilogue.  partials[0 .. *n_partials): block
+// sums of n - c log(n + eps);  grad (+)= coef * exposure * corr(g, psf).
+int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposure, const float2* khat, const float* background,
+                      const float* counts, double* partials, int* n_partials, float eps, float inv_n, float* grad, float coef,
+                      int accumulate, hipStream_t stream) {
+  int rc = launch_rows_fwd(n, flux, exposure, stream);
+  if (rc) return rc;
+  if ((rc = launch_cols(n, khat, 0, stream))) return rc;
+  {
+    static size_t set = 0;
+    const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
+    RowsPoissonArgs a{};
+    a.work = n.work, a.spec = n.spec, a.tw = n.tw_x, a.background = background, a.counts = counts, a.partials = partials;
+    a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
+    a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx);
+    if ((rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_poisson_kernel), lds_rows, &set))) return rc;
+    ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
+    hipLaunchKernelGGL(fftn_rows_poisson_kernel, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
+    JD_LAUNCH_CHECK();
+  }
+  *n_partials = n.Hh;
+  if ((rc = launch_cols(n, khat, 1, stream))) return rc;
+  return launch_rows_inv(n, grad, exposure, 1, coef, accumulate, stream);
+}
+
+}  // namespace jd

@@ -67,7 +67,7 @@ enum JdOption {
   OPT_GMM_SCREEN_NP, OPT_GMM_SCREEN_NO_LDS_CONSTS, OPT_GMM_SCREEN_DEBUG, OPT_GMM_SCREEN, OPT_GMM_FUSED_BWD,
   OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_SEP_JOINT, OPT_SEP_JOINT_ROWS, OPT_SEP_JOINT_CHUNK,
   OPT_SEP_WALK_ADJ_ALL, OPT_SEP_WALK_COST33, OPT_SEP_WALK_ROWS33, OPT_SEP_NO_TRIM, OPT_SEP_WALK_ADJ_ROWS33,
-  OPT_SEP_WALK_ADJ33, OPT_COUNT
+  OPT_SEP_WALK_ADJ33, OPT_FFT_NATIVE, OPT_FFT_DEBUG, OPT_COUNT
 };
 bool opt_is_set(int id);
 int opt_value(int id, int unset_value);
@@ -199,6 +199,26 @@ int launch_sep_conv_poisson(const float* in, const float* in_scale, const float*
                             int kw, int oy, int ox, const float* background, const float* counts, float* npred_out,
                             double* partials, float eps, float inv_n, int write_grad, int* n_partials,
                             hipStream_t stream);
+
+// native FFT convolution (fftnative.hip): three launches per convolution on hand-written complex FFTs of lengths
+// 2^a * {1, 3, 9}; image rows packed pairwise (upper half real, lower half imaginary)
+struct FftNative {
+  int H = 0, W = 0, kh = 0, kw = 0, oy = 0, ox = 0, Hh = 0, Nx = 0, Ny = 0;
+  float2* spec = nullptr;  // (Hh, Nx) row spectra
+  float2* work = nullptr;  // (Ny, Nx) after the column pass
+  float2* tw_x = nullptr;  // exp(-2 pi i m / Nx)
+  float2* tw_y = nullptr;
+};
+bool fftn_supported(int H, int W, int kh, int kw);
+int fftn_create(FftNative* n, int H, int W, int kh, int kw);
+void fftn_destroy(FftNative* n);
+size_t fftn_spectrum_elements(const FftNative& n);
+int fftn_spectrum(const FftNative& n, const float* psf, float2* khat, hipStream_t stream);
+int fftn_conv(const FftNative& n, const float* in, const float* in_scale, const float2* khat, float* out, const float* out_scale,
+              int adjoint, float coef, int accumulate, hipStream_t stream);
+int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposure, const float2* khat, const float* background,
+                      const float* counts, double* partials, int* n_partials, float eps, float inv_n, float* grad, float coef,
+                      int accumulate, hipStream_t stream);
 
 // kernel timers (profile.hip): RAII bracket around one launch
 int prof_begin(int kernel, hipStream_t s);

@@ -29,7 +29,8 @@ OptionSlot g_options[OPT_COUNT] = {
     {"JD_GMM_WINNER_ROWS", {INT_MIN}},   {"JD_SEP_JOINT", {INT_MIN}},        {"JD_SEP_JOINT_ROWS", {INT_MIN}},
     {"JD_SEP_JOINT_CHUNK", {INT_MIN}},   {"JD_SEP_WALK_ADJ_ALL", {INT_MIN}}, {"JD_SEP_WALK_COST33", {INT_MIN}},
     {"JD_SEP_WALK_ROWS33", {INT_MIN}},   {"JD_SEP_NO_TRIM", {INT_MIN}},      {"JD_SEP_WALK_ADJ_ROWS33", {INT_MIN}},
-    {"JD_SEP_WALK_ADJ33", {INT_MIN}},
+    {"JD_SEP_WALK_ADJ33", {INT_MIN}},    {"JD_FFT_NATIVE", {INT_MIN}},
+    {"JD_FFT_DEBUG", {INT_MIN}},
 };
 
 int parse(const char* text) {

@@ -16,6 +16,8 @@ __all__ = [
     "gauss_and_point_sources_gauss_psf",
     "synthetic_gmm",
     "synthetic_observations",
+    "instrument_like_psf",
+    "instrument_observations",
 ]
 
 BACKGROUND_LEVEL_DEFAULT = 2
@@ -159,6 +161,38 @@ def image_like_gmm(n_components=128, patch=8, seed=0, ridge=1e-4):
 def psf_shape(sigma):
     """PSF array size of the synthetic observations: 17x17, 33x33 for sigma >= 3."""
     return (33, 33) if sigma >= 3 else (17, 17)
+
+
+def instrument_like_psf(index, shape=(65, 65), dtype=np.float32):
+    """A PSF that is NOT a short sum of outer products (what a simulated instrument PSF looks like; the reference's
+    Chandra example draws 128x128 MARX simulations, examples/chandra-e0102-filament.py:91-93): an elliptical core
+    rotated by an angle that changes with ``index``, an off-axis coma lobe and broad wings.  Unit sum."""
+    ny, nx = shape
+    y, x = np.meshgrid(_grid(ny), _grid(nx), indexing="ij")
+    angle = 0.35 + 0.4 * index
+    c, s_ = np.cos(angle), np.sin(angle)
+    u, v = c * x + s_ * y, -s_ * x + c * y
+    core = np.exp(-0.5 * ((u / (1.6 + 0.15 * index)) ** 2 + (v / (0.9 + 0.05 * index)) ** 2))
+    lobe = 0.25 * np.exp(-0.5 * (((u - 3.5) / 2.5) ** 2 + ((v + 1.0) / 1.4) ** 2))
+    wings = 0.05 / (1.0 + (x * x + y * y) / 36.0) ** 1.5
+    psf = core + lobe + wings
+    return (psf / psf.sum()).astype(dtype)
+
+
+def instrument_observations(shape=(2048, 2048), n_obs=8, seed=0, psf_shape=(65, 65), dtype=np.float32):
+    """`n_obs` observations shaped like the reference's Chandra example (examples/chandra-e0102-filament.py:91-93,
+    178-203): general (not low-rank) `psf_shape` PSFs on the counts grid, meant to be fitted with
+    ``upsampling_factor=2`` and one `NPredCalibration` per observation.  Same sky, exposures and backgrounds as
+    `synthetic_observations`.  Returns (datasets, truth, flux_init, calibration values {name: (shift_x, shift_y, norm)})."""
+    datasets, truth, flux_init = synthetic_observations(shape=shape, n_obs=n_obs, seed=seed, dtype=dtype)
+    rs = np.random.RandomState(seed + 1)
+    cal = {}
+    for i, (name, d) in enumerate(datasets.items()):
+        d["psf"] = instrument_like_psf(i, psf_shape, dtype)
+        npred = d["background"] + np.clip(convolve_same(truth * d["exposure"], d["psf"]), 0, None)
+        d["counts"] = rs.poisson(npred).astype(dtype)
+        cal[name] = (0.15 * ((i % 3) - 1) + 0.05, -0.1 * ((i % 4) - 1.5), 1.0 + 0.02 * (i - n_obs / 2))
+    return datasets, truth, flux_init, cal
 
 
 def synthetic_observations(shape=(2048, 2048), n_obs=8, seed=0, n_points=64, dtype=np.float32):

@@ -135,6 +135,12 @@ class ConvPlan:
             _hip.lib().jd_conv_plan_destroy(self._handle)
             self._handle = None
 
+    @property
+    def native_fft(self):
+        """True when an "fft" plan runs on the hand-written transforms of csrc/fftnative.hip (no padded grid) instead of
+        rocFFT (sizes 2^a * {1, 3, 9} reach; even H, W % 4 == 0; option JD_FFT_NATIVE=0 switches it off)."""
+        return self.method == "fft" and (self.Hp, self.Wp) == (self.H, self.W)
+
     def takes_walk(self, n_datasets=1):
         """True when a launch over ``n_datasets`` datasets runs on the strip-walk kernels (jd_conv_plan_takes_walk)."""
         return bool(_hip.lib().jd_conv_plan_takes_walk(self._handle, int(n_datasets)))
