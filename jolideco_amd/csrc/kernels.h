@@ -142,6 +142,9 @@ struct SepBatchTable {
   // the 33-tap frame -- the order of the batched forward launch of the strip-walk kernels (walk_batch_order fills it)
   int order[SEP_MAX_BATCH];
   int n17;
+  // bit d * n_comp + c: the operator of (dataset d, component c) walks in the 33-tap frame (several components: the
+  // waves of a block choose their frame by it)
+  unsigned long long frame33;
 };
 void walk_batch_order(SepBatchTable& table, int n, int n_comp, int kh, int kw, int oy, int ox);
 // *n_partials <- partial sums written per dataset: partials[d * *n_partials + i]

@@ -577,23 +577,25 @@ struct MultiArgs {
   const float* flux[MULTI_MAX];
   double* partials;
   int H, W, strips, tiles_y, rows;
-  int taps_u, taps_v, kh, kw, offy, offx;
+  int taps_u, taps_v, kh, kw, oy0, ox0;  // (image offset of the first stored tap: frame position WH + oy0, see walk_body)
   float eps, inv_n;
   int write_grad, n_comp;
   const SepBatchTable* table;
   int* guard;
 };
 
-template <int C, int P>
-__global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a) {
+// (round 4: the frame is a template parameter of the WAVE's body -- a dataset whose components need different frames has
+// waves of both kinds in its block; they meet at the same barriers, one pair per group of MG output rows)
+template <int WKT, int C, int P>
+__device__ __forceinline__ void walk_multi_body(const MultiArgs& a, float* multi_lds) {
 #pragma clang fp contract(off)
+  constexpr int WK = Frame<WKT>::WK, WH = Frame<WKT>::WH, WS = Frame<WKT>::WS;
   typedef typename Vec<C>::T vC;
   static_assert(WS % MG == 0 && WS % P == 0, "group size and prefetch depth must divide the rotation period");
   constexpr int NX = 2 * WH / C;
   constexpr int NWIN = 2 * WH + C;
   // LDS (dynamic, n_comp x 64 C x (2 + 3 MG) floats): per wave a row buffer; [row of the group][component][lane * C]
   // finished convolution rows; per wave [row][background | counts][lane * C]
-  extern __shared__ __attribute__((aligned(16))) float multi_lds[];
   const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6), nc = a.n_comp;
   float* const cbuf = multi_lds + nc * 2 * 64 * C;
   float* const bcbase = cbuf + MG * nc * 64 * C;
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a)
   {
     if ((int)op[0] != 1 && lane == 0) *a.guard = 1;
     float mu = 0.f, mv = 0.f;
-    const int iu = lane - a.offy, iv = lane - a.offx;
+    const int iu = lane - (WH + a.oy0), iv = lane - (WH + a.ox0);
     if (iu >= 0 && iu < a.kh) mu = op[a.taps_u + iu];
     if (iv >= 0 && iv < a.kw) mv = op[a.taps_v + iv];
 #pragma unroll
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a)
 #ifndef JD_WALK_MULTI_PK
 #define JD_WALK_MULTI_PK 1
 #endif
-  constexpr bool PK = C == 4 && JD_WALK_MULTI_PK;  // packed FMAs in the column pass: see walk_kernel
+  constexpr bool PK = (C == 4 && JD_WALK_MULTI_PK) || WKT == 33;  // packed FMAs in the column pass: see walk_kernel
   v2f tup[PK ? (WK + 1) / 2 : 1];
   if constexpr (PK) {
 #pragma unroll
@@ -795,6 +797,24 @@ __global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a)
   if (wv == 0) {
     loss = wave_sum(loss);
     if (lane == 0) a.partials[(size_t)d * n_tiles + tile] = loss;
+  }
+}
+
+// FRAMES = 17: every operator of the launch walks in the 17-tap frame; 33: some need the 33-tap frame (two columns per
+// lane only) -- table->frame33 says which (bit d * n_comp + c)
+template <int C, int P, int FRAMES>
+__global__ __launch_bounds__(64 * MULTI_MAX) void walk_multi_kernel(MultiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float multi_lds[];
+  if constexpr (FRAMES == 33) {
+    static_assert(C == 2, "the 33-tap frame runs two columns per lane");
+    const int per_xcd = (a.strips * a.tiles_y + 7) / 8;
+    const int d = (int)(blockIdx.x / 8) / per_xcd, wv = (int)(threadIdx.x >> 6);
+    if ((a.table->frame33 >> (d * a.n_comp + wv)) & 1ull)  // (wave-uniform)
+      walk_multi_body<33, C, P>(a, multi_lds);
+    else
+      walk_multi_body<17, C, P>(a, multi_lds);
+  } else {
+    walk_multi_body<17, C, P>(a, multi_lds);
   }
 }
 
@@ -1230,6 +1250,9 @@ void walk_batch_order(SepBatchTable& table, int n, int n_comp, int kh, int kw, i
       if (is17 && pass == 0) ++table.n17;
     }
   for (; k < SEP_MAX_BATCH; ++k) table.order[k] = 0;
+  table.frame33 = 0;
+  for (int i = 0; i < n * n_comp && i < 64; ++i)
+    if (walk_frame(table.op[i], kh, kw, oy, ox) == 33) table.frame33 |= 1ull << i;
 }
 
 bool sep_batch_is_mixed(int n, int n_comp, const SepBatchTable& table, int H, int W, int kh, int kw, int oy, int ox) {
@@ -1239,7 +1262,7 @@ bool sep_batch_is_mixed(int n, int n_comp, const SepBatchTable& table, int H, in
   for (int d = 0; d < n; ++d)
     for (int c = 0; c < n_comp; ++c) {
       const int f = dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox);
-      yes += (n_comp == 1 ? f != 0 : f == 17) ? 1 : 0;  // (several components: the 17-tap frame only)
+      yes += f != 0 ? 1 : 0;
     }
   return yes != 0 && yes != n * n_comp;
 }
@@ -1365,23 +1388,29 @@ int walk_conv_poisson_batch_multi(int n, int n_comp, const float* const* flux, c
   if (n_comp < 2 || n_comp > MULTI_MAX) return JD_WALK_NOT_TAKEN;
   for (int c = 0; c < n_comp; ++c)
     if (!aligned16(flux[c])) return JD_WALK_NOT_TAKEN;
-  if (!walk_enabled(H, W, n * n_comp)) return JD_WALK_NOT_TAKEN;
+  if (!walk_enabled(H, W, n * n_comp) || n * n_comp > 64) return JD_WALK_NOT_TAKEN;
+  bool any33 = false;
   for (int d = 0; d < n; ++d)
-    for (int c = 0; c < n_comp; ++c)  // (this kernel walks in the 17-tap frame only)
-      if (dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox) != 17) return JD_WALK_NOT_TAKEN;
+    for (int c = 0; c < n_comp; ++c) {
+      const int f = dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox);
+      if (!f) return JD_WALK_NOT_TAKEN;
+      any33 = any33 || f == 33;
+    }
   MultiArgs a{};
   for (int c = 0; c < n_comp; ++c) a.flux[c] = flux[c];
   a.partials = partials, a.H = H, a.W = W, a.eps = eps, a.inv_n = inv_n, a.write_grad = write_grad, a.n_comp = n_comp;
   a.table = table_dev;
   const SepGeom g = sep_geom(kh, kw, oy, ox, false);
-  a.offy = WH + g.oy0, a.offx = WH + g.ox0 + g.shiftx;
+  a.oy0 = g.oy0, a.ox0 = g.ox0 + g.shiftx;
   a.kh = kh, a.kw = kw, a.taps_u = 4, a.taps_v = 4 + g.khp + g.shiftx;
-  // 4 columns per lane (184 registers: 2 waves per SIMD) unless that leaves CUs without a block
+  // 4 columns per lane (184 registers: 2 waves per SIMD) unless that leaves CUs without a block; a launch with operators
+  // of the 33-tap frame: 2 columns per lane for every block (its 36 accumulator rows: 2 waves per SIMD at that width)
   int C = opt_value(OPT_SEP_WALK_COLS, 0);
   const int per_cu4 = 8 / n_comp;
   auto blocks_of = [&](int c, int r) { return (long)((W + 64 * c - 1) / (64 * c)) * ((H + r - 1) / r) * n; };
   if (C != 2 && C != 4) C = blocks_of(4, 36) >= (long)device_cus() * per_cu4 / 2 ? 4 : 2;
-  const int per_cu = (C == 4 ? 8 : 16) / n_comp;  // (126 registers at C = 2: 4 waves per SIMD)
+  if (any33) C = 2;
+  const int per_cu = (C == 4 || any33 ? 8 : 16) / n_comp;  // (126 registers at C = 2 in the 17-tap frame: 4 waves per SIMD)
   // Rows per tile (a multiple of MG).  Measured inside the fit, 2048^2 x 16 x 2 components, C = 4: 72 / 96 / 120 / 144 /
   // 168 / 192 / 240 / 294 rows = 432 / 434 / 456 / 416-436 / 465 / 505 / 550 / 510 us: unlike the one-component launch this
   // one prefers SEVERAL rounds of short blocks to one round of long ones, and loses what its last round leaves empty
@@ -1413,13 +1442,15 @@ int walk_conv_poisson_batch_multi(int n, int n_comp, const float* const* flux, c
   if (C == 4) {
     static size_t lds_set = 0;
     if (lds > 64 * 1024 && lds > lds_set) {
-      JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(walk_multi_kernel<4, WALK_PREFETCH>),
+      JD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(walk_multi_kernel<4, WALK_PREFETCH, 17>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       lds_set = lds;
     }
-    hipLaunchKernelGGL((walk_multi_kernel<4, WALK_PREFETCH>), dim3(blocks), dim3(64 * n_comp), lds, stream, a);
+    hipLaunchKernelGGL((walk_multi_kernel<4, WALK_PREFETCH, 17>), dim3(blocks), dim3(64 * n_comp), lds, stream, a);
+  } else if (any33) {
+    hipLaunchKernelGGL((walk_multi_kernel<2, WALK_PREFETCH, 33>), dim3(blocks), dim3(64 * n_comp), lds, stream, a);
   } else {
-    hipLaunchKernelGGL((walk_multi_kernel<2, WALK_PREFETCH>), dim3(blocks), dim3(64 * n_comp), lds, stream, a);
+    hipLaunchKernelGGL((walk_multi_kernel<2, WALK_PREFETCH, 17>), dim3(blocks), dim3(64 * n_comp), lds, stream, a);
   }
   JD_LAUNCH_CHECK();
   return JD_OK;
@@ -1439,7 +1470,7 @@ int walk_conv_adjoint_batch(int n, int n_comp, int comp, const SepBatchTable& ta
   for (int d = 0; d < n; ++d)
     for (int c = 0; c < n_comp; ++c) {  // (all components: the forward launch of the step must have been a walk launch too)
       const int f = dataset_frame(table, d * n_comp + c, d, kh, kw, oy, ox);
-      if (!f || (n_comp > 1 && f != 17)) return JD_WALK_NOT_TAKEN;
+      if (!f) return JD_WALK_NOT_TAKEN;
       if (c == comp) frames[d] = f;
     }
   WalkArgs a{};

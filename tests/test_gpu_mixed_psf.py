@@ -181,3 +181,42 @@ def test_datasets_with_different_psf_sizes_share_the_batched_joint_step(monkeypa
     gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
     final, _ = cpu_ref.map_fit_joint(datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o)}, n_epochs=4)
     assert rel_linf(results["batch"], final["flux"]) < 1e-5
+
+
+@pytest.mark.parametrize("kernels", ["walk", "tile"])
+def test_two_components_with_psfs_of_both_frames_match_the_loop_and_the_oracle(monkeypatch, jd_option, kernels):
+    """BASELINE config 5 in small with the section-8(d) PSF sizes: "extended" sees 17x17 PSFs and, from observation 6 on,
+    33x33 ones; "points" 17x17 throughout.  The batched multi-component step (walk_multi_kernel: one wave per component,
+    each in the frame ITS operator needs; adjoint per component, one launch per run of datasets of one frame) is the
+    per-dataset loop bit for bit and the oracle's joint fit to 1e-5."""
+    from jolideco_amd import FluxComponents, InverseGammaPrior, MAPDeconvolver, SpatialFluxComponent, UniformPrior
+    from jolideco_amd.data import gaussian_kernel, synthetic_observations
+    from oracle import cpu_ref
+
+    jd_option("JD_SEP_WALK", 1 if kernels == "walk" else 0)
+    datasets, _, flux_init = synthetic_observations(shape=(72, 136), n_obs=9, seed=11)
+    for i, d in enumerate(datasets.values()):
+        d["psf"] = {"extended": d["psf"], "points": gaussian_kernel(1.0 + 0.1 * i, (17, 17)).astype(np.float32)}
+    results = {}
+    for mode in ("batch", "loop"):
+        if mode == "loop":
+            monkeypatch.setenv("JOLIDECO_NO_BATCH", "1")
+        comps = FluxComponents()
+        comps["extended"] = SpatialFluxComponent.from_numpy(flux=flux_init, prior=UniformPrior())
+        comps["points"] = SpatialFluxComponent.from_numpy(flux=0.1 * flux_init, prior=InverseGammaPrior(alpha=10))
+        deconvolver = MAPDeconvolver(n_epochs=4, display_progress=False, device=DEV, fit_mode="joint")
+        session = deconvolver.session(datasets, components=comps)
+        models = session.total_loss.poisson_loss.npred_models_all
+        assert session.batch_joint == (mode == "batch") and len({id(m.plan) for m in models}) == 1
+        if kernels == "walk":
+            assert [models[i].plan.walk_frame(models[i]["extended"].khat) for i in (0, 5, 6, 8)] == [17, 17, 33, 33]
+            assert all(m.plan.walk_frame(m["points"].khat) == 17 for m in models)
+        res = deconvolver.run(datasets, components=comps)
+        results[mode] = {name: res.components[name].flux_upsampled_numpy for name in ("extended", "points")}
+    for name in ("extended", "points"):
+        assert np.array_equal(results["batch"][name], results["loop"][name]), name
+    final, _ = cpu_ref.map_fit_joint(
+        datasets, {"extended": flux_init, "points": 0.1 * flux_init},
+        {"extended": cpu_ref.UniformPriorRef(), "points": cpu_ref.InverseGammaPriorRef(alpha=10)}, n_epochs=4)
+    for name in ("extended", "points"):
+        assert rel_linf(results["batch"][name], final[name]) < 1e-5, name
