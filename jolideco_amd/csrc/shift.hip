@@ -9,6 +9,8 @@
 
 namespace jd {
 
+constexpr int SHIFT_ROWS = 16;  // rows per block of the backward kernel
+
 struct ShiftGeom {
   int fy, fx;          // integer parts
   float wy0, wy1, wx0, wx1;  // weights of rows fy, fy + 1 / columns fx, fx + 1
@@ -48,10 +50,13 @@ __global__ __launch_bounds__(256) void shift_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ shift_xy, float scale,
                                                         double* __restrict__ partials) {
   __shared__ double smem[256 / 64];
-  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  const int x = blockIdx.x * 256 + threadIdx.x;
   const ShiftGeom g = shift_geom(shift_xy, scale);
   double dsx = 0.0, dsy = 0.0;
-  if (x < W) {
+  // a block owns SHIFT_ROWS rows of its 256 columns: one pair of partial sums per 16 rows (at 4096^2 the one-block
+  // finalize kernel behind this one summed 131 072 partials in 92 us -- 0.7 ms per step of eight calibrated observations)
+  for (int y = blockIdx.y * SHIFT_ROWS; y < min((int)(blockIdx.y + 1) * SHIFT_ROWS, H); ++y) {
+    if (x >= W) break;
     const int py = y - g.fy, px = x - g.fx;
     float v = at(gs, H, W, py, px) * (g.wx0 * g.wy0) + at(gs, H, W, py, px - 1) * (g.wx1 * g.wy0) +
               at(gs, H, W, py - 1, px) * (g.wx0 * g.wy1) + at(gs, H, W, py - 1, px - 1) * (g.wx1 * g.wy1);
@@ -63,8 +68,8 @@ __global__ __launch_bounds__(256) void shift_bwd_kernel(const float* __restrict_
     const float nw = at(in, H, W, y0, x0), ne = at(in, H, W, y0, x0 + 1);
     const float sw = at(in, H, W, y0 + 1, x0), se = at(in, H, W, y0 + 1, x0 + 1);
     const float go = gs[off];
-    dsx = (double)(go * ((ne - nw) * g.wy0 + (se - sw) * g.wy1));
-    dsy = (double)(go * ((sw - nw) * g.wx0 + (se - ne) * g.wx1));
+    dsx += (double)(go * ((ne - nw) * g.wy0 + (se - sw) * g.wy1));
+    dsy += (double)(go * ((sw - nw) * g.wx0 + (se - ne) * g.wx1));
   }
   const double tx = block_sum<256>(dsx, smem);
   __syncthreads();
@@ -99,11 +104,11 @@ int launch_shift_fwd(const float* in, float* out, int H, int W, const float* shi
   return JD_OK;
 }
 
-int shift_bwd_max_blocks(int H, int W) { return ((W + 255) / 256) * H; }
+int shift_bwd_max_blocks(int H, int W) { return ((W + 255) / 256) * ((H + SHIFT_ROWS - 1) / SHIFT_ROWS); }
 
 int launch_shift_bwd(const float* in, const float* gs, float* grad_in, int accumulate, int H, int W,
                      const float* shift_xy, float scale, double* partials, int* n_blocks, hipStream_t stream) {
-  dim3 grid((W + 255) / 256, H);
+  dim3 grid((W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
   *n_blocks = grid.x * grid.y;
   shift_bwd_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
   JD_LAUNCH_CHECK();
