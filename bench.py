@@ -5,16 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json `metric`, configs[2]): 2048x2048 image, 8 synthetic observations with
-varying PSF / exposure / background, one flux component with a GMM patch prior (8x8 patches, stride
-4, K = 128 components), fp32, JOINT fit: one "step" = one optimizer iteration on
+Workload (BASELINE.json `metric`, configs[2], inputs as SURVEY.md section 8(d) specifies them): 2048x2048 image, 8
+synthetic observations with varying PSF (Gaussian, sigma = 1.5 + 0.25 i, on 17x17 arrays and -- sigma >= 3: observations 6
+and 7 -- on 33x33 arrays; `config.psf_shapes`) / exposure / background, one flux component with a GMM patch prior (8x8
+patches, stride 4, K = 128 components), fp32, JOINT fit: one "step" = one optimizer iteration on
 sum_d L_d - beta * logprior = the forward models of all observations (PSF convolution, clip, + background) with
 the fused Poisson NLL + gradient pass, the adjoint convolutions, the GMM prior value + gradient, (N > 1) ONE RCCL
 all-reduce of the likelihood gradient (started before the prior, overlapped with it) and one all-gather of the compact
 prior bands, the fused chain rule + Adam update.  The convolution method is "auto": the
-benchmark's Gaussian PSFs are rank 1, so the headline runs the separable kernel (forward launch = convolution +
-Poisson pass of all local observations); the same fit with the PSFs as general 17x17 kernels (MFMA direct
-convolution, `general_psf`) and through rocFFT (`fft_psf`, the path the north star names) is timed beside it.
+benchmark's Gaussian PSFs are rank 1, so the headline runs the separable strip-walk kernels (the PSFs of both sizes share
+one plan and one batched step: forward launch = convolution + Poisson pass of all local observations); the same fit
+with the PSFs treated as general kernels (MFMA direct convolution, `general_psf`) and through the FFT path (`fft_psf`,
+the path the north star names: the native FFT convolution of csrc/fftnative.hip on these sizes) is timed beside it, and
+so is `c6_chandra_like` (calibrations + up-sampling x2 + general 65x65 PSFs: the reference's Chandra example).
 Total work is fixed as N grows (observations round-robin over the ranks, the prior split by patch
 rows): strong scaling.  All inputs are resident in HBM before the timed region.
 
@@ -28,8 +31,8 @@ steps nor rest on two samples.  `clock_mhz` is the shader clock the device holds
 
 Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the step (the fp16 screen of the
 GMM arg-max: matrix-core roof; `roofline_section8d` prices the whole GMM forward pass by SURVEY section 8(d)'s
-dense fp32 definition), `roofline_poisson` the fused Poisson pass (HBM roof), `roofline_poisson_standalone` the
-stand-alone Poisson kernel as it runs in the rocFFT side run.  `--config c2|c4|c5` run the other BASELINE configurations (parity-test cases; the default c3
+dense fp32 definition), `roofline_poisson` the fused Poisson pass (HBM roof), `roofline_fft` the five launches of one
+observation's likelihood step on the native FFT convolution (the FFT side run).  `--config c2|c4|c5` run the other BASELINE configurations (parity-test cases; the default c3
 is the one the metric is quoted on).  `cpu_baseline` times oracle/cpu_ref.py (the PyTorch-CPU restatement of the
 reference) on a bounded sample on rank 0 at N = 1.
 """
@@ -674,10 +677,13 @@ def main():
             side = region_stats(timed_regions(other, args.steps, side_repeats, device, dist_ctx), args.steps)
             prof_other = profile_phase(other, device, n_obs)
             used = sorted({m.plan.method for m in other.total_loss.poisson_loss.npred_models_all})
+            plan_info = [(m.plan.kh, m.plan.kw, bool(m.plan.native_fft))
+                         for mm in other.total_loss.poisson_loss.npred_models_all for m in mm.values()]
             result = {
                 "value": side["value"], "unit": "iters/s", "ms_per_step": side["ms_per_step"],
                 "conv_method": "+".join(used), "note": note,
                 "kernel_ms_per_step": {k: v[0] / n_profiled for k, v in prof_other.items() if v[1] and k not in nested},
+                "plans": plan_info,
             }
             del other
             return result, prof_other
@@ -692,23 +698,46 @@ def main():
             "direct", "same workload with the PSFs convolved as general 17x17 / 33x33 kernels (MFMA Toeplitz convolution, "
                       "fp16 x 3 split operands; Poisson pass in the forward launch's epilogue)")
         out["fft_psf"], prof_fft = conv_method_run(
-            "fft", "same workload through rocFFT: pad+scale, R2C, k-space multiply, C2R, stand-alone Poisson pass, "
-                   "R2C, conj multiply, C2R, adjoint epilogue per observation")
-        # the rocFFT run is the one that executes the STAND-ALONE fused Poisson kernel (conv, background, counts in; g out
-        # = 16 B/pixel at one component): the kernel BASELINE.json's "HBM GB/s on fused Poisson pass" was defined on
-        total_p, count_p = prof_fft.get("poisson_fused", (0.0, 0))
-        if count_p and out["fft_psf"]["conv_method"] == "fft":
-            ms = total_p / count_p
-            px_bytes = 8 * n_comp + 8
-            achieved = px_bytes * H * W / (ms * 1e-3) / 1e9
-            out["roofline_poisson_standalone"] = {
-                "kernel": "poisson_fused_kernel (stand-alone pass of the rocFFT side run)", "bound": "hbm",
-                "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic_bytes(args.config, "poisson_fused_kernel<4, 1"),
-                "traffic_source": pmc_traffic_source("poisson_fused_kernel<4, 1"),
-                "avg_launch_ms": ms, "launches": count_p, "bytes_per_launch": px_bytes * H * W,
-                "note": "hipEvent pairs add ~2 us to this ~13 us kernel; rocprofv3: profiles/README.md",
+            "fft", "same workload through the FFT path (native FFT convolution, csrc/fftnative.hip): per observation rows, "
+                   "columns (FFT x kernel spectrum x inverse FFT), rows^-1 + Poisson pass + rows of g, columns, rows^-1 + "
+                   "adjoint epilogue; the timers fft_r2c / cmul / fft_c2r carry the rows / columns / rows^-1 launches")
+        # The native FFT convolution against the HBM roof: algorithmic bytes of the FIVE launches of one observation's
+        # likelihood step (rows: flux + exposure in, row spectra out; columns: spectra + kernel spectrum in, spectra out,
+        # twice; rows^-1 + Poisson + rows of g: spectra + background + counts in, spectra out; rows^-1 + adjoint epilogue:
+        # spectra + exposure + gradient in, gradient out) over their summed duration.
+        plan_list = out["fft_psf"].pop("plans")
+        out["general_psf"].pop("plans", None)
+        plans = sorted(set(plan_list))
+        out["fft_psf"]["native_fft"] = all(p[2] for p in plans)
+
+        def fft_length(n, with_three=True):
+            best = None
+            for odd in (1, 3, 9) if with_three else (1, 9):
+                m = 8
+                while m * odd < max(n, 32):
+                    m *= 2
+                best = m * odd if best is None or m * odd < best else best
+            return best
+
+        if out["fft_psf"]["native_fft"] and n_comp == 1:
+            per_obs_bytes = 0.0
+            for kh, kw, _ in plans:
+                n_with = sum(1 for q in plan_list if q[:2] == (kh, kw))
+                nx, ny, hh = fft_length(W + max((kw - 1) // 2, kw - 1 - (kw - 1) // 2)), fft_length(H // 2 + kh - 1, False), H // 2
+                spec, kept, khat_b, img = hh * nx * 8, (hh + kh - 1) * nx * 8, nx * ny * 8, 4 * H * W
+                per_obs = (2 * img + spec) + 2 * (spec + khat_b + kept) + (kept + 2 * img + spec) + (kept + 2 * img + img)
+                per_obs_bytes += per_obs * n_with
+            per_obs_bytes /= max(len(plan_list), 1)
+            k = out["fft_psf"]["kernel_ms_per_step"]
+            ms_obs = sum(k.get(name, 0.0) for name in ("fft_r2c", "cmul", "poisson_fused", "fft_c2r")) / max(len(plan_list), 1)
+            achieved = per_obs_bytes / (ms_obs * 1e-3) / 1e9
+            out["roofline_fft"] = {
+                "kernel": "native FFT convolution: fftn_rows_fwd + 2 x fftn_cols + fftn_rows_poisson + fftn_rows_inv<adjoint> "
+                          "(one observation's likelihood step)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "ms_per_observation": ms_obs,
+                "bytes_per_observation": per_obs_bytes,
+                "launch_ms_per_step": {name: k.get(name) for name in ("fft_r2c", "cmul", "poisson_fused", "fft_c2r")},
+                "note": "PMC traffic of these kernels: profiles/r04/pmc_hbm_traffic.csv rows c3fft",
             }
     # The same fit with the GMM arg-max evaluated by the dense fp32 MFMA kernel for every (patch, component) pair
     # (JD_GMM_SCREEN=0; bit-identical results): reported next to the headline for whoever wants the number without the
