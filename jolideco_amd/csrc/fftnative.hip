@@ -68,26 +68,35 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, int N, const Ff
   return a;
 }
 
-// The same transform IN PLACE by ONE WAVE (the column kernel: one buffer per column instead of two, twice the columns
-// in flight per CU): in every pass a lane first reads the inputs of all its butterflies (at most MAXB of them) into
-// registers, then writes their outputs.  LDS operations of one wave execute in program order, so all reads of a pass
-// are done before its first write lands; the fence only keeps the compiler from reordering them.
-template <int R, int DIR, int MAXB>
-__device__ __forceinline__ void wave_pass_inplace(float2* x, int N, int p, const float2* tw, int lane) {
+// The same transform IN PLACE by the LANES threads of one column (the column kernel: one buffer per column instead of
+// two, twice the columns in flight per CU): in every pass a thread first reads the inputs of all its butterflies (at
+// most MAXB of them) into registers, then writes their outputs.  LANES = 64: one wave per column -- LDS operations of one
+// wave execute in program order, so all reads of a pass are done before its first write lands, and the fence only keeps
+// the compiler from reordering them.  LANES = 128: two waves per column (the long columns of 4096-row images: half the
+// butterflies per thread, no register spills), block barriers between the phases -- every column of the block runs the
+// same pass schedule.
+template <int LANES>
+__device__ __forceinline__ void column_sync() {
+  if constexpr (LANES == 64) lds_wave_fence();
+  else __syncthreads();
+}
+
+template <int R, int DIR, int MAXB, int LANES>
+__device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, const float2* tw, int lane) {
   const int nb = N / R;
   float2 u[MAXB][R];
 #pragma unroll
   for (int q = 0; q < MAXB; ++q) {
-    const int b = lane + 64 * q;
+    const int b = lane + LANES * q;
     if (b < nb) {
 #pragma unroll
       for (int t = 0; t < R; ++t) u[q][t] = x[lp(b + t * nb)];
     }
   }
-  lds_wave_fence();
+  column_sync<LANES>();
 #pragma unroll
   for (int q = 0; q < MAXB; ++q) {
-    const int b = lane + 64 * q;
+    const int b = lane + LANES * q;
     if (b < nb) {
       const int k = b & (p - 1);
       if (p > 1) {
@@ -105,40 +114,34 @@ __device__ __forceinline__ void wave_pass_inplace(float2* x, int N, int p, const
       for (int t = 0; t < R; ++t) x[lp(j + t * p)] = u[q][t];
     }
   }
-  lds_wave_fence();
+  column_sync<LANES>();
 }
 
-// butterflies per lane (N / R / 64 rounded up) the instantiations below hold: column lengths 2^a * {1, 9} up to 2304
-// (16: 144 butterflies -> 3; 8: 256 at N = 2048 -> 4; 9: 256 at N = 2304 -> 4; 4: only N = 32, 288 -> 2)
-__host__ __device__ inline bool wave_fft_fits(int N, const FftPasses& f) {
-  for (int s = 0; s < f.n; ++s) {
-    const int R = f.r[s], per_lane = (N / R + 63) / 64;
-    if ((R == 16 && per_lane > 3) || (R == 8 && per_lane > 4) || (R == 9 && per_lane > 4) || (R == 4 && per_lane > 2) || R == 2 || R == 3)
-      return false;
+// butterflies per thread (N / R / LANES rounded up) the instantiations hold: 2 / 3 / 2 / 2 at radix 16 / 8 / 9 / 4 --
+// one wave per column up to N = 1152 (16: 72 butterflies, 8: 144, 9: 128) and N = 1024, two waves up to 2304 (144 / 256 /
+// 256) and 2048; 0: the length is not a column length (radix 2 or 3 passes, or too long)
+__host__ __device__ inline int column_lanes(int N, const FftPasses& f) {
+  for (int lanes = 64; lanes <= 128; lanes *= 2) {
+    bool ok = true;
+    for (int s = 0; s < f.n; ++s) {
+      const int R = f.r[s], per = (N / R + lanes - 1) / lanes;
+      ok = ok && ((R == 16 && per <= 2) || (R == 8 && per <= 3) || (R == 9 && per <= 2) || (R == 4 && per <= 2));
+    }
+    if (ok) return lanes;
   }
-  return true;
+  return 0;
 }
 
-// BIG = false: at most 2 / 3 / 2 butterflies per lane at radix 16 / 8 / 9 (column lengths up to 1152 -- a 2048-row image),
-// fewer registers and twice the waves per SIMD; BIG = true: 3 / 4 / 4 (up to 2304)
-__host__ __device__ inline bool wave_fft_is_big(int N, const FftPasses& f) {
-  for (int s = 0; s < f.n; ++s) {
-    const int R = f.r[s], per_lane = (N / R + 63) / 64;
-    if ((R == 16 && per_lane > 2) || (R == 8 && per_lane > 3) || (R == 9 && per_lane > 2)) return true;
-  }
-  return false;
-}
-
-template <int DIR, bool BIG>
-__device__ __forceinline__ void wave_fft_inplace(float2* x, int N, const FftPasses& f, const float2* tw, int lane) {
+template <int DIR, int LANES>
+__device__ __forceinline__ void column_fft_inplace(float2* x, int N, const FftPasses& f, const float2* tw, int lane) {
   int p = 1;
   for (int s = 0; s < f.n; ++s) {
     const int R = f.r[s];
     switch (R) {
-      case 16: wave_pass_inplace<16, DIR, BIG ? 3 : 2>(x, N, p, tw, lane); break;
-      case 8: wave_pass_inplace<8, DIR, BIG ? 4 : 3>(x, N, p, tw, lane); break;
-      case 9: wave_pass_inplace<9, DIR, BIG ? 4 : 2>(x, N, p, tw, lane); break;
-      default: wave_pass_inplace<4, DIR, 2>(x, N, p, tw, lane); break;
+      case 16: column_pass_inplace<16, DIR, 2, LANES>(x, N, p, tw, lane); break;
+      case 8: column_pass_inplace<8, DIR, 3, LANES>(x, N, p, tw, lane); break;
+      case 9: column_pass_inplace<9, DIR, 2, LANES>(x, N, p, tw, lane); break;
+      default: column_pass_inplace<4, DIR, 2, LANES>(x, N, p, tw, lane); break;
     }
     p *= R;
   }
@@ -194,11 +197,12 @@ struct ColsArgs {
   FftPasses f;
 };
 
-// columns: one wave per column, CB = blockDim / 64 columns per block, transforms in place (one padded sequence per column)
-template <bool BIG>
-__global__ __launch_bounds__(512, BIG ? 2 : 3) void fftn_cols_kernel(ColsArgs a) {
+// columns: LANES threads per column (one wave, or two for the long columns), CB = blockDim / LANES columns per block,
+// transforms in place (one padded sequence per column)
+template <int LANES>
+__global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   extern __shared__ float2 lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, CB = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid % LANES, wc = tid / LANES, CB = blockDim.x / LANES;
   // neighbouring column groups (the same 128-byte lines of every spectrum row) go to the same XCD (blockIdx % 8), one
   // after the other: the partial lines they read and write meet in that XCD's L2
   const int per_xcd = (a.groups + 7) / 8;
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(512, BIG ? 2 : 3) void fftn_cols_kernel(ColsArgs a)
   if (g >= a.groups) return;
   const int x0 = g * CB;
   const int stride = lp_size(a.Ny);
-  float2* col = lds + (size_t)wv * stride;
+  float2* col = lds + (size_t)wc * stride;
   // ---- load: row-major pieces of CB columns, two columns (16 bytes) per thread ---------------------------------------
   const int half = CB / 2;  // float4 pieces per row
   for (int i = tid; i < a.Ny * half; i += blockDim.x) {
@@ -218,17 +222,17 @@ __global__ __launch_bounds__(512, BIG ? 2 : 3) void fftn_cols_kernel(ColsArgs a)
     c0[stride + lp(row)] = float2{v.z, v.w};
   }
   __syncthreads();
-  // ---- per wave: FFT, product with the kernel spectrum, inverse FFT --------------------------------------------------
-  if (!(a.debug & 1)) wave_fft_inplace<-1, BIG>(col, a.Ny, a.f, a.tw, lane);
-  const float2* kcol = a.khat + (size_t)(x0 + wv) * a.Ny;
+  // ---- per column: FFT, product with the kernel spectrum, inverse FFT ------------------------------------------------
+  if (!(a.debug & 1)) column_fft_inplace<-1, LANES>(col, a.Ny, a.f, a.tw, lane);
+  const float2* kcol = a.khat + (size_t)(x0 + wc) * a.Ny;
   if (!(a.debug & 2))
-    for (int v = lane; v < a.Ny; v += 64) {
+    for (int v = lane; v < a.Ny; v += LANES) {
       float2 k = kcol[v];
       if (a.conj) k.y = -k.y;
       col[lp(v)] = cmul(col[lp(v)], k);
     }
-  lds_wave_fence();
-  if (!(a.debug & 1)) wave_fft_inplace<1, BIG>(col, a.Ny, a.f, a.tw, lane);
+  column_sync<LANES>();
+  if (!(a.debug & 1)) column_fft_inplace<1, LANES>(col, a.Ny, a.f, a.tw, lane);
   __syncthreads();
   // ---- store: rows [0, keep_lo) and [keep_hi, Ny), row-major pieces --------------------------------------------------
   for (int i = tid; i < a.Ny * half; i += blockDim.x) {
@@ -469,7 +473,7 @@ bool fftn_supported(int H, int W, int kh, int kw) {
   const int nx = next_length(W + std::max(ox, kw - 1 - ox)), ny = next_length(H / 2 + kh - 1, false);
   // LDS: two padded sequences per row block, one per wave of a column block
   if (!(nx > 0 && ny > 0 && nx <= 4608 && ny <= 2304 && ny >= 2 * kh)) return false;
-  return factorize(nx).n > 0 && wave_fft_fits(ny, passes_of(ny));
+  return factorize(nx).n > 0 && column_lanes(ny, passes_of(ny)) != 0;
 }
 
 int fftn_create(FftNative* n, int H, int W, int kh, int kw) {
@@ -531,21 +535,23 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   a.spec = n.spec, a.work = n.work, a.khat = khat, a.tw = n.tw_y, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.conj = adjoint ? 1 : 0;
   a.keep_lo = n.Hh + rb, a.keep_hi = n.Ny - ra, a.f = fy;
   a.debug = opt_value(OPT_FFT_DEBUG, 0);
-  const size_t per_wave = (size_t)lp_size(n.Ny) * sizeof(float2);
-  // columns per block: 4 (32 contiguous bytes of every spectrum row; three blocks per CU), 2 for the long columns
-  // (measured at 2048^2, Ny = 1152: 8 columns per block 45 us -- one block per CU --, 4: 33 us, 2: 35 us)
-  int cb = 4 * per_wave <= 80 * 1024 ? 4 : 2;
+  const size_t per_col = (size_t)lp_size(n.Ny) * sizeof(float2);
+  const int lanes = column_lanes(n.Ny, fy);
+  if (!lanes) return fail(JD_ERR_INVALID, "native FFT: no column kernel for length %d", n.Ny);
+  // columns per block: 4 one-wave columns (32 contiguous bytes of every spectrum row; three blocks per CU), 2 two-wave
+  // columns for the long ones.  Measured at 2048^2, Ny = 1152: 8 columns per block 45 us -- one block per CU --, 4: 33 us,
+  // 2: 35 us
+  int cb = lanes == 64 ? 4 : 2;
   const int ocb = opt_value(OPT_FFT_NATIVE, 1);  // (tuning: JD_FFT_NATIVE = 2 / 4 / 8 forces the columns per block)
-  if ((ocb == 2 || ocb == 4 || ocb == 8) && (size_t)ocb * per_wave <= 160 * 1024 && n.Nx % ocb == 0) cb = ocb;
+  if ((ocb == 2 || ocb == 4 || ocb == 8) && (size_t)ocb * per_col <= 160 * 1024 && n.Nx % ocb == 0 && ocb * lanes <= 512) cb = ocb;
   a.groups = n.Nx / cb;
   static size_t lds_cols_set[2] = {0, 0};
-  const bool big = wave_fft_is_big(n.Ny, fy);
-  const void* kernel = big ? reinterpret_cast<const void*>(fftn_cols_kernel<true>) : reinterpret_cast<const void*>(fftn_cols_kernel<false>);
-  int rc = lds_attr(kernel, cb * per_wave, &lds_cols_set[big ? 1 : 0]);
+  const void* kernel = lanes == 64 ? reinterpret_cast<const void*>(fftn_cols_kernel<64>) : reinterpret_cast<const void*>(fftn_cols_kernel<128>);
+  int rc = lds_attr(kernel, cb * per_col, &lds_cols_set[lanes == 64 ? 0 : 1]);
   if (rc) return rc;
   ProfScope prof(JD_KERNEL_CMUL, stream);
-  if (big) hipLaunchKernelGGL(fftn_cols_kernel<true>, dim3(((a.groups + 7) / 8) * 8), dim3(64 * cb), cb * per_wave, stream, a);
-  else hipLaunchKernelGGL(fftn_cols_kernel<false>, dim3(((a.groups + 7) / 8) * 8), dim3(64 * cb), cb * per_wave, stream, a);
+  if (lanes == 64) hipLaunchKernelGGL(fftn_cols_kernel<64>, dim3(((a.groups + 7) / 8) * 8), dim3(lanes * cb), cb * per_col, stream, a);
+  else hipLaunchKernelGGL(fftn_cols_kernel<128>, dim3(((a.groups + 7) / 8) * 8), dim3(lanes * cb), cb * per_col, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 CASES = [((64, 128), (5, 7)), ((200, 328), (17, 17)), ((130, 516), (33, 17)), ((256, 256), (65, 65)), ((96, 132), (32, 33)),
-         ((512, 1024), (129, 129)), ((72, 2048), (9, 9)), ((1024, 64), (3, 41))]
+         ((512, 1024), (129, 129)), ((72, 2048), (9, 9)), ((1024, 64), (3, 41)),
+         ((2600, 64), (9, 9)), ((4096, 128), (17, 17))]  # (the last two: column lengths 2048 and 2304 -- two waves per column)
 
 
 def _psf(kshape, seed):

@@ -29,7 +29,15 @@ for case in range(n_cases):
         n_obs = int(rs.randint(2, 17))
     names = ["a", "b", "c"][:n_comp]
 
+    # round 4: every third case gives each PSF its OWN array size (rank 1 only: that is what shares one plan by embedding,
+    # models/npred.py::common_kernel_shape) -- operators of both strip-walk frames, and trimmed windows, in one batch
+    mixed_sizes = case % 3 == 1
+
     def psf():
+        if mixed_sizes:
+            shape = (int(rs.randint(3, 34)), int(rs.randint(3, 34)))
+            k = gaussian_kernel(rs.uniform(0.8, 4.0), shape)
+            return (k / k.sum()).astype(np.float32)
         k = gaussian_kernel(rs.uniform(0.8, 3.0), (kh, kw))
         if rs.rand() < 0.4:
             k = 0.7 * k + 0.3 * gaussian_kernel(rs.uniform(3.0, 5.0), (kh, kw))
@@ -71,7 +79,7 @@ for case in range(n_cases):
         continue
     if not all(np.array_equal(results["batch"][n], results["loop"][n]) for n in names):
         bad += 1
-        print(f"MISMATCH case {case}: H={H} W={W} psf={kh}x{kw} n_obs={n_obs} n_comp={n_comp}")
+        print(f"MISMATCH case {case}: H={H} W={W} psf={kh}x{kw} n_obs={n_obs} n_comp={n_comp} mixed_sizes={mixed_sizes}")
 os.environ.pop("JOLIDECO_NO_BATCH", None)
 print(f"{n_cases} cases, {skipped} without a batched path, {bad} mismatches")
 sys.exit(1 if bad else 0)
