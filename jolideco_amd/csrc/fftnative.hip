@@ -40,6 +40,23 @@ __device__ __forceinline__ void lds_wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef JD_FFT_LOOP_OUTSIDE
+#define JD_FFT_LOOP_OUTSIDE 0  // 1: one butterfly loop per radix (switch outside): more registers, fewer instructions
+#endif
+#ifndef JD_FFT_LIN
+#define JD_FFT_LIN 0           // 1: linear padded indices where a pass allows them (jd_fftcore.h)
+#endif
+
+// one pass of radix R by `nthreads` threads: butterflies tid, tid + nthreads, ...
+template <int R, int DIR>
+__device__ __forceinline__ void pass_loop(const float2* x, float2* y, int N, int p, const float2* tw, int tid, int nthreads) {
+  if (JD_FFT_LIN && pass_is_linear(N, R, p)) {  // (uniform)
+    for (int i = tid; i < N / R; i += nthreads) pass_one<R, DIR, true>(x, y, N, p, tw, i);
+  } else {
+    for (int i = tid; i < N / R; i += nthreads) pass_one<R, DIR, false>(x, y, N, p, tw, i);
+  }
+}
+
 template <int DIR>
 __device__ __forceinline__ void pass_dispatch(int R, const float2* x, float2* y, int N, int p, const float2* tw, int b) {
   switch (R) {
@@ -57,8 +74,19 @@ template <int DIR, bool BLOCK_SYNC>
 __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, int N, const FftPasses& f, const float2* tw, int tid, int nthreads) {
   int p = 1;
   for (int s = 0; s < f.n; ++s) {
-    const int R = f.r[s], nb = N / R;
-    for (int i = tid; i < nb; i += nthreads) pass_dispatch<DIR>(R, a, b, N, p, tw, i);
+    const int R = f.r[s];
+#if JD_FFT_LOOP_OUTSIDE
+    switch (R) {  // (the loop over the butterflies INSIDE each case: one simple loop per radix)
+      case 16: pass_loop<16, DIR>(a, b, N, p, tw, tid, nthreads); break;
+      case 8: pass_loop<8, DIR>(a, b, N, p, tw, tid, nthreads); break;
+      case 4: pass_loop<4, DIR>(a, b, N, p, tw, tid, nthreads); break;
+      case 2: pass_loop<2, DIR>(a, b, N, p, tw, tid, nthreads); break;
+      case 9: pass_loop<9, DIR>(a, b, N, p, tw, tid, nthreads); break;
+      default: pass_loop<3, DIR>(a, b, N, p, tw, tid, nthreads); break;
+    }
+#else
+    for (int i = tid; i < N / R; i += nthreads) pass_dispatch<DIR>(R, a, b, N, p, tw, i);
+#endif
     if (BLOCK_SYNC) __syncthreads();
     else lds_wave_fence();
     p *= R;

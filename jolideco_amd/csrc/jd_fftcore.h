@@ -125,13 +125,26 @@ struct Dft<9, DIR> {
 // p (a power of two; the product of the radices of the passes before).  `tw`: exp(-2 pi i m / N), m < N.
 // Butterfly b of N / R: inputs x[b + t N / R], twiddles w^(t k) with k = b mod p, w = exp(DIR 2 pi i / (p R)), outputs
 // y[(b - k) R + k + t p].
-template <int R, int DIR>
+// LIN: the padded index is LINEAR in t on both sides -- inputs when N / R is a multiple of 16 (lp(b + t nb) = lp(b) +
+// t (nb + nb / 16)), outputs when p = 1 (the R <= 16 outputs of a butterfly share one group of 16) or p is a multiple
+// of 16 -- one base address each plus compile-time multiples of a uniform step instead of an add, a shift and an add per
+// element.
+JD_FFT_HD bool pass_is_linear(int N, int R, int p) { return ((N / R) & 15) == 0 && (p == 1 || (p & 15) == 0); }
+
+template <int R, int DIR, bool LIN = false>
 JD_FFT_HD void pass_one(const float2* x, float2* y, int N, int p, const float2* tw, int b) {
   const int nb = N / R;
   const int k = b & (p - 1);
   float2 u[R];
+  if (LIN) {
+    const float2* xb = x + lp(b);
+    const int step = nb + (nb >> 4);
 #pragma unroll
-  for (int t = 0; t < R; ++t) u[t] = x[lp(b + t * nb)];
+    for (int t = 0; t < R; ++t) u[t] = xb[t * step];
+  } else {
+#pragma unroll
+    for (int t = 0; t < R; ++t) u[t] = x[lp(b + t * nb)];
+  }
   if (p > 1) {
     // w^t built from one table entry by a product tree (depth <= 4: a few ulp), not by R - 1 dependent products
     float2 w[R];
@@ -144,8 +157,15 @@ JD_FFT_HD void pass_one(const float2* x, float2* y, int N, int p, const float2* 
   }
   Dft<R, DIR>::run(u);
   const int j = (b - k) * R + k;
+  if (LIN) {
+    float2* yb = y + lp(j);
+    const int step = p == 1 ? 1 : p + (p >> 4);
 #pragma unroll
-  for (int t = 0; t < R; ++t) y[lp(j + t * p)] = u[t];
+    for (int t = 0; t < R; ++t) yb[t * step] = u[t];
+  } else {
+#pragma unroll
+    for (int t = 0; t < R; ++t) y[lp(j + t * p)] = u[t];
+  }
 }
 
 struct Radices {
