@@ -109,9 +109,19 @@ __device__ __forceinline__ void column_sync() {
   else __syncthreads();
 }
 
-template <int R, int DIR, int MAXB, int LANES>
+// k = b mod p for b < 2^23 and any p >= 1 (the sub-transform lengths of the inverse column transform are not powers of
+// two: its radices run in reverse order, the odd one first)
+__device__ __forceinline__ int mod_small(int b, int p, float inv_p) {
+  int q = (int)(((float)b + 0.5f) * inv_p);
+  int k = b - q * p;
+  k += k < 0 ? p : 0;
+  return k >= p ? k - p : k;
+}
+
+template <int R, int DIR, int MAXB, int LANES, bool POW2>
 __device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, const float2* tw, int lane) {
   const int nb = N / R;
+  const float inv_p = 1.f / (float)p;
   float2 u[MAXB][R];
 #pragma unroll
   for (int q = 0; q < MAXB; ++q) {
@@ -126,7 +136,7 @@ __device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, con
   for (int q = 0; q < MAXB; ++q) {
     const int b = lane + LANES * q;
     if (b < nb) {
-      const int k = b & (p - 1);
+      const int k = POW2 ? (b & (p - 1)) : mod_small(b, p, inv_p);
       if (p > 1) {
         float2 w[R];
         w[1] = tw[k * (nb / p)];
@@ -145,10 +155,59 @@ __device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, con
   column_sync<LANES>();
 }
 
+// The middle of the column pass in registers: the LAST pass of the forward transform (radix R, sub-transform length
+// p = N / R: butterfly b reads x[b + t p] and produces the spectrum elements b + t p), the product with the kernel
+// spectrum, and the FIRST pass of the inverse transform, whose radices run in reverse order -- its first pass (radix R,
+// sub-transform length 1) reads exactly the elements b + t p the thread holds.  Two LDS exchanges and the separate pass
+// over the column for the product are gone.
+template <int R, int MAXB, int LANES>
+__device__ __forceinline__ void column_mid_inplace(float2* x, int N, const float2* tw, const float2* kcol, int conj, int lane) {
+  const int nb = N / R;  // = p of the forward pass
+  float2 u[MAXB][R];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int b = lane + LANES * q;
+    if (b < nb) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) u[q][t] = x[lp(b + t * nb)];
+    }
+  }
+  column_sync<LANES>();
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    const int b = lane + LANES * q;
+    if (b < nb) {
+      float2 kh[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) kh[t] = kcol[b + t * nb];
+      {
+        float2 w[R];
+        w[1] = tw[b];  // k = b, nb / p = 1
+#pragma unroll
+        for (int t = 2; t < R; ++t) w[t] = cmul(w[t / 2], w[t - t / 2]);
+#pragma unroll
+        for (int t = 1; t < R; ++t) u[q][t] = cmul(u[q][t], w[t]);
+      }
+      Dft<R, -1>::run(u[q]);
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        float2 k = kh[t];
+        if (conj) k.y = -k.y;
+        u[q][t] = cmul(u[q][t], k);
+      }
+      Dft<R, 1>::run(u[q]);
+#pragma unroll
+      for (int t = 0; t < R; ++t) x[lp(b * R + t)] = u[q][t];
+    }
+  }
+  column_sync<LANES>();
+}
+
 // butterflies per thread (N / R / LANES rounded up) the instantiations hold: 2 / 3 / 2 / 2 at radix 16 / 8 / 9 / 4 --
 // one wave per column up to N = 1152 (16: 72 butterflies, 8: 144, 9: 128) and N = 1024, two waves up to 2304 (144 / 256 /
-// 256) and 2048; 0: the length is not a column length (radix 2 or 3 passes, or too long)
+// 256) and 2048; 0: the length is not a column length (radix 2 or 3 passes, a single pass, or too long)
 __host__ __device__ inline int column_lanes(int N, const FftPasses& f) {
+  if (f.n < 2) return 0;
   for (int lanes = 64; lanes <= 128; lanes *= 2) {
     bool ok = true;
     for (int s = 0; s < f.n; ++s) {
@@ -160,18 +219,39 @@ __host__ __device__ inline int column_lanes(int N, const FftPasses& f) {
   return 0;
 }
 
-template <int DIR, int LANES>
-__device__ __forceinline__ void column_fft_inplace(float2* x, int N, const FftPasses& f, const float2* tw, int lane) {
+template <int DIR, int LANES, bool POW2>
+__device__ __forceinline__ void column_pass_any(int R, float2* x, int N, int p, const float2* tw, int lane) {
+  switch (R) {
+    case 16: column_pass_inplace<16, DIR, 2, LANES, POW2>(x, N, p, tw, lane); break;
+    case 8: column_pass_inplace<8, DIR, 3, LANES, POW2>(x, N, p, tw, lane); break;
+    case 9: column_pass_inplace<9, DIR, 2, LANES, POW2>(x, N, p, tw, lane); break;
+    default: column_pass_inplace<4, DIR, 2, LANES, POW2>(x, N, p, tw, lane); break;
+  }
+}
+
+// circular convolution of one column with the kernel whose spectrum is kcol: forward passes 0 .. n - 2, the fused middle
+// (pass n - 1, product, first inverse pass), inverse passes n - 2 .. 0 (radices in reverse order; unnormalised, the
+// normalisation is folded into the kernel spectrum)
+template <int LANES>
+__device__ __forceinline__ void column_conv_inplace(float2* x, int N, const FftPasses& f, const float2* tw, const float2* kcol,
+                                                    int conj, int lane) {
   int p = 1;
-  for (int s = 0; s < f.n; ++s) {
-    const int R = f.r[s];
-    switch (R) {
-      case 16: column_pass_inplace<16, DIR, 2, LANES>(x, N, p, tw, lane); break;
-      case 8: column_pass_inplace<8, DIR, 3, LANES>(x, N, p, tw, lane); break;
-      case 9: column_pass_inplace<9, DIR, 2, LANES>(x, N, p, tw, lane); break;
-      default: column_pass_inplace<4, DIR, 2, LANES>(x, N, p, tw, lane); break;
-    }
-    p *= R;
+  for (int s = 0; s + 1 < f.n; ++s) {
+    column_pass_any<-1, LANES, true>(f.r[s], x, N, p, tw, lane);
+    p *= f.r[s];
+  }
+  const int Rm = f.r[f.n - 1];
+  switch (Rm) {
+    case 16: column_mid_inplace<16, 2, LANES>(x, N, tw, kcol, conj, lane); break;
+    case 8: column_mid_inplace<8, 3, LANES>(x, N, tw, kcol, conj, lane); break;
+    case 9: column_mid_inplace<9, 2, LANES>(x, N, tw, kcol, conj, lane); break;
+    default: column_mid_inplace<4, 2, LANES>(x, N, tw, kcol, conj, lane); break;
+  }
+  p = Rm;
+  for (int s = f.n - 2; s >= 0; --s) {
+    if (Rm == 9) column_pass_any<1, LANES, false>(f.r[s], x, N, p, tw, lane);
+    else column_pass_any<1, LANES, true>(f.r[s], x, N, p, tw, lane);
+    p *= f.r[s];
   }
 }
 
@@ -220,28 +300,44 @@ struct ColsArgs {
   const float2* khat;  // [Nx][Ny] (column-major), normalisation folded in
   const float2* tw;
   int Hh, Nx, Ny, conj, groups;
-  int debug;  // (timing experiments only, option JD_FFT_DEBUG: bit 0 skips the transforms, bit 1 the kernel spectrum)
   int keep_lo, keep_hi;  // rows [0, keep_lo) and [keep_hi, Ny) of the result are written (the others are never read)
   FftPasses f;
 };
 
-// columns: LANES threads per column (one wave, or two for the long columns), CB = blockDim / LANES columns per block,
-// transforms in place (one padded sequence per column)
-template <int LANES>
+// columns: LANES threads per column (one wave, or two for the long columns), CB columns per block, transforms in place
+// (one padded sequence per column).  R0 > 0: the radix schedule (R0, R1, R2), the length Ny = R0 R1 R2 and CB are compile
+// time constants -- index arithmetic folds, and the kernel holds the five passes it runs instead of every radix in both
+// directions (the generic form is 13 000 instructions, more than the instruction cache); R0 = 0: the generic form.
+constexpr int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+template <int LANES, int R0, int R1, int R2>
+__device__ __forceinline__ void column_conv_static(float2* x, const float2* tw, const float2* kcol, int conj, int lane) {
+  constexpr int N = R0 * R1 * R2;
+  constexpr bool POW2 = (R2 & (R2 - 1)) == 0;
+  column_pass_inplace<R0, -1, ceil_div(N / R0, LANES), LANES, true>(x, N, 1, tw, lane);
+  column_pass_inplace<R1, -1, ceil_div(N / R1, LANES), LANES, true>(x, N, R0, tw, lane);
+  column_mid_inplace<R2, ceil_div(N / R2, LANES), LANES>(x, N, tw, kcol, conj, lane);
+  column_pass_inplace<R1, 1, ceil_div(N / R1, LANES), LANES, POW2>(x, N, R2, tw, lane);
+  column_pass_inplace<R0, 1, ceil_div(N / R0, LANES), LANES, POW2>(x, N, R2 * R1, tw, lane);
+}
+
+template <int LANES, int CBS, int R0, int R1, int R2>
 __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   extern __shared__ float2 lds[];
-  const int tid = threadIdx.x, lane = tid % LANES, wc = tid / LANES, CB = blockDim.x / LANES;
+  constexpr bool STATIC = R0 > 0;
+  const int tid = threadIdx.x, lane = tid % LANES, wc = tid / LANES, CB = STATIC ? CBS : (int)blockDim.x / LANES;
+  const int Ny = STATIC ? R0 * R1 * R2 : a.Ny;
   // neighbouring column groups (the same 128-byte lines of every spectrum row) go to the same XCD (blockIdx % 8), one
   // after the other: the partial lines they read and write meet in that XCD's L2
   const int per_xcd = (a.groups + 7) / 8;
   const int g = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (g >= a.groups) return;
   const int x0 = g * CB;
-  const int stride = lp_size(a.Ny);
+  const int stride = lp_size(Ny);
   float2* col = lds + (size_t)wc * stride;
   // ---- load: row-major pieces of CB columns, two columns (16 bytes) per thread ---------------------------------------
   const int half = CB / 2;  // float4 pieces per row
-  for (int i = tid; i < a.Ny * half; i += blockDim.x) {
+  for (int i = tid; i < Ny * half; i += LANES * CB) {
     const int row = i / half, piece = i - row * half;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < a.Hh) v = *reinterpret_cast<const float4*>(a.spec + (size_t)row * a.Nx + x0 + 2 * piece);
@@ -251,19 +347,12 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   }
   __syncthreads();
   // ---- per column: FFT, product with the kernel spectrum, inverse FFT ------------------------------------------------
-  if (!(a.debug & 1)) column_fft_inplace<-1, LANES>(col, a.Ny, a.f, a.tw, lane);
-  const float2* kcol = a.khat + (size_t)(x0 + wc) * a.Ny;
-  if (!(a.debug & 2))
-    for (int v = lane; v < a.Ny; v += LANES) {
-      float2 k = kcol[v];
-      if (a.conj) k.y = -k.y;
-      col[lp(v)] = cmul(col[lp(v)], k);
-    }
-  column_sync<LANES>();
-  if (!(a.debug & 1)) column_fft_inplace<1, LANES>(col, a.Ny, a.f, a.tw, lane);
+  const float2* kcol = a.khat + (size_t)(x0 + wc) * Ny;
+  if constexpr (STATIC) column_conv_static<LANES, R0, R1, R2>(col, a.tw, kcol, a.conj, lane);
+  else column_conv_inplace<LANES>(col, Ny, a.f, a.tw, kcol, a.conj, lane);
   __syncthreads();
   // ---- store: rows [0, keep_lo) and [keep_hi, Ny), row-major pieces --------------------------------------------------
-  for (int i = tid; i < a.Ny * half; i += blockDim.x) {
+  for (int i = tid; i < Ny * half; i += LANES * CB) {
     const int row = i / half, piece = i - row * half;
     if (row >= a.keep_lo && row < a.keep_hi) continue;
     const float2* c0 = lds + (size_t)(2 * piece) * stride;
@@ -562,7 +651,6 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   ColsArgs a{};
   a.spec = n.spec, a.work = n.work, a.khat = khat, a.tw = n.tw_y, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.conj = adjoint ? 1 : 0;
   a.keep_lo = n.Hh + rb, a.keep_hi = n.Ny - ra, a.f = fy;
-  a.debug = opt_value(OPT_FFT_DEBUG, 0);
   const size_t per_col = (size_t)lp_size(n.Ny) * sizeof(float2);
   const int lanes = column_lanes(n.Ny, fy);
   if (!lanes) return fail(JD_ERR_INVALID, "native FFT: no column kernel for length %d", n.Ny);
@@ -573,13 +661,33 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   const int ocb = opt_value(OPT_FFT_NATIVE, 1);  // (tuning: JD_FFT_NATIVE = 2 / 4 / 8 forces the columns per block)
   if ((ocb == 2 || ocb == 4 || ocb == 8) && (size_t)ocb * per_col <= 160 * 1024 && n.Nx % ocb == 0 && ocb * lanes <= 512) cb = ocb;
   a.groups = n.Nx / cb;
-  static size_t lds_cols_set[2] = {0, 0};
-  const void* kernel = lanes == 64 ? reinterpret_cast<const void*>(fftn_cols_kernel<64>) : reinterpret_cast<const void*>(fftn_cols_kernel<128>);
-  int rc = lds_attr(kernel, cb * per_col, &lds_cols_set[lanes == 64 ? 0 : 1]);
+  // the kernel of the schedule: compile-time forms for the lengths of the usual image sizes (default columns per block),
+  // the generic form for everything else
+  using Kernel = void (*)(ColsArgs);
+  struct Entry {
+    int lanes, cb, r0, r1, r2;
+    Kernel kernel;
+    size_t lds_set;
+  };
+  static Entry table[] = {
+      {64, 4, 16, 8, 9, fftn_cols_kernel<64, 4, 16, 8, 9>, 0},    // 1152: 2048-row images, PSFs up to 129 rows
+      {128, 2, 16, 16, 9, fftn_cols_kernel<128, 2, 16, 16, 9>, 0},  // 2304: 4096-row images
+      {64, 4, 16, 8, 8, fftn_cols_kernel<64, 4, 16, 8, 8>, 0},    // 1024
+      {128, 2, 16, 16, 8, fftn_cols_kernel<128, 2, 16, 16, 8>, 0},  // 2048
+      {64, 4, 8, 8, 9, fftn_cols_kernel<64, 4, 8, 8, 9>, 0},      // 576: 1024-row images
+      {64, 4, 8, 8, 8, fftn_cols_kernel<64, 4, 8, 8, 8>, 0},      // 512
+      {64, 0, 0, 0, 0, fftn_cols_kernel<64, 0, 0, 0, 0>, 0},      // generic
+      {128, 0, 0, 0, 0, fftn_cols_kernel<128, 0, 0, 0, 0>, 0},
+  };
+  Entry* e = nullptr;
+  for (Entry& t : table) {
+    const bool is_static = t.r0 && fy.n == 3 && t.r0 == fy.r[0] && t.r1 == fy.r[1] && t.r2 == fy.r[2] && t.cb == cb;
+    if (t.lanes == lanes && (is_static || !t.r0) && !e) e = &t;
+  }
+  int rc = lds_attr(reinterpret_cast<const void*>(e->kernel), cb * per_col, &e->lds_set);
   if (rc) return rc;
   ProfScope prof(JD_KERNEL_CMUL, stream);
-  if (lanes == 64) hipLaunchKernelGGL(fftn_cols_kernel<64>, dim3(((a.groups + 7) / 8) * 8), dim3(lanes * cb), cb * per_col, stream, a);
-  else hipLaunchKernelGGL(fftn_cols_kernel<128>, dim3(((a.groups + 7) / 8) * 8), dim3(lanes * cb), cb * per_col, stream, a);
+  hipLaunchKernelGGL(e->kernel, dim3(((a.groups + 7) / 8) * 8), dim3(lanes * cb), cb * per_col, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
