@@ -96,6 +96,45 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, int N, const Ff
   return a;
 }
 
+// Compile-time radix schedule (R0, R1, R2[, R3]) of a row transform: N, every sub-transform length and every loop bound
+// are constants (the generic form dispatches on the radix inside the butterfly loop).  R0 = 0: generic.
+template <int R0, int R1, int R2, int R3>
+struct RowSched {
+  static constexpr bool STATIC = R0 > 0;
+  static constexpr int N = STATIC ? R0 * R1 * R2 * (R3 ? R3 : 1) : 0;
+};
+
+template <int R, int DIR, int N, int P>
+__device__ __forceinline__ void pass_static(const float2* x, float2* y, const float2* tw, int tid) {
+#pragma unroll
+  for (int i0 = 0; i0 < N / R; i0 += ROW_THREADS) {
+    const int i = i0 + tid;
+    if (i < N / R) pass_one<R, DIR>(x, y, N, P, tw, i);
+  }
+  __syncthreads();
+}
+
+template <int DIR, int R0, int R1, int R2, int R3>
+__device__ __forceinline__ float2* fft_lds_static(float2* a, float2* b, const float2* tw, int tid) {
+  constexpr int N = RowSched<R0, R1, R2, R3>::N;
+  pass_static<R0, DIR, N, 1>(a, b, tw, tid);
+  pass_static<R1, DIR, N, R0>(b, a, tw, tid);
+  pass_static<R2, DIR, N, R0 * R1>(a, b, tw, tid);
+  if constexpr (R3 > 0) {
+    pass_static<R3, DIR, N, R0 * R1 * R2>(b, a, tw, tid);
+    return a;
+  } else {
+    return b;
+  }
+}
+
+// the row transform of a kernel instantiated for the schedule S (generic: the passes of `f`)
+template <int DIR, class S, int R0, int R1, int R2, int R3>
+__device__ __forceinline__ float2* row_fft(float2* a, float2* b, int Nx, const FftPasses& f, const float2* tw, int tid) {
+  if constexpr (S::STATIC) return fft_lds_static<DIR, R0, R1, R2, R3>(a, b, tw, tid);
+  else return fft_lds<DIR, true>(a, b, Nx, f, tw, tid, ROW_THREADS);
+}
+
 // The same transform IN PLACE by the LANES threads of one column (the column kernel: one buffer per column instead of
 // two, twice the columns in flight per CU): in every pass a thread first reads the inputs of all its butterflies (at
 // most MAXB of them) into registers, then writes their outputs.  LANES = 64: one wave per column -- LDS operations of one
@@ -265,13 +304,16 @@ struct RowsFwdArgs {
 };
 
 // rows: z[x] = in[y][x] s[y][x] + i in[y + Hh][x] s[y + Hh][x], zero beyond W -> FFT -> spec[y][.]
+template <int R0, int R1, int R2, int R3>
 __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs a) {
   extern __shared__ float2 lds[];
+  using S = RowSched<R0, R1, R2, R3>;
+  const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, y = blockIdx.x;
   float2* bufa = lds;
-  float2* bufb = lds + lp_size(a.Nx);
+  float2* bufb = lds + lp_size(Nx);
   const size_t ra = (size_t)y * a.W, rb = (size_t)(y + a.Hh) * a.W;
-  for (int x = 4 * tid; x < a.Nx; x += 4 * ROW_THREADS) {
+  for (int x = 4 * tid; x < Nx; x += 4 * ROW_THREADS) {
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
     if (x < a.W) {
       u = *reinterpret_cast<const float4*>(a.in + ra + x);
@@ -286,9 +328,9 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
     bufa[e] = float2{u.x, v.x}, bufa[e + 1] = float2{u.y, v.y}, bufa[e + 2] = float2{u.z, v.z}, bufa[e + 3] = float2{u.w, v.w};
   }
   __syncthreads();
-  const float2* res = fft_lds<-1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
-  float2* out = a.spec + (size_t)y * a.Nx;
-  for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+  const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
+  float2* out = a.spec + (size_t)y * Nx;
+  for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
   }
@@ -373,12 +415,14 @@ struct RowsInvArgs {
 };
 
 // rows^-1 + epilogue.  ADJ = false: out = conv;  ADJ = true: out (+)= (coef * corr) * scale
-template <bool ADJ>
+template <bool ADJ, int R0, int R1, int R2, int R3>
 __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs a) {
   extern __shared__ float2 lds[];
+  using S = RowSched<R0, R1, R2, R3>;
+  const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, y = blockIdx.x;
   float2* bufa = lds;
-  float2* bufb = lds + lp_size(a.Nx);
+  float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5;  // float4 pieces of a row per thread: W <= 4 * 256 * 5
   // the spill of the OTHER half into this block's two output rows: at most one of them has one (Hh >= ra + rb + 1)
   //   row y      (upper half) receives Im C[Ny - Hh + y] when y >= Hh - ra   (the lower half's rows above its top)
@@ -388,8 +432,8 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) extra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_row = [&](int row) {
-    const float2* src = a.work + (size_t)row * a.Nx;
-    for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+    const float2* src = a.work + (size_t)row * Nx;
+    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
       const float4 v = *reinterpret_cast<const float4*>(src + x);
       bufa[lp(x)] = float2{v.x, v.y}, bufa[lp(x + 1)] = float2{v.z, v.w};
     }
@@ -397,7 +441,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
   };
   if (spill_up || spill_down) {  // (block-uniform)
     load_row(spill_up ? a.Ny - a.Hh + y : a.Hh + y);
-    const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+    const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
       const int x = 4 * (tid + q * ROW_THREADS);
@@ -409,7 +453,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
     __syncthreads();
   }
   load_row(y);
-  const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+  const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
@@ -455,20 +499,23 @@ struct RowsPoissonArgs {
 // finished image rows (clip, + background, NLL term, g = d loss / d conv where conv >= 0: `poisson_point`, the
 // arithmetic of every Poisson pass of the library), and at once the forward row transform of the g rows -- they ARE the
 // row pair the adjoint's first launch would read.  The convolution image and the g image never exist.
+template <int R0, int R1, int R2, int R3>
 __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPoissonArgs a) {
   extern __shared__ float2 lds[];
   __shared__ double red[ROW_THREADS / 64];
+  using S = RowSched<R0, R1, R2, R3>;
+  const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, y = blockIdx.x;
   float2* bufa = lds;
-  float2* bufb = lds + lp_size(a.Nx);
+  float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5;
   const bool spill_up = y >= a.Hh - a.ra, spill_down = y < a.rb;
   float4 extra[MAXQ];
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) extra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_row = [&](int row) {
-    const float2* src = a.work + (size_t)row * a.Nx;
-    for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+    const float2* src = a.work + (size_t)row * Nx;
+    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
       const float4 v = *reinterpret_cast<const float4*>(src + x);
       bufa[lp(x)] = float2{v.x, v.y}, bufa[lp(x + 1)] = float2{v.z, v.w};
     }
@@ -476,7 +523,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   };
   if (spill_up || spill_down) {  // (block-uniform)
     load_row(spill_up ? a.Ny - a.Hh + y : a.Hh + y);
-    const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+    const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
       const int x = 4 * (tid + q * ROW_THREADS);
@@ -488,7 +535,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
     __syncthreads();
   }
   load_row(y);
-  const float2* r = fft_lds<1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
+  const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
   float4 gu[MAXQ], gd[MAXQ];
   float local = 0.f;
@@ -527,15 +574,15 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {  // (Nx <= 4608 < 4 * 256 * MAXQ)
     const int x = 4 * (tid + q * ROW_THREADS), e = lp(x);
-    if (x >= a.Nx) continue;
+    if (x >= Nx) continue;
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
     if (x < a.W) u = gu[q], v = gd[q];
     bufa[e] = float2{u.x, v.x}, bufa[e + 1] = float2{u.y, v.y}, bufa[e + 2] = float2{u.z, v.z}, bufa[e + 3] = float2{u.w, v.w};
   }
   __syncthreads();
-  const float2* res = fft_lds<-1, true>(bufa, bufb, a.Nx, a.f, a.tw, tid, ROW_THREADS);
-  float2* out = a.spec + (size_t)y * a.Nx;
-  for (int x = 2 * tid; x < a.Nx; x += 2 * ROW_THREADS) {
+  const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
+  float2* out = a.spec + (size_t)y * Nx;
+  for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
   }
@@ -692,37 +739,52 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   return JD_OK;
 }
 
-int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream) {
-  static size_t set = 0;
+// The row kernels by schedule: compile-time forms for the row lengths of the usual image sizes, the generic form
+// otherwise.  Index into every table: row_schedule(f).
+constexpr int N_ROW_SCHED = 4;
+int row_schedule(const FftPasses& f) {
+  auto is = [&](int r0, int r1, int r2, int r3) {
+    return f.n == (r3 ? 4 : 3) && f.r[0] == r0 && f.r[1] == r1 && f.r[2] == r2 && (!r3 || f.r[3] == r3);
+  };
+  if (is(16, 16, 9, 0)) return 1;  // 2304: 2048-column images
+  if (is(8, 8, 8, 9)) return 2;    // 4608: 4096-column images
+  if (is(16, 8, 9, 0)) return 3;   // 1152: 1024-column images
+  return 0;
+}
+#define JD_ROW_KERNELS(NAME, ...)                                                                          \
+  {NAME<__VA_ARGS__ 0, 0, 0, 0>, NAME<__VA_ARGS__ 16, 16, 9, 0>, NAME<__VA_ARGS__ 8, 8, 8, 9>, NAME<__VA_ARGS__ 16, 8, 9, 0>}
+
+template <class Args>
+int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), size_t (&set)[N_ROW_SCHED], const FftNative& n, const Args& a,
+                      int kernel_id, hipStream_t stream) {
+  const int sched = row_schedule(a.f);
   const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
-  RowsFwdArgs a{};
-  a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
-  int rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_fwd_kernel), lds_rows, &set);
+  int rc = lds_attr(reinterpret_cast<const void*>(kernels[sched]), lds_rows, &set[sched]);
   if (rc) return rc;
-  ProfScope prof(JD_KERNEL_FFT_R2C, stream);
-  hipLaunchKernelGGL(fftn_rows_fwd_kernel, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
+  ProfScope prof(kernel_id, stream);
+  hipLaunchKernelGGL(kernels[sched], dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
 
+int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream) {
+  static void (*const kernels[N_ROW_SCHED])(RowsFwdArgs) = JD_ROW_KERNELS(fftn_rows_fwd_kernel, );
+  static size_t set[N_ROW_SCHED] = {};
+  RowsFwdArgs a{};
+  a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
+  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream);
+}
+
 int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream) {
-  static size_t set[2] = {0, 0};
-  const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
+  static void (*const kernels_fwd[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, false, );
+  static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
+  static size_t set[2][N_ROW_SCHED] = {};
   RowsInvArgs a{};
   a.work = n.work, a.tw = n.tw_x, a.out = out, a.scale = out_scale, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
   a.ra = adjoint ? n.kh - 1 - n.oy : n.oy, a.rb = adjoint ? n.oy : n.kh - 1 - n.oy;
   a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx);
-  ProfScope prof(JD_KERNEL_FFT_C2R, stream);
-  int rc;
-  if (adjoint) {
-    if ((rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_inv_kernel<true>), lds_rows, &set[1]))) return rc;
-    hipLaunchKernelGGL(fftn_rows_inv_kernel<true>, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
-  } else {
-    if ((rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_inv_kernel<false>), lds_rows, &set[0]))) return rc;
-    hipLaunchKernelGGL(fftn_rows_inv_kernel<false>, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
-  }
-  JD_LAUNCH_CHECK();
-  return JD_OK;
+  return adjoint ? launch_row_kernel(kernels_adj, set[1], n, a, JD_KERNEL_FFT_C2R, stream)
+                 : launch_row_kernel(kernels_fwd, set[0], n, a, JD_KERNEL_FFT_C2R, stream);
 }
 }  // namespace
 
@@ -746,16 +808,13 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
   if (rc) return rc;
   if ((rc = launch_cols(n, khat, 0, stream))) return rc;
   {
-    static size_t set = 0;
-    const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
+    static void (*const kernels[N_ROW_SCHED])(RowsPoissonArgs) = JD_ROW_KERNELS(fftn_rows_poisson_kernel, );
+    static size_t set[N_ROW_SCHED] = {};
     RowsPoissonArgs a{};
     a.work = n.work, a.spec = n.spec, a.tw = n.tw_x, a.background = background, a.counts = counts, a.partials = partials;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
     a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx);
-    if ((rc = lds_attr(reinterpret_cast<const void*>(fftn_rows_poisson_kernel), lds_rows, &set))) return rc;
-    ProfScope prof(JD_KERNEL_POISSON_FUSED, stream);
-    hipLaunchKernelGGL(fftn_rows_poisson_kernel, dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
-    JD_LAUNCH_CHECK();
+    if ((rc = launch_row_kernel(kernels, set, n, a, JD_KERNEL_POISSON_FUSED, stream))) return rc;
   }
   *n_partials = n.Hh;
   if ((rc = launch_cols(n, khat, 1, stream))) return rc;
