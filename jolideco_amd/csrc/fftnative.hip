@@ -403,6 +403,42 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   }
 }
 
+// The spectrum row of a block's row pair into LDS.  The two halves of the image are convolved as separate images (real and
+// imaginary part); where the convolution of one half spills across the seam into a row of the other, that row needs ONE
+// part of a second inverse transform: row y (upper half) += Im c_s with s = Ny - Hh + y when y >= Hh - ra, row y + Hh (lower
+// half) += Re c_s with s = Hh + y when y < rb (at most one of the two per block: Hh >= ra + rb + 1).  The part is taken
+// in the Fourier domain -- for c = IFFT(C): FFT(Re c)[k] = (C[k] + conj C[-k]) / 2, FFT(Im c)[k] = (C[k] - conj C[-k]) / 2i
+// -- and added to the block's own spectrum row (as a real part: + FFT(Im c_s); as an imaginary part: + i FFT(Re c_s)), so
+// that a seam block runs one transform like every other block: with two, the seam blocks set the duration of the whole
+// launch (every block of these launches is resident at once).
+__device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* work, int Nx, int y, int Hh, int Ny, int ra, int rb,
+                                                  int tid) {
+  const bool spill_up = y >= Hh - ra, spill_down = y < rb;
+  const float2* src = work + (size_t)y * Nx;
+  if (!(spill_up || spill_down)) {  // (block-uniform)
+    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+      const float4 v = *reinterpret_cast<const float4*>(src + x);
+      buf[lp(x)] = float2{v.x, v.y}, buf[lp(x + 1)] = float2{v.z, v.w};
+    }
+  } else {
+    const float2* sp = work + (size_t)(spill_up ? Ny - Hh + y : Hh + y) * Nx;
+    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+      const float4 v = *reinterpret_cast<const float4*>(src + x), c = *reinterpret_cast<const float4*>(sp + x);
+      const float2 m0 = sp[x == 0 ? 0 : Nx - x], m1 = sp[Nx - x - 1];  // C[-x], C[-(x + 1)]
+      float2 o0, o1;
+      if (spill_up) {  // + (C[k] - conj C[-k]) / 2i = ((Im C[k] + Im C[-k]) / 2, -(Re C[k] - Re C[-k]) / 2)
+        o0 = float2{v.x + 0.5f * (c.y + m0.y), v.y - 0.5f * (c.x - m0.x)};
+        o1 = float2{v.z + 0.5f * (c.w + m1.y), v.w - 0.5f * (c.z - m1.x)};
+      } else {  // + i (C[k] + conj C[-k]) / 2 = (-(Im C[k] - Im C[-k]) / 2, (Re C[k] + Re C[-k]) / 2)
+        o0 = float2{v.x - 0.5f * (c.y - m0.y), v.y + 0.5f * (c.x + m0.x)};
+        o1 = float2{v.z - 0.5f * (c.w - m1.y), v.w + 0.5f * (c.z + m1.x)};
+      }
+      buf[lp(x)] = o0, buf[lp(x + 1)] = o1;
+    }
+  }
+  __syncthreads();
+}
+
 struct RowsInvArgs {
   const float2* work;  // [Ny][Nx]
   const float2* tw;
@@ -424,35 +460,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5;  // float4 pieces of a row per thread: W <= 4 * 256 * 5
-  // the spill of the OTHER half into this block's two output rows: at most one of them has one (Hh >= ra + rb + 1)
-  //   row y      (upper half) receives Im C[Ny - Hh + y] when y >= Hh - ra   (the lower half's rows above its top)
-  //   row y + Hh (lower half) receives Re C[Hh + y]      when y <  rb        (the upper half's rows below its bottom)
-  const bool spill_up = y >= a.Hh - a.ra, spill_down = y < a.rb;
-  float4 extra[MAXQ];
-#pragma unroll
-  for (int q = 0; q < MAXQ; ++q) extra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_row = [&](int row) {
-    const float2* src = a.work + (size_t)row * Nx;
-    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
-      const float4 v = *reinterpret_cast<const float4*>(src + x);
-      bufa[lp(x)] = float2{v.x, v.y}, bufa[lp(x + 1)] = float2{v.z, v.w};
-    }
-    __syncthreads();
-  };
-  if (spill_up || spill_down) {  // (block-uniform)
-    load_row(spill_up ? a.Ny - a.Hh + y : a.Hh + y);
-    const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int x = 4 * (tid + q * ROW_THREADS);
-      if (x >= a.W) continue;
-      const int e = lp(x);
-      const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
-      extra[q] = spill_up ? make_float4(c0.y, c1.y, c2.y, c3.y) : make_float4(c0.x, c1.x, c2.x, c3.x);
-    }
-    __syncthreads();
-  }
-  load_row(y);
+  load_spectrum_row(bufa, a.work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
   const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
 #pragma unroll
@@ -462,8 +470,6 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
     const int e = lp(x);
     const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
     float4 up = make_float4(c0.x, c1.x, c2.x, c3.x), dn = make_float4(c0.y, c1.y, c2.y, c3.y);
-    if (spill_up) up.x += extra[q].x, up.y += extra[q].y, up.z += extra[q].z, up.w += extra[q].w;
-    if (spill_down) dn.x += extra[q].x, dn.y += extra[q].y, dn.z += extra[q].z, dn.w += extra[q].w;
     if (ADJ) {
       up.x *= a.coef, up.y *= a.coef, up.z *= a.coef, up.w *= a.coef;
       dn.x *= a.coef, dn.y *= a.coef, dn.z *= a.coef, dn.w *= a.coef;
@@ -509,32 +515,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5;
-  const bool spill_up = y >= a.Hh - a.ra, spill_down = y < a.rb;
-  float4 extra[MAXQ];
-#pragma unroll
-  for (int q = 0; q < MAXQ; ++q) extra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_row = [&](int row) {
-    const float2* src = a.work + (size_t)row * Nx;
-    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
-      const float4 v = *reinterpret_cast<const float4*>(src + x);
-      bufa[lp(x)] = float2{v.x, v.y}, bufa[lp(x + 1)] = float2{v.z, v.w};
-    }
-    __syncthreads();
-  };
-  if (spill_up || spill_down) {  // (block-uniform)
-    load_row(spill_up ? a.Ny - a.Hh + y : a.Hh + y);
-    const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
-#pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int x = 4 * (tid + q * ROW_THREADS);
-      if (x >= a.W) continue;
-      const int e = lp(x);
-      const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
-      extra[q] = spill_up ? make_float4(c0.y, c1.y, c2.y, c3.y) : make_float4(c0.x, c1.x, c2.x, c3.x);
-    }
-    __syncthreads();
-  }
-  load_row(y);
+  load_spectrum_row(bufa, a.work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
   const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
   float4 gu[MAXQ], gd[MAXQ];
@@ -547,7 +528,6 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
     const int e = lp(x);
     const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
     float up[4] = {c0.x, c1.x, c2.x, c3.x}, dn[4] = {c0.y, c1.y, c2.y, c3.y};
-    const float ex[4] = {extra[q].x, extra[q].y, extra[q].z, extra[q].w};
     const float4 b1 = *reinterpret_cast<const float4*>(a.background + o1 + x), b2 = *reinterpret_cast<const float4*>(a.background + o2 + x);
     const float4 n1 = *reinterpret_cast<const float4*>(a.counts + o1 + x), n2 = *reinterpret_cast<const float4*>(a.counts + o2 + x);
     const float bu[4] = {b1.x, b1.y, b1.z, b1.w}, bd[4] = {b2.x, b2.y, b2.z, b2.w};
@@ -555,8 +535,6 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
     float g1[4], g2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (spill_up) up[i] += ex[i];
-      if (spill_down) dn[i] += ex[i];
       float term, g;
       poisson_point(fmaxf(up[i], 0.f) + bu[i], cu[i], a.eps, a.inv_n, term, g);
       local += term;
