@@ -434,10 +434,9 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   if (p->native && n_comp == 1 && upsampling == 1 && !calibrated && grad_flux && !npred_out && !opt_is_set(OPT_SEP_NO_FUSION) &&
       p->partials_cap >= p->fftn.Hh) {
     // native FFT path, one component: rows, columns, rows^-1 + Poisson pass + rows of g, columns, rows^-1 + adjoint epilogue
-    if ((rc = fftn_poisson_step(p->fftn, flux[0], exposure[0], reinterpret_cast<const float2*>(khat[0]), background, counts,
-                                p->partials, &n_partials, eps, (float)(1.0 / n_pix), grad_flux[0], grad_scale, accumulate, s)))
-      return rc;
-    return launch_finalize_sum(p->partials, n_partials, 1.0 / n_pix, (double)stirling_mean, loss_out, 0, s);
+    return fftn_poisson_step(p->fftn, flux[0], exposure[0], reinterpret_cast<const float2*>(khat[0]), background, counts,
+                             p->partials, &n_partials, eps, (float)(1.0 / n_pix), grad_flux[0], grad_scale, accumulate, s,
+                             1.0 / n_pix, (double)stirling_mean, loss_out);
   }
   const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
                      upsampling == 1 && !cal.log_bkg_norm && !opt_is_set(OPT_SEP_NO_FUSION);

@@ -447,6 +447,12 @@ struct RowsInvArgs {
   int H, W, Hh, Nx, Ny, ra, rb;  // the convolution of a half spills ra rows above and rb rows below it
   float coef;
   int accumulate;
+  // the loss of a likelihood step: block 0 sums the fin_count partial sums the middle launch left (the arithmetic and
+  // order of finalize_sum_kernel) -- one dependent launch less per dataset
+  const double* fin_partials;
+  int fin_count;
+  double fin_scale, fin_offset;
+  float* fin_out;
   FftPasses f;
 };
 
@@ -486,6 +492,13 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
     }
     *reinterpret_cast<float4*>(a.out + o1 + x) = up;
     *reinterpret_cast<float4*>(a.out + o2 + x) = dn;
+  }
+  if (ADJ && a.fin_partials && blockIdx.x == 0) {  // (block-uniform)
+    __shared__ double red[ROW_THREADS / 64];
+    double acc = 0.0;
+    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += a.fin_partials[i];
+    const double total = block_sum<ROW_THREADS>(acc, red);
+    if (tid == 0) a.fin_out[0] = (float)(a.fin_scale * total + a.fin_offset);
   }
 }
 
@@ -679,9 +692,9 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   const size_t per_col = (size_t)lp_size(n.Ny) * sizeof(float2);
   const int lanes = column_lanes(n.Ny, fy);
   if (!lanes) return fail(JD_ERR_INVALID, "native FFT: no column kernel for length %d", n.Ny);
-  // columns per block: 4 one-wave columns (32 contiguous bytes of every spectrum row; three blocks per CU), 2 two-wave
-  // columns for the long ones.  Measured at 2048^2, Ny = 1152: 8 columns per block 45 us -- one block per CU --, 4: 33 us,
-  // 2: 35 us
+  // columns per block: 4 one-wave columns (32 contiguous bytes of every spectrum row), 2 two-wave columns for the long
+  // ones.  Measured at 2048^2, Ny = 1152 (round 4, compile-time schedules): 4 columns 24.2 us, 3 columns (768 blocks = 3 per
+  // CU, 24-byte pieces) 26.7, 9 columns (one block per CU) 25.9; at 4096^2, Ny = 2304: 2 two-wave columns 91 us, 4: 104
   int cb = lanes == 64 ? 4 : 2;
   const int ocb = opt_value(OPT_FFT_NATIVE, 1);  // (tuning: JD_FFT_NATIVE = 2 / 4 / 8 forces the columns per block)
   if ((ocb == 2 || ocb == 4 || ocb == 8) && (size_t)ocb * per_col <= 160 * 1024 && n.Nx % ocb == 0 && ocb * lanes <= 512) cb = ocb;
@@ -753,7 +766,8 @@ int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, 
   return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream);
 }
 
-int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream) {
+int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream,
+                    const SepLossFold* fold = nullptr) {
   static void (*const kernels_fwd[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, false, );
   static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
   static size_t set[2][N_ROW_SCHED] = {};
@@ -761,6 +775,8 @@ int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int 
   a.work = n.work, a.tw = n.tw_x, a.out = out, a.scale = out_scale, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
   a.ra = adjoint ? n.kh - 1 - n.oy : n.oy, a.rb = adjoint ? n.oy : n.kh - 1 - n.oy;
   a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx);
+  if (fold && adjoint)
+    a.fin_partials = fold->partials, a.fin_count = fold->count, a.fin_scale = fold->scale, a.fin_offset = fold->offset, a.fin_out = fold->out;
   return adjoint ? launch_row_kernel(kernels_adj, set[1], n, a, JD_KERNEL_FFT_C2R, stream)
                  : launch_row_kernel(kernels_fwd, set[0], n, a, JD_KERNEL_FFT_C2R, stream);
 }
@@ -778,10 +794,10 @@ int fftn_conv(const FftNative& n, const float* in, const float* in_scale, const 
 
 // The likelihood step of one dataset and one flux component in FIVE launches: rows(flux x exposure), columns(K^),
 // rows^-1 + Poisson pass + rows(g), columns(conj K^), rows^-1 + adjoint epilogue.  partials[0 .. *n_partials): block
-// sums of n - c log(n + eps);  grad (+)= coef * exposure * corr(g, psf).
+// sums of n - c log(n + eps);  grad (+)= coef * exposure * corr(g, psf);  *loss_out = loss_scale * sum(partials) + loss_offset.
 int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposure, const float2* khat, const float* background,
                       const float* counts, double* partials, int* n_partials, float eps, float inv_n, float* grad, float coef,
-                      int accumulate, hipStream_t stream) {
+                      int accumulate, hipStream_t stream, double loss_scale, double loss_offset, float* loss_out) {
   int rc = launch_rows_fwd(n, flux, exposure, stream);
   if (rc) return rc;
   if ((rc = launch_cols(n, khat, 0, stream))) return rc;
@@ -796,7 +812,9 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
   }
   *n_partials = n.Hh;
   if ((rc = launch_cols(n, khat, 1, stream))) return rc;
-  return launch_rows_inv(n, grad, exposure, 1, coef, accumulate, stream);
+  // the loss = loss_scale * sum(partials) + loss_offset, by block 0 of the last launch
+  const SepLossFold fold{partials, n.Hh, loss_scale, loss_offset, loss_out};
+  return launch_rows_inv(n, grad, exposure, 1, coef, accumulate, stream, &fold);
 }
 
 }  // namespace jd

@@ -221,7 +221,7 @@ int fftn_conv(const FftNative& n, const float* in, const float* in_scale, const 
               int adjoint, float coef, int accumulate, hipStream_t stream);
 int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposure, const float2* khat, const float* background,
                       const float* counts, double* partials, int* n_partials, float eps, float inv_n, float* grad, float coef,
-                      int accumulate, hipStream_t stream);
+                      int accumulate, hipStream_t stream, double loss_scale, double loss_offset, float* loss_out);
 
 // kernel timers (profile.hip): RAII bracket around one launch
 int prof_begin(int kernel, hipStream_t s);
