@@ -438,6 +438,30 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
                              p->partials, &n_partials, eps, (float)(1.0 / n_pix), grad_flux[0], grad_scale, accumulate, s,
                              1.0 / n_pix, (double)stirling_mean, loss_out);
   }
+  // native FFT path with up-sampling (and optionally the calibration): the sum-pool, the Poisson pass and the row transform
+  // of the up-sampled g are one launch between the two column passes; the loss and the background-norm gradient are
+  // finalised by the adjoint's last launch
+  if (p->native && n_comp == 1 && upsampling > 1 && fftn_pooled_supported(p->fftn, upsampling) && grad_flux && !npred_out &&
+      !opt_is_set(OPT_SEP_NO_FUSION) && p->partials_cap >= p->fftn.Hh) {
+    const float* in = flux[0];
+    if (cal.shift_xy) {
+      if ((rc = launch_shift_fwd(flux[0], p->shifted[0], p->H, p->W, cal.shift_xy, cal.shift_scale, s))) return rc;
+      in = p->shifted[0];
+    }
+    const bool want_norm = cal.log_bkg_norm && cal.grad_log_bkg_norm;
+    if ((rc = fftn_poisson_step_pooled(p->fftn, upsampling, in, exposure[0], reinterpret_cast<const float2*>(khat[0]), background,
+                                       counts, cal.log_bkg_norm, p->partials, want_norm ? p->partials_cal : nullptr, eps,
+                                       (float)(1.0 / n_pix), cal.shift_xy ? p->gshift[0] : grad_flux[0], grad_scale,
+                                       cal.shift_xy ? 0 : accumulate, s, 1.0 / n_pix, (double)stirling_mean, loss_out,
+                                       (double)grad_scale, want_norm ? cal.grad_log_bkg_norm : nullptr)))
+      return rc;
+    if (!cal.shift_xy) return JD_OK;
+    int n_blocks = 0;
+    if ((rc = launch_shift_bwd(flux[0], p->gshift[0], grad_flux[0], accumulate, p->H, p->W, cal.shift_xy, cal.shift_scale,
+                               p->partials_cal, &n_blocks, s)))
+      return rc;
+    return cal.grad_shift_xy ? launch_finalize_multi(p->partials_cal, n_blocks, 2, 1.0, cal.grad_shift_xy, 0, s) : JD_OK;
+  }
   const bool fused = (p->method == JD_CONV_SEPARABLE || p->method == JD_CONV_DIRECT) && n_comp == 1 &&
                      upsampling == 1 && !cal.log_bkg_norm && !opt_is_set(OPT_SEP_NO_FUSION);
   if (fused) {

@@ -453,6 +453,9 @@ struct RowsInvArgs {
   int fin_count;
   double fin_scale, fin_offset;
   float* fin_out;
+  const double* fin2_partials;  // a second sum of fin_count terms (block 1): d loss / d log background norm
+  double fin2_scale;
+  float* fin2_out;
   FftPasses f;
 };
 
@@ -499,6 +502,13 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
     for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += a.fin_partials[i];
     const double total = block_sum<ROW_THREADS>(acc, red);
     if (tid == 0) a.fin_out[0] = (float)(a.fin_scale * total + a.fin_offset);
+  }
+  if (ADJ && a.fin2_partials && blockIdx.x == 1) {
+    __shared__ double red2[ROW_THREADS / 64];
+    double acc = 0.0;
+    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += a.fin2_partials[i];
+    const double total = block_sum<ROW_THREADS>(acc, red2);
+    if (tid == 0) a.fin2_out[0] = (float)(a.fin2_scale * total);
   }
 }
 
@@ -576,6 +586,104 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
+  }
+}
+
+struct RowsPooledArgs {
+  const float2* work;  // [Ny][Nx]: the forward convolution on the flux grid after the column pass
+  float2* spec;        // [Hh][Nx]: <- row spectra of the up-sampled g
+  const float2* tw;
+  const float* background;    // counts grid (H / U, W / U)
+  const float* counts;
+  const float* log_bkg_norm;  // nullable, device [1]: background *= exp(.) (models/npred.py:236-239)
+  double* partials;           // [Hh / U]: block sums of the Poisson terms
+  double* partials_b;         // nullable [Hh / U]: block sums of g * background (d loss / d log norm up to the scale)
+  int H, W, Hh, Nx, Ny, ra, rb;
+  float eps, inv_n;
+  FftPasses f;
+};
+
+// The middle of a likelihood step with up-sampling (models/npred.py:181-191: sum-pool the convolution over U x U flux
+// pixels, THEN clip) in one launch: block Y owns the counts rows Y and Y + H / (2 U): U inverse row transforms (flux rows
+// U Y + j of both halves), pooled sums in registers, the Poisson pass on the two counts rows, and ONE forward row
+// transform of the up-sampled g rows -- the U flux rows of a counts row carry the same g, so their spectrum row is
+// computed once and stored U times.  Replaces rows^-1 -> convolution image -> pooled Poisson kernel -> g image -> rows.
+template <int U, int R0, int R1, int R2, int R3>
+__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPooledArgs a) {
+  extern __shared__ float2 lds[];
+  __shared__ double red[ROW_THREADS / 64];
+  using S = RowSched<R0, R1, R2, R3>;
+  const int Nx = S::STATIC ? S::N : a.Nx;
+  const int tid = threadIdx.x, Y = blockIdx.x;
+  float2* bufa = lds;
+  float2* bufb = lds + lp_size(Nx);
+  constexpr int MAXQ = 5, PC = 4 / U;  // float4 pieces of a flux row per thread; counts pixels per piece
+  float pu[MAXQ][PC], pd[MAXQ][PC];    // pooled sums: counts row Y (upper half) and Y + H / (2 U) (lower half)
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q)
+#pragma unroll
+    for (int c = 0; c < PC; ++c) pu[q][c] = pd[q][c] = 0.f;
+#pragma unroll 1
+  for (int j = 0; j < U; ++j) {
+    load_spectrum_row(bufa, a.work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+    const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int x = 4 * (tid + q * ROW_THREADS);
+      if (x >= a.W) continue;
+      const int e = lp(x);
+      const float2 v[4] = {r[e], r[e + 1], r[e + 2], r[e + 3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pu[q][i / U] += v[i].x, pd[q][i / U] += v[i].y;  // (row by row, left to right)
+    }
+    __syncthreads();  // the result buffer is the next transform's work space
+  }
+  const int Wd = a.W / U, Hdh = a.Hh / U;
+  const float norm = a.log_bkg_norm ? expf(a.log_bkg_norm[0]) : 1.f;
+  float gu[MAXQ][PC], gd[MAXQ][PC];
+  double local = 0.0, local_b = 0.0;
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int x = 4 * (tid + q * ROW_THREADS);
+#pragma unroll
+    for (int c = 0; c < PC; ++c) gu[q][c] = gd[q][c] = 0.f;
+    if (x >= a.W) continue;
+#pragma unroll
+    for (int c = 0; c < PC; ++c) {
+      const size_t o1 = (size_t)Y * Wd + x / U + c, o2 = (size_t)(Y + Hdh) * Wd + x / U + c;
+      const float b1 = a.log_bkg_norm ? a.background[o1] * norm : a.background[o1];
+      const float b2 = a.log_bkg_norm ? a.background[o2] * norm : a.background[o2];
+      float term, g;
+      poisson_point(fmaxf(pu[q][c], 0.f) + b1, a.counts[o1], a.eps, a.inv_n, term, g);
+      local += (double)term, local_b += (double)(g * b1);
+      gu[q][c] = pu[q][c] >= 0.f ? g : 0.f;  // clamp backward
+      poisson_point(fmaxf(pd[q][c], 0.f) + b2, a.counts[o2], a.eps, a.inv_n, term, g);
+      local += (double)term, local_b += (double)(g * b2);
+      gd[q][c] = pd[q][c] >= 0.f ? g : 0.f;
+    }
+  }
+  const double total = block_sum<ROW_THREADS>(local, red);
+  if (tid == 0) a.partials[Y] = total;
+  if (a.partials_b) {
+    __syncthreads();
+    const double total_b = block_sum<ROW_THREADS>(local_b, red);
+    if (tid == 0) a.partials_b[Y] = total_b;
+  }
+  // ---- z = g_up[y] + i g_up[y + Hh], zero padded: the adjoint's row transform, the same for the U flux rows ---------------
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int x = 4 * (tid + q * ROW_THREADS), e = lp(x);
+    if (x >= Nx) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bufa[e + i] = x < a.W ? float2{gu[q][i / U], gd[q][i / U]} : float2{0.f, 0.f};
+  }
+  __syncthreads();
+  const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
+  for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+    const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
+    const float4 v = make_float4(c0.x, c0.y, c1.x, c1.y);
+#pragma unroll
+    for (int j = 0; j < U; ++j) *reinterpret_cast<float4*>(a.spec + (size_t)(U * Y + j) * Nx + x) = v;
   }
 }
 
@@ -747,13 +855,13 @@ int row_schedule(const FftPasses& f) {
 
 template <class Args>
 int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), size_t (&set)[N_ROW_SCHED], const FftNative& n, const Args& a,
-                      int kernel_id, hipStream_t stream) {
+                      int kernel_id, hipStream_t stream, int blocks = 0) {
   const int sched = row_schedule(a.f);
   const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
   int rc = lds_attr(reinterpret_cast<const void*>(kernels[sched]), lds_rows, &set[sched]);
   if (rc) return rc;
   ProfScope prof(kernel_id, stream);
-  hipLaunchKernelGGL(kernels[sched], dim3(n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
+  hipLaunchKernelGGL(kernels[sched], dim3(blocks ? blocks : n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -767,7 +875,7 @@ int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, 
 }
 
 int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream,
-                    const SepLossFold* fold = nullptr) {
+                    const SepLossFold* fold = nullptr, const SepLossFold* fold2 = nullptr) {
   static void (*const kernels_fwd[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, false, );
   static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
   static size_t set[2][N_ROW_SCHED] = {};
@@ -777,6 +885,7 @@ int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int 
   a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx);
   if (fold && adjoint)
     a.fin_partials = fold->partials, a.fin_count = fold->count, a.fin_scale = fold->scale, a.fin_offset = fold->offset, a.fin_out = fold->out;
+  if (fold && fold2 && adjoint) a.fin2_partials = fold2->partials, a.fin2_scale = fold2->scale, a.fin2_out = fold2->out;
   return adjoint ? launch_row_kernel(kernels_adj, set[1], n, a, JD_KERNEL_FFT_C2R, stream)
                  : launch_row_kernel(kernels_fwd, set[0], n, a, JD_KERNEL_FFT_C2R, stream);
 }
@@ -815,6 +924,42 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
   // the loss = loss_scale * sum(partials) + loss_offset, by block 0 of the last launch
   const SepLossFold fold{partials, n.Hh, loss_scale, loss_offset, loss_out};
   return launch_rows_inv(n, grad, exposure, 1, coef, accumulate, stream, &fold);
+}
+
+// The same with up-sampling U = 2 or 4 (models/npred.py:181-184) and an optional background norm (:236-239): rows(flux x
+// exposure), columns, rows^-1 x U + pool + Poisson pass + rows(up-sampled g), columns(conj), rows^-1 + adjoint epilogue
+// into `target` (= coef * exposure * corr, overwritten or accumulated).  The loss and, if wanted, d loss / d log norm =
+// norm_grad_scale * sum(g * background) are finalised by blocks 0 and 1 of the last launch.
+bool fftn_pooled_supported(const FftNative& n, int upsampling) {
+  return (upsampling == 2 || upsampling == 4) && n.W % 4 == 0 && n.Hh % upsampling == 0 && n.Hh / upsampling >= 2 &&
+         n.W <= 4 * ROW_THREADS * 5;
+}
+
+int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
+                             const float* background, const float* counts, const float* log_bkg_norm, double* partials,
+                             double* partials_b, float eps, float inv_n, float* target, float coef, int accumulate,
+                             hipStream_t stream, double loss_scale, double loss_offset, float* loss_out, double norm_grad_scale,
+                             float* norm_grad_out) {
+  int rc = launch_rows_fwd(n, flux, exposure, stream);
+  if (rc) return rc;
+  if ((rc = launch_cols(n, khat, 0, stream))) return rc;
+  {
+    static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
+    static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
+    static size_t set[2][N_ROW_SCHED] = {};
+    RowsPooledArgs a{};
+    a.work = n.work, a.spec = n.spec, a.tw = n.tw_x, a.background = background, a.counts = counts, a.log_bkg_norm = log_bkg_norm;
+    a.partials = partials, a.partials_b = norm_grad_out ? partials_b : nullptr;
+    a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
+    a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx);
+    rc = upsampling == 2 ? launch_row_kernel(kernels2, set[0], n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 2)
+                         : launch_row_kernel(kernels4, set[1], n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 4);
+    if (rc) return rc;
+  }
+  if ((rc = launch_cols(n, khat, 1, stream))) return rc;
+  const SepLossFold fold{partials, n.Hh / upsampling, loss_scale, loss_offset, loss_out};
+  const SepLossFold fold2{partials_b, n.Hh / upsampling, norm_grad_scale, 0.0, norm_grad_out};
+  return launch_rows_inv(n, target, exposure, 1, coef, accumulate, stream, &fold, norm_grad_out ? &fold2 : nullptr);
 }
 
 }  // namespace jd

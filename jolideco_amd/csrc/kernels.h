@@ -223,6 +223,13 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
                       const float* counts, double* partials, int* n_partials, float eps, float inv_n, float* grad, float coef,
                       int accumulate, hipStream_t stream, double loss_scale, double loss_offset, float* loss_out);
 
+bool fftn_pooled_supported(const FftNative& n, int upsampling);
+int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
+                             const float* background, const float* counts, const float* log_bkg_norm, double* partials,
+                             double* partials_b, float eps, float inv_n, float* target, float coef, int accumulate,
+                             hipStream_t stream, double loss_scale, double loss_offset, float* loss_out, double norm_grad_scale,
+                             float* norm_grad_out);
+
 // kernel timers (profile.hip): RAII bracket around one launch
 int prof_begin(int kernel, hipStream_t s);
 void prof_end(int slot, hipStream_t s);

@@ -478,3 +478,79 @@ def test_c5_shaped_two_component_joint_step_1024_4obs():
                                       max_flip_fraction=1e-3)
     print(f"c5-shaped 1024^2 x 4 x 2 components: gradients within 1e-5 of the oracle (points {err_points:.1e}), {flips} "
           f"near-tie flips, scalars max rel {np.max(np.abs(scalars / scalars_o - 1)):.1e}")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 6 shape (bench.py c6, the reference's Chandra example): calibrations + up-sampling + general PSFs
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False])
+def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
+    """One joint step of a c6-shaped fit at 1024^2 flux pixels x 4 observations against autograd of the oracle
+    (`cpu_ref.DatasetRef.loss`: jolideco/models/npred.py:210-261 with the calibration of :298-402): counts grid 512^2,
+    ``upsampling_factor=2``, general 33x33 PSFs (66x66 up-sampled -> native FFT convolution: compile-time schedules for
+    rows of 1152 and columns of 1024), one trained `NPredCalibration` (sub-pixel shift + background norm) per observation.
+    Compared: the flux gradient, every dataset loss, d loss / d shift_xy and d loss / d log background norm.  ``fused``:
+    the pooled middle launch of the native FFT path (sum-pool + Poisson pass + row transform of the up-sampled g between
+    the two column passes; loss and background-norm gradient finalised by the adjoint's last launch) against the
+    separate kernels (``JD_SEP_NO_FUSION=1``)."""
+    from jolideco_amd import MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent, UniformPrior
+    from jolideco_amd.data import instrument_observations
+
+    if not fused:
+        jd_option("JD_SEP_NO_FUSION", "1")
+    counts_shape, n_obs, u = (512, 512), 4, 2
+    datasets, _, flux_init, cal = instrument_observations(shape=counts_shape, n_obs=n_obs, seed=0, psf_shape=(33, 33))
+    rs = np.random.RandomState(5)  # (a rough start image: the pooled sums and the clip see structure at the pixel scale)
+    flux_start = (flux_init * rs.uniform(0.6, 1.4, size=counts_shape)).astype(np.float32)
+    comp = SpatialFluxComponent.from_numpy(flux=flux_start, upsampling_factor=u, prior=UniformPrior())
+    cals = NPredCalibrations()
+    for name, (sx, sy, norm) in cal.items():
+        cals[name] = NPredCalibration(shift_x=sx, shift_y=sy, background_norm=norm)
+    deco = MAPDeconvolver(n_epochs=1, display_progress=False, device=DEV, fit_mode="joint")
+    session = deco.session(datasets, components=comp, calibrations=cals)
+    plans = {m.plan for m in session.total_loss.poisson_loss.npred_models_all}
+    assert all(p.method == "fft" and p.native_fft for p in plans)
+    session.cfg._optimizer_step = lambda states, step: None  # keep the gradient buffer, no update
+    session.epoch()
+    torch.cuda.synchronize()
+    n = 1024 * 1024
+    comm = session.comm.cpu().numpy()
+    grad, scalars = comm[:n].reshape(1024, 1024), comm[n : n + n_obs]
+    seen = session.states[0].flux_cur.cpu().numpy()
+
+    def oracle(precision):
+        with cpu_ref.precision(precision):
+            flux = cpu_ref._tensor(seen)[None, None].requires_grad_(True)
+            losses, cal_o = [], {}
+            for name, d in datasets.items():
+                sx, sy, norm = cal[name]
+                cal_o[name] = cpu_ref.CalibrationRef.create(sx, sy, norm)
+                loss = cpu_ref.DatasetRef.from_numpy(d, ["flux"], [u], cal_o[name]).loss((flux,))
+                loss.backward()
+                losses.append(float(loss.detach()))
+            return flux.grad.numpy()[0, 0], np.array(losses), cal_o
+
+    # The fp32 oracle (= the reference's arithmetic) is itself 3e-5 from exact arithmetic on this gradient: grid_sample
+    # rounds its pixel coordinates at W * 2^-24 px (see test_calibrations_match_the_reference).  float64 arbitrates: the
+    # HIP path must be within the north-star 1e-5 of the float64 oracle and no further from the fp32 oracle than that
+    # oracle's own distance to float64 allows.
+    grad_32, losses_32, cal_32 = oracle(np.float32)
+    grad_64, losses_64, cal_64 = oracle(np.float64)
+    np.testing.assert_allclose(scalars, losses_32, rtol=5e-6)
+    np.testing.assert_allclose(scalars, losses_64, rtol=5e-6)
+    err_64, err_32, ref_64 = rel_linf(grad, grad_64), rel_linf(grad, grad_32), rel_linf(grad_32, grad_64)
+    assert err_64 < 1e-5, err_64
+    assert err_32 < ref_64 + 1e-5, (err_32, ref_64)
+    worst = 0.0
+    for name in datasets:
+        got_shift = cals[name].shift_xy.grad.cpu().numpy().ravel()
+        got_norm = cals[name]._background_norm.grad.cpu().numpy().ravel()
+        ref_shift = cal_64[name].shift_xy.grad.numpy().ravel()
+        ref_norm = cal_64[name].log_background_norm.grad.numpy().ravel()
+        # (the shift gradient is a sum of 10^6 terms of both signs: absolute tolerance relative to the larger entry)
+        np.testing.assert_allclose(got_shift, ref_shift, rtol=1e-4, atol=2e-5 * np.abs(ref_shift).max())
+        np.testing.assert_allclose(got_norm, ref_norm, rtol=2e-5)
+        worst = max(worst, float(np.max(np.abs(got_shift - ref_shift)) / np.abs(ref_shift).max()))
+    print(f"c6-shaped 1024^2 x 4 (fused={fused}): flux gradient {err_64:.1e} from the float64 oracle, {err_32:.1e} from the fp32 "
+          f"oracle (itself {ref_64:.1e} from float64), losses max rel {np.max(np.abs(scalars / losses_64 - 1)):.1e}, "
+          f"shift gradient {worst:.1e}")
