@@ -443,17 +443,13 @@ static int npred_poisson_impl(const char* who, jd_conv_plan* p, int n_comp, cons
   // finalised by the adjoint's last launch
   if (p->native && n_comp == 1 && upsampling > 1 && fftn_pooled_supported(p->fftn, upsampling) && grad_flux && !npred_out &&
       !opt_is_set(OPT_SEP_NO_FUSION) && p->partials_cap >= p->fftn.Hh) {
-    const float* in = flux[0];
-    if (cal.shift_xy) {
-      if ((rc = launch_shift_fwd(flux[0], p->shifted[0], p->H, p->W, cal.shift_xy, cal.shift_scale, s))) return rc;
-      in = p->shifted[0];
-    }
     const bool want_norm = cal.log_bkg_norm && cal.grad_log_bkg_norm;
-    if ((rc = fftn_poisson_step_pooled(p->fftn, upsampling, in, exposure[0], reinterpret_cast<const float2*>(khat[0]), background,
+    if ((rc = fftn_poisson_step_pooled(p->fftn, upsampling, flux[0], exposure[0], reinterpret_cast<const float2*>(khat[0]), background,
                                        counts, cal.log_bkg_norm, p->partials, want_norm ? p->partials_cal : nullptr, eps,
                                        (float)(1.0 / n_pix), cal.shift_xy ? p->gshift[0] : grad_flux[0], grad_scale,
                                        cal.shift_xy ? 0 : accumulate, s, 1.0 / n_pix, (double)stirling_mean, loss_out,
-                                       (double)grad_scale, want_norm ? cal.grad_log_bkg_norm : nullptr)))
+                                       (double)grad_scale, want_norm ? cal.grad_log_bkg_norm : nullptr, cal.shift_xy,
+                                       cal.shift_scale)))
       return rc;
     if (!cal.shift_xy) return JD_OK;
     int n_blocks = 0;

@@ -294,8 +294,14 @@ __device__ __forceinline__ void column_conv_inplace(float2* x, int N, const FftP
   }
 }
 
+struct __attribute__((packed, aligned(4))) F4U4 {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
+  float x, y, z, w;
+};
+
 struct RowsFwdArgs {
   const float* in;
+  const float* shift_xy;  // nullable, device [2]: the input is the bilinearly shifted image (the calibration's shift_fwd)
+  float shift_scale;
   const float* scale;  // nullable
   float2* spec;        // [Hh][Nx]
   const float2* tw;
@@ -313,15 +319,67 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   const size_t ra = (size_t)y * a.W, rb = (size_t)(y + a.Hh) * a.W;
-  for (int x = 4 * tid; x < Nx; x += 4 * ROW_THREADS) {
+  constexpr int MAXQ = 5;  // float4 pieces of a row per thread (Nx <= 4608 < 4 * 256 * MAXQ)
+  float4 su[MAXQ], sv[MAXQ];
+  if (a.shift_xy) {  // (uniform)
+    // the bilinearly shifted rows of both halves, straight from global memory: per piece the five source columns of the two
+    // source rows (one 16-byte load at a 4-byte aligned address + one float each; element-wise with bounds checks where
+    // the window leaves the image) -- the arithmetic of shift_fwd_kernel, whose launch and image this replaces
+    const ShiftGeom g = shift_geom(a.shift_xy, a.shift_scale);
+    const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int r0 = y + half * a.Hh + g.fy, r1 = r0 + 1;
+      const bool in_r0 = r0 >= 0 && r0 < a.H, in_r1 = r1 >= 0 && r1 < a.H;
+      const float* row0 = a.in + (size_t)(in_r0 ? r0 : 0) * a.W;
+      const float* row1 = a.in + (size_t)(in_r1 ? r1 : 0) * a.W;
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
+        const int x = 4 * (tid + q * ROW_THREADS);
+        float t0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, t1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (x < a.W) {
+          const int c0 = x + g.fx;
+          if (c0 >= 0 && c0 + 4 < a.W) {
+            if (in_r0) {
+              const F4U4 v = *reinterpret_cast<const F4U4*>(row0 + c0);
+              t0[0] = v.x, t0[1] = v.y, t0[2] = v.z, t0[3] = v.w, t0[4] = row0[c0 + 4];
+            }
+            if (in_r1) {
+              const F4U4 v = *reinterpret_cast<const F4U4*>(row1 + c0);
+              t1[0] = v.x, t1[1] = v.y, t1[2] = v.z, t1[3] = v.w, t1[4] = row1[c0 + 4];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+              const bool in_c = c0 + i >= 0 && c0 + i < a.W;
+              t0[i] = in_c && in_r0 ? row0[c0 + i] : 0.f;
+              t1[i] = in_c && in_r1 ? row1[c0 + i] : 0.f;
+            }
+          }
+        }
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = t0[i] * w00 + t0[i + 1] * w10 + t1[i] * w01 + t1[i + 1] * w11;
+        (half ? sv[q] : su[q]) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int x = 4 * (tid + q * ROW_THREADS);
+    if (x >= Nx) continue;
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
     if (x < a.W) {
-      u = *reinterpret_cast<const float4*>(a.in + ra + x);
-      v = *reinterpret_cast<const float4*>(a.in + rb + x);
+      if (a.shift_xy) {
+        u = su[q], v = sv[q];
+      } else {
+        u = *reinterpret_cast<const float4*>(a.in + ra + x);
+        v = *reinterpret_cast<const float4*>(a.in + rb + x);
+      }
       if (a.scale) {
-        const float4 su = *reinterpret_cast<const float4*>(a.scale + ra + x), sv = *reinterpret_cast<const float4*>(a.scale + rb + x);
-        u.x *= su.x, u.y *= su.y, u.z *= su.z, u.w *= su.w;
-        v.x *= sv.x, v.y *= sv.y, v.z *= sv.z, v.w *= sv.w;
+        const float4 su_ = *reinterpret_cast<const float4*>(a.scale + ra + x), sv_ = *reinterpret_cast<const float4*>(a.scale + rb + x);
+        u.x *= su_.x, u.y *= su_.y, u.z *= su_.z, u.w *= su_.w;
+        v.x *= sv_.x, v.y *= sv_.y, v.z *= sv_.z, v.w *= sv_.w;
       }
     }
     const int e = lp(x);  // (x % 4 == 0: the four elements share a group of 16, consecutive in the padded layout)
@@ -866,11 +924,13 @@ int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), size_t (&set)
   return JD_OK;
 }
 
-int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream) {
+int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream, const float* shift_xy = nullptr,
+                    float shift_scale = 1.f) {
   static void (*const kernels[N_ROW_SCHED])(RowsFwdArgs) = JD_ROW_KERNELS(fftn_rows_fwd_kernel, );
   static size_t set[N_ROW_SCHED] = {};
   RowsFwdArgs a{};
   a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
+  a.shift_xy = shift_xy, a.shift_scale = shift_scale;
   return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream);
 }
 
@@ -927,7 +987,8 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
 }
 
 // The same with up-sampling U = 2 or 4 (models/npred.py:181-184) and an optional background norm (:236-239): rows(flux x
-// exposure), columns, rows^-1 x U + pool + Poisson pass + rows(up-sampled g), columns(conj), rows^-1 + adjoint epilogue
+// exposure; `shift_xy` != null: of the bilinearly shifted flux), columns, rows^-1 x U + pool + Poisson pass + rows(up-sampled
+// g), columns(conj), rows^-1 + adjoint epilogue
 // into `target` (= coef * exposure * corr, overwritten or accumulated).  The loss and, if wanted, d loss / d log norm =
 // norm_grad_scale * sum(g * background) are finalised by blocks 0 and 1 of the last launch.
 bool fftn_pooled_supported(const FftNative& n, int upsampling) {
@@ -939,8 +1000,8 @@ int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* fl
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,
                              double* partials_b, float eps, float inv_n, float* target, float coef, int accumulate,
                              hipStream_t stream, double loss_scale, double loss_offset, float* loss_out, double norm_grad_scale,
-                             float* norm_grad_out) {
-  int rc = launch_rows_fwd(n, flux, exposure, stream);
+                             float* norm_grad_out, const float* shift_xy, float shift_scale) {
+  int rc = launch_rows_fwd(n, flux, exposure, stream, shift_xy, shift_scale);
   if (rc) return rc;
   if ((rc = launch_cols(n, khat, 0, stream))) return rc;
   {

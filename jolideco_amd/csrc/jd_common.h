@@ -88,6 +88,24 @@ __device__ __forceinline__ void poisson_point(float n, float c, float eps, float
   g = fmaf(-c, r, 1.f) * inv_n;
 }
 
+// Sub-pixel shift of the calibration (jolideco/models/npred.py:298-402, utils/torch.py:196-223: affine_grid + grid_sample,
+// bilinear, zero padding, align_corners=False, pure translation): in pixel units the sample point of output pixel (i, j) is
+// (i + scale * shift_y, j + scale * shift_x) -- the same integer offsets and bilinear weights for every pixel.
+struct ShiftGeom {
+  int fy, fx;                // integer parts
+  float wy0, wy1, wx0, wx1;  // weights of rows fy, fy + 1 / columns fx, fx + 1
+};
+
+__device__ __forceinline__ ShiftGeom shift_geom(const float* shift_xy, float scale) {
+  const float sx = scale * shift_xy[0], sy = scale * shift_xy[1];
+  const float flx = floorf(sx), fly = floorf(sy);
+  ShiftGeom g;
+  g.fx = (int)flx, g.fy = (int)fly;
+  g.wx1 = sx - flx, g.wx0 = 1.f - g.wx1;
+  g.wy1 = sy - fly, g.wy0 = 1.f - g.wy1;
+  return g;
+}
+
 // out = (accumulate ? out : 0) + scale * sum(partials[0..n)) + offset, summed in index order in fp64.
 int launch_finalize_sum(const double* partials, int n, double scale, double offset, float* out,
                         int accumulate, hipStream_t stream);

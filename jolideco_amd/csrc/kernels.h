@@ -228,7 +228,7 @@ int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* fl
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,
                              double* partials_b, float eps, float inv_n, float* target, float coef, int accumulate,
                              hipStream_t stream, double loss_scale, double loss_offset, float* loss_out, double norm_grad_scale,
-                             float* norm_grad_out);
+                             float* norm_grad_out, const float* shift_xy, float shift_scale);
 
 // kernel timers (profile.hip): RAII bracket around one launch
 int prof_begin(int kernel, hipStream_t s);

@@ -11,21 +11,6 @@ namespace jd {
 
 constexpr int SHIFT_ROWS = 16;  // rows per block of the backward kernel
 
-struct ShiftGeom {
-  int fy, fx;          // integer parts
-  float wy0, wy1, wx0, wx1;  // weights of rows fy, fy + 1 / columns fx, fx + 1
-};
-
-__device__ __forceinline__ ShiftGeom shift_geom(const float* shift_xy, float scale) {
-  const float sx = scale * shift_xy[0], sy = scale * shift_xy[1];
-  const float flx = floorf(sx), fly = floorf(sy);
-  ShiftGeom g;
-  g.fx = (int)flx, g.fy = (int)fly;
-  g.wx1 = sx - flx, g.wx0 = 1.f - g.wx1;
-  g.wy1 = sy - fly, g.wy0 = 1.f - g.wy1;
-  return g;
-}
-
 __device__ __forceinline__ float at(const float* img, int H, int W, int y, int x) {
   return (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.f;
 }
