@@ -177,8 +177,14 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
   JD_REQUIRE(mode != JD_CONV_MODE_DIRECT || direct_conv_supported(kh, kw),
              "jd_conv_plan_create: the direct method supports PSFs up to 33x33, got %dx%d", kh, kw);
   const bool exact_shape = mode == JD_CONV_MODE_FFT_EXACT;
-  if (mode == JD_CONV_MODE_SEPARABLE || mode == JD_CONV_MODE_DIRECT ||
-      (mode == JD_CONV_MODE_AUTO && direct_conv_supported(kh, kw))) {
+  // "auto" for a general PSF: the MFMA Toeplitz kernel up to 17 taps; beyond, its cost grows with the PSF area while the
+  // native FFT convolution's does not (2048^2, forward convolution: 21 taps 77 against 49 us, 33 taps 136 against 48 us;
+  // 1024^2: 24 against 23 and 38 against 23 us; 17 taps: 27 against 49 us -- tools/conv_bench.py), so images of a
+  // megapixel and more take the native FFT path where its sizes allow
+  const bool native_ok = !exact_shape && opt_value(OPT_FFT_NATIVE, 1) != 0 && fftn_supported(H, W, kh, kw);
+  const bool auto_direct = direct_conv_supported(kh, kw) &&
+                           (std::max(kh, kw) <= 17 || !native_ok || (long)H * W < (1L << 20) || opt_is_set(OPT_DIRECT_AUTO_ALL));
+  if (mode == JD_CONV_MODE_SEPARABLE || mode == JD_CONV_MODE_DIRECT || (mode == JD_CONV_MODE_AUTO && auto_direct)) {
     // both work on the unpadded (H, W) grid: no FFT plans, only the image-sized work buffers
     jd_conv_plan* p = new (std::nothrow) jd_conv_plan();
     if (!p) return fail(JD_ERR_ALLOC, "jd_conv_plan_create: out of host memory");
@@ -200,7 +206,7 @@ extern "C" int jd_conv_plan_create(int H, int W, int kh, int kw, int mode, jd_co
     *plan_out = p;
     return JD_OK;
   }
-  if (!exact_shape && opt_value(OPT_FFT_NATIVE, 1) != 0 && fftn_supported(H, W, kh, kw)) {
+  if (native_ok) {
     // FFT method on the hand-written transforms: works on the un-padded (H, W) grid like the direct kernels
     jd_conv_plan* p = new (std::nothrow) jd_conv_plan();
     if (!p) return fail(JD_ERR_ALLOC, "jd_conv_plan_create: out of host memory");

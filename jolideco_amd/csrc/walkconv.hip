@@ -85,6 +85,7 @@ struct WalkArgs {
   // batched forward launch over operators of BOTH frames: blocks < blocks17 walk the 17-tap datasets
   // table->order[0 .. n17) with the tiling above, the others the 33-tap datasets table->order[n17 ..) with this one
   int blocks17, n17;
+  int ilv17, ilv33;            // > 0 (tuning, JD_SEP_INTERLEAVE): the ilv datasets of a frame are neighbours in the launch order
   int strips33, tiles_y33, rows33;
   int part_stride;             // POISSON: partial sums per dataset in `partials` (>= tiles of either tiling; the rest zeroed)
   float coef;
@@ -203,8 +204,11 @@ __device__ __forceinline__ void walk_body(const WalkArgs& a, int bid, const int 
   if (XCHG && a.comp_blocks) comp = bid / a.comp_blocks, bid -= comp * a.comp_blocks;  // (comp_blocks: a multiple of 8)
   const int q = bid / 8;
   // batched forward launch: dataset-major, the datasets of this frame in the table's order
-  const int dsel = (!XCHG && a.n_batch > 0) ? a.table->order[slot0 + q / per_xcd] : 0;
-  const int tile = (bid % 8) * per_xcd + q % per_xcd;
+  // (JD_SEP_INTERLEAVE: tile-major instead -- the waves of one tile's datasets start together and read the flux rows they
+  // share within a row or two of each other)
+  const int ilv = !XCHG && a.n_batch > 0 ? (slot0 ? a.ilv33 : a.ilv17) : 0;
+  const int dsel = (!XCHG && a.n_batch > 0) ? a.table->order[slot0 + (ilv ? q % ilv : q / per_xcd)] : 0;
+  const int tile = (bid % 8) * per_xcd + (ilv ? q / ilv : q % per_xcd);
   if (tile >= n_tiles) return;  // (block-uniform)
   const int sx = tile / tiles_y, ty = tile - sx * tiles_y;
 
@@ -1331,6 +1335,7 @@ int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table
     walk_shape(a, n, false, frame, &C, &rows);
     walk_tiles(a, C, rows);
     *n_partials = a.strips * a.tiles_y;
+    if (opt_is_set(OPT_SEP_INTERLEAVE)) a.ilv17 = n;
     return launch_walk<true, true>(a, frame, C, n, stream);
   }
   // Both frames in one launch, all waves resident at once.  A 17-tap wave at 4 columns per lane issues ~226 vector
@@ -1364,6 +1369,7 @@ int walk_conv_poisson_batch(int n, const float* flux, const SepBatchTable& table
   a.rows33 = rows33, a.strips33 = (W + 127) / 128, a.tiles_y33 = (H + rows33 - 1) / rows33;
   const int t17 = a.strips * a.tiles_y, t33 = a.strips33 * a.tiles_y33;
   a.n17 = n17;
+  if (opt_is_set(OPT_SEP_INTERLEAVE)) a.ilv17 = n17, a.ilv33 = n33;
   a.blocks17 = ((t17 + 7) / 8) * 8 * n17;
   a.part_stride = t17 > t33 ? t17 : t33;
   *n_partials = a.part_stride;
