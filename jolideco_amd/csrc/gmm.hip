@@ -1179,11 +1179,37 @@ __device__ __forceinline__ float screen_q_half(const f32x16 (&acc)[2]) {
 // below exp(-25) = 1.4e-11 of the largest term of the sum, 128 components of it below 2e-9 of the sum.
 constexpr float LSE_MARGIN = 25.f;
 constexpr int LSE_KEEP = 28;  // candidates a patch may keep (a multiple of 4; <= LSE_ROWS, and 128 x (LSE_KEEP + 1) <= SCREEN_CAP)
+#ifndef JD_SCREEN_SCHED_NV
+#define JD_SCREEN_SCHED_NV 8
+#endif
+#ifndef JD_SCREEN_LATE_EMIT
+#define JD_SCREEN_LATE_EMIT 1  // records of both pairs are written at the END of a component's step (one basic block for
+                               // the MFMAs and the squares of a component); 0: inside each pair's epilogue (rounds 1-3)
+#endif
+
+// the candidate records of one pair: `mask` = ballot of the candidate lanes
+__device__ __forceinline__ void screen_emit(unsigned long long mask, bool cand, float ub, int n, int k, int lane, int& cnt,
+                                            int32_t* rec_n, int32_t* rec_k, float* rec_ub, int cap) {
+  if (mask) {
+    const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+#if JD_SCREEN_LATE_EMIT
+    cand = ((mask >> lane) & 1ull) != 0ull;  // (a lane flag kept alive across the component's step costs it two instructions)
+#endif
+    if (cand && pos < cap) {  // (the wave's record buffer: uniform base pointers, one 32-bit offset)
+      rec_n[pos] = n;
+      rec_k[pos] = k;
+      rec_ub[pos] = ub;
+    }
+    cnt += __popcll(mask);
+  }
+}
+
 template <bool LSE = false>
 __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], const f32x16 (&accB)[2], float ck, float ack,
                                                    float mnorm, float efro, float xn, float s2, bool ok, float& L,
                                                    float& qacc, int n, int k, int lane, int& cnt, int32_t* rec_n,
-                                                   int32_t* rec_k, float* rec_ub, int cap, int& pc, int keep) {
+                                                   int32_t* rec_k, float* rec_ub, int cap, int& pc, int keep,
+                                                   unsigned long long& mask_out, float& ub_out, unsigned long long okmask) {
   const float qa = screen_q_half(accA), qb = screen_q_half(accB);
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
   // lanes 0-31: tile A, lanes 32-63: tile B; s2 = (s_x s_k)^2 undoes the power-of-two operand scales (exactly)
@@ -1194,24 +1220,27 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   const float l = fmaf(-0.5f, q, ck);
   const float B = fmaf(__builtin_amdgcn_sqrtf(q), e1, fmaf(2e-5f, q, c2));
   const float ub = l + B;
-  bool cand = ok && ub >= (LSE ? L - LSE_MARGIN : L);
-  if (LSE) {  // a patch keeps at most `keep` candidates; one more marks it for the dense kernel (its records are dropped)
-    pc += cand ? 1 : 0;
-    cand = cand && pc <= keep;
-  }
   // L = max(L, l - B) as ONE v_max_f32 (fmaxf adds a canonicalising v_max in front; a NaN operand loses either way
   // and is caught through qacc)
-  asm("v_max_f32 %0, %1, %2" : "=v"(L) : "v"(L), "v"(l - B));
-  const unsigned long long mask = __ballot(cand);
-  if (mask) {
-    const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-    if (cand && pos < cap) {  // (the wave's record buffer: uniform base pointers, one 32-bit offset)
-      rec_n[pos] = n;
-      rec_k[pos] = k;
-      rec_ub[pos] = ub;
-    }
-    cnt += __popcll(mask);
+  unsigned long long mask;
+  bool cand;
+  if (LSE) {  // a patch keeps at most `keep` candidates; one more marks it for the dense kernel (its records are dropped)
+    cand = ok && ub >= L - LSE_MARGIN;
+    pc += cand ? 1 : 0;
+    cand = cand && pc <= keep;
+    mask = __ballot(cand);
+  } else {
+    // the ballot of the compare alone IS its lane mask; `ok` joins as a scalar AND with its own (loop-invariant) ballot --
+    // the ballot of `ok && compare` goes through a v_cndmask / v_cmp_ne pair
+    mask = __builtin_amdgcn_ballot_w64(ub >= L) & okmask;
+    cand = ((mask >> lane) & 1ull) != 0ull;  // (only the early-emit form reads it)
   }
+  asm("v_max_f32 %0, %1, %2" : "=v"(L) : "v"(L), "v"(l - B));
+#if JD_SCREEN_LATE_EMIT
+  mask_out = mask, ub_out = ub;
+#else
+  screen_emit(mask, cand, ub, n, k, lane, cnt, rec_n, rec_k, rec_ub, cap);
+#endif
 }
 
 // NP = tile pairs (of 2 x 32 patches) a wave works on.  Two decompositions:
@@ -1242,11 +1271,13 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
   __shared__ float rb_ub[4][SCREEN_RB];
   __shared__ int kc_k[KC_LDS ? SCREEN_KC_MAX : 1];
   __shared__ float4 kc_f[KC_LDS ? SCREEN_KC_MAX : 1];
+  __shared__ float kc_a[KC_LDS ? SCREEN_KC_MAX : 1];  // 1e-6 |c_k| + 1e-30: the rounding slack of the bound
   if (KC_LDS) {
     for (int i = threadIdx.x; i < a.K; i += 256) {
       const int k = a.korder[i];
       kc_k[i] = k;
       kc_f[i] = make_float4(a.const_k[k], a.efro_k[k], a.sk2_k[k], a.mnorm_k[k]);
+      kc_a[i] = fmaf(1e-6f, fabsf(a.const_k[k]), 1e-30f);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1278,7 +1309,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
   float* const lb_ub = rb_ub[wave];
   // room for one more emission of up to 64 records?  otherwise write the buffer out (wave-uniform, rare)
   auto flush = [&](bool force) {
-    if (!force && cnt_l <= SCREEN_RB - 64) return;
+    if (!force && cnt_l <= SCREEN_RB - 128) return;  // (room for the two emissions of the next component)
     for (int i = lane; i < cnt_l; i += 64)
       if (cnt + i < SCREEN_CAP) seg_n[cnt + i] = lb_n[i], seg_k[cnt + i] = lb_k[i], seg_ub[cnt + i] = lb_ub[i];
     cnt += cnt_l;
@@ -1289,6 +1320,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
   bool pok[NP];
   int pn[NP];
   int pc[NP];  // (logsumexp screen) candidates of the lane's patch so far
+  unsigned long long okm[NP];  // ballot of pok
   // candidates a patch may keep: 30 x 128 patches fit a wave's record list, and the four waves of a KSPLIT block, which
   // share the patches, stay below the 32 rows of the patch table together
   const int keep = KSPLIT ? LSE_KEEP / 4 : LSE_KEEP;
@@ -1301,6 +1333,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
     pL[p] = -INFINITY;
     pq[p] = 0.f;
     pc[p] = 0;
+    okm[p] = __ballot(pok[p]);
   }
 
   ScreenFrags f0, f1;
@@ -1316,17 +1349,18 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
   // (component, constants) at a position of the visiting order
   struct KConst {
     int k;
-    float ck, ef, sk2, mn;
+    float ck, ef, sk2, mn, ack;
   };
   auto fetch_consts = [&](int pos) {
     KConst r;
     if (KC_LDS) {
       r.k = kc_k[pos];
       const float4 c4 = kc_f[pos];
-      r.ck = c4.x, r.ef = c4.y, r.sk2 = c4.z, r.mn = c4.w;
+      r.ck = c4.x, r.ef = c4.y, r.sk2 = c4.z, r.mn = c4.w, r.ack = kc_a[pos];
     } else {
       r.k = a.korder[pos];
       r.ck = a.const_k[r.k], r.ef = a.efro_k[r.k], r.sk2 = a.sk2_k[r.k], r.mn = a.mnorm_k[r.k];
+      r.ack = fmaf(1e-6f, fabsf(r.ck), 1e-30f);
     }
     return r;
   };
@@ -1347,30 +1381,59 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
     constexpr int PHASE = decltype(phase)::value;
     const int k = __builtin_amdgcn_readfirstlane(cur.k);
     const float ck = cur.ck, ef = cur.ef, sk2 = cur.sk2, mn = cur.mn;
-    const float ack = fmaf(1e-6f, fabsf(ck), 1e-30f);
+    const float ack = cur.ack;
     const int k_ahead = k_ahead_next;                    // the component after next: read from LDS a component ago
     k_ahead_next = fetch_k(clamp_pos(kk + 3 * KSTEP));  // (consumed at once it would expose the LDS latency)
     cur = nxt;
     nxt = fetch_consts(clamp_pos(kk + 2 * KSTEP));  // ... and fetched two ahead of its use
+    unsigned long long m0 = 0ull, m1 = 0ull;
+    float u0 = 0.f, u1 = 0.f;
     if (NP == 2) {
       // pair 1 of k on the matrix pipe while pair 0 of k finishes in its shadow, then pair 0 of k + 1 | pair 1 of k
       issue_pair(acc[1], fa, 1);
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // unconditional (clamped) prefetch
       screen_finish_pair<LSE>(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
-                         cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep);
+                         cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep, m0, u0, okm[0]);
+#if !JD_SCREEN_LATE_EMIT
       flush(false);
+#endif
       issue_pair(acc[0], fb, 0);
       screen_finish_pair<LSE>(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[NP - 1], ps2[NP - 1] * sk2, pok[NP - 1], pL[NP - 1],
-                         pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[NP - 1], keep);
+                         pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[NP - 1], keep, m1, u1, okm[NP - 1]);
+#if !JD_SCREEN_LATE_EMIT
       flush(false);
+#endif
     } else {
       // the only pair of k + 1 on the matrix pipe while the pair of k finishes; the accumulator buffers alternate
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // (fa's MFMAs were issued by the previous component)
       issue_pair(acc[1 - PHASE], fb, 0);
       screen_finish_pair<LSE>(acc[PHASE][0], acc[PHASE][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k,
-                         lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep);
+                         lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep, m0, u0, okm[0]);
+#if !JD_SCREEN_LATE_EMIT
+      flush(false);
+#endif
+    }
+#if JD_SCREEN_SCHED_NV > 0
+    // the component's step is one scheduling region: one MFMA, then JD_SCREEN_SCHED_NV vector instructions, 12 NP times --
+    // the squares of one pair spread under the MFMAs of the other (left alone, the scheduler bunches the second pair's
+    // MFMAs behind its predecessor's epilogue)
+    if (NP == 2 && !LSE && !KSPLIT) {
+#pragma unroll
+      for (int i = 0; i < 12 * NP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, JD_SCREEN_SCHED_NV, 0);
+      }
+    }
+#endif
+#if JD_SCREEN_LATE_EMIT
+    // the records of the component, written behind its MFMAs and squares (SCREEN_RB holds two emissions of 64 + the
+    // buffered rest: the flush check runs once per component)
+    if (m0 | m1) {
+      screen_emit(m0, false, u0, pn[0], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
+      if (NP == 2) screen_emit(m1, false, u1, pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB);
       flush(false);
     }
+#endif
   };
   for (int kk = kk0; kk < a.K; kk += 2 * KSTEP) {
     component(f0, f1, kk, std::integral_constant<int, 0>{});
