@@ -13,7 +13,10 @@ DEV = "cuda:0"
 
 CASES = [((64, 128), (5, 7)), ((200, 328), (17, 17)), ((130, 516), (33, 17)), ((256, 256), (65, 65)), ((96, 132), (32, 33)),
          ((512, 1024), (129, 129)), ((72, 2048), (9, 9)), ((1024, 64), (3, 41)),
-         ((2600, 64), (9, 9)), ((4096, 128), (17, 17))]  # (the last two: column lengths 2048 and 2304 -- two waves per column)
+         ((2600, 64), (9, 9)), ((4096, 128), (17, 17)),  # (column lengths 2048 and 2304 -- two waves per column)
+         # column schedules with the odd radix in the fused middle pass, generic kernel: 288 = 8 * 4 * 9, 144 = 16 * 9, 72 = 8 * 9;
+         # compile-time schedules 1024 = 16 * 8 * 8 and 1152 = 16 * 8 * 9 on a narrow image
+         ((520, 64), (9, 9)), ((264, 64), (9, 5)), ((120, 68), (9, 9)), ((1800, 64), (9, 9)), ((2048, 64), (17, 9))]
 
 
 def _psf(kshape, seed):
