@@ -15,7 +15,7 @@ all-reduce of the likelihood gradient (started before the prior, overlapped with
 prior bands, the fused chain rule + Adam update.  The convolution method is "auto": the
 benchmark's Gaussian PSFs are rank 1, so the headline runs the separable strip-walk kernels (the PSFs of both sizes share
 one plan and one batched step: forward launch = convolution + Poisson pass of all local observations); the same fit
-with the PSFs treated as general kernels (MFMA direct convolution, `general_psf`) and through the FFT path (`fft_psf`,
+with the PSFs treated as general kernels (MFMA direct convolution up to 17 taps, native FFT beyond: `general_psf`) and through the FFT path (`fft_psf`,
 the path the north star names: the native FFT convolution of csrc/fftnative.hip on these sizes) is timed beside it, and
 so is `c6_chandra_like` (calibrations + up-sampling x2 + general 65x65 PSFs: the reference's Chandra example).
 Total work is fixed as N grows (observations round-robin over the ranks, the prior split by patch
@@ -695,8 +695,13 @@ def main():
 
     if world == 1 and fake is None and "separable" in methods and not args.no_general_psf:
         out["general_psf"], _ = conv_method_run(
-            "direct", "same workload with the PSFs convolved as general 17x17 / 33x33 kernels (MFMA Toeplitz convolution, "
-                      "fp16 x 3 split operands; Poisson pass in the forward launch's epilogue)")
+            "general", "same workload with the PSFs convolved as general kernels, each by the method \"auto\" gives a general "
+                       "PSF of its size: 17x17 MFMA Toeplitz convolution (fp16 x 3 split operands, Poisson pass in the forward "
+                       "launch's epilogue), 33x33 native FFT convolution")
+        out["direct_psf"], _ = conv_method_run(
+            "direct", "same workload with every PSF through the MFMA Toeplitz convolution (the 33x33 ones included: rounds "
+                      "1-3's general_psf)")
+        out["direct_psf"].pop("plans", None)
         out["fft_psf"], prof_fft = conv_method_run(
             "fft", "same workload through the FFT path (native FFT convolution, csrc/fftnative.hip): per observation rows, "
                    "columns (FFT x kernel spectrum x inverse FFT), rows^-1 + Poisson pass + rows of g, columns, rows^-1 + "

@@ -60,9 +60,12 @@ int jd_get_option(const char* key, int* is_set, int* value);
  * linear "same" convolution of an (H, W) image with a (kh, kw) kernel, zero outside the image; the
  * crop offset is the reference's `_centered` offset ((kh-1)/2, (kw-1)/2) (utils/torch.py:337-344).
  * Two methods compute the same function:
- *   FFT    rocFFT R2C / k-space multiply / C2R on a zero padded (Hp, Wp) grid, Hp >= H+kh-1,
- *          Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5-smooth, Wp % 4 == 0) sizes
- *          (JD_CONV_MODE_FFT_EXACT forces the reference's own grid (H+kh-1, W+kw-1));
+ *   FFT    where H is even, W % 4 == 0 and the padded lengths are of the form 2^a * {1, 3, 9} (<= 4608 columns, <= 2304 rows
+ *          per image half): hand-written transforms on the un-padded grid (csrc/fftnative.hip: rows, columns with the
+ *          k-space product, rows^-1 with the epilogue; the likelihood step of a dataset in five launches, with
+ *          up-sampling and calibration too); otherwise rocFFT R2C / k-space multiply / C2R on a zero padded (Hp, Wp)
+ *          grid, Hp >= H+kh-1, Wp >= W+kw-1 rounded up to FFT-friendly (2,3,5-smooth, Wp % 4 == 0) sizes
+ *          (JD_CONV_MODE_FFT_EXACT forces rocFFT on the reference's own grid (H+kh-1, W+kw-1));
  *   DIRECT the sum over PSF taps as Toeplitz products on the matrix cores, PSFs up to 33x33; padding, exposure
  *          scaling and crop are folded into the kernel (csrc/directconv.hip).  Default where the operands fit in LDS
  *          (up to ~25x33): both operands split into two fp16 terms (22 significant bits, three fp16 MFMAs per
@@ -72,7 +75,8 @@ int jd_get_option(const char* key, int* is_set, int* value);
  *          double Gaussian 2): a row pass and a column pass of kh + kw taps per rank instead of kh * kw,
  *          PSFs up to 68x68 (csrc/sepconv.hip).  Whether a PSF qualifies is decided by
  *          jd_psf_separable_rank() / jd_conv_psf_spectrum(); a PSF that does not is an error for such a plan.
- * JD_CONV_MODE_AUTO picks DIRECT when the PSF is small enough for it to be faster than FFT; it never picks
+ * JD_CONV_MODE_AUTO picks DIRECT when the PSF is small enough for it to be faster than FFT -- up to 17 taps; up to 33
+ * where the native FFT sizes do not fit, on images below 2^20 pixels, or with option JD_DIRECT_AUTO_ALL --; it never picks
  * SEPARABLE, because the choice depends on the PSF values, which a plan does not know: the caller asks
  * jd_psf_separable_rank() and requests JD_CONV_MODE_SEPARABLE (jolideco_amd.NPredModel does). */
 enum {

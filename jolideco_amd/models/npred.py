@@ -94,6 +94,8 @@ class NPredModel(nn.Module):
         H, W = exposure_t.shape
         kh, kw = psf_t.shape
         method = default_conv_method()
+        if method == "general":  # every PSF as a general kernel
+            method, allow_separable = "auto", False
         if method == "auto" and allow_separable and max(kh, kw) <= SEPARABLE_MAX_EDGE:
             rank = psf_separable_rank(psf)
             if rank and rescaled is not psf:

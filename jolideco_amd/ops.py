@@ -66,14 +66,16 @@ def psf_separable_rank(psf, tol=0.0):
 
 
 def default_conv_method():
-    """Convolution method used when none is requested: "auto" (the separable kernel when the PSF is a sum
-    of at most three outer products, else the MFMA direct kernel for PSFs up to 33x33, else rocFFT) unless
-    JOLIDECO_CONV_METHOD overrides it."""
+    """Convolution method used when none is requested: "auto" -- the separable kernels when the PSF is a sum of at most
+    three outer products; else the MFMA direct kernel up to 17 taps (up to 33 on images below a megapixel or where the
+    native FFT sizes do not fit); else the FFT path (native transforms where the sizes allow, rocFFT otherwise) -- unless
+    JOLIDECO_CONV_METHOD overrides it.  "general" = "auto" without the low-rank test (every PSF as a general kernel: what
+    an instrument PSF that is no short sum of outer products gets; `bench.py`'s `general_psf` run)."""
     import os
 
     method = os.environ.get("JOLIDECO_CONV_METHOD", "auto")
-    if method not in CONV_MODES:
-        raise ValueError(f"JOLIDECO_CONV_METHOD={method!r}, must be one of {sorted(CONV_MODES)}")
+    if method not in CONV_MODES and method != "general":
+        raise ValueError(f"JOLIDECO_CONV_METHOD={method!r}, must be one of {sorted(CONV_MODES) + ['general']}")
     return method
 
 
@@ -99,6 +101,8 @@ class ConvPlan:
             raise RuntimeError("ConvPlan needs a HIP device (no CPU fallback)")
         if method is None:
             method = "fft-exact" if exact_shape else default_conv_method()
+        if method == "general":  # (the low-rank test is the caller's: a plan asked for by size alone is "auto")
+            method = "auto"
         if method not in CONV_MODES:
             raise ValueError(f"unknown convolution method {method!r}, must be one of {sorted(CONV_MODES)}")
         handle = c_void_p()
@@ -119,6 +123,8 @@ class ConvPlan:
             device = torch.device("cuda", torch.cuda.current_device())
         if method is None:
             method = "fft-exact" if exact_shape else default_conv_method()
+        if method == "general":
+            method = "auto"
         key = (str(device), H, W, kh, kw, method)
         if key not in cls._cache:
             cls._cache[key] = cls(H, W, kh, kw, device, method=method)
