@@ -1209,7 +1209,8 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
                                                    float mnorm, float efro, float xn, float s2, bool ok, float& L,
                                                    float& qacc, int n, int k, int lane, int& cnt, int32_t* rec_n,
                                                    int32_t* rec_k, float* rec_ub, int cap, int& pc, int keep,
-                                                   unsigned long long& mask_out, float& ub_out, unsigned long long okmask) {
+                                                   unsigned long long& mask_out, float& ub_out, unsigned long long okmask,
+                                                   bool live) {
   const float qa = screen_q_half(accA), qb = screen_q_half(accB);
   const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(qa), __float_as_uint(qb), false, false);
   // lanes 0-31: tile A, lanes 32-63: tile B; s2 = (s_x s_k)^2 undoes the power-of-two operand scales (exactly)
@@ -1225,7 +1226,7 @@ __device__ __forceinline__ void screen_finish_pair(const f32x16 (&accA)[2], cons
   unsigned long long mask;
   bool cand;
   if (LSE) {  // a patch keeps at most `keep` candidates; one more marks it for the dense kernel (its records are dropped)
-    cand = ok && ub >= L - LSE_MARGIN;
+    cand = ok && live && ub >= L - LSE_MARGIN;
     pc += cand ? 1 : 0;
     cand = cand && pc <= keep;
     mask = __ballot(cand);
@@ -1370,14 +1371,18 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
   KConst nxt = fetch_consts(clamp_pos(kk0 + KSTEP));  // always one component ahead of `cur` ...
   load_frags16(f0, af, __builtin_amdgcn_readfirstlane(cur.k));
   load_frags16(f1, af, __builtin_amdgcn_readfirstlane(nxt.k));
-  if (kk0 < a.K) issue_pair(acc[0], f0, 0);  // prologue: pair 0 of the first component
+  // prologue: pair 0 of the first component.  Unconditional (a wave without components computes on the clamped position and
+  // drops the result): with the fragments of f0 consumed on EVERY path into the loop the compiler knows them loaded there,
+  // and the first half of a component does not wait -- behind a conditional prologue it drained ALL outstanding loads at the
+  // top of every other component, the prefetch of the component after next included
+  issue_pair(acc[0], f0, 0);
   int k_ahead_next = fetch_k(clamp_pos(kk0 + 2 * KSTEP));
   // One component: `fa` holds its fragments, `fb` those of the next one (requested during the PREVIOUS component).  As
   // soon as the last MFMA that reads `fa` has been issued, the fragments of the component after next are requested into
   // it: 1.75 components (~3000 cycles) ahead of their first use -- with the request at the top of the component that
   // precedes the use the waves were parked on its vmcnt for a fifth of their cycles (SQ_WAIT_ANY).  The loop alternates
   // the two buffers, so no fragment is ever copied; PHASE = parity of the component within this wave's sweep.
-  auto component = [&](ScreenFrags& fa, const ScreenFrags& fb, int kk, auto phase) {
+  auto component = [&](ScreenFrags& fa, const ScreenFrags& fb, int kk, auto phase, bool live) {
     constexpr int PHASE = decltype(phase)::value;
     const int k = __builtin_amdgcn_readfirstlane(cur.k);
     const float ck = cur.ck, ef = cur.ef, sk2 = cur.sk2, mn = cur.mn;
@@ -1393,13 +1398,13 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
       issue_pair(acc[1], fa, 1);
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // unconditional (clamped) prefetch
       screen_finish_pair<LSE>(acc[0][0], acc[0][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k, lane,
-                         cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep, m0, u0, okm[0]);
+                         cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep, m0, u0, live ? okm[0] : 0ull, live);
 #if !JD_SCREEN_LATE_EMIT
       flush(false);
 #endif
       issue_pair(acc[0], fb, 0);
       screen_finish_pair<LSE>(acc[1][0], acc[1][1], ck, ack, mn, ef, pxn[NP - 1], ps2[NP - 1] * sk2, pok[NP - 1], pL[NP - 1],
-                         pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[NP - 1], keep, m1, u1, okm[NP - 1]);
+                         pq[NP - 1], pn[NP - 1], k, lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[NP - 1], keep, m1, u1, live ? okm[NP - 1] : 0ull, live);
 #if !JD_SCREEN_LATE_EMIT
       flush(false);
 #endif
@@ -1408,7 +1413,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
       load_frags16(fa, af, __builtin_amdgcn_readfirstlane(k_ahead));  // (fa's MFMAs were issued by the previous component)
       issue_pair(acc[1 - PHASE], fb, 0);
       screen_finish_pair<LSE>(acc[PHASE][0], acc[PHASE][1], ck, ack, mn, ef, pxn[0], ps2[0] * sk2, pok[0], pL[0], pq[0], pn[0], k,
-                         lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep, m0, u0, okm[0]);
+                         lane, cnt_l, lb_n, lb_k, lb_ub, SCREEN_RB, pc[0], keep, m0, u0, live ? okm[0] : 0ull, live);
 #if !JD_SCREEN_LATE_EMIT
       flush(false);
 #endif
@@ -1435,9 +1440,15 @@ __global__ __launch_bounds__(256, NP == 1 ? 2 : 1) void gmm_screen_kernel(GmmScr
     }
 #endif
   };
+  // Components go in PAIRS, the loop has one exit: where a wave's share of the components is odd, the second component of
+  // its last pair is the (clamped) first position once more with its records suppressed (`live`; its bound changes
+  // nothing: L already holds it).  A conditional second component -- or a second exit -- leaves an edge from the end of the
+  // first component to the top of the loop, on which that component's prefetch (six loads into f0) is the newest thing in
+  // flight: the compiler then makes the first half of EVERY even component wait for all outstanding loads, the prefetch
+  // of the component after next included (s_waitcnt vmcnt(5) ... vmcnt(0) at the loop header).
   for (int kk = kk0; kk < a.K; kk += 2 * KSTEP) {
-    component(f0, f1, kk, std::integral_constant<int, 0>{});
-    if (kk + KSTEP < a.K) component(f1, f0, kk + KSTEP, std::integral_constant<int, 1>{});
+    component(f0, f1, kk, std::integral_constant<int, 0>{}, true);
+    component(f1, f0, kk + KSTEP, std::integral_constant<int, 1>{}, kk + KSTEP < a.K);
   }
   bool trouble = false;
 #pragma unroll
