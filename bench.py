@@ -95,7 +95,8 @@ def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
 def build_session_c6(device, shape=(2048, 2048), n_obs=8, seed=0, K=128):
     """Config "c6" (round-3 verdict): the fit the reference's Chandra example runs (examples/chandra-e0102-filament.py:
     91-93,178-203) at the benchmark's size -- 2048^2 counts grid, 8 observations, ``upsampling_factor=2`` (flux, exposure,
-    PSF and the GMM prior live on the 4096^2 grid), general 65x65 PSFs (130x130 after up-sampling: rocFFT), one
+    PSF and the GMM prior live on the 4096^2 grid), general 65x65 PSFs (130x130 after up-sampling: the native FFT
+    convolution, with the sum-pool + Poisson pass fused between its column passes), one
     `NPredCalibration` per observation (trained sub-pixel shift + background norm), joint fit."""
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent
     from jolideco_amd.data import instrument_observations, synthetic_gmm
@@ -114,7 +115,7 @@ def build_session_c6(device, shape=(2048, 2048), n_obs=8, seed=0, K=128):
 
 def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), n_obs=8):
     """Time config c6 (see `build_session_c6`): it/s and the per-kernel table.  No roofline object: the step is a chain of
-    rocFFT transforms, shift kernels and the 4096^2 prior -- the table says where the time goes."""
+    FFT launches, the transposed shift and the 4096^2 prior -- the table says where the time goes."""
     session = build_session_c6(device, shape=shape, n_obs=n_obs)
     for _ in range(warmup):
         session.epoch()

@@ -32,7 +32,7 @@ traffic() {  # <label> <bench args...>: FETCH_SIZE and WRITE_SIZE per kernel, se
   done
   python3 tools/pmc_traffic_csv.py ${label} $OUT/pmc_${label}_FETCH_SIZE $OUT/pmc_${label}_WRITE_SIZE > $OUT/pmc_${label}.csv
 }
-for cfg in c3 c4 c5; do kernel_stats $cfg --config $cfg; done
+for cfg in c3 c4 c5 c6; do kernel_stats $cfg --config $cfg; done
 traffic c3 --config c3
 traffic c4 --config c4
 # the same fit through the FFT path (the native FFT convolution on these sizes)
@@ -40,12 +40,20 @@ export JOLIDECO_CONV_METHOD=fft
 kernel_stats c3fft --config c3
 traffic c3fft --config c3
 unset JOLIDECO_CONV_METHOD
-# SQ counters of the default c3 step (the GMM screen kernel is the dominant launch): two passes
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq_a -o pmc -- \
-    python3 bench.py --steps 5 --warmup 2 --repeats 1 --settle-seconds 0 --no-cpu-baseline --no-general-psf > $OUT/sq_a.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq_b -o pmc -- \
-    python3 bench.py --steps 5 --warmup 2 --repeats 1 --settle-seconds 0 --no-cpu-baseline --no-general-psf > $OUT/sq_b.log 2>&1
-python3 tools/pmc_summary.py $OUT/sq_a $OUT/sq_b > $OUT/sq_counters.txt
+# SQ counters of the default c3 step (the GMM screen kernel is the dominant launch): five passes of four counters
+sq_pass() {
+  local name=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/sq_$name -o pmc -- \
+      python3 bench.py --steps 5 --warmup 2 --repeats 1 --settle-seconds 0 --no-cpu-baseline --no-general-psf > $OUT/sq_$name.log 2>&1
+}
+sq_pass a SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU
+sq_pass b SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+sq_pass c SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
+sq_pass d SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_COEXEC_CYCLES
+sq_pass e SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SALU SQ_ACTIVE_INST_LDS
+python3 tools/pmc_summary.py $OUT/sq_a $OUT/sq_b $OUT/sq_c $OUT/sq_d $OUT/sq_e > $OUT/sq_counters.txt
+# MFMA Toeplitz convolution against the native FFT convolution by PSF size (the rule of the method "auto")
+bash tools/gpu/convab.sh > $OUT/conv_method_crossover.txt 2>&1
 find $OUT -name "*.csv" -size +3M -delete
 find $OUT -name "*kernel_trace.csv" -delete
 ls -la $OUT

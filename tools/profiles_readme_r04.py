@@ -53,7 +53,7 @@ def sq(kernel):
 
 
 def main():
-    c3, c4, c5, f3 = stats("c3"), stats("c4"), stats("c5"), stats("c3fft")
+    c3, c4, c5, f3, c6 = stats("c3"), stats("c4"), stats("c5"), stats("c3fft"), stats("c6")
     b3, b3d, b2, b4, b5, b6 = (line(n) for n in ("c3_n1_bench", "c3_n1_bench_driver_flags", "c2_n1_bench", "c4_n1_bench", "c5_n1_bench", "c6_n1_bench"))
     fw = find(c3, "walk_mixed_kernel")
     ad17, ad33 = find(c3, "walk_kernel<17, 4, 3, false, false, 6"), find(c3, "walk_kernel<33, 2, 2, false, false, 2")
@@ -62,7 +62,7 @@ def main():
     be, dn = find(c3, "gmm_best"), find(c3, "gmm_fwd_kernel")
     f4, a4 = find(c4, "walk_kernel<17, 4, 2, true"), find(c4, "walk_kernel<17, 4, 2, false")
     m5 = find(c5, "walk_multi_kernel")
-    rows, cols, mid, inv = (find(f3, k) for k in ("fftn_rows_fwd", "fftn_cols", "fftn_rows_poisson", "fftn_rows_inv_kernel<true>"))
+    rows, cols, mid, inv = (find(f3, k) for k in ("fftn_rows_fwd", "fftn_cols", "fftn_rows_poisson", "fftn_rows_inv_kernel<true"))
     fw_mb = (16 * 8 + 4) * MPX
     rf, rw = pmc("c3", "walk_mixed_kernel")
     s = sq("gmm_screen_kernel")
@@ -70,6 +70,12 @@ def main():
     valu = s.get("SQ_ACTIVE_INST_VALU", float("nan")) / max(s.get("SQ_WAVE_CYCLES", float("nan")), 1)
     wait = s.get("SQ_WAIT_INST_ANY", float("nan")) / max(s.get("SQ_WAVE_CYCLES", float("nan")), 1)
     c6k = b6["kernel_ms_per_step"]
+    waitany = s.get("SQ_WAIT_ANY", float("nan")) / max(s.get("SQ_WAVE_CYCLES", float("nan")), 1)
+    coexec = s.get("SQ_VALU_MFMA_COEXEC_CYCLES", float("nan")) / max(s.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")), 1)
+    per_wc = s.get("SQ_INSTS_VALU", float("nan")) / (2040 * 128)
+    n6 = max(c6.get(next(k for k in c6 if 'gmm_screen' in k))[1], 1)  # steps in the profiled c6 run
+    c6rows = sorted(((v[0] * v[1] / n6, k, v[0], v[1] / n6) for k, v in c6.items() if v[1] >= n6 and 'elementwise_kernel' not in k), reverse=True)[:14]
+    c6table = '\n'.join(f'| `{k[:90]}` | {per:.1f} | {avg:.1f} | {tot / 1e3:.2f} |' for tot, k, avg, per in c6rows)
     fft = b3.get("fft_psf", {})
     text = f"""## r04 (round 4)
 
@@ -79,21 +85,23 @@ SURVEY section 8(d)'s: 6 x 17x17 + 2 x 33x33 PSFs (`config.psf_shapes` in the be
 
 | file | what |
 |---|---|
-| `r04/c3_n1_bench.json` | `python bench.py` (200 steps x 9 regions after 20 warm-up + >= 0.3 s settle): **{b3['value']:.0f} it/s, {b3['ms_per_step']:.4f} ms/step** (regions {b3['ms_per_step_min']:.4f}-{b3['ms_per_step_max']:.4f}), host enqueue {b3['host_enqueue_ms_per_step']:.3f} ms/step; `general_psf` {b3['general_psf']['value']:.0f}, `fft_psf` {fft.get('value', float('nan')):.0f} it/s ({fft.get('ms_per_step', float('nan')):.3f} ms; round 3: 375 through rocFFT), `dense_fp32_gmm` {b3['dense_fp32_gmm']['value']:.0f} it/s, `sequential_mode` {b3['sequential_mode']['epochs_per_s']:.0f} epochs/s, `c6_chandra_like` {b3['c6_chandra_like']['value']:.0f} it/s; CPU oracle {b3['cpu_baseline']['value']:.2f} it/s on {b3['cpu_baseline']['cores']} cores |
+| `r04/c3_n1_bench.json` | `python bench.py` (200 steps x 9 regions after 20 warm-up + >= 0.3 s settle): **{b3['value']:.0f} it/s, {b3['ms_per_step']:.4f} ms/step** (regions {b3['ms_per_step_min']:.4f}-{b3['ms_per_step_max']:.4f}), host enqueue {b3['host_enqueue_ms_per_step']:.3f} ms/step; `general_psf` {b3['general_psf']['value']:.0f} (17x17 MFMA Toeplitz, 33x33 native FFT; everything MFMA Toeplitz, `direct_psf`: {b3.get('direct_psf', {}).get('value', float('nan')):.0f}), `fft_psf` {fft.get('value', float('nan')):.0f} it/s ({fft.get('ms_per_step', float('nan')):.3f} ms; round 3: 375 through rocFFT; start of round 4: 690), `dense_fp32_gmm` {b3['dense_fp32_gmm']['value']:.0f} it/s, `sequential_mode` {b3['sequential_mode']['epochs_per_s']:.0f} epochs/s, `c6_chandra_like` {b3['c6_chandra_like']['value']:.0f} it/s; CPU oracle {b3['cpu_baseline']['value']:.2f} it/s on {b3['cpu_baseline']['cores']} cores |
 | `r04/c3_n1_bench_driver_flags.json` | the same box, `--steps 20 --warmup 5` (the driver's flags): {b3d['value']:.0f} it/s, {b3d['ms_per_step']:.4f} ms/step |
 | `r04/c3_n1_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-general-psf`: the per-kernel table below |
 | `r04/c2_n1_bench.json`, `c4_n1_bench.json`, `c5_n1_bench.json` | `--config c2|c4|c5 --steps 100 --warmup 10`: c2 {b2['value']:.0f} it/s ({b2['ms_per_step']:.3f} ms), c4 {b4['value']:.0f} it/s ({b4['ms_per_step']:.3f} ms), c5 {b5['value']:.0f} it/s ({b5['ms_per_step']:.3f} ms; 16 observations: 6 x 17x17 + 10 x 33x33 "extended" PSFs) |
-| `r04/c6_n1_bench.json` | `--config c6`: 2048^2 counts grid, up-sampling x2, 8 calibrated observations, general 65x65 PSFs (the reference's Chandra example at the benchmark's size): **{b6['value']:.0f} it/s, {b6['ms_per_step']:.2f} ms/step**, host enqueue {b6['host_enqueue_ms_per_step']:.2f} ms/step; per step: native FFT rows {c6k.get('fft_r2c', 0):.2f} + columns {c6k.get('cmul', 0):.2f} + rows^-1 {c6k.get('fft_c2r', 0):.2f} ms, Poisson {c6k.get('poisson_fused', 0):.2f}, prior {c6k.get('gmm_fwd', 0):.2f} + gather {c6k.get('gmm_gather', 0):.2f} ms (the shift kernels carry no timer) |
+| `r04/c6_n1_bench.json` | `--config c6`: 2048^2 counts grid, up-sampling x2, 8 calibrated observations, general 65x65 PSFs (the reference's Chandra example at the benchmark's size): **{b6['value']:.0f} it/s, {b6['ms_per_step']:.2f} ms/step** (first measurement of the round: 119 it/s, 8.41 ms), host enqueue {b6['host_enqueue_ms_per_step']:.2f} ms/step; per step: native FFT rows (+ shift) {c6k.get('fft_r2c', 0):.2f} + columns {c6k.get('cmul', 0):.2f} + rows^-1 {c6k.get('fft_c2r', 0):.2f} ms, rows^-1 x 2 + pool + Poisson + rows of g {c6k.get('poisson_fused', 0):.2f}, prior {c6k.get('gmm_fwd', 0):.2f} + gather {c6k.get('gmm_gather', 0):.2f} ms (the transposed-shift kernel carries no timer) |
+| `r04/c6_n1_kernel_stats.csv` | rocprofv3 summary of `--config c6`: the table at the end of this section |
 | `r04/c4_n1_kernel_stats.csv`, `r04/c5_n1_kernel_stats.csv`, `r04/c3fft_n1_kernel_stats.csv` | rocprofv3 summaries of c4, c5 and of c3 through the FFT path (`JOLIDECO_CONV_METHOD=fft`: the native FFT convolution) |
 | `r04/pmc_hbm_traffic.csv` (+ `.commit`) | FETCH_SIZE / WRITE_SIZE per kernel, separate passes; rows `c3`, `c4`, `c3fft`; HBM reads = 2 x FETCH_SIZE (`MI355X_MICROARCH.md`) |
-| `r04/sq_counters.txt` | SQ counters of the c3 step (two passes), per launch: the screen kernel's matrix / vector / wait shares below |
-| `r04/ab_*.txt` | the A/B runs of the round (one process or one call each): packed row pass, mixed-launch balance, 33-tap adjoint tiling, native FFT column kernel with parts switched off |
+| `r04/sq_counters.txt` | SQ counters of the c3 step (five passes of four counters), per launch: the screen kernel's matrix / vector / wait shares below |
+| `r04/conv_method_crossover.txt` | `tools/conv_bench.py`: MFMA Toeplitz against native FFT convolution at 1024^2 / 2048^2 / 4096^2, 17-33 taps (the rule of the method "auto") |
+| `r04/ab_*.txt` | the A/B runs of the round (one process or one call each): packed row pass, mixed-launch balance, 33-tap adjoint tiling, native FFT column kernel with parts switched off; second session: `ab_fft8_*` (FFT kernels of the round's start against the last build: c3 through the FFT path and c6), `ab_fft9_*` (columns per block), `ab_ilv_*` (dataset order of the walk forward launch), `ab_scr_*` (screen kernel builds) |
 
 Fractions of the roofs, recomputable from `r04/c3_n1_kernel_stats.csv` (AverageNs) and the algorithmic bytes of DESIGN.md section 3:
 
 | kernel | rocprofv3 avg | achieved | PMC traffic per launch |
 |---|---|---|---|
-| `gmm_screen_kernel<2, false, true, false>` | {sc:.1f} us | 0.2054 TFLOP fp16 / {sc:.1f} us = {0.2054 / sc * 1e6:.0f} TFLOP/s = **{0.2054 / sc * 1e6 / 2516.6 * 100:.1f} %** of 2516.6; SQ: matrix pipe busy {busy * 100:.0f} % of the wave cycles, vector instructions active {valu * 100:.0f} %, waiting on an instruction's operands {wait * 100:.0f} % | {pmc('c3', 'gmm_screen')[0]:.0f} MB read + {pmc('c3', 'gmm_screen')[1]:.0f} MB written |
+| `gmm_screen_kernel<2, false, true, false>` | {sc:.1f} us | 0.2054 TFLOP fp16 / {sc:.1f} us = {0.2054 / sc * 1e6:.0f} TFLOP/s = **{0.2054 / sc * 1e6 / 2516.6 * 100:.1f} %** of 2516.6; SQ: matrix pipe busy {busy * 100:.0f} % of the wave cycles, vector instructions active {valu * 100:.0f} %, parked on s_waitcnt {waitany * 100:.0f} %, waiting on an instruction's operands {wait * 100:.0f} %; {per_wc:.0f} vector + matrix instructions per wave and component; vector and matrix pipes busy together in {coexec * 100:.0f} % of the matrix pipe's busy cycles | {pmc('c3', 'gmm_screen')[0]:.0f} MB read + {pmc('c3', 'gmm_screen')[1]:.0f} MB written |
 | `walk_mixed_kernel<4, 2>` (8 forward models + Poisson passes: 6 in the 17-tap frame at 4 columns per lane, 2 in the 33-tap frame at 2) | **{fw:.1f} us** | {fw_mb:.1f} MB (flux counted once) / {fw:.1f} us = {fw_mb / fw:.2f} TB/s = **{fw_mb / fw / 8 * 100:.1f} %** of 8 TB/s | {rf:.0f} MB read + {rw:.0f} MB written = {(rf + rw) / fw_mb:.2f} x algorithmic |
 | `walk_kernel<17, 4, 3, false, false, 6, 8>` (adjoints of the 6 17-tap observations) | {ad17:.1f} us | {(8 * 6 + 8) * MPX:.0f} MB / {ad17:.1f} us = {(8 * 6 + 8) * MPX / ad17:.2f} TB/s = {(8 * 6 + 8) * MPX / ad17 / 8 * 100:.1f} % | {pmc('c3', 'walk_kernel<17, 4, 3')[0]:.0f} MB read + {pmc('c3', 'walk_kernel<17, 4, 3')[1]:.0f} MB written |
 | `walk_kernel<33, 2, 2, false, false, 2, 8>` (adjoints of the 2 33-tap observations, accumulated) | {ad33:.1f} us | {(8 * 2 + 8) * MPX:.0f} MB / {ad33:.1f} us = {(8 * 2 + 8) * MPX / ad33:.2f} TB/s = {(8 * 2 + 8) * MPX / ad33 / 8 * 100:.1f} % (vector-instruction bound: 36 + 32 warm-up rows per tile) | {pmc('c3', 'walk_kernel<33, 2, 2, false, false, 2')[0]:.0f} MB read + {pmc('c3', 'walk_kernel<33, 2, 2, false, false, 2')[1]:.0f} MB written |
@@ -111,6 +119,12 @@ c4 (`r04/c4_n1_kernel_stats.csv`): screen {find(c4, 'gmm_screen'):.0f} us, exact
 c5 (`r04/c5_n1_kernel_stats.csv`): `walk_multi_kernel<2, 2, 33>` {m5:.0f} us (16 x 2 forward models + 16 Poisson passes, the "extended" component of
 10 observations in the 33-tap frame: 32 B per (pixel, dataset) -> {32 * 16 * MPX / m5:.2f} TB/s), five adjoint launches
 ({', '.join(f'{v[0]:.0f} us x {v[1] // max(c5[next(iter(c5))][1] // c5[next(iter(c5))][1], 1)}' for k, v in c5.items() if 'walk_kernel<' in k and 'false, false' in k)} calls in the profiled run), prior as in c3.
+
+c6 (`r04/c6_n1_kernel_stats.csv`; per step = 8 calibrated observations at 4096^2 flux pixels + the prior):
+
+| kernel | launches per step | avg us | ms per step |
+|---|---|---|---|
+{c6table}
 
 """
     text = re.sub(r" x (\d+) calls", r" x \1 calls", text)
