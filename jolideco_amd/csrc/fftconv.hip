@@ -47,6 +47,9 @@ struct jd_conv_plan {
   float* gbatch[jd::SEP_MAX_BATCH * jd::SEP_BATCH_MAX_COMP] = {nullptr};
   double* partials_batch = nullptr;
   int partials_batch_cap = 0;
+  // batched joint step on the native FFT path: the work arrays of datasets 1 .. (dataset 0 uses fftn's own)
+  float2* fft_extra_spec[jd::FFT_MAX_BATCH - 1] = {nullptr};
+  float2* fft_extra_work[jd::FFT_MAX_BATCH - 1] = {nullptr};
   // pointer tables of the batched joint step in device memory: a few slots keyed by content, so that sessions (or the
   // chunks of a fit with more than SEP_MAX_BATCH datasets) that alternate between tables never re-upload -- an upload
   // has to wait for the stream
@@ -285,6 +288,10 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
   if (!p) return JD_OK;
   (void)hipDeviceSynchronize();
   if (p->native) fftn_destroy(&p->fftn);
+  for (int i = 0; i < jd::FFT_MAX_BATCH - 1; ++i) {
+    if (p->fft_extra_spec[i]) (void)hipFree(p->fft_extra_spec[i]);
+    if (p->fft_extra_work[i]) (void)hipFree(p->fft_extra_work[i]);
+  }
   if (p->fwd) rocfft_plan_destroy(p->fwd);
   if (p->inv) rocfft_plan_destroy(p->inv);
   if (p->info) rocfft_execution_info_destroy(p->info);
@@ -585,8 +592,47 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
                                                     void* stream) {
   const char* who = "jd_npred_poisson_batch_multi_fwd_bwd";
   JD_REQUIRE(p && flux && exposure && khat && background && counts && stirling_mean && loss_out, "%s: null argument", who);
-  JD_REQUIRE(p->method == JD_CONV_SEPARABLE,
-             "%s: the plan must use the separable method (one jd_npred_poisson_fwd_bwd per dataset otherwise)", who);
+  JD_REQUIRE(p->method == JD_CONV_SEPARABLE || (p->native && n_comp == 1),
+             "%s: the plan must use the separable method, or the native FFT path with one flux component (one "
+             "jd_npred_poisson_fwd_bwd per dataset otherwise)", who);
+  if (p->native) {
+    // native FFT path: every launch of the likelihood step covers all datasets (fftn_poisson_step_batch); forward-only
+    // evaluations (the trace) and switched-off fusion run the per-dataset calls this stands for
+    JD_REQUIRE(flux[0], "%s: flux[0] is null", who);
+    for (int d = 0; d < n_datasets; ++d)
+      JD_REQUIRE(exposure[d] && khat[d] && background[d] && counts[d] && loss_out[d], "%s: null pointer for dataset %d", who, d);
+    hipStream_t s = as_stream(stream);
+    if (!grad_flux || !grad_flux[0] || n_datasets > FFT_MAX_BATCH || n_datasets < 2 || opt_is_set(OPT_SEP_NO_FUSION) ||
+        opt_value(OPT_FFT_BATCH, 1) == 0) {
+      for (int d = 0; d < n_datasets; ++d) {
+        int rc = npred_poisson_impl(who, p, 1, flux, exposure + d, khat + d, background[d], counts[d], stirling_mean[d], eps,
+                                    loss_out[d], grad_flux, accumulate || d > 0, grad_scale, nullptr, 1, Calibration{}, stream);
+        if (rc) return rc;
+      }
+      return JD_OK;
+    }
+    const FftNative& fn = p->fftn;
+    for (int d = 0; d + 1 < n_datasets; ++d) {
+      if (!p->fft_extra_spec[d]) JD_HIP(hipMalloc(&p->fft_extra_spec[d], (size_t)fn.Hh * fn.Nx * sizeof(float2)));
+      if (!p->fft_extra_work[d]) JD_HIP(hipMalloc(&p->fft_extra_work[d], (size_t)fn.Ny * fn.Nx * sizeof(float2)));
+    }
+    if (p->partials_batch_cap < n_datasets * fn.Hh) {
+      if (p->partials_batch) (void)hipFree(p->partials_batch);
+      p->partials_batch = nullptr, p->partials_batch_cap = 0;
+      JD_HIP(hipMalloc(&p->partials_batch, (size_t)n_datasets * fn.Hh * sizeof(double)));
+      p->partials_batch_cap = n_datasets * fn.Hh;
+    }
+    FftBatch batch{};
+    batch.n = n_datasets;
+    for (int d = 0; d < n_datasets; ++d) {
+      batch.exposure[d] = exposure[d], batch.khat[d] = reinterpret_cast<const float2*>(khat[d]);
+      batch.background[d] = background[d], batch.counts[d] = counts[d];
+      batch.loss_out[d] = loss_out[d], batch.loss_offset[d] = stirling_mean[d];
+    }
+    const double n_pix = (double)p->H * (double)p->W;
+    return fftn_poisson_step_batch(fn, batch, p->fft_extra_spec, p->fft_extra_work, flux[0], p->partials_batch, eps,
+                                   (float)(1.0 / n_pix), grad_flux[0], grad_scale, accumulate, s, 1.0 / n_pix);
+  }
   JD_REQUIRE(n_datasets >= 1 && n_datasets <= SEP_MAX_BATCH, "%s: n_datasets = %d not in [1, %d]", who, n_datasets,
              SEP_MAX_BATCH);
   JD_REQUIRE(n_comp >= 1 && n_comp <= SEP_BATCH_MAX_COMP, "%s: n_comp = %d not in [1, %d]", who, n_comp, SEP_BATCH_MAX_COMP);

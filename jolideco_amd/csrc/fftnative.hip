@@ -294,6 +294,12 @@ __device__ __forceinline__ void column_conv_inplace(float2* x, int N, const FftP
   }
 }
 
+// Per-dataset pointers of a batched likelihood step (several datasets of one flux image in every launch: the blocks of a
+// launch then run in several rounds and at different stages, and the load, transform and store phases of the launch
+// overlap -- a single dataset's launch is ONE round of blocks that all load, then all transform, then all store).
+// n = 0: one dataset, described by the scalar members of the kernel's arguments.
+// (struct FftBatch: kernels.h)
+
 struct __attribute__((packed, aligned(4))) F4U4 {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
   float x, y, z, w;
 };
@@ -302,6 +308,7 @@ struct RowsFwdArgs {
   const float* in;
   const float* shift_xy;  // nullable, device [2]: the input is the bilinearly shifted image (the calibration's shift_fwd)
   float shift_scale;
+  FftBatch batch;      // batch.n > 0: block b = row pair b / n of dataset b % n (scale, spec from the table)
   const float* scale;  // nullable
   float2* spec;        // [Hh][Nx]
   const float2* tw;
@@ -315,7 +322,10 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
-  const int tid = threadIdx.x, y = blockIdx.x;
+  const int tid = threadIdx.x, nb = a.batch.n;
+  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
+  const float* const scale = nb ? a.batch.exposure[d] : a.scale;
+  float2* const spec = nb ? a.batch.spec[d] : a.spec;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   const size_t ra = (size_t)y * a.W, rb = (size_t)(y + a.Hh) * a.W;
@@ -376,8 +386,8 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
         u = *reinterpret_cast<const float4*>(a.in + ra + x);
         v = *reinterpret_cast<const float4*>(a.in + rb + x);
       }
-      if (a.scale) {
-        const float4 su_ = *reinterpret_cast<const float4*>(a.scale + ra + x), sv_ = *reinterpret_cast<const float4*>(a.scale + rb + x);
+      if (scale) {
+        const float4 su_ = *reinterpret_cast<const float4*>(scale + ra + x), sv_ = *reinterpret_cast<const float4*>(scale + rb + x);
         u.x *= su_.x, u.y *= su_.y, u.z *= su_.z, u.w *= su_.w;
         v.x *= sv_.x, v.y *= sv_.y, v.z *= sv_.z, v.w *= sv_.w;
       }
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
   }
   __syncthreads();
   const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
-  float2* out = a.spec + (size_t)y * Nx;
+  float2* out = spec + (size_t)y * Nx;
   for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
@@ -401,6 +411,7 @@ struct ColsArgs {
   const float2* tw;
   int Hh, Nx, Ny, conj, groups;
   int keep_lo, keep_hi;  // rows [0, keep_lo) and [keep_hi, Ny) of the result are written (the others are never read)
+  FftBatch batch;        // batch.n > 0: block b = column group b / n of dataset b % n (spec, work, khat from the table)
   FftPasses f;
 };
 
@@ -429,8 +440,13 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   const int Ny = STATIC ? R0 * R1 * R2 : a.Ny;
   // neighbouring column groups (the same 128-byte lines of every spectrum row) go to the same XCD (blockIdx % 8), one
   // after the other: the partial lines they read and write meet in that XCD's L2
+  const int nb = a.batch.n;
+  const int bq = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - bq * nb : 0;
+  const float2* const spec_in = nb ? a.batch.spec[d] : a.spec;
+  float2* const work_out = nb ? a.batch.work[d] : a.work;
+  const float2* const khat = nb ? a.batch.khat[d] : a.khat;
   const int per_xcd = (a.groups + 7) / 8;
-  const int g = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const int g = (bq % 8) * per_xcd + bq / 8;
   if (g >= a.groups) return;
   const int x0 = g * CB;
   const int stride = lp_size(Ny);
@@ -440,14 +456,14 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   for (int i = tid; i < Ny * half; i += LANES * CB) {
     const int row = i / half, piece = i - row * half;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < a.Hh) v = *reinterpret_cast<const float4*>(a.spec + (size_t)row * a.Nx + x0 + 2 * piece);
+    if (row < a.Hh) v = *reinterpret_cast<const float4*>(spec_in + (size_t)row * a.Nx + x0 + 2 * piece);
     float2* c0 = lds + (size_t)(2 * piece) * stride;
     c0[lp(row)] = float2{v.x, v.y};
     c0[stride + lp(row)] = float2{v.z, v.w};
   }
   __syncthreads();
   // ---- per column: FFT, product with the kernel spectrum, inverse FFT ------------------------------------------------
-  const float2* kcol = a.khat + (size_t)(x0 + wc) * Ny;
+  const float2* kcol = khat + (size_t)(x0 + wc) * Ny;
   if constexpr (STATIC) column_conv_static<LANES, R0, R1, R2>(col, a.tw, kcol, a.conj, lane);
   else column_conv_inplace<LANES>(col, Ny, a.f, a.tw, kcol, a.conj, lane);
   __syncthreads();
@@ -457,7 +473,7 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
     if (row >= a.keep_lo && row < a.keep_hi) continue;
     const float2* c0 = lds + (size_t)(2 * piece) * stride;
     const float2 p = c0[lp(row)], q = c0[stride + lp(row)];
-    *reinterpret_cast<float4*>(a.work + (size_t)row * a.Nx + x0 + 2 * piece) = make_float4(p.x, p.y, q.x, q.y);
+    *reinterpret_cast<float4*>(work_out + (size_t)row * a.Nx + x0 + 2 * piece) = make_float4(p.x, p.y, q.x, q.y);
   }
 }
 
@@ -514,12 +530,14 @@ struct RowsInvArgs {
   const double* fin2_partials;  // a second sum of fin_count terms (block 1): d loss / d log background norm
   double fin2_scale;
   float* fin2_out;
+  FftBatch batch;               // fftn_rows_inv_batch_kernel: the datasets whose adjoints one block adds up, in order
   FftPasses f;
 };
 
 // rows^-1 + epilogue.  ADJ = false: out = conv;  ADJ = true: out (+)= (coef * corr) * scale
 template <bool ADJ, int R0, int R1, int R2, int R3>
 __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs a) {
+#pragma clang fp contract(off)  // (product, product, sum: the batched form below must give the same bits)
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
@@ -570,15 +588,79 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
   }
 }
 
+// The adjoint's last launch for SEVERAL datasets: block y runs the inverse row transform of every dataset's row pair in
+// turn and adds (coef * corr_d) * exposure_d in dataset order -- the sums the per-dataset launches leave in `out` when
+// each accumulates onto its predecessor, bit for bit -- and writes the two gradient rows once.  Blocks 0 .. n - 1
+// finalise the datasets' losses (fin_count partial sums each).
+template <int R0, int R1, int R2, int R3>
+__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_batch_kernel(RowsInvArgs a) {
+#pragma clang fp contract(off)
+  extern __shared__ float2 lds[];
+  using S = RowSched<R0, R1, R2, R3>;
+  const int Nx = S::STATIC ? S::N : a.Nx;
+  const int tid = threadIdx.x, y = blockIdx.x;
+  float2* bufa = lds;
+  float2* bufb = lds + lp_size(Nx);
+  constexpr int MAXQ = 5;
+  const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
+  float4 au[MAXQ], ad[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) au[q] = ad[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+  for (int d = 0; d < a.batch.n; ++d) {
+    load_spectrum_row(bufa, a.batch.work[d], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+    const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
+    const float* scale = a.batch.exposure[d];
+    const bool add = d > 0 || a.accumulate;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int x = 4 * (tid + q * ROW_THREADS);
+      if (x >= a.W) continue;
+      const int e = lp(x);
+      const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
+      float4 up = make_float4(c0.x, c1.x, c2.x, c3.x), dn = make_float4(c0.y, c1.y, c2.y, c3.y);
+      up.x *= a.coef, up.y *= a.coef, up.z *= a.coef, up.w *= a.coef;
+      dn.x *= a.coef, dn.y *= a.coef, dn.z *= a.coef, dn.w *= a.coef;
+      const float4 s1 = *reinterpret_cast<const float4*>(scale + o1 + x), s2 = *reinterpret_cast<const float4*>(scale + o2 + x);
+      up.x *= s1.x, up.y *= s1.y, up.z *= s1.z, up.w *= s1.w;
+      dn.x *= s2.x, dn.y *= s2.y, dn.z *= s2.z, dn.w *= s2.w;
+      if (add) {
+        float4 g1 = au[q], g2 = ad[q];
+        if (d == 0) g1 = *reinterpret_cast<const float4*>(a.out + o1 + x), g2 = *reinterpret_cast<const float4*>(a.out + o2 + x);
+        up.x += g1.x, up.y += g1.y, up.z += g1.z, up.w += g1.w;
+        dn.x += g2.x, dn.y += g2.y, dn.z += g2.z, dn.w += g2.w;
+      }
+      au[q] = up, ad[q] = dn;
+    }
+    __syncthreads();  // the result buffer is the next dataset's work space
+  }
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) {
+    const int x = 4 * (tid + q * ROW_THREADS);
+    if (x >= a.W) continue;
+    *reinterpret_cast<float4*>(a.out + o1 + x) = au[q];
+    *reinterpret_cast<float4*>(a.out + o2 + x) = ad[q];
+  }
+  if (a.fin_partials && (int)blockIdx.x < a.batch.n) {  // (block-uniform)
+    __shared__ double red[ROW_THREADS / 64];
+    const double* part = a.fin_partials + (size_t)blockIdx.x * a.fin_count;
+    double acc = 0.0;
+    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
+    const double total = block_sum<ROW_THREADS>(acc, red);
+    if (tid == 0) a.batch.loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.batch.loss_offset[blockIdx.x]);
+  }
+}
+
 struct RowsPoissonArgs {
   const float2* work;  // [Ny][Nx]: the forward convolution after the column pass
   float2* spec;        // [Hh][Nx]: <- row spectra of g (the input of the adjoint's column pass)
   const float2* tw;
   const float* background;
   const float* counts;
-  double* partials;    // [Hh]
+  double* partials;    // [Hh] ([n][Hh] for a batch)
   int H, W, Hh, Nx, Ny, ra, rb;
   float eps, inv_n;
+  FftBatch batch;      // batch.n > 0: block b = row pair b / n of dataset b % n
   FftPasses f;
 };
 
@@ -592,11 +674,16 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   __shared__ double red[ROW_THREADS / 64];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
-  const int tid = threadIdx.x, y = blockIdx.x;
+  const int tid = threadIdx.x, nb = a.batch.n;
+  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
+  const float2* const work = nb ? a.batch.work[d] : a.work;
+  float2* const spec = nb ? a.batch.spec[d] : a.spec;
+  const float* const background = nb ? a.batch.background[d] : a.background;
+  const float* const counts = nb ? a.batch.counts[d] : a.counts;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5;
-  load_spectrum_row(bufa, a.work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  load_spectrum_row(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
   const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
   float4 gu[MAXQ], gd[MAXQ];
@@ -609,8 +696,8 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
     const int e = lp(x);
     const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
     float up[4] = {c0.x, c1.x, c2.x, c3.x}, dn[4] = {c0.y, c1.y, c2.y, c3.y};
-    const float4 b1 = *reinterpret_cast<const float4*>(a.background + o1 + x), b2 = *reinterpret_cast<const float4*>(a.background + o2 + x);
-    const float4 n1 = *reinterpret_cast<const float4*>(a.counts + o1 + x), n2 = *reinterpret_cast<const float4*>(a.counts + o2 + x);
+    const float4 b1 = *reinterpret_cast<const float4*>(background + o1 + x), b2 = *reinterpret_cast<const float4*>(background + o2 + x);
+    const float4 n1 = *reinterpret_cast<const float4*>(counts + o1 + x), n2 = *reinterpret_cast<const float4*>(counts + o2 + x);
     const float bu[4] = {b1.x, b1.y, b1.z, b1.w}, bd[4] = {b2.x, b2.y, b2.z, b2.w};
     const float cu[4] = {n1.x, n1.y, n1.z, n1.w}, cd[4] = {n2.x, n2.y, n2.z, n2.w};
     float g1[4], g2[4];
@@ -627,7 +714,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
     gu[q] = make_float4(g1[0], g1[1], g1[2], g1[3]), gd[q] = make_float4(g2[0], g2[1], g2[2], g2[3]);
   }
   const double total = block_sum<ROW_THREADS>((double)local, red);
-  if (tid == 0) a.partials[y] = total;
+  if (tid == 0) a.partials[(size_t)d * a.Hh + y] = total;
   __syncthreads();  // every thread has read its part of the convolution row: the buffers are free
   // ---- z = g[y] + i g[y + Hh], zero padded: the adjoint's row transform ---------------------------------------------
 #pragma unroll
@@ -640,7 +727,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   }
   __syncthreads();
   const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
-  float2* out = a.spec + (size_t)y * Nx;
+  float2* out = spec + (size_t)y * Nx;
   for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
@@ -849,12 +936,13 @@ int lds_attr(const void* kernel, size_t bytes, size_t* set) {
   return JD_OK;
 }
 
-int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream) {
+int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream, const FftBatch* batch = nullptr) {
   const FftPasses fy = passes_of(n.Ny);
   const int ra = adjoint ? n.kh - 1 - n.oy : n.oy, rb = adjoint ? n.oy : n.kh - 1 - n.oy;
   ColsArgs a{};
   a.spec = n.spec, a.work = n.work, a.khat = khat, a.tw = n.tw_y, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.conj = adjoint ? 1 : 0;
   a.keep_lo = n.Hh + rb, a.keep_hi = n.Ny - ra, a.f = fy;
+  if (batch) a.batch = *batch;
   const size_t per_col = (size_t)lp_size(n.Ny) * sizeof(float2);
   const int lanes = column_lanes(n.Ny, fy);
   if (!lanes) return fail(JD_ERR_INVALID, "native FFT: no column kernel for length %d", n.Ny);
@@ -891,7 +979,7 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   int rc = lds_attr(reinterpret_cast<const void*>(e->kernel), cb * per_col, &e->lds_set);
   if (rc) return rc;
   ProfScope prof(JD_KERNEL_CMUL, stream);
-  hipLaunchKernelGGL(e->kernel, dim3(((a.groups + 7) / 8) * 8), dim3(lanes * cb), cb * per_col, stream, a);
+  hipLaunchKernelGGL(e->kernel, dim3(((a.groups + 7) / 8) * 8 * (batch ? batch->n : 1)), dim3(lanes * cb), cb * per_col, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -925,13 +1013,14 @@ int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), size_t (&set)
 }
 
 int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream, const float* shift_xy = nullptr,
-                    float shift_scale = 1.f) {
+                    float shift_scale = 1.f, const FftBatch* batch = nullptr) {
   static void (*const kernels[N_ROW_SCHED])(RowsFwdArgs) = JD_ROW_KERNELS(fftn_rows_fwd_kernel, );
   static size_t set[N_ROW_SCHED] = {};
   RowsFwdArgs a{};
   a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
   a.shift_xy = shift_xy, a.shift_scale = shift_scale;
-  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream);
+  if (batch) a.batch = *batch;
+  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream, batch ? n.Hh * batch->n : 0);
 }
 
 int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream,
@@ -1021,6 +1110,44 @@ int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* fl
   const SepLossFold fold{partials, n.Hh / upsampling, loss_scale, loss_offset, loss_out};
   const SepLossFold fold2{partials_b, n.Hh / upsampling, norm_grad_scale, 0.0, norm_grad_out};
   return launch_rows_inv(n, target, exposure, 1, coef, accumulate, stream, &fold, norm_grad_out ? &fold2 : nullptr);
+}
+
+// The likelihood steps of `nd` datasets of ONE flux image in five launches (every launch covers all datasets; the last one
+// adds the datasets' gradients in order inside its blocks): the same sums, bit for bit, as fftn_poisson_step called for
+// the datasets one after the other with `accumulate` from the second on.  batch: exposure, khat, background, counts,
+// loss_out, loss_offset per dataset; spec / work are filled in here (dataset 0 uses the plan's own arrays, the others
+// `extra`: nd - 1 pairs of (spec, work) arrays).  partials: nd * Hh doubles.
+int fftn_poisson_step_batch(const FftNative& n, FftBatch batch, float2* const* extra_spec, float2* const* extra_work, const float* flux,
+                            double* partials, float eps, float inv_n, float* grad, float coef, int accumulate, hipStream_t stream,
+                            double loss_scale) {
+  const int nd = batch.n;
+  if (nd < 1 || nd > FFT_MAX_BATCH) return fail(JD_ERR_INVALID, "native FFT batch: %d datasets not in [1, %d]", nd, FFT_MAX_BATCH);
+  for (int d = 0; d < nd; ++d) {
+    batch.spec[d] = d ? extra_spec[d - 1] : n.spec;
+    batch.work[d] = d ? extra_work[d - 1] : n.work;
+  }
+  int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, 1.f, &batch);
+  if (rc) return rc;
+  if ((rc = launch_cols(n, nullptr, 0, stream, &batch))) return rc;
+  {
+    static void (*const kernels[N_ROW_SCHED])(RowsPoissonArgs) = JD_ROW_KERNELS(fftn_rows_poisson_kernel, );
+    static size_t set[N_ROW_SCHED] = {};
+    RowsPoissonArgs a{};
+    a.tw = n.tw_x, a.partials = partials;
+    a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
+    a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch;
+    if ((rc = launch_row_kernel(kernels, set, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh * nd))) return rc;
+  }
+  if ((rc = launch_cols(n, nullptr, 1, stream, &batch))) return rc;
+  static void (*const kernels[N_ROW_SCHED])(RowsInvArgs) = {fftn_rows_inv_batch_kernel<0, 0, 0, 0>, fftn_rows_inv_batch_kernel<16, 16, 9, 0>,
+                                                            fftn_rows_inv_batch_kernel<8, 8, 8, 9>, fftn_rows_inv_batch_kernel<16, 8, 9, 0>};
+  static size_t set[N_ROW_SCHED] = {};
+  RowsInvArgs a{};
+  a.tw = n.tw_x, a.out = grad, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
+  a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
+  a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx), a.batch = batch;
+  a.fin_partials = partials, a.fin_count = n.Hh, a.fin_scale = loss_scale;
+  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_C2R, stream);
 }
 
 }  // namespace jd

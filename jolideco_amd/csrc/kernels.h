@@ -67,7 +67,7 @@ enum JdOption {
   OPT_GMM_SCREEN_NP, OPT_GMM_SCREEN_NO_LDS_CONSTS, OPT_GMM_SCREEN_DEBUG, OPT_GMM_SCREEN, OPT_GMM_FUSED_BWD,
   OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_SEP_JOINT, OPT_SEP_JOINT_ROWS, OPT_SEP_JOINT_CHUNK,
   OPT_SEP_WALK_ADJ_ALL, OPT_SEP_WALK_COST33, OPT_SEP_WALK_ROWS33, OPT_SEP_NO_TRIM, OPT_SEP_WALK_ADJ_ROWS33,
-  OPT_SEP_WALK_ADJ33, OPT_FFT_NATIVE, OPT_DIRECT_AUTO_ALL, OPT_COUNT
+  OPT_SEP_WALK_ADJ33, OPT_FFT_NATIVE, OPT_DIRECT_AUTO_ALL, OPT_FFT_BATCH, OPT_COUNT
 };
 bool opt_is_set(int id);
 int opt_value(int id, int unset_value);
@@ -223,6 +223,21 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
                       const float* counts, double* partials, int* n_partials, float eps, float inv_n, float* grad, float coef,
                       int accumulate, hipStream_t stream, double loss_scale, double loss_offset, float* loss_out);
 
+constexpr int FFT_MAX_BATCH = 16;
+struct FftBatch {  // per-dataset pointers of a batched likelihood step on the native FFT path (fftnative.hip)
+  int n;
+  const float* exposure[FFT_MAX_BATCH];
+  const float2* khat[FFT_MAX_BATCH];
+  const float* background[FFT_MAX_BATCH];
+  const float* counts[FFT_MAX_BATCH];
+  float2* spec[FFT_MAX_BATCH];
+  float2* work[FFT_MAX_BATCH];
+  float* loss_out[FFT_MAX_BATCH];
+  float loss_offset[FFT_MAX_BATCH];
+};
+int fftn_poisson_step_batch(const FftNative& n, FftBatch batch, float2* const* extra_spec, float2* const* extra_work, const float* flux,
+                            double* partials, float eps, float inv_n, float* grad, float coef, int accumulate, hipStream_t stream,
+                            double loss_scale);
 bool fftn_pooled_supported(const FftNative& n, int upsampling);
 int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,

@@ -83,7 +83,8 @@ class PoissonLoss:
 
     def batchable(self, indices):
         """True if the datasets `indices` can take the batched joint step: at most 4 flux components, no up-sampling,
-        no calibration, ONE separable plan shared by every (dataset, component) model."""
+        no calibration, ONE plan shared by every (dataset, component) model -- a separable plan, or (one flux
+        component) a plan of the native FFT convolution."""
         models_all = [self.npred_models_all[i] for i in indices]
         if len(models_all) < 2:
             return False
@@ -96,7 +97,12 @@ class PoissonLoss:
                     return False
                 plans.add(id(model.plan))
                 methods.add(model.plan.method)
-        return len(plans) == 1 and methods == {"separable"}
+        if len(plans) != 1:
+            return False
+        if methods == {"separable"}:
+            return True
+        plan = next(iter(models_all[0].values())).plan
+        return methods == {"fft"} and bool(plan.native_fft) and all(len(models) == 1 for models in models_all)
 
     def fwd_bwd_batch(self, indices, flux, loss_outs, grad=None, accumulate=False, grad_scale=1.0):
         """Forward model + Poisson NLL (+ gradient, summed over the datasets in order) of the datasets `indices`

@@ -156,8 +156,10 @@ def common_kernel_shape(datasets, components, calibrations=None):
     is), no calibration, no up-sampling, at most 4 components, nothing wider than 33 taps -- the PSFs are embedded in
     zeros up to the largest array shape: the same 'same' convolution (`embed_kernel`), one separable plan, and the
     kernels work on the non-zero taps of each operator, not on the array size (include/jolideco_hip.h,
-    jd_conv_operator_walk_frame)."""
-    if default_conv_method() != "auto" or calibrations or len(datasets) < 2 or not 1 <= len(components) <= 4:
+    jd_conv_operator_walk_frame).  The same for one flux component whose PSFs all take the FFT path: its batched joint
+    step needs one plan too, and an FFT convolution costs the same for every PSF size."""
+    method = default_conv_method()
+    if method not in ("auto", "general", "fft") or calibrations or len(datasets) < 2 or not 1 <= len(components) <= 4:
         return None
     if any((c.upsampling_factor or 1) != 1 for c in components.values()):
         return None
@@ -166,9 +168,19 @@ def common_kernel_shape(datasets, components, calibrations=None):
     if len(shapes) < 2:
         return None
     shape = (max(s[0] for s in shapes), max(s[1] for s in shapes))
-    if max(shape) > WALK_MAX_EDGE or any(p.ndim != 2 or psf_separable_rank(p) != 1 for p in psfs):
-        return None
-    return shape
+    if method == "auto" and max(shape) <= WALK_MAX_EDGE and all(p.ndim == 2 and psf_separable_rank(p) == 1 for p in psfs):
+        return shape
+    # FFT path (one flux component: its batched joint step): the cost of the convolution does not depend on the PSF size,
+    # so PSFs of different sizes share the plan of the largest -- where every one of them takes the FFT path anyway (the
+    # method is "fft", or none is low-rank and all are wider than the direct kernel's 17 taps)
+    if len(components) == 1 and all(p.ndim == 2 for p in psfs):
+        if method == "fft":
+            return shape
+        general = method == "general" or all(psf_separable_rank(p) == 0 for p in psfs)
+        counts_shape = np.shape(next(iter(datasets.values()))["counts"])
+        if general and all(max(p.shape) > DIRECT_FAST_EDGE for p in psfs) and counts_shape[0] * counts_shape[1] >= 1 << 20:
+            return shape
+    return None
 
 
 def rescale_psf(psf, factor):
