@@ -50,6 +50,8 @@ struct jd_conv_plan {
   // batched joint step on the native FFT path: the work arrays of datasets 1 .. (dataset 0 uses fftn's own)
   float2* fft_extra_spec[jd::FFT_MAX_BATCH - 1] = {nullptr};
   float2* fft_extra_work[jd::FFT_MAX_BATCH - 1] = {nullptr};
+  jd::FftBatch fft_batch_host = {};       // the table last uploaded (a session passes the same pointers every step)
+  jd::FftBatch* fft_batch_dev = nullptr;
   // pointer tables of the batched joint step in device memory: a few slots keyed by content, so that sessions (or the
   // chunks of a fit with more than SEP_MAX_BATCH datasets) that alternate between tables never re-upload -- an upload
   // has to wait for the stream
@@ -292,6 +294,7 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
     if (p->fft_extra_spec[i]) (void)hipFree(p->fft_extra_spec[i]);
     if (p->fft_extra_work[i]) (void)hipFree(p->fft_extra_work[i]);
   }
+  if (p->fft_batch_dev) (void)hipFree(p->fft_batch_dev);
   if (p->fwd) rocfft_plan_destroy(p->fwd);
   if (p->inv) rocfft_plan_destroy(p->inv);
   if (p->info) rocfft_execution_info_destroy(p->info);
@@ -628,10 +631,18 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
       batch.exposure[d] = exposure[d], batch.khat[d] = reinterpret_cast<const float2*>(khat[d]);
       batch.background[d] = background[d], batch.counts[d] = counts[d];
       batch.loss_out[d] = loss_out[d], batch.loss_offset[d] = stirling_mean[d];
+      batch.spec[d] = d ? p->fft_extra_spec[d - 1] : fn.spec, batch.work[d] = d ? p->fft_extra_work[d - 1] : fn.work;
+    }
+    if (!p->fft_batch_dev) JD_HIP(hipMalloc(&p->fft_batch_dev, sizeof(FftBatch)));
+    if (memcmp(&batch, &p->fft_batch_host, sizeof(batch)) != 0) {
+      // a new table: wait for launches that may still read the old one, then copy synchronously (stack source)
+      JD_HIP(hipStreamSynchronize(s));
+      JD_HIP(hipMemcpy(p->fft_batch_dev, &batch, sizeof(batch), hipMemcpyHostToDevice));
+      p->fft_batch_host = batch;
     }
     const double n_pix = (double)p->H * (double)p->W;
-    return fftn_poisson_step_batch(fn, batch, p->fft_extra_spec, p->fft_extra_work, flux[0], p->partials_batch, eps,
-                                   (float)(1.0 / n_pix), grad_flux[0], grad_scale, accumulate, s, 1.0 / n_pix);
+    return fftn_poisson_step_batch(fn, n_datasets, p->fft_batch_dev, flux[0], p->partials_batch, eps, (float)(1.0 / n_pix),
+                                   grad_flux[0], grad_scale, accumulate, s, 1.0 / n_pix);
   }
   JD_REQUIRE(n_datasets >= 1 && n_datasets <= SEP_MAX_BATCH, "%s: n_datasets = %d not in [1, %d]", who, n_datasets,
              SEP_MAX_BATCH);

@@ -308,7 +308,8 @@ struct RowsFwdArgs {
   const float* in;
   const float* shift_xy;  // nullable, device [2]: the input is the bilinearly shifted image (the calibration's shift_fwd)
   float shift_scale;
-  FftBatch batch;      // batch.n > 0: block b = row pair b / n of dataset b % n (scale, spec from the table)
+  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = row pair b / n of dataset b % n (scale, spec from the table)
+  int n_batch;
   const float* scale;  // nullable
   float2* spec;        // [Hh][Nx]
   const float2* tw;
@@ -322,10 +323,10 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
-  const int tid = threadIdx.x, nb = a.batch.n;
+  const int tid = threadIdx.x, nb = a.n_batch;
   const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
-  const float* const scale = nb ? a.batch.exposure[d] : a.scale;
-  float2* const spec = nb ? a.batch.spec[d] : a.spec;
+  const float* const scale = nb ? a.batch->exposure[d] : a.scale;
+  float2* const spec = nb ? a.batch->spec[d] : a.spec;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   const size_t ra = (size_t)y * a.W, rb = (size_t)(y + a.Hh) * a.W;
@@ -411,7 +412,8 @@ struct ColsArgs {
   const float2* tw;
   int Hh, Nx, Ny, conj, groups;
   int keep_lo, keep_hi;  // rows [0, keep_lo) and [keep_hi, Ny) of the result are written (the others are never read)
-  FftBatch batch;        // batch.n > 0: block b = column group b / n of dataset b % n (spec, work, khat from the table)
+  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = column group b / n of dataset b % n (spec, work, khat from the table)
+  int n_batch;
   FftPasses f;
 };
 
@@ -440,11 +442,11 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   const int Ny = STATIC ? R0 * R1 * R2 : a.Ny;
   // neighbouring column groups (the same 128-byte lines of every spectrum row) go to the same XCD (blockIdx % 8), one
   // after the other: the partial lines they read and write meet in that XCD's L2
-  const int nb = a.batch.n;
+  const int nb = a.n_batch;
   const int bq = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - bq * nb : 0;
-  const float2* const spec_in = nb ? a.batch.spec[d] : a.spec;
-  float2* const work_out = nb ? a.batch.work[d] : a.work;
-  const float2* const khat = nb ? a.batch.khat[d] : a.khat;
+  const float2* const spec_in = nb ? a.batch->spec[d] : a.spec;
+  float2* const work_out = nb ? a.batch->work[d] : a.work;
+  const float2* const khat = nb ? a.batch->khat[d] : a.khat;
   const int per_xcd = (a.groups + 7) / 8;
   const int g = (bq % 8) * per_xcd + bq / 8;
   if (g >= a.groups) return;
@@ -513,6 +515,42 @@ __device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* wor
   __syncthreads();
 }
 
+// The same in two steps, for a block that runs several transforms in a row: the (combined) spectrum row into REGISTERS --
+// the loads of the next row are in flight while the block transforms the current one -- and from there into LDS.
+constexpr int ROW_PRE = 9;  // float4 pieces (two spectrum elements) of a row per thread: Nx <= 2 * 256 * 9
+__device__ __forceinline__ void load_spectrum_row_regs(float4 (&pre)[ROW_PRE], const float2* work, int Nx, int y, int Hh, int Ny, int ra,
+                                                       int rb, int tid) {
+  const bool spill_up = y >= Hh - ra, spill_down = y < rb;
+  const float2* src = work + (size_t)y * Nx;
+  const float2* sp = work + (size_t)(spill_up ? Ny - Hh + y : Hh + y) * Nx;
+#pragma unroll
+  for (int i = 0; i < ROW_PRE; ++i) {
+    const int x = 2 * (tid + i * ROW_THREADS);
+    if (x >= Nx) continue;
+    float4 v = *reinterpret_cast<const float4*>(src + x);
+    if (spill_up || spill_down) {  // (block-uniform; see load_spectrum_row)
+      const float4 c = *reinterpret_cast<const float4*>(sp + x);
+      const float2 m0 = sp[x == 0 ? 0 : Nx - x], m1 = sp[Nx - x - 1];
+      if (spill_up) {
+        v = make_float4(v.x + 0.5f * (c.y + m0.y), v.y - 0.5f * (c.x - m0.x), v.z + 0.5f * (c.w + m1.y), v.w - 0.5f * (c.z - m1.x));
+      } else {
+        v = make_float4(v.x - 0.5f * (c.y - m0.y), v.y + 0.5f * (c.x + m0.x), v.z - 0.5f * (c.w - m1.y), v.w + 0.5f * (c.z + m1.x));
+      }
+    }
+    pre[i] = v;
+  }
+}
+
+__device__ __forceinline__ void store_spectrum_row_regs(float2* buf, const float4 (&pre)[ROW_PRE], int Nx, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROW_PRE; ++i) {
+    const int x = 2 * (tid + i * ROW_THREADS);
+    if (x >= Nx) continue;
+    buf[lp(x)] = float2{pre[i].x, pre[i].y}, buf[lp(x + 1)] = float2{pre[i].z, pre[i].w};
+  }
+  __syncthreads();
+}
+
 struct RowsInvArgs {
   const float2* work;  // [Ny][Nx]
   const float2* tw;
@@ -530,7 +568,8 @@ struct RowsInvArgs {
   const double* fin2_partials;  // a second sum of fin_count terms (block 1): d loss / d log background norm
   double fin2_scale;
   float* fin2_out;
-  FftBatch batch;               // fftn_rows_inv_batch_kernel: the datasets whose adjoints one block adds up, in order
+  const FftBatch* batch;        // fftn_rows_inv_batch_kernel (device memory): the n_batch datasets whose adjoints one block adds up, in order
+  int n_batch;
   FftPasses f;
 };
 
@@ -606,11 +645,14 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_batch_kernel(RowsIn
   float4 au[MAXQ], ad[MAXQ];
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) au[q] = ad[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pre[ROW_PRE];
+  load_spectrum_row_regs(pre, a.batch->work[0], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
 #pragma unroll 1
-  for (int d = 0; d < a.batch.n; ++d) {
-    load_spectrum_row(bufa, a.batch.work[d], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  for (int d = 0; d < a.n_batch; ++d) {
+    store_spectrum_row_regs(bufa, pre, Nx, tid);
+    if (d + 1 < a.n_batch) load_spectrum_row_regs(pre, a.batch->work[d + 1], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
-    const float* scale = a.batch.exposure[d];
+    const float* scale = a.batch->exposure[d];
     const bool add = d > 0 || a.accumulate;
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
@@ -641,13 +683,13 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_batch_kernel(RowsIn
     *reinterpret_cast<float4*>(a.out + o1 + x) = au[q];
     *reinterpret_cast<float4*>(a.out + o2 + x) = ad[q];
   }
-  if (a.fin_partials && (int)blockIdx.x < a.batch.n) {  // (block-uniform)
+  if (a.fin_partials && (int)blockIdx.x < a.n_batch) {  // (block-uniform)
     __shared__ double red[ROW_THREADS / 64];
     const double* part = a.fin_partials + (size_t)blockIdx.x * a.fin_count;
     double acc = 0.0;
     for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
     const double total = block_sum<ROW_THREADS>(acc, red);
-    if (tid == 0) a.batch.loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.batch.loss_offset[blockIdx.x]);
+    if (tid == 0) a.batch->loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.batch->loss_offset[blockIdx.x]);
   }
 }
 
@@ -660,7 +702,8 @@ struct RowsPoissonArgs {
   double* partials;    // [Hh] ([n][Hh] for a batch)
   int H, W, Hh, Nx, Ny, ra, rb;
   float eps, inv_n;
-  FftBatch batch;      // batch.n > 0: block b = row pair b / n of dataset b % n
+  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = row pair b / n of dataset b % n
+  int n_batch;
   FftPasses f;
 };
 
@@ -674,12 +717,12 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   __shared__ double red[ROW_THREADS / 64];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
-  const int tid = threadIdx.x, nb = a.batch.n;
+  const int tid = threadIdx.x, nb = a.n_batch;
   const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
-  const float2* const work = nb ? a.batch.work[d] : a.work;
-  float2* const spec = nb ? a.batch.spec[d] : a.spec;
-  const float* const background = nb ? a.batch.background[d] : a.background;
-  const float* const counts = nb ? a.batch.counts[d] : a.counts;
+  const float2* const work = nb ? a.batch->work[d] : a.work;
+  float2* const spec = nb ? a.batch->spec[d] : a.spec;
+  const float* const background = nb ? a.batch->background[d] : a.background;
+  const float* const counts = nb ? a.batch->counts[d] : a.counts;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5;
@@ -936,13 +979,13 @@ int lds_attr(const void* kernel, size_t bytes, size_t* set) {
   return JD_OK;
 }
 
-int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream, const FftBatch* batch = nullptr) {
+int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream, const FftBatch* batch = nullptr, int n_batch = 0) {
   const FftPasses fy = passes_of(n.Ny);
   const int ra = adjoint ? n.kh - 1 - n.oy : n.oy, rb = adjoint ? n.oy : n.kh - 1 - n.oy;
   ColsArgs a{};
   a.spec = n.spec, a.work = n.work, a.khat = khat, a.tw = n.tw_y, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.conj = adjoint ? 1 : 0;
   a.keep_lo = n.Hh + rb, a.keep_hi = n.Ny - ra, a.f = fy;
-  if (batch) a.batch = *batch;
+  a.batch = batch, a.n_batch = n_batch;
   const size_t per_col = (size_t)lp_size(n.Ny) * sizeof(float2);
   const int lanes = column_lanes(n.Ny, fy);
   if (!lanes) return fail(JD_ERR_INVALID, "native FFT: no column kernel for length %d", n.Ny);
@@ -979,7 +1022,7 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   int rc = lds_attr(reinterpret_cast<const void*>(e->kernel), cb * per_col, &e->lds_set);
   if (rc) return rc;
   ProfScope prof(JD_KERNEL_CMUL, stream);
-  hipLaunchKernelGGL(e->kernel, dim3(((a.groups + 7) / 8) * 8 * (batch ? batch->n : 1)), dim3(lanes * cb), cb * per_col, stream, a);
+  hipLaunchKernelGGL(e->kernel, dim3(((a.groups + 7) / 8) * 8 * (n_batch ? n_batch : 1)), dim3(lanes * cb), cb * per_col, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -1013,14 +1056,14 @@ int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), size_t (&set)
 }
 
 int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream, const float* shift_xy = nullptr,
-                    float shift_scale = 1.f, const FftBatch* batch = nullptr) {
+                    float shift_scale = 1.f, const FftBatch* batch = nullptr, int n_batch = 0) {
   static void (*const kernels[N_ROW_SCHED])(RowsFwdArgs) = JD_ROW_KERNELS(fftn_rows_fwd_kernel, );
   static size_t set[N_ROW_SCHED] = {};
   RowsFwdArgs a{};
   a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
   a.shift_xy = shift_xy, a.shift_scale = shift_scale;
-  if (batch) a.batch = *batch;
-  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream, batch ? n.Hh * batch->n : 0);
+  a.batch = batch, a.n_batch = n_batch;
+  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream, n_batch ? n.Hh * n_batch : 0);
 }
 
 int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream,
@@ -1114,38 +1157,31 @@ int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* fl
 
 // The likelihood steps of `nd` datasets of ONE flux image in five launches (every launch covers all datasets; the last one
 // adds the datasets' gradients in order inside its blocks): the same sums, bit for bit, as fftn_poisson_step called for
-// the datasets one after the other with `accumulate` from the second on.  batch: exposure, khat, background, counts,
-// loss_out, loss_offset per dataset; spec / work are filled in here (dataset 0 uses the plan's own arrays, the others
-// `extra`: nd - 1 pairs of (spec, work) arrays).  partials: nd * Hh doubles.
-int fftn_poisson_step_batch(const FftNative& n, FftBatch batch, float2* const* extra_spec, float2* const* extra_work, const float* flux,
-                            double* partials, float eps, float inv_n, float* grad, float coef, int accumulate, hipStream_t stream,
-                            double loss_scale) {
-  const int nd = batch.n;
+// the datasets one after the other with `accumulate` from the second on.  batch_dev (device memory): exposure, khat,
+// background, counts, spec, work, loss_out, loss_offset per dataset.  partials: nd * Hh doubles.
+int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_dev, const float* flux, double* partials, float eps,
+                            float inv_n, float* grad, float coef, int accumulate, hipStream_t stream, double loss_scale) {
   if (nd < 1 || nd > FFT_MAX_BATCH) return fail(JD_ERR_INVALID, "native FFT batch: %d datasets not in [1, %d]", nd, FFT_MAX_BATCH);
-  for (int d = 0; d < nd; ++d) {
-    batch.spec[d] = d ? extra_spec[d - 1] : n.spec;
-    batch.work[d] = d ? extra_work[d - 1] : n.work;
-  }
-  int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, 1.f, &batch);
+  int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, 1.f, batch_dev, nd);
   if (rc) return rc;
-  if ((rc = launch_cols(n, nullptr, 0, stream, &batch))) return rc;
+  if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, nd))) return rc;
   {
     static void (*const kernels[N_ROW_SCHED])(RowsPoissonArgs) = JD_ROW_KERNELS(fftn_rows_poisson_kernel, );
     static size_t set[N_ROW_SCHED] = {};
     RowsPoissonArgs a{};
     a.tw = n.tw_x, a.partials = partials;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
-    a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch;
+    a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
     if ((rc = launch_row_kernel(kernels, set, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh * nd))) return rc;
   }
-  if ((rc = launch_cols(n, nullptr, 1, stream, &batch))) return rc;
+  if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
   static void (*const kernels[N_ROW_SCHED])(RowsInvArgs) = {fftn_rows_inv_batch_kernel<0, 0, 0, 0>, fftn_rows_inv_batch_kernel<16, 16, 9, 0>,
                                                             fftn_rows_inv_batch_kernel<8, 8, 8, 9>, fftn_rows_inv_batch_kernel<16, 8, 9, 0>};
   static size_t set[N_ROW_SCHED] = {};
   RowsInvArgs a{};
   a.tw = n.tw_x, a.out = grad, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
   a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
-  a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx), a.batch = batch;
+  a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
   a.fin_partials = partials, a.fin_count = n.Hh, a.fin_scale = loss_scale;
   return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_C2R, stream);
 }

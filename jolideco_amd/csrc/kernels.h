@@ -224,7 +224,7 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
                       int accumulate, hipStream_t stream, double loss_scale, double loss_offset, float* loss_out);
 
 constexpr int FFT_MAX_BATCH = 16;
-struct FftBatch {  // per-dataset pointers of a batched likelihood step on the native FFT path (fftnative.hip)
+struct FftBatch {  // per-dataset pointers of a batched likelihood step on the native FFT path (fftnative.hip); device memory
   int n;
   const float* exposure[FFT_MAX_BATCH];
   const float2* khat[FFT_MAX_BATCH];
@@ -235,9 +235,8 @@ struct FftBatch {  // per-dataset pointers of a batched likelihood step on the n
   float* loss_out[FFT_MAX_BATCH];
   float loss_offset[FFT_MAX_BATCH];
 };
-int fftn_poisson_step_batch(const FftNative& n, FftBatch batch, float2* const* extra_spec, float2* const* extra_work, const float* flux,
-                            double* partials, float eps, float inv_n, float* grad, float coef, int accumulate, hipStream_t stream,
-                            double loss_scale);
+int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_dev, const float* flux, double* partials, float eps,
+                            float inv_n, float* grad, float coef, int accumulate, hipStream_t stream, double loss_scale);
 bool fftn_pooled_supported(const FftNative& n, int upsampling);
 int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,
