@@ -62,7 +62,12 @@ def main():
     be, dn = find(c3, "gmm_best"), find(c3, "gmm_fwd_kernel")
     f4, a4 = find(c4, "walk_kernel<17, 4, 2, true"), find(c4, "walk_kernel<17, 4, 2, false")
     m5 = find(c5, "walk_multi_kernel")
-    rows, cols, mid, inv = (find(f3, k) for k in ("fftn_rows_fwd", "fftn_cols", "fftn_rows_poisson", "fftn_rows_inv_kernel<true"))
+    # per OBSERVATION (the batched joint step of the FFT path covers the 8 observations of a step in one launch per phase)
+    steps3 = max(find(f3, "gmm_screen_kernel", 1), 1)
+    per_obs = lambda key: sum(v[0] * v[1] for k, v in f3.items() if key in k) / (steps3 * 8)  # noqa: E731
+    rows, cols2, mid, inv = per_obs("fftn_rows_fwd"), per_obs("fftn_cols"), per_obs("fftn_rows_poisson"), per_obs("fftn_rows_inv")
+    cols = cols2 / 2
+    launches3 = sum(v[1] for k, v in f3.items() if "fftn_" in k and "spectrum" not in k) / steps3
     fw_mb = (16 * 8 + 4) * MPX
     rf, rw = pmc("c3", "walk_mixed_kernel")
     s = sq("gmm_screen_kernel")
@@ -111,9 +116,10 @@ Fractions of the roofs, recomputable from `r04/c3_n1_kernel_stats.csv` (AverageN
 | record sort: scatter {sca:.1f}, count {cnt:.1f}, binscan {bs:.1f} | {sca + cnt + bs:.1f} us | | |
 | `gmm_best_kernel` {be:.1f}, gated dense kernel {dn:.1f} | {be + dn:.1f} us | | |
 
-c3 through the native FFT convolution (`r04/c3fft_n1_kernel_stats.csv`; five launches per observation): rows {rows:.1f} us
-(52 MB -> {52.4 / rows:.2f} TB/s), columns {cols:.1f} us (61 MB -> {61.3 / cols:.2f} TB/s; PMC {sum(pmc('c3fft', 'fftn_cols')):.0f} MB), rows^-1 + Poisson + rows of g
-{mid:.1f} us, rows^-1 + adjoint epilogue {inv:.1f} us (72 MB -> {71.7 / inv:.2f} TB/s).
+c3 through the native FFT convolution (`r04/c3fft_n1_kernel_stats.csv`; the batched joint step: {launches3:.0f} launches per step, each over
+the 8 observations; per OBSERVATION): rows {rows:.1f} us (52 MB -> {52.4 / rows:.2f} TB/s), columns {cols:.1f} us (61 MB -> {61.3 / cols:.2f} TB/s; PMC per
+launch of 8: {sum(pmc('c3fft', 'fftn_cols')):.0f} MB), rows^-1 + Poisson + rows of g {mid:.1f} us, rows^-1 + adjoint epilogue {inv:.1f} us
+(55 MB -> {54.8 / inv:.2f} TB/s); {rows + 2 * cols + mid + inv:.0f} us per observation (start of the round: 132).
 c4 (`r04/c4_n1_kernel_stats.csv`): screen {find(c4, 'gmm_screen'):.0f} us, exact {find(c4, 'gmm_exact'):.0f}, gather + optimizer step {find(c4, 'gmm_gather'):.0f}, forward + Poisson
 {f4:.1f} us (335 MB -> {335 / f4:.2f} TB/s = {335 / f4 / 8 * 100:.1f} %; PMC {sum(pmc('c4', 'walk_kernel<17, 4, 2, true')):.0f} MB = {sum(pmc('c4', 'walk_kernel<17, 4, 2, true')) / 335.5:.2f} x), adjoint {a4:.1f} us (268 MB -> {268 / a4:.1f} TB/s = {268 / a4 / 8 * 100:.1f} %).
 c5 (`r04/c5_n1_kernel_stats.csv`): `walk_multi_kernel<2, 2, 33>` {m5:.0f} us (16 x 2 forward models + 16 Poisson passes, the "extended" component of
