@@ -157,9 +157,11 @@ int jd_npred_poisson_fwd_bwd(jd_conv_plan* plan, int n_comp, const float* const*
 /* The joint step over SEVERAL datasets in three launches instead of four per dataset (new: the reference has no joint
  * mode; this is the batched form of the loop `for dataset: jd_npred_poisson_fwd_bwd(..., accumulate = dataset > 0)` that
  * jolideco_amd's fit_mode="joint" runs, jolideco/core.py:214-229 being its per-dataset counterpart).  Restrictions: one
- * flux component, no up-sampling, no calibration, a plan with the SEPARABLE method shared by all datasets (same image
- * and PSF shape); at most 16 datasets per call.  Same results as the loop, bit for bit (the per-dataset gradient
- * contributions are added in dataset order).
+ * flux component, no up-sampling, no calibration, ONE plan shared by all datasets (same image and PSF array shape) with
+ * the SEPARABLE method or with the FFT method on the native transforms (then every launch of the likelihood step covers
+ * all datasets: csrc/fftnative.hip; a forward-only call and option JD_FFT_BATCH=0 run the per-dataset calls); at most 16
+ * datasets per call.  Same results as the loop, bit for bit (the per-dataset gradient contributions are added in
+ * dataset order).
  *   exposure, khat, background, counts, loss_out : host arrays of n_datasets device pointers
  *   stirling_mean                                : host array of n_datasets floats
  *   grad_flux                                    : nullable (forward only) */
