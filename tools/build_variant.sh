@@ -9,7 +9,7 @@ BUILD=/tmp/jdvar_$NAME
 mkdir -p $BUILD
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form $EXTRA"
 pids=()
-for f in elementwise fftconv directconv sepconv walkconv shift gmm profile options; do
+for f in elementwise fftconv fftnative directconv sepconv walkconv shift gmm profile options; do
   /opt/rocm/bin/hipcc $FLAGS -c $ROOT/jolideco_amd/csrc/$f.hip -o $BUILD/$f.o &
   pids+=($!)
 done
