@@ -4,17 +4,29 @@
 //   rows    one block per PAIR of image rows: z = (a * scale)[y] + i (a * scale)[y + H/2] -- the image is split into its
 //           upper and lower half, one in the real and one in the imaginary part; a convolution with a REAL kernel acts on
 //           both independently -- zero padded to Nx, complex FFT of length Nx in LDS, spectrum row to HBM.  No padded
-//           real image, no Hermitian bookkeeping: every transform of the path is a plain complex FFT.
-//   columns one wave per column (four columns per block): the H/2 spectrum rows of the column, zero extended to Ny, FFT of
-//           length Ny in LDS, times the kernel spectrum K^ (stored column-major: a contiguous read), inverse FFT, back.
+//           real image, no Hermitian bookkeeping: every transform of the path is a plain complex FFT.  With a
+//           calibration the input is the bilinearly shifted image (the shift kernel's arithmetic inside the load).
+//   columns one wave per column (four columns per block; two waves per column for 4096-row images): the H/2 spectrum rows
+//           of the column, zero extended to Ny, in LDS and in place: the forward passes but the last; then the last
+//           forward pass, the product with the kernel spectrum K^ (column-major) and the first inverse pass in one
+//           register block (the inverse transform's radices run in reverse order: its first butterfly reads what the
+//           forward's last one holds); then the remaining inverse passes.
 //   rows^-1 one block per row pair: inverse FFT of length Nx, then the epilogue on the un-padded image: Re -> row y, Im ->
-//           row y + H/2, plus the few rows where the convolution of one half spills into the other (the halves are
-//           convolved as separate images: overlap-add across the seam).  Epilogues: plain store, or the adjoint's
-//           grad (+)= coef * exposure * corr.
+//           row y + H/2.  Where the convolution of one half spills into rows of the other (the halves are convolved as
+//           separate images), the needed part of the spill row is added in the Fourier domain BEFORE the transform
+//           (load_spectrum_row): every block runs one transform.  Epilogues: plain store, or the adjoint's
+//           grad (+)= coef * exposure * corr (+ the loss of the dataset, finalised by block 0).
+//   A dataset's likelihood step is FIVE launches: rows, columns, [rows^-1 + Poisson pass + rows of g] (with up-sampling:
+//   U inverse transforms + sum-pool + Poisson pass + one transform of the up-sampled g rows), columns, rows^-1 + adjoint
+//   epilogue; for the datasets of a joint step every launch covers all of them (FftBatch).
+//
+// Row and column lengths of 1024- / 2048- / 4096-pixel images run kernels whose radix schedule, length and loop bounds are
+// template parameters; the generic runtime-radix kernels serve every other length 2^a * {1, 3, 9} (jd_fftcore.h), rocFFT
+// everything else.
 //
 // HBM traffic of one forward convolution at 2048^2 with a 33 x 33 PSF (Nx = 2304, Ny = 1152): 33.6 MB in, 18.9 MB
 // spectrum out, 18.9 + 21.2 (K^) in, 21.2 out, 21.2 in, 16.8 out = 152 MB against rocFFT's ~6 passes over a 2100 x 2100
-// grid per transform (profiles/r01).  Lengths 2^a * {1, 3, 9} (jd_fftcore.h); everything else stays with rocFFT.
+// grid per transform (profiles/r01).
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -297,8 +309,9 @@ __device__ __forceinline__ void column_conv_inplace(float2* x, int N, const FftP
 // Per-dataset pointers of a batched likelihood step (several datasets of one flux image in every launch: the blocks of a
 // launch then run in several rounds and at different stages, and the load, transform and store phases of the launch
 // overlap -- a single dataset's launch is ONE round of blocks that all load, then all transform, then all store).
-// n = 0: one dataset, described by the scalar members of the kernel's arguments.
-// (struct FftBatch: kernels.h)
+// n_batch = 0: one dataset, described by the scalar members of the kernel's arguments.  The table (struct FftBatch,
+// kernels.h) lives in device memory: as a by-value kernel argument, indexing it with the dataset number made the compiler
+// copy it to scratch in every kernel.
 
 struct __attribute__((packed, aligned(4))) F4U4 {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
   float x, y, z, w;
