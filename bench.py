@@ -138,6 +138,9 @@ def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), 
         "conv_method": "+".join(sorted({m.plan.method for m in models})),
         "padded_grid": [plan.Hp, plan.Wp],
         "batched": bool(getattr(session, "batch_joint", False)),
+        # the calibrated batched entry (jd_npred_poisson_calibrated_batch_fwd_bwd) is called; beyond 2048 flux rows the
+        # library runs its per-dataset launches (measured faster there)
+        "batched_calibrated_entry": bool(getattr(session, "batch_joint_calibrated", False)),
         "kernel_ms_per_step": {k: v[0] / 4 for k, v in prof.items() if v[1] and k not in nested},
         "launches_per_step": {k: v[1] / 4 for k, v in prof.items() if v[1] and k not in nested},
     }

@@ -201,6 +201,26 @@ int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* plan, int n_comp, const fl
                                         const float* log_background_norm, float* grad_shift_xy,
                                         float* grad_log_background_norm, void* stream);
 
+/* The joint step over SEVERAL datasets of ONE flux component with the per-dataset calibration and / or up-sampling (the
+ * fits of the reference's examples: examples/chandra-e0102-filament.py:178-203): the batched form of the loop
+ * `for dataset: jd_npred_poisson_calibrated_fwd_bwd(..., accumulate = dataset > 0)` -- same results, bit for bit.  On a
+ * plan of the native FFT convolution with up-sampling 2 or 4, rows (with the dataset's shift), columns, the pooled
+ * Poisson launch and the adjoint's column pass each cover all datasets in one launch; the adjoint's last launch and the
+ * transposed shift run per dataset, in order (flux grids up to 2048 rows: beyond, a dataset's own launches already run in
+ * several rounds of blocks and the per-dataset calls are faster; option JD_FFT_BATCH=2 batches regardless).  Every other
+ * case runs the per-dataset calls.
+ *   exposure, khat, background, counts, loss_out : host arrays of n_datasets device pointers
+ *   shift_xy, log_background_norm, grad_shift_xy, grad_log_background_norm : NULL, or host arrays of n_datasets device
+ *                                                  pointers with NULL entries where a dataset has none (see above) */
+int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* plan, int n_datasets, const float* flux,
+                                              const float* const* exposure, const float* const* khat,
+                                              const float* const* background, const float* const* counts,
+                                              const float* stirling_mean, float eps, float* const* loss_out,
+                                              float* grad_flux, int accumulate, float grad_scale, int upsampling,
+                                              const float* const* shift_xy, const float* const* log_background_norm,
+                                              float* const* grad_shift_xy, float* const* grad_log_background_norm,
+                                              void* stream);
+
 /* Same chain split at the reference's object seams, for callers that keep the reference's own
  * loop structure (autograd.Function wrappers in jolideco_amd/ops.py):
  * conv_padded[c] are plan-owned buffers exposed through jd_conv_plan_conv_buffer. */

@@ -54,6 +54,11 @@ EXPORTS = {
         [c_void_p, c_int, fpp, fpp, fpp, c_void_p, c_void_p, c_float, c_float, c_void_p, fpp, c_int, c_float,
          c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "jd_npred_poisson_calibrated_batch_fwd_bwd": (
+        c_int,
+        [c_void_p, c_int, c_void_p, fpp, fpp, fpp, fpp, fp, c_float, fpp, c_void_p, c_int, c_float, c_int, fpp, fpp, fpp, fpp,
+         c_void_p],
+    ),
     "jd_npred_poisson_batch_fwd_bwd": (
         c_int,
         [c_void_p, c_int, c_void_p, fpp, fpp, fpp, fpp, fp, c_float, fpp, c_void_p, c_int, c_float, c_void_p],

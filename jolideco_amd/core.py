@@ -495,6 +495,11 @@ class FitSession:
             [li for _, li in self.local_idx]
         )
         self.batch_joint = self.joint and batchable
+        # calibrated / up-sampled datasets of one flux component on the native FFT path: their own batched step
+        self.batch_joint_calibrated = bool(
+            self.joint and not batchable and not os.environ.get("JOLIDECO_NO_BATCH") and self.n_c == 1
+            and self.total_loss.poisson_loss.batchable_calibrated([li for _, li in self.local_idx])
+        )
         # sequential mode: the per-epoch trace evaluates every dataset on the same stale flux -- one batched launch
         self.batch_trace = (not self.joint) and batchable
 
@@ -654,6 +659,14 @@ class FitSession:
                 total_loss.poisson_loss.fwd_bwd_batch(
                     [li for _, li in self.local_idx], fluxes if n_c > 1 else fluxes[0],
                     [slot(gslot) for gslot, _ in self.local_idx], grad=grads if n_c > 1 else grads[0], accumulate=False,
+                )
+                first = False
+            elif self.batch_joint_calibrated:
+                for _, li in self.local_idx:
+                    self._cal_zero_grad(li)
+                total_loss.poisson_loss.fwd_bwd_batch_calibrated(
+                    [li for _, li in self.local_idx], fluxes[0], [slot(gslot) for gslot, _ in self.local_idx], grad=grads[0],
+                    accumulate=False,
                 )
                 first = False
             else:

@@ -754,6 +754,91 @@ extern "C" int jd_npred_poisson_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, c
                                               eps, loss_out, grad_flux ? grads : nullptr, accumulate, grad_scale, stream);
 }
 
+// The joint step over several CALIBRATED and / or UP-SAMPLED datasets of one flux component on the native FFT path
+// (include/jolideco_hip.h).  Anything else -- another method, an up-sampling factor the fused launches do not take, a
+// forward-only evaluation, switched-off fusion -- runs the per-dataset calls this stands for.
+extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_datasets, const float* flux,
+                                                         const float* const* exposure, const float* const* khat,
+                                                         const float* const* background, const float* const* counts,
+                                                         const float* stirling_mean, float eps, float* const* loss_out,
+                                                         float* grad_flux, int accumulate, float grad_scale, int upsampling,
+                                                         const float* const* shift_xy, const float* const* log_background_norm,
+                                                         float* const* grad_shift_xy, float* const* grad_log_background_norm,
+                                                         void* stream) {
+  const char* who = "jd_npred_poisson_calibrated_batch_fwd_bwd";
+  JD_REQUIRE(p && flux && exposure && khat && background && counts && stirling_mean && loss_out, "%s: null argument", who);
+  JD_REQUIRE(n_datasets >= 1, "%s: n_datasets = %d", who, n_datasets);
+  JD_REQUIRE(upsampling >= 1 && upsampling <= 8 && p->H % upsampling == 0 && p->W % upsampling == 0,
+             "%s: upsampling = %d must be in [1, 8] and divide the flux grid (%d, %d)", who, upsampling, p->H, p->W);
+  for (int d = 0; d < n_datasets; ++d)
+    JD_REQUIRE(exposure[d] && khat[d] && background[d] && counts[d] && loss_out[d], "%s: null pointer for dataset %d", who, d);
+  hipStream_t s = as_stream(stream);
+  const bool any_cal = shift_xy || log_background_norm;
+  // Measured (tools/gpu/cb1024.py, 8 calibrated observations, up-sampling x2, batched against per-dataset calls): flux grid
+  // 512^2 452 against 559 us per step, 1024^2 443 against 641, 2048^2 975 against 1124 -- and 4096^2 (bench config c6) 5.68
+  // against 5.52 ms: there a dataset's launches already run in several rounds of blocks, and the per-dataset tail finds its
+  // rows colder behind a column launch over all datasets.  So: batched up to 2048 rows (JD_FFT_BATCH=2: always).
+  const bool batched = p->native && grad_flux && n_datasets >= 2 && n_datasets <= FFT_MAX_BATCH &&
+                       fftn_pooled_supported(p->fftn, upsampling) && !opt_is_set(OPT_SEP_NO_FUSION) &&
+                       opt_value(OPT_FFT_BATCH, 1) != 0 && (p->fftn.Hh <= 1024 || opt_value(OPT_FFT_BATCH, 1) == 2);
+  if (!batched) {
+    const float* fluxes[1] = {flux};
+    float* grads[1] = {grad_flux};
+    for (int d = 0; d < n_datasets; ++d) {
+      Calibration cal;
+      cal.shift_xy = shift_xy ? shift_xy[d] : nullptr, cal.shift_scale = (float)upsampling;
+      cal.log_bkg_norm = log_background_norm ? log_background_norm[d] : nullptr;
+      cal.grad_shift_xy = grad_shift_xy ? grad_shift_xy[d] : nullptr;
+      cal.grad_log_bkg_norm = grad_log_background_norm ? grad_log_background_norm[d] : nullptr;
+      int rc = npred_poisson_impl(who, p, 1, fluxes, exposure + d, khat + d, background[d], counts[d], stirling_mean[d], eps,
+                                  loss_out[d], grad_flux ? grads : nullptr, accumulate || d > 0, grad_scale, nullptr, upsampling,
+                                  cal, stream);
+      if (rc) return rc;
+    }
+    return JD_OK;
+  }
+  int rc = ensure_component_buffers(p, 1);
+  if (rc) return rc;
+  bool any_shift = false;
+  for (int d = 0; d < n_datasets; ++d) any_shift = any_shift || (shift_xy && shift_xy[d]);
+  if (any_cal && (rc = ensure_calibration_buffers(p, 1, any_shift))) return rc;
+  const FftNative& fn = p->fftn;
+  for (int d = 0; d + 1 < n_datasets; ++d) {
+    if (!p->fft_extra_spec[d]) JD_HIP(hipMalloc(&p->fft_extra_spec[d], (size_t)fn.Hh * fn.Nx * sizeof(float2)));
+    if (!p->fft_extra_work[d]) JD_HIP(hipMalloc(&p->fft_extra_work[d], (size_t)fn.Ny * fn.Nx * sizeof(float2)));
+  }
+  const int per = fn.Hh / upsampling;
+  if (p->partials_batch_cap < 2 * n_datasets * per) {  // [losses | background-norm gradients], n_datasets * per each
+    if (p->partials_batch) (void)hipFree(p->partials_batch);
+    p->partials_batch = nullptr, p->partials_batch_cap = 0;
+    JD_HIP(hipMalloc(&p->partials_batch, (size_t)2 * n_datasets * per * sizeof(double)));
+    p->partials_batch_cap = 2 * n_datasets * per;
+  }
+  FftBatch batch{};
+  batch.n = n_datasets;
+  for (int d = 0; d < n_datasets; ++d) {
+    batch.exposure[d] = exposure[d], batch.khat[d] = reinterpret_cast<const float2*>(khat[d]);
+    batch.background[d] = background[d], batch.counts[d] = counts[d];
+    batch.loss_out[d] = loss_out[d], batch.loss_offset[d] = stirling_mean[d];
+    batch.spec[d] = d ? p->fft_extra_spec[d - 1] : fn.spec, batch.work[d] = d ? p->fft_extra_work[d - 1] : fn.work;
+    batch.shift_xy[d] = shift_xy ? shift_xy[d] : nullptr;
+    batch.log_bkg_norm[d] = log_background_norm ? log_background_norm[d] : nullptr;
+    batch.grad_shift_xy[d] = grad_shift_xy ? grad_shift_xy[d] : nullptr;
+    batch.grad_log_bkg_norm[d] = (batch.log_bkg_norm[d] && grad_log_background_norm) ? grad_log_background_norm[d] : nullptr;
+  }
+  if (!p->fft_batch_dev) JD_HIP(hipMalloc(&p->fft_batch_dev, sizeof(FftBatch)));
+  if (memcmp(&batch, &p->fft_batch_host, sizeof(batch)) != 0) {
+    JD_HIP(hipStreamSynchronize(s));
+    JD_HIP(hipMemcpy(p->fft_batch_dev, &batch, sizeof(batch), hipMemcpyHostToDevice));
+    p->fft_batch_host = batch;
+  }
+  const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
+  return fftn_poisson_step_pooled_batch(fn, upsampling, n_datasets, p->fft_batch_dev, p->fft_batch_host, flux, p->partials_batch,
+                                        p->partials_batch + (size_t)n_datasets * per, eps, (float)(1.0 / n_pix), grad_flux,
+                                        any_shift ? p->gshift[0] : nullptr, p->partials_cal, grad_scale, accumulate, s, 1.0 / n_pix,
+                                        (double)grad_scale);
+}
+
 extern "C" int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,
                                                    const float* const* exposure, const float* const* khat,
                                                    const float* background, const float* counts,

@@ -340,16 +340,17 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
   const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
   const float* const scale = nb ? a.batch->exposure[d] : a.scale;
   float2* const spec = nb ? a.batch->spec[d] : a.spec;
+  const float* const shift_xy = nb ? a.batch->shift_xy[d] : a.shift_xy;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   const size_t ra = (size_t)y * a.W, rb = (size_t)(y + a.Hh) * a.W;
   constexpr int MAXQ = 5;  // float4 pieces of a row per thread (Nx <= 4608 < 4 * 256 * MAXQ)
   float4 su[MAXQ], sv[MAXQ];
-  if (a.shift_xy) {  // (uniform)
+  if (shift_xy) {  // (block-uniform)
     // the bilinearly shifted rows of both halves, straight from global memory: per piece the five source columns of the two
     // source rows (one 16-byte load at a 4-byte aligned address + one float each; element-wise with bounds checks where
     // the window leaves the image) -- the arithmetic of shift_fwd_kernel, whose launch and image this replaces
-    const ShiftGeom g = shift_geom(a.shift_xy, a.shift_scale);
+    const ShiftGeom g = shift_geom(shift_xy, a.shift_scale);
     const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
     if (x >= Nx) continue;
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
     if (x < a.W) {
-      if (a.shift_xy) {
+      if (shift_xy) {
         u = su[q], v = sv[q];
       } else {
         u = *reinterpret_cast<const float4*>(a.in + ra + x);
@@ -801,6 +802,8 @@ struct RowsPooledArgs {
   double* partials_b;         // nullable [Hh / U]: block sums of g * background (d loss / d log norm up to the scale)
   int H, W, Hh, Nx, Ny, ra, rb;
   float eps, inv_n;
+  const FftBatch* batch;      // device memory, nullable; n_batch > 0: block b = counts-row pair b / n of dataset b % n
+  int n_batch;
   FftPasses f;
 };
 
@@ -815,7 +818,14 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
   __shared__ double red[ROW_THREADS / 64];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
-  const int tid = threadIdx.x, Y = blockIdx.x;
+  const int tid = threadIdx.x, nb = a.n_batch;
+  const int Y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - Y * nb : 0;
+  const float2* const work = nb ? a.batch->work[d] : a.work;
+  float2* const spec = nb ? a.batch->spec[d] : a.spec;
+  const float* const background = nb ? a.batch->background[d] : a.background;
+  const float* const counts = nb ? a.batch->counts[d] : a.counts;
+  const float* const log_bkg_norm = nb ? a.batch->log_bkg_norm[d] : a.log_bkg_norm;
+  const size_t pbase = (size_t)d * (a.Hh / U);
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5, PC = 4 / U;  // float4 pieces of a flux row per thread; counts pixels per piece
@@ -826,7 +836,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
     for (int c = 0; c < PC; ++c) pu[q][c] = pd[q][c] = 0.f;
 #pragma unroll 1
   for (int j = 0; j < U; ++j) {
-    load_spectrum_row(bufa, a.work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+    load_spectrum_row(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
@@ -840,7 +850,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
     __syncthreads();  // the result buffer is the next transform's work space
   }
   const int Wd = a.W / U, Hdh = a.Hh / U;
-  const float norm = a.log_bkg_norm ? expf(a.log_bkg_norm[0]) : 1.f;
+  const float norm = log_bkg_norm ? expf(log_bkg_norm[0]) : 1.f;
   float gu[MAXQ][PC], gd[MAXQ][PC];
   double local = 0.0, local_b = 0.0;
 #pragma unroll
@@ -852,23 +862,23 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
 #pragma unroll
     for (int c = 0; c < PC; ++c) {
       const size_t o1 = (size_t)Y * Wd + x / U + c, o2 = (size_t)(Y + Hdh) * Wd + x / U + c;
-      const float b1 = a.log_bkg_norm ? a.background[o1] * norm : a.background[o1];
-      const float b2 = a.log_bkg_norm ? a.background[o2] * norm : a.background[o2];
+      const float b1 = log_bkg_norm ? background[o1] * norm : background[o1];
+      const float b2 = log_bkg_norm ? background[o2] * norm : background[o2];
       float term, g;
-      poisson_point(fmaxf(pu[q][c], 0.f) + b1, a.counts[o1], a.eps, a.inv_n, term, g);
+      poisson_point(fmaxf(pu[q][c], 0.f) + b1, counts[o1], a.eps, a.inv_n, term, g);
       local += (double)term, local_b += (double)(g * b1);
       gu[q][c] = pu[q][c] >= 0.f ? g : 0.f;  // clamp backward
-      poisson_point(fmaxf(pd[q][c], 0.f) + b2, a.counts[o2], a.eps, a.inv_n, term, g);
+      poisson_point(fmaxf(pd[q][c], 0.f) + b2, counts[o2], a.eps, a.inv_n, term, g);
       local += (double)term, local_b += (double)(g * b2);
       gd[q][c] = pd[q][c] >= 0.f ? g : 0.f;
     }
   }
   const double total = block_sum<ROW_THREADS>(local, red);
-  if (tid == 0) a.partials[Y] = total;
+  if (tid == 0) a.partials[pbase + Y] = total;
   if (a.partials_b) {
     __syncthreads();
     const double total_b = block_sum<ROW_THREADS>(local_b, red);
-    if (tid == 0) a.partials_b[Y] = total_b;
+    if (tid == 0) a.partials_b[pbase + Y] = total_b;
   }
   // ---- z = g_up[y] + i g_up[y + Hh], zero padded: the adjoint's row transform, the same for the U flux rows ---------------
 #pragma unroll
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     const float4 v = make_float4(c0.x, c0.y, c1.x, c1.y);
 #pragma unroll
-    for (int j = 0; j < U; ++j) *reinterpret_cast<float4*>(a.spec + (size_t)(U * Y + j) * Nx + x) = v;
+    for (int j = 0; j < U; ++j) *reinterpret_cast<float4*>(spec + (size_t)(U * Y + j) * Nx + x) = v;
   }
 }
 
@@ -1080,12 +1090,12 @@ int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, 
 }
 
 int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream,
-                    const SepLossFold* fold = nullptr, const SepLossFold* fold2 = nullptr) {
+                    const SepLossFold* fold = nullptr, const SepLossFold* fold2 = nullptr, const float2* work = nullptr) {
   static void (*const kernels_fwd[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, false, );
   static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
   static size_t set[2][N_ROW_SCHED] = {};
   RowsInvArgs a{};
-  a.work = n.work, a.tw = n.tw_x, a.out = out, a.scale = out_scale, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
+  a.work = work ? work : n.work, a.tw = n.tw_x, a.out = out, a.scale = out_scale, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
   a.ra = adjoint ? n.kh - 1 - n.oy : n.oy, a.rb = adjoint ? n.oy : n.kh - 1 - n.oy;
   a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx);
   if (fold && adjoint)
@@ -1197,6 +1207,54 @@ int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_de
   a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
   a.fin_partials = partials, a.fin_count = n.Hh, a.fin_scale = loss_scale;
   return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_C2R, stream);
+}
+
+// The likelihood steps of `nd` datasets of one flux image with up-sampling U = 2 / 4 and, per dataset, an optional
+// calibration (shift_xy / log_bkg_norm entries of the table, nullable): rows (with the dataset's shift), columns, pooled
+// middle launch and the adjoint's column pass each cover ALL datasets; the tail runs per dataset in order -- rows^-1 +
+// adjoint epilogue (into `gshift` where the dataset has a shift, else accumulated into `grad`; its blocks 0 / 1 finalise
+// the dataset's loss and d loss / d log norm), then the transposed shift (+ its two partial sums) and their finalize -- so
+// the gradient is summed in dataset order: the per-dataset calls' results, bit for bit.
+// partials / partials_b: nd * Hh / U doubles each; partials_shift: the transposed shift's own.
+int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, const FftBatch* batch_dev, const FftBatch& host,
+                                   const float* flux, double* partials, double* partials_b, float eps, float inv_n, float* grad,
+                                   float* gshift, double* partials_shift, float coef, int accumulate, hipStream_t stream,
+                                   double loss_scale, double norm_grad_scale) {
+  if (nd < 1 || nd > FFT_MAX_BATCH) return fail(JD_ERR_INVALID, "native FFT batch: %d datasets not in [1, %d]", nd, FFT_MAX_BATCH);
+  if (!fftn_pooled_supported(n, upsampling)) return fail(JD_ERR_INVALID, "native FFT batch: up-sampling %d not supported", upsampling);
+  int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, (float)upsampling, batch_dev, nd);
+  if (rc) return rc;
+  if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, nd))) return rc;
+  const int per = n.Hh / upsampling;
+  {
+    static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
+    static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
+    static size_t set[2][N_ROW_SCHED] = {};
+    RowsPooledArgs a{};
+    a.tw = n.tw_x, a.partials = partials, a.partials_b = partials_b;
+    a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
+    a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
+    rc = upsampling == 2 ? launch_row_kernel(kernels2, set[0], n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd)
+                         : launch_row_kernel(kernels4, set[1], n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd);
+    if (rc) return rc;
+  }
+  if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
+  for (int d = 0; d < nd; ++d) {
+    const bool shifted = host.shift_xy[d] != nullptr;
+    const bool acc = accumulate || d > 0;
+    const SepLossFold fold{partials + (size_t)d * per, per, loss_scale, (double)host.loss_offset[d], host.loss_out[d]};
+    const SepLossFold fold2{partials_b + (size_t)d * per, per, norm_grad_scale, 0.0, host.grad_log_bkg_norm[d]};
+    if ((rc = launch_rows_inv(n, shifted ? gshift : grad, host.exposure[d], 1, coef, shifted ? 0 : (acc ? 1 : 0), stream, &fold,
+                              host.grad_log_bkg_norm[d] ? &fold2 : nullptr, host.work[d])))
+      return rc;
+    if (!shifted) continue;
+    int n_blocks = 0;
+    if ((rc = launch_shift_bwd(flux, gshift, grad, acc ? 1 : 0, n.H, n.W, host.shift_xy[d], (float)upsampling, partials_shift, &n_blocks,
+                               stream)))
+      return rc;
+    if (host.grad_shift_xy[d] && (rc = launch_finalize_multi(partials_shift, n_blocks, 2, 1.0, host.grad_shift_xy[d], 0, stream))) return rc;
+  }
+  return JD_OK;
 }
 
 }  // namespace jd

@@ -234,9 +234,18 @@ struct FftBatch {  // per-dataset pointers of a batched likelihood step on the n
   float2* work[FFT_MAX_BATCH];
   float* loss_out[FFT_MAX_BATCH];
   float loss_offset[FFT_MAX_BATCH];
+  // calibrated steps (jd_npred_poisson_calibrated_batch_fwd_bwd): nullable entries
+  const float* shift_xy[FFT_MAX_BATCH];
+  const float* log_bkg_norm[FFT_MAX_BATCH];
+  float* grad_shift_xy[FFT_MAX_BATCH];      // (host side only)
+  float* grad_log_bkg_norm[FFT_MAX_BATCH];  // (host side only)
 };
 int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_dev, const float* flux, double* partials, float eps,
                             float inv_n, float* grad, float coef, int accumulate, hipStream_t stream, double loss_scale);
+int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, const FftBatch* batch_dev, const FftBatch& host,
+                                   const float* flux, double* partials, double* partials_b, float eps, float inv_n, float* grad,
+                                   float* gshift, double* partials_shift, float coef, int accumulate, hipStream_t stream,
+                                   double loss_scale, double norm_grad_scale);
 bool fftn_pooled_supported(const FftNative& n, int upsampling);
 int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,

@@ -104,6 +104,34 @@ class PoissonLoss:
         plan = next(iter(models_all[0].values())).plan
         return methods == {"fft"} and bool(plan.native_fft) and all(len(models) == 1 for models in models_all)
 
+    def batchable_calibrated(self, indices):
+        """True if the datasets `indices` can take the batched CALIBRATED / UP-SAMPLED joint step
+        (`fwd_bwd_batch_calibrated`): one flux component, ONE plan of the native FFT convolution shared by all datasets,
+        one up-sampling factor (2 or 4), each dataset with or without a calibration."""
+        models_all = [self.npred_models_all[i] for i in indices]
+        if len(models_all) < 2 or any(len(models) != 1 for models in models_all):
+            return False
+        first = next(iter(models_all[0].values()))
+        u = first.upsampling_factor or 1
+        if u not in (2, 4) or first.plan.method != "fft" or not first.plan.native_fft:
+            return False
+        return all(
+            (m.upsampling_factor or 1) == u and m.plan is first.plan for models in models_all for m in models.values()
+        )
+
+    def fwd_bwd_batch_calibrated(self, indices, flux, loss_outs, grad=None, accumulate=False, grad_scale=1.0):
+        """The batched joint step of calibrated / up-sampled datasets (requires `batchable_calibrated(indices)`): the
+        numbers of `fwd_bwd` per dataset with ``accumulate`` from the second dataset on."""
+        per_dataset = [self.npred_models_all[i] for i in indices]
+        models = [next(iter(mm.values())) for mm in per_dataset]
+        models[0].plan.npred_poisson_calibrated_batch_fwd_bwd(
+            flux=flux, exposures=[m.exposure for m in models], khats=[m.khat for m in models],
+            backgrounds=[mm.background for mm in per_dataset], counts=[self.counts_all[i] for i in indices],
+            stirlings=[self.stirling_all[i] for i in indices], loss_outs=loss_outs,
+            calibrations=[mm.calibration_pointers(grad is not None) for mm in per_dataset],
+            upsampling=models[0].upsampling_factor or 1, grad=grad, accumulate=accumulate, grad_scale=grad_scale,
+        )
+
     def fwd_bwd_batch(self, indices, flux, loss_outs, grad=None, accumulate=False, grad_scale=1.0):
         """Forward model + Poisson NLL (+ gradient, summed over the datasets in order) of the datasets `indices`
         in three launches (+ one adjoint launch per further component); requires `batchable(indices)`.

@@ -344,28 +344,33 @@ class NPredModels(nn.ModuleDict):
             raise NotImplementedError("components of one dataset must share the PSF shape (one FFT plan)")
         return next(iter(plans.values()))
 
+    def calibration_pointers(self, want_grad):
+        """(shift_xy | None, log_background_norm, grad_shift_xy | None, grad_log_background_norm | None) of this dataset's
+        calibration -- the device tensors the C-ABI reads and writes -- or None without a calibration.  Gradients land in
+        `.grad` (allocated here, so a parameter that takes no part keeps grad None and the optimizer skips it, as in the
+        reference)."""
+        cal = self.calibration
+        if cal is None:
+            return None
+        want_grad = want_grad and not cal.frozen
+        shift = cal.shift_xy if self.shift_active else None
+        if want_grad:
+            if shift is not None and cal.shift_xy.grad is None:
+                cal.shift_xy.grad = torch.zeros_like(cal.shift_xy)
+            if cal._background_norm.grad is None:
+                cal._background_norm.grad = torch.zeros_like(cal._background_norm)
+        return (
+            None if shift is None else shift.data,
+            cal._background_norm.data,
+            cal.shift_xy.grad if (want_grad and shift is not None) else None,
+            cal._background_norm.grad if want_grad else None,
+        )
+
     def fwd_bwd(self, fluxes, counts, stirling, loss_out, grads=None, accumulate=False, grad_scale=1.0,
                 npred_out=None):
         """One fused C-ABI call: forward model + Poisson NLL (+ d loss / d flux_c)."""
         models = list(self.values())
-        cal = self.calibration
-        calibration = None
-        if cal is not None:
-            # device pointers of the calibration parameters; gradients land in `.grad` (allocated here, so
-            # a parameter that takes no part keeps grad None and the optimizer skips it, as in the reference)
-            want_grad = grads is not None and not cal.frozen
-            shift = cal.shift_xy if self.shift_active else None
-            if want_grad:
-                if shift is not None and cal.shift_xy.grad is None:
-                    cal.shift_xy.grad = torch.zeros_like(cal.shift_xy)
-                if cal._background_norm.grad is None:
-                    cal._background_norm.grad = torch.zeros_like(cal._background_norm)
-            calibration = (
-                None if shift is None else shift.data,
-                cal._background_norm.data,
-                cal.shift_xy.grad if (want_grad and shift is not None) else None,
-                cal._background_norm.grad if want_grad else None,
-            )
+        calibration = self.calibration_pointers(grads is not None)
         self.plan.npred_poisson_fwd_bwd(
             fluxes=list(fluxes), exposures=[m.exposure for m in models], khats=[m.khat for m in models],
             background=self.background, counts=counts, stirling=stirling, loss_out=loss_out, grads=grads,

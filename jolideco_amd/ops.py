@@ -271,6 +271,33 @@ class ConvPlan:
                 )
             )
 
+    def npred_poisson_calibrated_batch_fwd_bwd(self, flux, exposures, khats, backgrounds, counts, stirlings, loss_outs,
+                                               calibrations, upsampling=1, grad=None, accumulate=False, grad_scale=1.0,
+                                               eps=POISSON_EPS):
+        """All datasets of a joint step of ONE flux component with per-dataset calibrations and / or up-sampling
+        (jd_npred_poisson_calibrated_batch_fwd_bwd): the batched form of `npred_poisson_fwd_bwd(..., calibration=...)`
+        per dataset with ``accumulate`` from the second dataset on -- same numbers.
+        ``calibrations``: per dataset None or (shift_xy | None, log_background_norm | None, grad_shift_xy | None,
+        grad_log_background_norm | None)."""
+        n = len(exposures)
+        if not (len(khats) == len(backgrounds) == len(counts) == len(stirlings) == len(loss_outs) == len(calibrations) == n):
+            raise ValueError("all per-dataset lists must have the same length")
+        self._check_image(flux, "flux")
+        cals = [c if c is not None else (None, None, None, None) for c in calibrations]
+        for start in range(0, n, self.MAX_BATCH):
+            sl = slice(start, min(n, start + self.MAX_BATCH))
+            m = sl.stop - sl.start
+            stirling_arr = (c_float * m)(*[float(v) for v in stirlings[sl]])
+            check(
+                _hip.lib().jd_npred_poisson_calibrated_batch_fwd_bwd(
+                    self._handle, m, ptr(flux), ptr_array(exposures[sl]), ptr_array(khats[sl]), ptr_array(backgrounds[sl]),
+                    ptr_array(counts[sl]), stirling_arr, c_float(eps), ptr_array(loss_outs[sl]), ptr(grad),
+                    int(accumulate or start > 0), c_float(grad_scale), int(upsampling),
+                    ptr_array([c[0] for c in cals[sl]]), ptr_array([c[1] for c in cals[sl]]),
+                    ptr_array([c[2] for c in cals[sl]]), ptr_array([c[3] for c in cals[sl]]), stream_ptr(flux.device),
+                )
+            )
+
 
 class GmmHandle:
     """GMM constants in MFMA fragment order on the device (jd_gmm)."""

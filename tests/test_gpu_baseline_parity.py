@@ -490,9 +490,10 @@ def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
     ``upsampling_factor=2``, general 33x33 PSFs (66x66 up-sampled -> native FFT convolution: compile-time schedules for
     rows of 1152 and columns of 1024), one trained `NPredCalibration` (sub-pixel shift + background norm) per observation.
     Compared: the flux gradient, every dataset loss, d loss / d shift_xy and d loss / d log background norm.  ``fused``:
-    the pooled middle launch of the native FFT path (sum-pool + Poisson pass + row transform of the up-sampled g between
-    the two column passes; loss and background-norm gradient finalised by the adjoint's last launch) against the
-    separate kernels (``JD_SEP_NO_FUSION=1``)."""
+    the batched calibrated step (jd_npred_poisson_calibrated_batch_fwd_bwd: rows with each dataset's shift, columns, the
+    pooled middle launch -- sum-pool + Poisson pass + row transform of the up-sampled g -- and the adjoint's column pass
+    over all four datasets; loss and background-norm gradient finalised by each dataset's last launch) against the
+    separate kernels of the per-dataset calls (``JD_SEP_NO_FUSION=1``)."""
     from jolideco_amd import MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import instrument_observations
 

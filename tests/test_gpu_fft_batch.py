@@ -67,3 +67,40 @@ def test_batched_fft_step_matches_the_oracle(monkeypatch):
     np.testing.assert_allclose(scalars, np.array(losses), rtol=5e-6)
     err = rel_linf(grad, flux.grad.numpy()[0, 0])
     assert err < 1e-5, err
+
+
+def test_batched_calibrated_upsampled_step_equals_the_per_dataset_calls_bit_for_bit(monkeypatch, jd_option):
+    """jd_npred_poisson_calibrated_batch_fwd_bwd (calibrations + up-sampling x2, general PSFs: the c6 shape at 512^2 flux
+    pixels x 4 observations, one of them without a trained shift) against the per-dataset calls: flux gradient, losses and
+    the gradients of every calibration parameter, bit for bit.  (Oracle parity of the same step:
+    test_gpu_baseline_parity.py::test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs, which runs this path.)"""
+    from jolideco_amd import MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent, UniformPrior
+    from jolideco_amd.data import instrument_observations
+
+    datasets, _, flux_init, cal = instrument_observations(shape=(256, 256), n_obs=4, seed=1, psf_shape=(17, 17))
+    out = {}
+    for batched in (1, 0):
+        jd_option("JD_FFT_BATCH", batched)
+        comp = SpatialFluxComponent.from_numpy(flux=flux_init, upsampling_factor=2, prior=UniformPrior())
+        cals = NPredCalibrations()
+        for i, (name, (sx, sy, norm)) in enumerate(cal.items()):
+            cals[name] = NPredCalibration(shift_x=sx if i else 0.0, shift_y=sy if i else 0.0, background_norm=norm)
+        first = next(iter(cals.values()))
+        first.shift_xy.requires_grad = False  # (the reference observation of the Chandra example)
+        deco = MAPDeconvolver(n_epochs=1, display_progress=False, device=DEV, fit_mode="joint")
+        session = deco.session(datasets, components=comp, calibrations=cals)
+        assert session.batch_joint_calibrated and not session.batch_joint
+        session.cfg._optimizer_step = lambda states, step: None
+        session.epoch()
+        torch.cuda.synchronize()
+        grads = []
+        for c in session.calibrations.values():
+            grads.append(None if c.shift_xy.grad is None else c.shift_xy.grad.cpu().numpy().copy())
+            grads.append(c._background_norm.grad.cpu().numpy().copy())
+        out[batched] = (session.comm.cpu().numpy().copy(), grads)
+    assert np.all(np.isfinite(out[1][0])) and np.any(out[1][0] != 0)
+    np.testing.assert_array_equal(out[1][0], out[0][0])
+    for a, b in zip(out[1][1], out[0][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            np.testing.assert_array_equal(a, b)
