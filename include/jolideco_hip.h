@@ -349,6 +349,13 @@ int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* gra
                  float* exp_avg_sq, const float* mask, size_t n, float step_size, float beta1,
                  float beta2, float one_minus_beta1, float one_minus_beta2, float bias2_sqrt, float eps,
                  int zero_grad, int use_log_flux, void* stream);
+/* jd_adam_step with use_log_flux = 0 for MANY small parameter vectors in ONE launch (the calibration parameters of the
+ * datasets of a joint step, jolideco/core.py:197-204,229): tensor i (sizes[i] floats) takes its own step_size[i] /
+ * bias2_sqrt[i] (its own step count, as torch.optim.Adam keeps one per parameter).  Host arrays of n_tensors <= 64
+ * entries.  Same bits as n_tensors calls of jd_adam_step. */
+int jd_adam_step_multi(int n_tensors, float* const* theta, const float* const* grad, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int* sizes, const float* step_size, const float* bias2_sqrt,
+                       float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps, void* stream);
 /* plain SGD (core.py:41): theta -= lr * grad_flux * flux_in */
 int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
                 const float* mask, size_t n, float lr, int zero_grad, int use_log_flux, void* stream);

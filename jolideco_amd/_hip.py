@@ -103,6 +103,10 @@ EXPORTS = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
          c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
     ),
+    "jd_adam_step_multi": (
+        c_int,
+        [c_int, fpp, fpp, fpp, fpp, POINTER(c_int), fp, fp, c_float, c_float, c_float, c_float, c_float, c_void_p],
+    ),
     "jd_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_int, c_void_p]),
     "jd_profile_enable": (c_int, [c_int]),
     "jd_profile_disable": (c_int, []),

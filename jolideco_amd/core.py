@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _hip
-from ._hip import check, ptr, stream_ptr
+from ._hip import check, ptr, ptr_array, stream_ptr
 from .distributed import DistContext
 from .loss import TotalLoss
 from .models import FluxComponents, SpatialFluxComponent
@@ -591,6 +591,48 @@ class FitSession:
         if opt is not None:
             opt.step()
 
+    def _cal_step_all(self):
+        """The calibration steps of all local datasets (a joint step updates them together): with Adam ONE launch for every
+        parameter that has a gradient (jd_adam_step_multi: the update of `_CalibrationStepper.step`, each parameter with
+        its own step count); otherwise the per-dataset steps."""
+        steppers = [self.cal_optimizers[li] for _, li in self.local_idx if self.cal_optimizers[li] is not None]
+        if not steppers:
+            return
+        cfg = self.cfg
+        if cfg.optimizer_type != "adam":
+            for opt in steppers:
+                opt.step()
+            return
+        import ctypes
+
+        lr = cfg.optimizer_kwargs["lr"]
+        beta1, beta2 = cfg.optimizer_kwargs.get("betas", (0.9, 0.999))
+        todo = []
+        for opt in steppers:
+            for p, st in zip(opt.params, opt.state):
+                if p.grad is None:
+                    continue
+                st["step"] += 1
+                todo.append((p, st, adam_bias_terms(st["step"], lr, beta1, beta2)))
+        lib = _hip.lib()
+        cache = self.__dict__.setdefault("_cal_step_cache", {})
+        for start in range(0, len(todo), 64):
+            part = todo[start : start + 64]
+            n = len(part)
+            # (the pointer arrays of an unchanged set of tensors are built once: gradients live in persistent buffers)
+            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _, _ in part)
+            arrays = cache.get(key)
+            if arrays is None:
+                arrays = cache[key] = (
+                    ptr_array([p.data for p, _, _ in part]), ptr_array([p.grad for p, _, _ in part]),
+                    ptr_array([st["exp_avg"] for _, st, _ in part]), ptr_array([st["exp_avg_sq"] for _, st, _ in part]),
+                    (ctypes.c_int * n)(*[p.numel() for p, _, _ in part]),
+                )
+            check(lib.jd_adam_step_multi(
+                n, *arrays, (ctypes.c_float * n)(*[b[0] for _, _, b in part]), (ctypes.c_float * n)(*[b[1] for _, _, b in part]),
+                beta1, beta2, 1 - beta1, 1 - beta2, cfg.optimizer_kwargs.get("eps", 1e-8), stream_ptr(part[0][0].device),
+            ))
+
     def _prior_rows(self, prior, state):
         if self.joint and self.dist.sharded and prior.shardable:
             return self.dist.shard_range(prior.n_patch_rows(state.shape))
@@ -731,8 +773,7 @@ class FitSession:
                 self._timed("all_reduce_blocking", lambda: dist.all_reduce_sum(self.comm))
             self.step += 1
             self._apply_step(states, stepped)
-            for _, li in self.local_idx:
-                self._cal_step(li)
+            self._cal_step_all()
         else:
             # ---- the reference loop: one step per dataset (core.py:214-229) -------------------
             for gslot, li in self.local_idx:

@@ -344,6 +344,13 @@ class NPredModels(nn.ModuleDict):
             raise NotImplementedError("components of one dataset must share the PSF shape (one FFT plan)")
         return next(iter(plans.values()))
 
+    def _grad_buffer(self, name, like):
+        buffers = self.__dict__.setdefault("_cal_grad_buffers", {})
+        buf = buffers.get(name)
+        if buf is None or buf.shape != like.shape or buf.device != like.device:
+            buf = buffers[name] = torch.zeros_like(like)
+        return buf
+
     def calibration_pointers(self, want_grad):
         """(shift_xy | None, log_background_norm, grad_shift_xy | None, grad_log_background_norm | None) of this dataset's
         calibration -- the device tensors the C-ABI reads and writes -- or None without a calibration.  Gradients land in
@@ -355,10 +362,12 @@ class NPredModels(nn.ModuleDict):
         want_grad = want_grad and not cal.frozen
         shift = cal.shift_xy if self.shift_active else None
         if want_grad:
+            # (the buffers are allocated once and re-attached after every zero_grad(set_to_none=True): the library OVERWRITES
+            # both gradients, so no fill launch per parameter and step is needed -- 16 of them per step of 8 observations)
             if shift is not None and cal.shift_xy.grad is None:
-                cal.shift_xy.grad = torch.zeros_like(cal.shift_xy)
+                cal.shift_xy.grad = self._grad_buffer("shift_xy", cal.shift_xy)
             if cal._background_norm.grad is None:
-                cal._background_norm.grad = torch.zeros_like(cal._background_norm)
+                cal._background_norm.grad = self._grad_buffer("background_norm", cal._background_norm)
         return (
             None if shift is None else shift.data,
             cal._background_norm.data,

@@ -1104,3 +1104,46 @@ def test_fused_likelihood_step_equals_the_two_launch_path_bit_for_bit(jd_option,
         np.testing.assert_allclose(loss, ref_loss, rtol=1e-6)
     assert np.abs(ref_grad - 0.25).max() > 0
     plan.close()
+
+
+def test_adam_step_multi_equals_the_single_tensor_steps_bit_for_bit():
+    """jd_adam_step_multi (many small parameter vectors, one launch, each with its own step count) == one jd_adam_step
+    with use_log_flux = 0 per tensor: parameters and both moments, bit for bit, over several steps."""
+    import ctypes
+
+    from jolideco_amd import _hip
+    from jolideco_amd._hip import check, ptr, ptr_array, stream_ptr
+    from jolideco_amd.ops import adam_bias_terms
+
+    rs = np.random.RandomState(4)
+    sizes = [2, 1, 2, 1, 7, 64, 130]
+    lr, beta1, beta2, eps = 0.1, 0.9, 0.999, 1e-8
+
+    def fresh():
+        rs2 = np.random.RandomState(5)
+        return [[torch.from_numpy(rs2.normal(size=n).astype(np.float32)).to(DEV) for n in sizes],
+                [torch.zeros(n, device=DEV) for n in sizes], [torch.zeros(n, device=DEV) for n in sizes]]
+
+    (ta, ma, va), (tb, mb, vb) = fresh(), fresh()
+    steps = [0] * len(sizes)
+    for it in range(4):
+        grads = [torch.from_numpy(rs.normal(size=n).astype(np.float32)).to(DEV) for n in sizes]
+        active = [i for i in range(len(sizes)) if not (it == 1 and i == 2)]  # tensor 2 sits one step out: own step count
+        terms = {}
+        for i in active:
+            steps[i] += 1
+            terms[i] = adam_bias_terms(steps[i], lr, beta1, beta2)
+        for i in active:
+            check(_hip.lib().jd_adam_step(ptr(ta[i]), ptr(ta[i]), ptr(ta[i]), ptr(grads[i]), ptr(ma[i]), ptr(va[i]), None, sizes[i],
+                                          terms[i][0], beta1, beta2, 1 - beta1, 1 - beta2, terms[i][1], eps, 0, 0, stream_ptr(ta[i].device)))
+        n = len(active)
+        check(_hip.lib().jd_adam_step_multi(
+            n, ptr_array([tb[i] for i in active]), ptr_array([grads[i] for i in active]), ptr_array([mb[i] for i in active]),
+            ptr_array([vb[i] for i in active]), (ctypes.c_int * n)(*[sizes[i] for i in active]),
+            (ctypes.c_float * n)(*[terms[i][0] for i in active]), (ctypes.c_float * n)(*[terms[i][1] for i in active]),
+            beta1, beta2, 1 - beta1, 1 - beta2, eps, stream_ptr(tb[0].device)))
+    torch.cuda.synchronize()
+    for i in range(len(sizes)):
+        np.testing.assert_array_equal(ta[i].cpu().numpy(), tb[i].cpu().numpy())
+        np.testing.assert_array_equal(ma[i].cpu().numpy(), mb[i].cpu().numpy())
+        np.testing.assert_array_equal(va[i].cpu().numpy(), vb[i].cpu().numpy())
