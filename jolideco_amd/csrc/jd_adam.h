@@ -22,7 +22,9 @@ struct AdamArgs {
 __device__ inline void adam_update(float& th, float& m, float& v, float g, const AdamArgs& a) {
   // every product and sum rounded on its own: whether the compiler fuses a multiply-add depends on the kernel around it
   // (adam_multi_kernel came out one ulp from adam_kernel), and every kernel that steps a parameter must give the same bits
+#ifndef JD_ADAM_CONTRACT  // (A/B only: -DJD_ADAM_CONTRACT leaves the fusing to the compiler)
 #pragma clang fp contract(off)
+#endif
   if (a.sgd) {
     th = th - a.lr * g;
     return;
