@@ -367,6 +367,38 @@ class MAPDeconvolver:
             total_loss.poisson_loss.names_all = local
 
 
+def _adam_step_many(cfg, items, cache):
+    """ONE launch for the Adam steps of the small parameter tensors `items` = [(parameter, state)] that have a gradient
+    (jd_adam_step_multi: each tensor with its own step count); `cache`: pointer arrays by tensor set."""
+    import ctypes
+
+    lr = cfg.optimizer_kwargs["lr"]
+    beta1, beta2 = cfg.optimizer_kwargs.get("betas", (0.9, 0.999))
+    todo = []
+    for p, st in items:
+        if p.grad is None:
+            continue
+        st["step"] += 1
+        todo.append((p, st, adam_bias_terms(st["step"], lr, beta1, beta2)))
+    lib = _hip.lib()
+    for start in range(0, len(todo), 64):
+        part = todo[start : start + 64]
+        n = len(part)
+        # (the pointer arrays of an unchanged set of tensors are built once: gradients live in persistent buffers)
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _, _ in part)
+        arrays = cache.get(key)
+        if arrays is None:
+            arrays = cache[key] = (
+                ptr_array([p.data for p, _, _ in part]), ptr_array([p.grad for p, _, _ in part]),
+                ptr_array([st["exp_avg"] for _, st, _ in part]), ptr_array([st["exp_avg_sq"] for _, st, _ in part]),
+                (ctypes.c_int * n)(*[p.numel() for p, _, _ in part]),
+            )
+        check(lib.jd_adam_step_multi(
+            n, *arrays, (ctypes.c_float * n)(*[b[0] for _, _, b in part]), (ctypes.c_float * n)(*[b[1] for _, _, b in part]),
+            beta1, beta2, 1 - beta1, 1 - beta2, cfg.optimizer_kwargs.get("eps", 1e-8), stream_ptr(part[0][0].device),
+        ))
+
+
 class _CalibrationStepper:
     """The optimizer of ONE dataset's calibration parameters (a (1, 2) shift and a (1,) log background norm) on the
     library's step kernel: `jd_adam_step` / `jd_sgd_step` with ``use_log_flux=0`` is the plain `torch.optim.Adam` /
@@ -390,20 +422,16 @@ class _CalibrationStepper:
 
     def step(self):
         lib, cfg = _hip.lib(), self.cfg
+        if cfg.optimizer_type == "adam":  # both parameters of the dataset in one launch
+            _adam_step_many(cfg, list(zip(self.params, self.state)), self.__dict__.setdefault("_arrays", {}))
+            return
         lr = cfg.optimizer_kwargs["lr"]
         for p, st in zip(self.params, self.state):
             if p.grad is None:
                 continue
             st["step"] += 1
             data, n, stream = p.data, p.numel(), stream_ptr(p.device)
-            if cfg.optimizer_type == "adam":
-                beta1, beta2 = cfg.optimizer_kwargs.get("betas", (0.9, 0.999))
-                step_size, bias2_sqrt = adam_bias_terms(st["step"], lr, beta1, beta2)
-                check(lib.jd_adam_step(ptr(data), ptr(data), ptr(data), ptr(p.grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]),
-                                       None, n, step_size, beta1, beta2, 1 - beta1, 1 - beta2, bias2_sqrt,
-                                       cfg.optimizer_kwargs.get("eps", 1e-8), 0, 0, stream))
-            else:
-                check(lib.jd_sgd_step(ptr(data), ptr(data), ptr(data), ptr(p.grad), None, n, lr, 0, 0, stream))
+            check(lib.jd_sgd_step(ptr(data), ptr(data), ptr(data), ptr(p.grad), None, n, lr, 0, 0, stream))
 
 
 class FitSession:
@@ -603,35 +631,8 @@ class FitSession:
             for opt in steppers:
                 opt.step()
             return
-        import ctypes
-
-        lr = cfg.optimizer_kwargs["lr"]
-        beta1, beta2 = cfg.optimizer_kwargs.get("betas", (0.9, 0.999))
-        todo = []
-        for opt in steppers:
-            for p, st in zip(opt.params, opt.state):
-                if p.grad is None:
-                    continue
-                st["step"] += 1
-                todo.append((p, st, adam_bias_terms(st["step"], lr, beta1, beta2)))
-        lib = _hip.lib()
-        cache = self.__dict__.setdefault("_cal_step_cache", {})
-        for start in range(0, len(todo), 64):
-            part = todo[start : start + 64]
-            n = len(part)
-            # (the pointer arrays of an unchanged set of tensors are built once: gradients live in persistent buffers)
-            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _, _ in part)
-            arrays = cache.get(key)
-            if arrays is None:
-                arrays = cache[key] = (
-                    ptr_array([p.data for p, _, _ in part]), ptr_array([p.grad for p, _, _ in part]),
-                    ptr_array([st["exp_avg"] for _, st, _ in part]), ptr_array([st["exp_avg_sq"] for _, st, _ in part]),
-                    (ctypes.c_int * n)(*[p.numel() for p, _, _ in part]),
-                )
-            check(lib.jd_adam_step_multi(
-                n, *arrays, (ctypes.c_float * n)(*[b[0] for _, _, b in part]), (ctypes.c_float * n)(*[b[1] for _, _, b in part]),
-                beta1, beta2, 1 - beta1, 1 - beta2, cfg.optimizer_kwargs.get("eps", 1e-8), stream_ptr(part[0][0].device),
-            ))
+        items = [(p, st) for opt in steppers for p, st in zip(opt.params, opt.state)]
+        _adam_step_many(cfg, items, self.__dict__.setdefault("_cal_step_cache", {}))
 
     def _prior_rows(self, prior, state):
         if self.joint and self.dist.sharded and prior.shardable:
