@@ -100,7 +100,7 @@ SURVEY section 8(d)'s: 6 x 17x17 + 2 x 33x33 PSFs (`config.psf_shapes` in the be
 | `r04/pmc_hbm_traffic.csv` (+ `.commit`) | FETCH_SIZE / WRITE_SIZE per kernel, separate passes; rows `c3`, `c4`, `c3fft`; HBM reads = 2 x FETCH_SIZE (`MI355X_MICROARCH.md`) |
 | `r04/sq_counters.txt` | SQ counters of the c3 step (five passes of four counters), per launch: the screen kernel's matrix / vector / wait shares below |
 | `r04/conv_method_crossover.txt` | `tools/conv_bench.py`: MFMA Toeplitz against native FFT convolution at 1024^2 / 2048^2 / 4096^2, 17-33 taps (the rule of the method "auto") |
-| `r04/ab_*.txt` | the A/B runs of the round (one process or one call each): packed row pass, mixed-launch balance, 33-tap adjoint tiling, native FFT column kernel with parts switched off; second session: `ab_fft8_*` (FFT kernels of the round's start against the last build: c3 through the FFT path and c6), `ab_fft9_*` (columns per block), `ab_ilv_*` (dataset order of the walk forward launch), `ab_scr_*` (screen kernel builds) |
+| `r04/ab_*.txt` | the A/B runs of the round (one process or one call each): packed row pass, mixed-launch balance, 33-tap adjoint tiling, native FFT column kernel with parts switched off; second session: `ab_fft8_*` (FFT kernels of the round's start against the last build: c3 through the FFT path and c6), `ab_fft9_*` (columns per block), `ab_ilv_*` (dataset order of the walk forward launch), `ab_scr_*` (screen kernel builds), `ab_fb_*` / `ab_fb4096_*` (batched against per-dataset FFT joint step), `ab_cb1024_*` (the same for calibrated + up-sampled datasets, 512^2-2048^2 flux pixels), `ab_blk_*` (blocked layout of the spectrum arrays), `ab_raw_*` (exact stage on staged fp32 patches), `ab_c4w_*` (tile shapes of the forward launch at 4096^2) |
 
 Fractions of the roofs, recomputable from `r04/c3_n1_kernel_stats.csv` (AverageNs) and the algorithmic bytes of DESIGN.md section 3:
 
