@@ -52,6 +52,8 @@ struct jd_conv_plan {
   float2* fft_extra_work[jd::FFT_MAX_BATCH - 1] = {nullptr};
   jd::FftBatch fft_batch_host = {};       // the table last uploaded (a session passes the same pointers every step)
   jd::FftBatch* fft_batch_dev = nullptr;
+  double* partials_shift_batch = nullptr;  // calibrated batched step: 2 x shift blocks doubles per dataset
+  int partials_shift_batch_cap = 0;
   // pointer tables of the batched joint step in device memory: a few slots keyed by content, so that sessions (or the
   // chunks of a fit with more than SEP_MAX_BATCH datasets) that alternate between tables never re-upload -- an upload
   // has to wait for the stream
@@ -295,6 +297,7 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
     if (p->fft_extra_work[i]) (void)hipFree(p->fft_extra_work[i]);
   }
   if (p->fft_batch_dev) (void)hipFree(p->fft_batch_dev);
+  if (p->partials_shift_batch) (void)hipFree(p->partials_shift_batch);
   if (p->fwd) rocfft_plan_destroy(p->fwd);
   if (p->inv) rocfft_plan_destroy(p->inv);
   if (p->info) rocfft_execution_info_destroy(p->info);
@@ -814,6 +817,13 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
     JD_HIP(hipMalloc(&p->partials_batch, (size_t)2 * n_datasets * per * sizeof(double)));
     p->partials_batch_cap = 2 * n_datasets * per;
   }
+  const int shift_need = any_shift ? 2 * shift_bwd_max_blocks(p->H, p->W) * n_datasets : 0;
+  if (p->partials_shift_batch_cap < shift_need) {
+    if (p->partials_shift_batch) (void)hipFree(p->partials_shift_batch);
+    p->partials_shift_batch = nullptr, p->partials_shift_batch_cap = 0;
+    JD_HIP(hipMalloc(&p->partials_shift_batch, (size_t)shift_need * sizeof(double)));
+    p->partials_shift_batch_cap = shift_need;
+  }
   FftBatch batch{};
   batch.n = n_datasets;
   for (int d = 0; d < n_datasets; ++d) {
@@ -835,8 +845,8 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
   const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   return fftn_poisson_step_pooled_batch(fn, upsampling, n_datasets, p->fft_batch_dev, p->fft_batch_host, flux, p->partials_batch,
                                         p->partials_batch + (size_t)n_datasets * per, eps, (float)(1.0 / n_pix), grad_flux,
-                                        any_shift ? p->gshift[0] : nullptr, p->partials_cal, grad_scale, accumulate, s, 1.0 / n_pix,
-                                        (double)grad_scale);
+                                        any_shift ? p->gshift[0] : nullptr, p->partials_shift_batch, grad_scale, accumulate, s,
+                                        1.0 / n_pix, (double)grad_scale);
 }
 
 extern "C" int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,

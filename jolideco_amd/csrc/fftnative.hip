@@ -1215,7 +1215,7 @@ int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_de
 // adjoint epilogue (into `gshift` where the dataset has a shift, else accumulated into `grad`; its blocks 0 / 1 finalise
 // the dataset's loss and d loss / d log norm), then the transposed shift (+ its two partial sums) and their finalize -- so
 // the gradient is summed in dataset order: the per-dataset calls' results, bit for bit.
-// partials / partials_b: nd * Hh / U doubles each; partials_shift: the transposed shift's own.
+// partials / partials_b: nd * Hh / U doubles each; partials_shift: nd * 2 * shift_bwd_max_blocks(H, W) doubles.
 int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, const FftBatch* batch_dev, const FftBatch& host,
                                    const float* flux, double* partials, double* partials_b, float eps, float inv_n, float* grad,
                                    float* gshift, double* partials_shift, float coef, int accumulate, hipStream_t stream,
@@ -1239,6 +1239,9 @@ int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, c
     if (rc) return rc;
   }
   if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
+  const size_t shift_stride = (size_t)2 * shift_bwd_max_blocks(n.H, n.W);
+  int shift_blocks = 0;
+  float* shift_out[FFT_MAX_BATCH] = {nullptr};
   for (int d = 0; d < nd; ++d) {
     const bool shifted = host.shift_xy[d] != nullptr;
     const bool acc = accumulate || d > 0;
@@ -1248,13 +1251,13 @@ int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, c
                               host.grad_log_bkg_norm[d] ? &fold2 : nullptr, host.work[d])))
       return rc;
     if (!shifted) continue;
-    int n_blocks = 0;
-    if ((rc = launch_shift_bwd(flux, gshift, grad, acc ? 1 : 0, n.H, n.W, host.shift_xy[d], (float)upsampling, partials_shift, &n_blocks,
-                               stream)))
+    // (every dataset's partial sums in its own region of partials_shift: ONE finalize launch behind the loop)
+    if ((rc = launch_shift_bwd(flux, gshift, grad, acc ? 1 : 0, n.H, n.W, host.shift_xy[d], (float)upsampling,
+                               partials_shift + (size_t)d * shift_stride, &shift_blocks, stream)))
       return rc;
-    if (host.grad_shift_xy[d] && (rc = launch_finalize_multi(partials_shift, n_blocks, 2, 1.0, host.grad_shift_xy[d], 0, stream))) return rc;
+    shift_out[d] = host.grad_shift_xy[d];
   }
-  return JD_OK;
+  return shift_blocks ? launch_finalize_multi_batch(partials_shift, shift_stride, shift_blocks, nd, shift_out, stream) : JD_OK;
 }
 
 }  // namespace jd

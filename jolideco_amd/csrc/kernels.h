@@ -39,6 +39,8 @@ int launch_shift_bwd(const float* in, const float* gs, float* grad_in, int accum
                      const float* shift_xy, float scale, double* partials, int* n_blocks, hipStream_t stream);
 int shift_bwd_max_blocks(int H, int W);
 // out[i] = [out[i] +] scale * sum_b partials[n_out * b + i]   (i < n_out; one fixed-order pass)
+int launch_finalize_multi_batch(const double* partials, size_t stride, int n_blocks, int n_datasets, float* const* out,
+                                hipStream_t stream);
 int launch_finalize_multi(const double* partials, int n_blocks, int n_out, double scale, float* out, int accumulate,
                           hipStream_t stream);
 

@@ -82,6 +82,46 @@ __global__ __launch_bounds__(256) void finalize_multi_kernel(const double* __res
   }
 }
 
+// finalize_multi_kernel for SEVERAL datasets in one launch: block d sums the n_blocks x 2 partial sums of dataset d
+// (partials + d * stride) into out[d][0 .. 1] -- the arithmetic and order of finalize_multi_kernel per dataset.
+constexpr int FINALIZE_BATCH_MAX = 16;
+struct FinalizeBatchArgs {
+  const double* partials;
+  size_t stride;  // doubles between the partial sums of consecutive datasets
+  int n_blocks;
+  float* out[FINALIZE_BATCH_MAX];  // nullable entries
+};
+
+__global__ __launch_bounds__(256) void finalize_multi_batch_kernel(FinalizeBatchArgs a) {
+  __shared__ double smem[256 / 64];
+  float* out = nullptr;
+#pragma unroll
+  for (int d = 0; d < FINALIZE_BATCH_MAX; ++d)  // (compile-time indices into the by-value argument array)
+    if ((int)blockIdx.x == d) out = a.out[d];
+  if (!out) return;  // (block-uniform)
+  const double* partials = a.partials + (size_t)blockIdx.x * a.stride;
+  for (int i = 0; i < 2; ++i) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < a.n_blocks; b += 256) acc += partials[(size_t)2 * b + i];
+    const double total = block_sum<256>(acc, smem);
+    if (threadIdx.x == 0) out[i] = (float)(1.0 * total);
+    __syncthreads();
+  }
+}
+
+int launch_finalize_multi_batch(const double* partials, size_t stride, int n_blocks, int n_datasets, float* const* out,
+                                hipStream_t stream) {
+  if (n_datasets < 1 || n_datasets > FINALIZE_BATCH_MAX) return fail(JD_ERR_INVALID, "finalize_multi_batch: %d datasets", n_datasets);
+  FinalizeBatchArgs a{};
+  a.partials = partials, a.stride = stride, a.n_blocks = n_blocks;
+  bool any = false;
+  for (int d = 0; d < n_datasets; ++d) a.out[d] = out[d], any = any || out[d];
+  if (!any) return JD_OK;
+  finalize_multi_batch_kernel<<<n_datasets, 256, 0, stream>>>(a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
 int launch_shift_fwd(const float* in, float* out, int H, int W, const float* shift_xy, float scale, hipStream_t stream) {
   dim3 grid((W + 255) / 256, H);
   shift_fwd_kernel<<<grid, 256, 0, stream>>>(in, out, H, W, shift_xy, scale);
