@@ -53,6 +53,7 @@ struct jd_conv_plan {
   jd::FftBatch fft_batch_host = {};       // the table last uploaded (a session passes the same pointers every step)
   jd::FftBatch* fft_batch_dev = nullptr;
   double* partials_shift_batch = nullptr;  // calibrated batched step: 2 x shift blocks doubles per dataset
+  float* gshift_batch[jd::FFT_MAX_BATCH] = {nullptr};  // and one (H, W) image per dataset: exposure x corr
   int partials_shift_batch_cap = 0;
   // pointer tables of the batched joint step in device memory: a few slots keyed by content, so that sessions (or the
   // chunks of a fit with more than SEP_MAX_BATCH datasets) that alternate between tables never re-upload -- an upload
@@ -298,6 +299,8 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
   }
   if (p->fft_batch_dev) (void)hipFree(p->fft_batch_dev);
   if (p->partials_shift_batch) (void)hipFree(p->partials_shift_batch);
+  for (int i = 0; i < jd::FFT_MAX_BATCH; ++i)
+    if (p->gshift_batch[i]) (void)hipFree(p->gshift_batch[i]);
   if (p->fwd) rocfft_plan_destroy(p->fwd);
   if (p->inv) rocfft_plan_destroy(p->inv);
   if (p->info) rocfft_execution_info_destroy(p->info);
@@ -817,7 +820,9 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
     JD_HIP(hipMalloc(&p->partials_batch, (size_t)2 * n_datasets * per * sizeof(double)));
     p->partials_batch_cap = 2 * n_datasets * per;
   }
-  const int shift_need = any_shift ? 2 * shift_bwd_max_blocks(p->H, p->W) * n_datasets : 0;
+  for (int d = 0; d < n_datasets; ++d)
+    if (!p->gshift_batch[d]) JD_HIP(hipMalloc(&p->gshift_batch[d], (size_t)p->H * p->W * sizeof(float)));
+  const int shift_need = 2 * shift_bwd_max_blocks(p->H, p->W) * n_datasets;
   if (p->partials_shift_batch_cap < shift_need) {
     if (p->partials_shift_batch) (void)hipFree(p->partials_shift_batch);
     p->partials_shift_batch = nullptr, p->partials_shift_batch_cap = 0;
@@ -835,6 +840,7 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
     batch.log_bkg_norm[d] = log_background_norm ? log_background_norm[d] : nullptr;
     batch.grad_shift_xy[d] = grad_shift_xy ? grad_shift_xy[d] : nullptr;
     batch.grad_log_bkg_norm[d] = (batch.log_bkg_norm[d] && grad_log_background_norm) ? grad_log_background_norm[d] : nullptr;
+    batch.gshift[d] = p->gshift_batch[d];
   }
   if (!p->fft_batch_dev) JD_HIP(hipMalloc(&p->fft_batch_dev, sizeof(FftBatch)));
   if (memcmp(&batch, &p->fft_batch_host, sizeof(batch)) != 0) {
@@ -845,8 +851,7 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
   const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   return fftn_poisson_step_pooled_batch(fn, upsampling, n_datasets, p->fft_batch_dev, p->fft_batch_host, flux, p->partials_batch,
                                         p->partials_batch + (size_t)n_datasets * per, eps, (float)(1.0 / n_pix), grad_flux,
-                                        any_shift ? p->gshift[0] : nullptr, p->partials_shift_batch, grad_scale, accumulate, s,
-                                        1.0 / n_pix, (double)grad_scale);
+                                        p->partials_shift_batch, grad_scale, accumulate, s, 1.0 / n_pix, (double)grad_scale);
 }
 
 extern "C" int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,

@@ -594,11 +594,17 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
-  const int tid = threadIdx.x, y = blockIdx.x;
+  // n_batch > 0 (ADJ, calibrated batched step): block b = row pair b / n of dataset b % n; out = the dataset's gshift image
+  // (overwritten), scale = its exposure, and the blocks of row pairs 0 / 1 finalise the dataset's loss / norm gradient
+  const int tid = threadIdx.x, nb = ADJ ? a.n_batch : 0;
+  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
+  const float2* const work = nb ? a.batch->work[d] : a.work;
+  const float* const scale = nb ? a.batch->exposure[d] : a.scale;
+  float* const out = nb ? a.batch->gshift[d] : a.out;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = 5;  // float4 pieces of a row per thread: W <= 4 * 256 * 5
-  load_spectrum_row(bufa, a.work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  load_spectrum_row(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
   const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
 #pragma unroll
@@ -611,33 +617,38 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
     if (ADJ) {
       up.x *= a.coef, up.y *= a.coef, up.z *= a.coef, up.w *= a.coef;
       dn.x *= a.coef, dn.y *= a.coef, dn.z *= a.coef, dn.w *= a.coef;
-      if (a.scale) {
-        const float4 s1 = *reinterpret_cast<const float4*>(a.scale + o1 + x), s2 = *reinterpret_cast<const float4*>(a.scale + o2 + x);
+      if (scale) {
+        const float4 s1 = *reinterpret_cast<const float4*>(scale + o1 + x), s2 = *reinterpret_cast<const float4*>(scale + o2 + x);
         up.x *= s1.x, up.y *= s1.y, up.z *= s1.z, up.w *= s1.w;
         dn.x *= s2.x, dn.y *= s2.y, dn.z *= s2.z, dn.w *= s2.w;
       }
-      if (a.accumulate) {
-        const float4 g1 = *reinterpret_cast<const float4*>(a.out + o1 + x), g2 = *reinterpret_cast<const float4*>(a.out + o2 + x);
+      if (a.accumulate && !nb) {
+        const float4 g1 = *reinterpret_cast<const float4*>(out + o1 + x), g2 = *reinterpret_cast<const float4*>(out + o2 + x);
         up.x += g1.x, up.y += g1.y, up.z += g1.z, up.w += g1.w;
         dn.x += g2.x, dn.y += g2.y, dn.z += g2.z, dn.w += g2.w;
       }
     }
-    *reinterpret_cast<float4*>(a.out + o1 + x) = up;
-    *reinterpret_cast<float4*>(a.out + o2 + x) = dn;
+    *reinterpret_cast<float4*>(out + o1 + x) = up;
+    *reinterpret_cast<float4*>(out + o2 + x) = dn;
   }
-  if (ADJ && a.fin_partials && blockIdx.x == 0) {  // (block-uniform)
+  if (ADJ && a.fin_partials && y == 0) {  // (block-uniform)
     __shared__ double red[ROW_THREADS / 64];
+    const double* part = a.fin_partials + (size_t)d * a.fin_count;
     double acc = 0.0;
-    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += a.fin_partials[i];
+    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
     const double total = block_sum<ROW_THREADS>(acc, red);
-    if (tid == 0) a.fin_out[0] = (float)(a.fin_scale * total + a.fin_offset);
+    if (tid == 0) {
+      if (nb) a.batch->loss_out[d][0] = (float)(a.fin_scale * total + (double)a.batch->loss_offset[d]);
+      else a.fin_out[0] = (float)(a.fin_scale * total + a.fin_offset);
+    }
   }
-  if (ADJ && a.fin2_partials && blockIdx.x == 1) {
+  if (ADJ && a.fin2_partials && y == 1 && (!nb || a.batch->grad_log_bkg_norm[d])) {
     __shared__ double red2[ROW_THREADS / 64];
+    const double* part = a.fin2_partials + (size_t)d * a.fin_count;
     double acc = 0.0;
-    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += a.fin2_partials[i];
+    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
     const double total = block_sum<ROW_THREADS>(acc, red2);
-    if (tid == 0) a.fin2_out[0] = (float)(a.fin2_scale * total);
+    if (tid == 0) (nb ? a.batch->grad_log_bkg_norm[d] : a.fin2_out)[0] = (float)(a.fin2_scale * total);
   }
 }
 
@@ -1218,8 +1229,8 @@ int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_de
 // partials / partials_b: nd * Hh / U doubles each; partials_shift: nd * 2 * shift_bwd_max_blocks(H, W) doubles.
 int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, const FftBatch* batch_dev, const FftBatch& host,
                                    const float* flux, double* partials, double* partials_b, float eps, float inv_n, float* grad,
-                                   float* gshift, double* partials_shift, float coef, int accumulate, hipStream_t stream,
-                                   double loss_scale, double norm_grad_scale) {
+                                   double* partials_shift, float coef, int accumulate, hipStream_t stream, double loss_scale,
+                                   double norm_grad_scale) {
   if (nd < 1 || nd > FFT_MAX_BATCH) return fail(JD_ERR_INVALID, "native FFT batch: %d datasets not in [1, %d]", nd, FFT_MAX_BATCH);
   if (!fftn_pooled_supported(n, upsampling)) return fail(JD_ERR_INVALID, "native FFT batch: up-sampling %d not supported", upsampling);
   int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, (float)upsampling, batch_dev, nd);
@@ -1239,25 +1250,29 @@ int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, c
     if (rc) return rc;
   }
   if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
+  // the tail over all datasets: rows^-1 + adjoint epilogue into every dataset's own image (blocks of row pairs 0 / 1
+  // finalise its loss / norm gradient), ONE transposed-shift launch that adds the datasets up in order (a dataset without
+  // a shift: its image as it is), one launch for the shift gradients
+  {
+    static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
+    static size_t set[N_ROW_SCHED] = {};
+    RowsInvArgs a{};
+    a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
+    a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
+    a.coef = coef, a.accumulate = 0, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
+    a.fin_partials = partials, a.fin_count = per, a.fin_scale = loss_scale;
+    a.fin2_partials = partials_b, a.fin2_scale = norm_grad_scale;
+    if ((rc = launch_row_kernel(kernels_adj, set, n, a, JD_KERNEL_FFT_C2R, stream, n.Hh * nd))) return rc;
+  }
   const size_t shift_stride = (size_t)2 * shift_bwd_max_blocks(n.H, n.W);
   int shift_blocks = 0;
+  if ((rc = launch_shift_bwd_batch(flux, batch_dev, nd, grad, accumulate, n.H, n.W, (float)upsampling, partials_shift, shift_stride,
+                                   &shift_blocks, stream)))
+    return rc;
   float* shift_out[FFT_MAX_BATCH] = {nullptr};
-  for (int d = 0; d < nd; ++d) {
-    const bool shifted = host.shift_xy[d] != nullptr;
-    const bool acc = accumulate || d > 0;
-    const SepLossFold fold{partials + (size_t)d * per, per, loss_scale, (double)host.loss_offset[d], host.loss_out[d]};
-    const SepLossFold fold2{partials_b + (size_t)d * per, per, norm_grad_scale, 0.0, host.grad_log_bkg_norm[d]};
-    if ((rc = launch_rows_inv(n, shifted ? gshift : grad, host.exposure[d], 1, coef, shifted ? 0 : (acc ? 1 : 0), stream, &fold,
-                              host.grad_log_bkg_norm[d] ? &fold2 : nullptr, host.work[d])))
-      return rc;
-    if (!shifted) continue;
-    // (every dataset's partial sums in its own region of partials_shift: ONE finalize launch behind the loop)
-    if ((rc = launch_shift_bwd(flux, gshift, grad, acc ? 1 : 0, n.H, n.W, host.shift_xy[d], (float)upsampling,
-                               partials_shift + (size_t)d * shift_stride, &shift_blocks, stream)))
-      return rc;
-    shift_out[d] = host.grad_shift_xy[d];
-  }
-  return shift_blocks ? launch_finalize_multi_batch(partials_shift, shift_stride, shift_blocks, nd, shift_out, stream) : JD_OK;
+  bool any = false;
+  for (int d = 0; d < nd; ++d) shift_out[d] = host.shift_xy[d] ? host.grad_shift_xy[d] : nullptr, any = any || shift_out[d];
+  return any ? launch_finalize_multi_batch(partials_shift, shift_stride, shift_blocks, nd, shift_out, stream) : JD_OK;
 }
 
 }  // namespace jd

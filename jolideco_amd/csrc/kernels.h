@@ -39,6 +39,11 @@ int launch_shift_bwd(const float* in, const float* gs, float* grad_in, int accum
                      const float* shift_xy, float scale, double* partials, int* n_blocks, hipStream_t stream);
 int shift_bwd_max_blocks(int H, int W);
 // out[i] = [out[i] +] scale * sum_b partials[n_out * b + i]   (i < n_out; one fixed-order pass)
+// grad_in (+)= sum_d shift_d^T(gs_d) in dataset order (datasets without a shift: + gs_d), and per dataset the partial sums of
+// d loss / d shift_xy; batch (device memory): gshift, shift_xy per dataset
+struct FftBatch;
+int launch_shift_bwd_batch(const float* in, const FftBatch* batch, int n_datasets, float* grad_in, int accumulate, int H, int W,
+                           float scale, double* partials, size_t partials_stride, int* n_blocks, hipStream_t stream);
 int launch_finalize_multi_batch(const double* partials, size_t stride, int n_blocks, int n_datasets, float* const* out,
                                 hipStream_t stream);
 int launch_finalize_multi(const double* partials, int n_blocks, int n_out, double scale, float* out, int accumulate,
@@ -239,15 +244,16 @@ struct FftBatch {  // per-dataset pointers of a batched likelihood step on the n
   // calibrated steps (jd_npred_poisson_calibrated_batch_fwd_bwd): nullable entries
   const float* shift_xy[FFT_MAX_BATCH];
   const float* log_bkg_norm[FFT_MAX_BATCH];
-  float* grad_shift_xy[FFT_MAX_BATCH];      // (host side only)
-  float* grad_log_bkg_norm[FFT_MAX_BATCH];  // (host side only)
+  float* grad_shift_xy[FFT_MAX_BATCH];
+  float* grad_log_bkg_norm[FFT_MAX_BATCH];
+  float* gshift[FFT_MAX_BATCH];             // exposure x corr of the dataset: the transposed shift's input
 };
 int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_dev, const float* flux, double* partials, float eps,
                             float inv_n, float* grad, float coef, int accumulate, hipStream_t stream, double loss_scale);
 int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, const FftBatch* batch_dev, const FftBatch& host,
                                    const float* flux, double* partials, double* partials_b, float eps, float inv_n, float* grad,
-                                   float* gshift, double* partials_shift, float coef, int accumulate, hipStream_t stream,
-                                   double loss_scale, double norm_grad_scale);
+                                   double* partials_shift, float coef, int accumulate, hipStream_t stream, double loss_scale,
+                                   double norm_grad_scale);
 bool fftn_pooled_supported(const FftNative& n, int upsampling);
 int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,

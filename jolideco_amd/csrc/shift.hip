@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void shift_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ grad_in, int accumulate, int H, int W,
                                                         const float* __restrict__ shift_xy, float scale,
                                                         double* __restrict__ partials) {
+#pragma clang fp contract(off)  // (every operation rounded on its own: the batched form below must give the same bits)
   __shared__ double smem[256 / 64];
   const int x = blockIdx.x * 256 + threadIdx.x;
   const ShiftGeom g = shift_geom(shift_xy, scale);
@@ -64,6 +65,74 @@ __global__ __launch_bounds__(256) void shift_bwd_kernel(const float* __restrict_
     partials[2 * b] = tx * (double)scale;
     partials[2 * b + 1] = ty * (double)scale;
   }
+}
+
+// The transposed shifts of SEVERAL datasets in one launch (calibrated batched step): per pixel the datasets' terms are
+// added in dataset order -- v = [grad_in +] t_0, then v = t_d + v -- exactly as the per-dataset launches leave them when each
+// accumulates onto its predecessor; a dataset without a shift contributes its image as it is (what its adjoint launch
+// would have accumulated directly).  Partial sums of d loss / d shift_xy per dataset: partials + d * partials_stride.
+__global__ __launch_bounds__(256) void shift_bwd_batch_kernel(const float* __restrict__ in, const FftBatch* __restrict__ batch,
+                                                              int n_datasets, float* __restrict__ grad_in, int accumulate, int H,
+                                                              int W, float scale, double* __restrict__ partials,
+                                                              size_t partials_stride) {
+#pragma clang fp contract(off)
+  __shared__ double smem[256 / 64];
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int y_begin = blockIdx.y * SHIFT_ROWS, y_end = min((int)(blockIdx.y + 1) * SHIFT_ROWS, H);
+  // (rows outer, datasets inner would keep v in a register; datasets outer keeps the per-dataset sums in registers --
+  // the per-dataset block sums need the latter: v goes through the gradient image, which this block owns)
+  for (int d = 0; d < n_datasets; ++d) {
+    const float* gs = batch->gshift[d];
+    const float* shift_xy = batch->shift_xy[d];
+    const bool add = accumulate || d > 0;
+    double dsx = 0.0, dsy = 0.0;
+    if (shift_xy) {
+      const ShiftGeom g = shift_geom(shift_xy, scale);
+      for (int y = y_begin; y < y_end; ++y) {
+        if (x >= W) break;
+        const int py = y - g.fy, px = x - g.fx;
+        float v = at(gs, H, W, py, px) * (g.wx0 * g.wy0) + at(gs, H, W, py, px - 1) * (g.wx1 * g.wy0) +
+                  at(gs, H, W, py - 1, px) * (g.wx0 * g.wy1) + at(gs, H, W, py - 1, px - 1) * (g.wx1 * g.wy1);
+        const size_t off = (size_t)y * W + x;
+        if (add) v += grad_in[off];
+        grad_in[off] = v;
+        const int y0 = y + g.fy, x0 = x + g.fx;
+        const float nw = at(in, H, W, y0, x0), ne = at(in, H, W, y0, x0 + 1);
+        const float sw = at(in, H, W, y0 + 1, x0), se = at(in, H, W, y0 + 1, x0 + 1);
+        const float go = gs[off];
+        dsx += (double)(go * ((ne - nw) * g.wy0 + (se - sw) * g.wy1));
+        dsy += (double)(go * ((sw - nw) * g.wx0 + (se - ne) * g.wx1));
+      }
+    } else {
+      for (int y = y_begin; y < y_end; ++y) {
+        if (x >= W) break;
+        const size_t off = (size_t)y * W + x;
+        float v = gs[off];
+        if (add) v += grad_in[off];
+        grad_in[off] = v;
+      }
+    }
+    if (shift_xy) {  // (uniform)
+      const double tx = block_sum<256>(dsx, smem);
+      __syncthreads();
+      const double ty = block_sum<256>(dsy, smem);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        partials[(size_t)d * partials_stride + 2 * b] = tx * (double)scale;
+        partials[(size_t)d * partials_stride + 2 * b + 1] = ty * (double)scale;
+      }
+    }
+  }
+}
+
+int launch_shift_bwd_batch(const float* in, const FftBatch* batch, int n_datasets, float* grad_in, int accumulate, int H, int W,
+                           float scale, double* partials, size_t partials_stride, int* n_blocks, hipStream_t stream) {
+  dim3 grid((W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
+  *n_blocks = grid.x * grid.y;
+  shift_bwd_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
 }
 
 __global__ __launch_bounds__(256) void finalize_multi_kernel(const double* __restrict__ partials, int n_blocks, int n_out,
