@@ -204,11 +204,11 @@ int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* plan, int n_comp, const fl
 /* The joint step over SEVERAL datasets of ONE flux component with the per-dataset calibration and / or up-sampling (the
  * fits of the reference's examples: examples/chandra-e0102-filament.py:178-203): the batched form of the loop
  * `for dataset: jd_npred_poisson_calibrated_fwd_bwd(..., accumulate = dataset > 0)` -- same results, bit for bit.  On a
- * plan of the native FFT convolution with up-sampling 2 or 4, rows (with the dataset's shift), columns, the pooled
- * Poisson launch and the adjoint's column pass each cover all datasets in one launch; the adjoint's last launch and the
- * transposed shift run per dataset, in order (flux grids up to 2048 rows: beyond, a dataset's own launches already run in
- * several rounds of blocks and the per-dataset calls are faster; option JD_FFT_BATCH=2 batches regardless).  Every other
- * case runs the per-dataset calls.
+ * plan of the native FFT convolution with up-sampling 2 or 4 every launch covers all datasets: rows (with the dataset's
+ * shift), columns, the pooled Poisson launch, the adjoint's column pass, rows^-1 + adjoint epilogue into one image per
+ * dataset, a transposed shift that adds the datasets up in dataset order, and the finalize of the shift gradients (flux
+ * grids up to 2048 rows: beyond, a dataset's own launches already run in several rounds of blocks and the per-dataset
+ * calls do as well; option JD_FFT_BATCH=2 batches regardless).  Every other case runs the per-dataset calls.
  *   exposure, khat, background, counts, loss_out : host arrays of n_datasets device pointers
  *   shift_xy, log_background_norm, grad_shift_xy, grad_log_background_norm : NULL, or host arrays of n_datasets device
  *                                                  pointers with NULL entries where a dataset has none (see above) */

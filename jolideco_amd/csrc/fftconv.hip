@@ -781,9 +781,9 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
   hipStream_t s = as_stream(stream);
   const bool any_cal = shift_xy || log_background_norm;
   // Measured (tools/gpu/cb1024.py, 8 calibrated observations, up-sampling x2, batched against per-dataset calls): flux grid
-  // 512^2 262 against 493 us per step, 1024^2 381 against 580, 2048^2 900 against 1063 -- and 4096^2 (bench config c6) 3 %
-  // SLOWER: there a dataset's launches already run in several rounds of blocks, and the per-dataset tail finds its rows
-  // colder behind a column launch over all datasets.  So: batched up to 2048 rows (JD_FFT_BATCH=2: always).
+  // 512^2 204 against 499 us per step, 1024^2 330 against 590, 2048^2 855 against 1071; at 4096^2 (bench config c6), where a
+  // dataset's launches already run in several rounds of blocks, the two tie (5.5 ms).  So: batched up to 2048 rows
+  // (JD_FFT_BATCH=2: always).
   const bool batched = p->native && grad_flux && n_datasets >= 2 && n_datasets <= FFT_MAX_BATCH &&
                        fftn_pooled_supported(p->fftn, upsampling) && !opt_is_set(OPT_SEP_NO_FUSION) &&
                        opt_value(OPT_FFT_BATCH, 1) != 0 && (p->fftn.Hh <= 1024 || opt_value(OPT_FFT_BATCH, 1) == 2);
