@@ -96,6 +96,11 @@ int jd_conv_plan_destroy(jd_conv_plan* plan);
 int jd_conv_plan_shape(const jd_conv_plan* plan, int* shape6);
 /* 0 = FFT, 1 = DIRECT, 2 = SEPARABLE */
 int jd_conv_plan_method(const jd_conv_plan* plan);
+/* 1 when a plan of this geometry with the FFT method runs the hand-written transforms of csrc/fftnative.hip (and with them
+ * the batched joint steps), 0 when it runs rocFFT (a size the native kernels do not cover, or option JD_FFT_NATIVE=0).
+ * Host logic only, no device needed: a caller that is about to embed PSFs of different sizes in one array so that their
+ * datasets share a plan (jolideco_amd/models/npred.py common_kernel_shape) asks first. */
+int jd_conv_native_fft_supported(int H, int W, int kh, int kw);
 /* 1 when a SEPARABLE plan runs a launch over `n_datasets` datasets (1 = the per-dataset calls) on the strip-walk kernels
  * of csrc/walkconv.hip instead of the tile kernel of csrc/sepconv.hip, given rank-1 operators (PSFs up to 17 x 17, image
  * width a multiple of 4, enough pixels x datasets to fill the chip; option JD_SEP_WALK = 0 / 1 forces either).  Both

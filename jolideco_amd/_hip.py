@@ -37,6 +37,7 @@ EXPORTS = {
     "jd_conv_plan_shape": (c_int, [c_void_p, POINTER(c_int)]),
     "jd_conv_plan_spectrum_size": (c_size_t, [c_void_p]),
     "jd_conv_plan_method": (c_int, [c_void_p]),
+    "jd_conv_native_fft_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "jd_conv_plan_takes_walk": (c_int, [c_void_p, c_int]),
     "jd_conv_operator_walk_frame": (c_int, [c_void_p, c_void_p]),
     "jd_conv_operator_forget": (c_int, [c_void_p]),

@@ -388,6 +388,8 @@ def _adam_step_many(cfg, items, cache):
         key = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _, _ in part)
         arrays = cache.get(key)
         if arrays is None:
+            if len(cache) >= 64:  # (a fit has a handful of tensor sets; gradients re-allocated every step must not pile up)
+                cache.clear()
             arrays = cache[key] = (
                 ptr_array([p.data for p, _, _ in part]), ptr_array([p.grad for p, _, _ in part]),
                 ptr_array([st["exp_avg"] for _, st, _ in part]), ptr_array([st["exp_avg_sq"] for _, st, _ in part]),

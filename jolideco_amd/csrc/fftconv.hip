@@ -50,8 +50,14 @@ struct jd_conv_plan {
   // batched joint step on the native FFT path: the work arrays of datasets 1 .. (dataset 0 uses fftn's own)
   float2* fft_extra_spec[jd::FFT_MAX_BATCH - 1] = {nullptr};
   float2* fft_extra_work[jd::FFT_MAX_BATCH - 1] = {nullptr};
-  jd::FftBatch fft_batch_host = {};       // the table last uploaded (a session passes the same pointers every step)
-  jd::FftBatch* fft_batch_dev = nullptr;
+  // the tables of the batched steps in device memory: a few slots keyed by content (the plain and the calibrated step, the
+  // chunks of a fit with more than FFT_MAX_BATCH datasets and several sessions on one plan alternate between tables; an
+  // upload has to wait for the stream)
+  static constexpr int N_FFT_TABLES = 6;
+  jd::FftBatch fft_batch_host[N_FFT_TABLES] = {};
+  jd::FftBatch* fft_batch_dev[N_FFT_TABLES] = {};
+  unsigned long long fft_batch_used[N_FFT_TABLES] = {};  // last use (call counter), 0 = empty
+  unsigned long long fft_batch_clock = 0;
   double* partials_shift_batch = nullptr;  // calibrated batched step: 2 x shift blocks doubles per dataset
   float* gshift_batch[jd::FFT_MAX_BATCH] = {nullptr};  // and one (H, W) image per dataset: exposure x corr
   int partials_shift_batch_cap = 0;
@@ -168,6 +174,28 @@ __global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict
                                                         size_t n, float s) {
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * s;
+}
+
+// The device copy of a batched step's table: looked up by content (`batch` must come from a value-initialised FftBatch{},
+// so that its padding bytes are zero), uploaded into the least recently used slot when it is new -- after waiting for the
+// launches of `s` that may still read that slot (a table is only ever read by launches of the stream that uploaded it:
+// handles are not shared between streams, include/jolideco_hip.h).
+static int fft_batch_table(jd_conv_plan* p, const FftBatch& batch, hipStream_t s, int* slot_out) {
+  int slot = -1, victim = 0;
+  for (int i = 0; i < jd_conv_plan::N_FFT_TABLES; ++i) {
+    if (p->fft_batch_used[i] && memcmp(&batch, &p->fft_batch_host[i], sizeof(batch)) == 0) slot = i;
+    if (p->fft_batch_used[i] < p->fft_batch_used[victim]) victim = i;
+  }
+  if (slot < 0) {
+    slot = victim;
+    if (!p->fft_batch_dev[slot]) JD_HIP(hipMalloc(&p->fft_batch_dev[slot], sizeof(FftBatch)));
+    if (p->fft_batch_used[slot]) JD_HIP(hipStreamSynchronize(s));
+    JD_HIP(hipMemcpy(p->fft_batch_dev[slot], &batch, sizeof(batch), hipMemcpyHostToDevice));
+    p->fft_batch_host[slot] = batch;
+  }
+  p->fft_batch_used[slot] = ++p->fft_batch_clock;
+  *slot_out = slot;
+  return JD_OK;
 }
 
 }  // namespace jd
@@ -297,7 +325,8 @@ extern "C" int jd_conv_plan_destroy(jd_conv_plan* p) {
     if (p->fft_extra_spec[i]) (void)hipFree(p->fft_extra_spec[i]);
     if (p->fft_extra_work[i]) (void)hipFree(p->fft_extra_work[i]);
   }
-  if (p->fft_batch_dev) (void)hipFree(p->fft_batch_dev);
+  for (auto* t : p->fft_batch_dev)
+    if (t) (void)hipFree(t);
   if (p->partials_shift_batch) (void)hipFree(p->partials_shift_batch);
   for (int i = 0; i < jd::FFT_MAX_BATCH; ++i)
     if (p->gshift_batch[i]) (void)hipFree(p->gshift_batch[i]);
@@ -332,6 +361,10 @@ extern "C" int jd_conv_plan_shape(const jd_conv_plan* p, int* shape6) {
 extern "C" size_t jd_conv_plan_spectrum_size(const jd_conv_plan* p) { return p ? p->nspec : 0; }
 
 extern "C" int jd_conv_plan_method(const jd_conv_plan* p) { return p ? p->method : -1; }
+
+extern "C" int jd_conv_native_fft_supported(int H, int W, int kh, int kw) {
+  return H > 0 && W > 0 && kh > 0 && kw > 0 && opt_value(OPT_FFT_NATIVE, 1) != 0 && fftn_supported(H, W, kh, kw) ? 1 : 0;
+}
 
 extern "C" int jd_conv_plan_takes_walk(const jd_conv_plan* p, int n_datasets) {
   if (!p || p->method != JD_CONV_SEPARABLE || n_datasets < 1) return 0;
@@ -611,8 +644,10 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
     for (int d = 0; d < n_datasets; ++d)
       JD_REQUIRE(exposure[d] && khat[d] && background[d] && counts[d] && loss_out[d], "%s: null pointer for dataset %d", who, d);
     hipStream_t s = as_stream(stream);
-    if (!grad_flux || !grad_flux[0] || n_datasets > FFT_MAX_BATCH || n_datasets < 2 || opt_is_set(OPT_SEP_NO_FUSION) ||
-        opt_value(OPT_FFT_BATCH, 1) == 0) {
+    // (block d of the last launch's Hh blocks finalises the loss of dataset d: a tiny image with more datasets than row
+    // pairs runs the per-dataset calls)
+    if (!grad_flux || !grad_flux[0] || n_datasets > FFT_MAX_BATCH || n_datasets < 2 || n_datasets > p->fftn.Hh ||
+        opt_is_set(OPT_SEP_NO_FUSION) || opt_value(OPT_FFT_BATCH, 1) == 0) {
       for (int d = 0; d < n_datasets; ++d) {
         int rc = npred_poisson_impl(who, p, 1, flux, exposure + d, khat + d, background[d], counts[d], stirling_mean[d], eps,
                                     loss_out[d], grad_flux, accumulate || d > 0, grad_scale, nullptr, 1, Calibration{}, stream);
@@ -639,15 +674,10 @@ extern "C" int jd_npred_poisson_batch_multi_fwd_bwd(jd_conv_plan* p, int n_datas
       batch.loss_out[d] = loss_out[d], batch.loss_offset[d] = stirling_mean[d];
       batch.spec[d] = d ? p->fft_extra_spec[d - 1] : fn.spec, batch.work[d] = d ? p->fft_extra_work[d - 1] : fn.work;
     }
-    if (!p->fft_batch_dev) JD_HIP(hipMalloc(&p->fft_batch_dev, sizeof(FftBatch)));
-    if (memcmp(&batch, &p->fft_batch_host, sizeof(batch)) != 0) {
-      // a new table: wait for launches that may still read the old one, then copy synchronously (stack source)
-      JD_HIP(hipStreamSynchronize(s));
-      JD_HIP(hipMemcpy(p->fft_batch_dev, &batch, sizeof(batch), hipMemcpyHostToDevice));
-      p->fft_batch_host = batch;
-    }
+    int slot = 0;
+    if (int rc = fft_batch_table(p, batch, s, &slot)) return rc;
     const double n_pix = (double)p->H * (double)p->W;
-    return fftn_poisson_step_batch(fn, n_datasets, p->fft_batch_dev, flux[0], p->partials_batch, eps, (float)(1.0 / n_pix),
+    return fftn_poisson_step_batch(fn, n_datasets, p->fft_batch_dev[slot], flux[0], p->partials_batch, eps, (float)(1.0 / n_pix),
                                    grad_flux[0], grad_scale, accumulate, s, 1.0 / n_pix);
   }
   JD_REQUIRE(n_datasets >= 1 && n_datasets <= SEP_MAX_BATCH, "%s: n_datasets = %d not in [1, %d]", who, n_datasets,
@@ -842,14 +872,10 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
     batch.grad_log_bkg_norm[d] = (batch.log_bkg_norm[d] && grad_log_background_norm) ? grad_log_background_norm[d] : nullptr;
     batch.gshift[d] = p->gshift_batch[d];
   }
-  if (!p->fft_batch_dev) JD_HIP(hipMalloc(&p->fft_batch_dev, sizeof(FftBatch)));
-  if (memcmp(&batch, &p->fft_batch_host, sizeof(batch)) != 0) {
-    JD_HIP(hipStreamSynchronize(s));
-    JD_HIP(hipMemcpy(p->fft_batch_dev, &batch, sizeof(batch), hipMemcpyHostToDevice));
-    p->fft_batch_host = batch;
-  }
+  int slot = 0;
+  if ((rc = fft_batch_table(p, batch, s, &slot))) return rc;
   const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
-  return fftn_poisson_step_pooled_batch(fn, upsampling, n_datasets, p->fft_batch_dev, p->fft_batch_host, flux, p->partials_batch,
+  return fftn_poisson_step_pooled_batch(fn, upsampling, n_datasets, p->fft_batch_dev[slot], p->fft_batch_host[slot], flux, p->partials_batch,
                                         p->partials_batch + (size_t)n_datasets * per, eps, (float)(1.0 / n_pix), grad_flux,
                                         p->partials_shift_batch, grad_scale, accumulate, s, 1.0 / n_pix, (double)grad_scale);
 }

@@ -29,6 +29,9 @@
 // grid per transform (profiles/r01).
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "jd_common.h"
@@ -708,13 +711,16 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_batch_kernel(RowsIn
     *reinterpret_cast<float4*>(a.out + o1 + x) = au[q];
     *reinterpret_cast<float4*>(a.out + o2 + x) = ad[q];
   }
-  if (a.fin_partials && (int)blockIdx.x < a.n_batch) {  // (block-uniform)
+  if (a.fin_partials) {
     __shared__ double red[ROW_THREADS / 64];
-    const double* part = a.fin_partials + (size_t)blockIdx.x * a.fin_count;
-    double acc = 0.0;
-    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
-    const double total = block_sum<ROW_THREADS>(acc, red);
-    if (tid == 0) a.batch->loss_out[blockIdx.x][0] = (float)(a.fin_scale * total + (double)a.batch->loss_offset[blockIdx.x]);
+    for (int d = blockIdx.x; d < a.n_batch; d += gridDim.x) {  // (block-uniform; more datasets than blocks: several per block)
+      const double* part = a.fin_partials + (size_t)d * a.fin_count;
+      double acc = 0.0;
+      for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
+      const double total = block_sum<ROW_THREADS>(acc, red);
+      if (tid == 0) a.batch->loss_out[d][0] = (float)(a.fin_scale * total + (double)a.batch->loss_offset[d]);
+      __syncthreads();
+    }
   }
 }
 
@@ -1005,10 +1011,19 @@ int fftn_spectrum(const FftNative& n, const float* psf, float2* khat, hipStream_
 }
 
 namespace {
-int lds_attr(const void* kernel, size_t bytes, size_t* set) {
-  if (bytes > 64 * 1024 && bytes > *set) {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, kernel): remembered per pair, under a lock (a
+// process may drive several devices, from several host threads)
+int lds_attr(const void* kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return JD_OK;
+  static std::mutex mutex;
+  static std::map<std::pair<int, const void*>, size_t> set;
+  int device = 0;
+  JD_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex);
+  size_t& have = set[{device, kernel}];
+  if (bytes > have) {
     JD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    *set = bytes;
+    have = bytes;
   }
   return JD_OK;
 }
@@ -1036,24 +1051,23 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   struct Entry {
     int lanes, cb, r0, r1, r2;
     Kernel kernel;
-    size_t lds_set;
   };
   static Entry table[] = {
-      {64, 4, 16, 8, 9, fftn_cols_kernel<64, 4, 16, 8, 9>, 0},    // 1152: 2048-row images, PSFs up to 129 rows
-      {128, 2, 16, 16, 9, fftn_cols_kernel<128, 2, 16, 16, 9>, 0},  // 2304: 4096-row images
-      {64, 4, 16, 8, 8, fftn_cols_kernel<64, 4, 16, 8, 8>, 0},    // 1024
-      {128, 2, 16, 16, 8, fftn_cols_kernel<128, 2, 16, 16, 8>, 0},  // 2048
-      {64, 4, 8, 8, 9, fftn_cols_kernel<64, 4, 8, 8, 9>, 0},      // 576: 1024-row images
-      {64, 4, 8, 8, 8, fftn_cols_kernel<64, 4, 8, 8, 8>, 0},      // 512
-      {64, 0, 0, 0, 0, fftn_cols_kernel<64, 0, 0, 0, 0>, 0},      // generic
-      {128, 0, 0, 0, 0, fftn_cols_kernel<128, 0, 0, 0, 0>, 0},
+      {64, 4, 16, 8, 9, fftn_cols_kernel<64, 4, 16, 8, 9>},    // 1152: 2048-row images, PSFs up to 129 rows
+      {128, 2, 16, 16, 9, fftn_cols_kernel<128, 2, 16, 16, 9>},  // 2304: 4096-row images
+      {64, 4, 16, 8, 8, fftn_cols_kernel<64, 4, 16, 8, 8>},    // 1024
+      {128, 2, 16, 16, 8, fftn_cols_kernel<128, 2, 16, 16, 8>},  // 2048
+      {64, 4, 8, 8, 9, fftn_cols_kernel<64, 4, 8, 8, 9>},      // 576: 1024-row images
+      {64, 4, 8, 8, 8, fftn_cols_kernel<64, 4, 8, 8, 8>},      // 512
+      {64, 0, 0, 0, 0, fftn_cols_kernel<64, 0, 0, 0, 0>},      // generic
+      {128, 0, 0, 0, 0, fftn_cols_kernel<128, 0, 0, 0, 0>},
   };
   Entry* e = nullptr;
   for (Entry& t : table) {
     const bool is_static = t.r0 && fy.n == 3 && t.r0 == fy.r[0] && t.r1 == fy.r[1] && t.r2 == fy.r[2] && t.cb == cb;
     if (t.lanes == lanes && (is_static || !t.r0) && !e) e = &t;
   }
-  int rc = lds_attr(reinterpret_cast<const void*>(e->kernel), cb * per_col, &e->lds_set);
+  int rc = lds_attr(reinterpret_cast<const void*>(e->kernel), cb * per_col);
   if (rc) return rc;
   ProfScope prof(JD_KERNEL_CMUL, stream);
   hipLaunchKernelGGL(e->kernel, dim3(((a.groups + 7) / 8) * 8 * (n_batch ? n_batch : 1)), dim3(lanes * cb), cb * per_col, stream, a);
@@ -1077,11 +1091,11 @@ int row_schedule(const FftPasses& f) {
   {NAME<__VA_ARGS__ 0, 0, 0, 0>, NAME<__VA_ARGS__ 16, 16, 9, 0>, NAME<__VA_ARGS__ 8, 8, 8, 9>, NAME<__VA_ARGS__ 16, 8, 9, 0>}
 
 template <class Args>
-int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), size_t (&set)[N_ROW_SCHED], const FftNative& n, const Args& a,
+int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), const FftNative& n, const Args& a,
                       int kernel_id, hipStream_t stream, int blocks = 0) {
   const int sched = row_schedule(a.f);
   const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
-  int rc = lds_attr(reinterpret_cast<const void*>(kernels[sched]), lds_rows, &set[sched]);
+  int rc = lds_attr(reinterpret_cast<const void*>(kernels[sched]), lds_rows);
   if (rc) return rc;
   ProfScope prof(kernel_id, stream);
   hipLaunchKernelGGL(kernels[sched], dim3(blocks ? blocks : n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
@@ -1092,19 +1106,17 @@ int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), size_t (&set)
 int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream, const float* shift_xy = nullptr,
                     float shift_scale = 1.f, const FftBatch* batch = nullptr, int n_batch = 0) {
   static void (*const kernels[N_ROW_SCHED])(RowsFwdArgs) = JD_ROW_KERNELS(fftn_rows_fwd_kernel, );
-  static size_t set[N_ROW_SCHED] = {};
   RowsFwdArgs a{};
   a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
   a.shift_xy = shift_xy, a.shift_scale = shift_scale;
   a.batch = batch, a.n_batch = n_batch;
-  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_R2C, stream, n_batch ? n.Hh * n_batch : 0);
+  return launch_row_kernel(kernels, n, a, JD_KERNEL_FFT_R2C, stream, n_batch ? n.Hh * n_batch : 0);
 }
 
 int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int adjoint, float coef, int accumulate, hipStream_t stream,
                     const SepLossFold* fold = nullptr, const SepLossFold* fold2 = nullptr, const float2* work = nullptr) {
   static void (*const kernels_fwd[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, false, );
   static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
-  static size_t set[2][N_ROW_SCHED] = {};
   RowsInvArgs a{};
   a.work = work ? work : n.work, a.tw = n.tw_x, a.out = out, a.scale = out_scale, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
   a.ra = adjoint ? n.kh - 1 - n.oy : n.oy, a.rb = adjoint ? n.oy : n.kh - 1 - n.oy;
@@ -1112,8 +1124,8 @@ int launch_rows_inv(const FftNative& n, float* out, const float* out_scale, int 
   if (fold && adjoint)
     a.fin_partials = fold->partials, a.fin_count = fold->count, a.fin_scale = fold->scale, a.fin_offset = fold->offset, a.fin_out = fold->out;
   if (fold && fold2 && adjoint) a.fin2_partials = fold2->partials, a.fin2_scale = fold2->scale, a.fin2_out = fold2->out;
-  return adjoint ? launch_row_kernel(kernels_adj, set[1], n, a, JD_KERNEL_FFT_C2R, stream)
-                 : launch_row_kernel(kernels_fwd, set[0], n, a, JD_KERNEL_FFT_C2R, stream);
+  return adjoint ? launch_row_kernel(kernels_adj, n, a, JD_KERNEL_FFT_C2R, stream)
+                 : launch_row_kernel(kernels_fwd, n, a, JD_KERNEL_FFT_C2R, stream);
 }
 }  // namespace
 
@@ -1138,12 +1150,11 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
   if ((rc = launch_cols(n, khat, 0, stream))) return rc;
   {
     static void (*const kernels[N_ROW_SCHED])(RowsPoissonArgs) = JD_ROW_KERNELS(fftn_rows_poisson_kernel, );
-    static size_t set[N_ROW_SCHED] = {};
     RowsPoissonArgs a{};
     a.work = n.work, a.spec = n.spec, a.tw = n.tw_x, a.background = background, a.counts = counts, a.partials = partials;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
     a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx);
-    if ((rc = launch_row_kernel(kernels, set, n, a, JD_KERNEL_POISSON_FUSED, stream))) return rc;
+    if ((rc = launch_row_kernel(kernels, n, a, JD_KERNEL_POISSON_FUSED, stream))) return rc;
   }
   *n_partials = n.Hh;
   if ((rc = launch_cols(n, khat, 1, stream))) return rc;
@@ -1173,14 +1184,13 @@ int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* fl
   {
     static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
     static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
-    static size_t set[2][N_ROW_SCHED] = {};
     RowsPooledArgs a{};
     a.work = n.work, a.spec = n.spec, a.tw = n.tw_x, a.background = background, a.counts = counts, a.log_bkg_norm = log_bkg_norm;
     a.partials = partials, a.partials_b = norm_grad_out ? partials_b : nullptr;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
     a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx);
-    rc = upsampling == 2 ? launch_row_kernel(kernels2, set[0], n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 2)
-                         : launch_row_kernel(kernels4, set[1], n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 4);
+    rc = upsampling == 2 ? launch_row_kernel(kernels2, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 2)
+                         : launch_row_kernel(kernels4, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 4);
     if (rc) return rc;
   }
   if ((rc = launch_cols(n, khat, 1, stream))) return rc;
@@ -1201,23 +1211,21 @@ int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_de
   if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, nd))) return rc;
   {
     static void (*const kernels[N_ROW_SCHED])(RowsPoissonArgs) = JD_ROW_KERNELS(fftn_rows_poisson_kernel, );
-    static size_t set[N_ROW_SCHED] = {};
     RowsPoissonArgs a{};
     a.tw = n.tw_x, a.partials = partials;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
     a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
-    if ((rc = launch_row_kernel(kernels, set, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh * nd))) return rc;
+    if ((rc = launch_row_kernel(kernels, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh * nd))) return rc;
   }
   if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
   static void (*const kernels[N_ROW_SCHED])(RowsInvArgs) = {fftn_rows_inv_batch_kernel<0, 0, 0, 0>, fftn_rows_inv_batch_kernel<16, 16, 9, 0>,
                                                             fftn_rows_inv_batch_kernel<8, 8, 8, 9>, fftn_rows_inv_batch_kernel<16, 8, 9, 0>};
-  static size_t set[N_ROW_SCHED] = {};
   RowsInvArgs a{};
   a.tw = n.tw_x, a.out = grad, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
   a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
   a.coef = coef, a.accumulate = accumulate, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
   a.fin_partials = partials, a.fin_count = n.Hh, a.fin_scale = loss_scale;
-  return launch_row_kernel(kernels, set, n, a, JD_KERNEL_FFT_C2R, stream);
+  return launch_row_kernel(kernels, n, a, JD_KERNEL_FFT_C2R, stream);
 }
 
 // The likelihood steps of `nd` datasets of one flux image with up-sampling U = 2 / 4 and, per dataset, an optional
@@ -1240,13 +1248,12 @@ int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, c
   {
     static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
     static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
-    static size_t set[2][N_ROW_SCHED] = {};
     RowsPooledArgs a{};
     a.tw = n.tw_x, a.partials = partials, a.partials_b = partials_b;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
     a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
-    rc = upsampling == 2 ? launch_row_kernel(kernels2, set[0], n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd)
-                         : launch_row_kernel(kernels4, set[1], n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd);
+    rc = upsampling == 2 ? launch_row_kernel(kernels2, n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd)
+                         : launch_row_kernel(kernels4, n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd);
     if (rc) return rc;
   }
   if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
@@ -1255,14 +1262,13 @@ int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, c
   // a shift: its image as it is), one launch for the shift gradients
   {
     static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
-    static size_t set[N_ROW_SCHED] = {};
     RowsInvArgs a{};
     a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
     a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
     a.coef = coef, a.accumulate = 0, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
     a.fin_partials = partials, a.fin_count = per, a.fin_scale = loss_scale;
     a.fin2_partials = partials_b, a.fin2_scale = norm_grad_scale;
-    if ((rc = launch_row_kernel(kernels_adj, set, n, a, JD_KERNEL_FFT_C2R, stream, n.Hh * nd))) return rc;
+    if ((rc = launch_row_kernel(kernels_adj, n, a, JD_KERNEL_FFT_C2R, stream, n.Hh * nd))) return rc;
   }
   const size_t shift_stride = (size_t)2 * shift_bwd_max_blocks(n.H, n.W);
   int shift_blocks = 0;

@@ -96,11 +96,20 @@ SepGeom sep_geom(int kh, int kw, int oy, int ox, bool adjoint);
 // different PSF sizes share one plan that way) has a support smaller than the plan's (kh, kw): the strip-walk kernels
 // choose their frame (17 or 33 taps) per operator from it, the tile kernel trims its window per launch.
 // rank 0 = a buffer the library has not seen (a copy made by the caller): such a buffer never takes a path that
-// assumes its rank or support
+// assumes its rank or support.
+// An operator buffer is IMMUTABLE once built: the registry is keyed by its device address.  The buffer carries its own
+// record in its four header floats -- [0] rank, [1] the strip-walk frame its taps need (17 / 33; 99: none), [2] / [3] the
+// support of the forward / adjoint taps as the BIT PATTERN ulo | uhi << 8 | vlo << 16 | vhi << 24 (sep_pack_support) --
+// and every kernel that trusted the registry for a narrower window or frame compares:
+// a registered buffer overwritten in place by an operator of wider support (khat.copy_(other), a state load) trips the
+// guard flag, and the next library call reports JD_ERR_INVALID instead of silently dropping taps.
 struct SepOpInfo {
   int rank = 0;
   int ulo[2] = {0, 0}, uhi[2] = {0, 0}, vlo[2] = {0, 0}, vhi[2] = {0, 0};
 };
+inline unsigned sep_pack_support(int ulo, int uhi, int vlo, int vhi) {
+  return (unsigned)ulo | (unsigned)uhi << 8 | (unsigned)vlo << 16 | (unsigned)vhi << 24;
+}
 void sep_register_operator(const void* op_dev, const SepOpInfo& info);
 void sep_forget_operator(const void* op_dev);
 int sep_operator_rank(const void* op_dev);
@@ -177,6 +186,9 @@ constexpr int JD_WALK_NOT_TAKEN = 1;
 bool walk_takes_launch(int H, int W, int n_datasets, int kh, int kw, int oy, int ox);
 // frame (17 / 33 taps) a registered operator of this plan geometry walks in, 0: none
 int walk_operator_frame(const float* op, int kh, int kw, int oy, int ox);
+// the same from a support record (sep_build_operator writes it into the operator's header, the kernels' guard reads it):
+// 17 / 33, 0: rank > 1 or a support no frame holds
+int walk_info_frame(const SepOpInfo& info, int kh, int kw, int oy, int ox);
 int walk_conv(const float* in, const float* in_scale, const float* op, float* out, const float* out_scale, int H, int W,
               int kh, int kw, int oy, int ox, int adjoint, float coef, int accumulate, hipStream_t stream);
 int walk_conv_poisson(const float* in, const float* in_scale, const float* op, float* g_out, int H, int W, int kh, int kw,

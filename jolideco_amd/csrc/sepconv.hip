@@ -18,6 +18,7 @@
 // two image rows, the column pass on two neighbouring columns), so one LDS read feeds ~5 FMAs; the taps stay
 // runtime values (no template per PSF size).
 #include <algorithm>
+#include <cstring>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -86,7 +87,9 @@ struct SepArgs {
   const float* in_c1;
   const float* in_c2;
   const float* in_c3;
-  int* guard;  // host-mapped flag: an operator contradicted the rank the host launched it for
+  int* guard;  // host-mapped flag: an operator contradicted the rank (or the trimmed tap window) the host launched it for
+  unsigned window;  // sep_pack_support of the trimmed tap window [tu, tu + khp) x [tv, tv + kwp) of the launch; 0: the plan's full window
+  int dir;          // 0 forward taps, 1 adjoint taps (header word 2 + dir holds the operator's own support)
 };
 
 // LDS images:
@@ -190,6 +193,12 @@ __global__ __launch_bounds__(THREADS, POISSON ? (MULTI ? JD_SEP_WAVES_MULTI : JD
     const float* counts = a.n_batch > 0 ? a.table->cnt[d] : a.counts;
     const int rank = (int)op[0];
     if (a.alias && rank != 1 && tid == 0) *a.guard = 1;  // launched for rank 1 (host registry): reported at the next call
+    if (a.window && tid == 0) {  // launched on a trimmed window: the operator's own support must lie inside it
+      const unsigned own = __float_as_uint(op[2 + a.dir]), w = a.window;
+      if ((own & 255u) < (w & 255u) || (own >> 8 & 255u) > (w >> 8 & 255u) || (own >> 16 & 255u) < (w >> 16 & 255u) ||
+          (own >> 24) > (w >> 24))
+        *a.guard = 1;
+    }
     if (u > 0) __syncthreads();  // the previous unit is done with the LDS images
     for (int i = tid; i < rank * tap_stride; i += THREADS) taps[i] = op[a.taps_off + i];
 
@@ -526,8 +535,10 @@ int sep_guard_check(int** guard_dev) {
   *guard_dev = g_guard_dev;
   if (*g_guard_host) {
     *g_guard_host = 0;
-    return fail(JD_ERR_INVALID, "separable convolution: an operator buffer registered as rank 1 held another rank on the "
-                "device (was it overwritten after jd_conv_psf_spectrum?)");
+    return fail(JD_ERR_INVALID, "separable convolution: an operator buffer held another rank, or taps outside the support / "
+                "frame it was registered with, on the device (operator buffers are immutable: was it overwritten after "
+                "jd_conv_psf_spectrum?  jd_conv_operator_forget() the address, or build the new operator into it with "
+                "jd_conv_psf_spectrum)");
   }
   return JD_OK;
 }
@@ -560,6 +571,14 @@ int sep_build_operator(const float* psf, int kh, int kw, int oy, int ox, double 
     if (uhi <= ulo) ulo = 0, uhi = 1;  // (all taps rounded to zero in fp32: an empty support is still one tap)
     if (vhi <= vlo) vlo = 0, vhi = 1;
     oi.ulo[adjoint] = ulo, oi.uhi[adjoint] = uhi, oi.vlo[adjoint] = vlo, oi.vhi[adjoint] = vhi;
+  }
+  // the operator's own record in its header (kernels.h: SepOpInfo): what the kernels' guard compares with the window /
+  // frame the host chose from the registry
+  const int frame = walk_info_frame(oi, kh, kw, oy, ox);
+  (*op)[1] = frame ? (float)frame : 99.f;
+  for (int adjoint = 0; adjoint < 2; ++adjoint) {
+    const unsigned packed = sep_pack_support(oi.ulo[adjoint], oi.uhi[adjoint], oi.vlo[adjoint], oi.vhi[adjoint]);
+    memcpy(&(*op)[2 + adjoint], &packed, sizeof(packed));
   }
   if (info) *info = oi;
   return rank;
@@ -594,6 +613,7 @@ int launch_sep(SepArgs a, int kh, int kw, int oy, int ox, int adjoint, bool pois
       const int au = ulo / 4 * 4, av = vlo / 4 * 4;
       const int khp = (uhi + 3) / 4 * 4 - au, kwp = (vhi + 3) / 4 * 4 - av;
       a.tu_off = au, a.tv_off = g.khp + av;
+      a.window = sep_pack_support(au, au + khp, av, av + kwp), a.dir = dir;
       g.oy0 += au, g.ox0 += av, g.khp = khp, g.kwp = kwp;
       g.rpairs = (TY + g.khp) / 2, g.pitch = TX + g.kwp + 2;
     }

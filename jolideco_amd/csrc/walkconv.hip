@@ -1,4 +1,6 @@
-// Strip-walk form of the separable 'same' convolution (rank-1 PSFs up to 17 x 17: every sampled Gaussian).
+// Strip-walk form of the separable 'same' convolution (rank-1 PSFs -- every sampled Gaussian -- whose non-zero taps fit a
+// frame of 17 or of 33 taps per direction; the text below describes the 17-tap frame, the 33-tap frame is the same walk on
+// 36 accumulator rows and two columns per lane).
 //
 // The tile kernel of sepconv.hip stages a (32 + halo) x (64 + halo) window in LDS, runs the row pass over ALL window
 // rows (1.63 x the output rows) into a second LDS image, then the column pass: ~1000 vector instructions and ~200 KB of
@@ -233,7 +235,7 @@ __device__ __forceinline__ void walk_body(const WalkArgs& a, int bid, const int 
   // taps -> SGPRs
   float tu[WK], tv[WK];
   {
-    if ((int)op[0] != 1 && lane == 0) *a.guard = 1;  // not a rank-1 operator: the host reports it at its next call
+    if (((int)op[0] != 1 || (int)op[1] > WK) && lane == 0) *a.guard = 1;  // not a rank-1 operator, or one whose own header asks for a wider frame (a registered buffer overwritten in place): the host reports it at its next call
     // (frame position t holds the stored tap t - WH - oy0: an operator whose PSF was embedded in a larger array of
     // zeros has its non-zero taps inside the frame the host chose for it, the taps outside are the zeros)
     float mu = 0.f, mv = 0.f;
@@ -625,7 +627,7 @@ __device__ __forceinline__ void walk_multi_body(const MultiArgs& a, float* multi
 
   float tu[WK], tv[WK];
   {
-    if ((int)op[0] != 1 && lane == 0) *a.guard = 1;
+    if (((int)op[0] != 1 || (int)op[1] > WK) && lane == 0) *a.guard = 1;
     float mu = 0.f, mv = 0.f;
     const int iu = lane - (WH + a.oy0), iv = lane - (WH + a.ox0);
     if (iu >= 0 && iu < a.kh) mu = op[a.taps_u + iu];
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(XG ? 64 * XW : 64) void walk_joint_kernel(JointArgs
 
   float tu[WK], tv[WK];
   {
-    if ((int)op[0] != 1 && lane == 0) *a.guard = 1;
+    if (((int)op[0] != 1 || (int)op[1] > WK) && lane == 0) *a.guard = 1;
     float mu = 0.f, mv = 0.f;
     const int iu = lane - a.offy, iv = lane - a.offx;
     if (iu >= 0 && iu < a.kh) mu = op[a.taps_u + iu];
@@ -1141,13 +1143,18 @@ bool frame_fits(const SepOpInfo& info, int kh, int kw, int oy, int ox, int WHf, 
   return true;
 }
 
-// The frame (17 or 33 taps) the walk kernels run a REGISTERED rank-1 operator of the plan geometry in, 0: none
-int walk_frame(const void* op, int kh, int kw, int oy, int ox) {
-  SepOpInfo info;
-  if (!sep_operator_info(op, &info) || info.rank != 1) return 0;
+int frame_of_info(const SepOpInfo& info, int kh, int kw, int oy, int ox) {
+  if (info.rank != 1) return 0;
   if (frame_fits(info, kh, kw, oy, ox, Frame<17>::WH, Frame<17>::WK)) return 17;
   if (frame_fits(info, kh, kw, oy, ox, Frame<33>::WH, Frame<33>::WK)) return 33;
   return 0;
+}
+
+// The frame (17 or 33 taps) the walk kernels run a REGISTERED rank-1 operator of the plan geometry in, 0: none
+int walk_frame(const void* op, int kh, int kw, int oy, int ox) {
+  SepOpInfo info;
+  if (!sep_operator_info(op, &info)) return 0;
+  return frame_of_info(info, kh, kw, oy, ox);
 }
 
 // the widest support a plan of this geometry can hold (a full kh x kw PSF)
@@ -1242,6 +1249,8 @@ bool walk_takes_launch(int H, int W, int n_datasets, int kh, int kw, int oy, int
 }
 
 int walk_operator_frame(const float* op, int kh, int kw, int oy, int ox) { return walk_frame(op, kh, kw, oy, ox); }
+
+int walk_info_frame(const SepOpInfo& info, int kh, int kw, int oy, int ox) { return frame_of_info(info, kh, kw, oy, ox); }
 
 // order <- the datasets with the 17-tap operators first (in dataset order), then the others; *n17 <- how many
 void walk_batch_order(SepBatchTable& table, int n, int n_comp, int kh, int kw, int oy, int ox) {

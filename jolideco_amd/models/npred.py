@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from .. import _hip
 from ..ops import ConvPlan, ConvSameFunction, default_conv_method, psf_separable_rank
 
 SEPARABLE_MAX_EDGE = 68  # SEP_MAX_K of csrc/kernels.h
@@ -178,7 +179,11 @@ def common_kernel_shape(datasets, components, calibrations=None):
             return shape
         general = method == "general" or all(psf_separable_rank(p) == 0 for p in psfs)
         counts_shape = np.shape(next(iter(datasets.values()))["counts"])
-        if general and all(max(p.shape) > DIRECT_FAST_EDGE for p in psfs) and counts_shape[0] * counts_shape[1] >= 1 << 20:
+        # ("auto" sends a general PSF beyond 17 taps to the FFT path only where the native transforms cover the size --
+        # elsewhere it takes the Toeplitz kernel up to 33 taps, whose cost grows with the array size: no embedding then)
+        native = bool(_hip.lib().jd_conv_native_fft_supported(int(counts_shape[0]), int(counts_shape[1]), shape[0], shape[1]))
+        if (general and native and all(max(p.shape) > DIRECT_FAST_EDGE for p in psfs)
+                and counts_shape[0] * counts_shape[1] >= 1 << 20):
             return shape
     return None
 

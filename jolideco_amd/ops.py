@@ -152,10 +152,19 @@ class ConvPlan:
         return bool(_hip.lib().jd_conv_plan_takes_walk(self._handle, int(n_datasets)))
 
     # --- kernel spectrum (once per dataset and component) -----------------------------------
-    def psf_spectrum(self, psf):
+    def psf_spectrum(self, psf, out=None):
+        """The kernel operator of `psf` for this plan (jd_conv_psf_spectrum).  Operator buffers are immutable: to change
+        the PSF of an existing buffer build the new operator INTO it (``out=``), which re-registers the address; an
+        in-place copy of another operator's bytes is reported by the next library call."""
         psf = require_hip_tensor(psf, "psf")
         if tuple(psf.shape[-2:]) != (self.kh, self.kw):
             raise ValueError(f"psf shape {tuple(psf.shape)} does not match the plan ({self.kh}, {self.kw})")
+        if out is not None:
+            out = require_hip_tensor(out, "out")
+            if out.numel() != 2 * self.spectrum_size or not out.is_contiguous():
+                raise ValueError("out must be a contiguous operator buffer of this plan")
+            check(_hip.lib().jd_conv_psf_spectrum(self._handle, ptr(psf), ptr(out), stream_ptr(psf.device)))
+            return out
         khat = torch.empty(2 * self.spectrum_size, dtype=torch.float32, device=psf.device)
         check(_hip.lib().jd_conv_psf_spectrum(self._handle, ptr(psf), ptr(khat), stream_ptr(psf.device)))
         if self.method == "separable":

@@ -6,10 +6,10 @@ The reference goes through astropy (jolideco/utils/io/fits.py:1-6), which is not
 PyTorch-ROCm in this image; this module writes the same bytes-on-disk conventions (FITS 4.0: 2880-byte
 blocks, 80-character cards, big-endian data, ``TFORMn`` / ``TDIMn`` columns, ``CONTINUE`` long
 strings) so that files written here open in astropy and files written by the reference open here.
-Interoperability is checked in tests/test_io_fits.py against astropy itself where an interpreter
+Interoperability is checked in tests/test_io_formats.py against astropy itself where an interpreter
 that has it exists (``/opt/conda/bin/python3.9`` in the build image) and against
-tests/golden/result_reference.fits, a file real astropy wrote from the HDUs the reference's writer
-produced.
+tests/golden/io/result.fits (and components / component / calibrations .fits), files real astropy wrote
+from the HDUs the reference's writer produced (oracle/refload/make_golden_fits.py, hdus_to_fits.py).
 
 Not supported (raises): variable-length array columns (P/Q), bit and complex columns, tile-compressed
 images, random groups.

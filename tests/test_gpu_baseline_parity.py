@@ -483,24 +483,15 @@ def test_c5_shaped_two_component_joint_step_1024_4obs():
 # ---------------------------------------------------------------------------------------------------------
 # config 6 shape (bench.py c6, the reference's Chandra example): calibrations + up-sampling + general PSFs
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("fused", [True, False])
-def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
-    """One joint step of a c6-shaped fit at 1024^2 flux pixels x 4 observations against autograd of the oracle
-    (`cpu_ref.DatasetRef.loss`: jolideco/models/npred.py:210-261 with the calibration of :298-402): counts grid 512^2,
-    ``upsampling_factor=2``, general 33x33 PSFs (66x66 up-sampled -> native FFT convolution: compile-time schedules for
-    rows of 1152 and columns of 1024), one trained `NPredCalibration` (sub-pixel shift + background norm) per observation.
-    Compared: the flux gradient, every dataset loss, d loss / d shift_xy and d loss / d log background norm.  ``fused``:
-    the batched calibrated step (jd_npred_poisson_calibrated_batch_fwd_bwd: rows with each dataset's shift, columns, the
-    pooled middle launch -- sum-pool + Poisson pass + row transform of the up-sampled g -- and the adjoint's column pass
-    over all four datasets; loss and background-norm gradient finalised by each dataset's last launch) against the
-    separate kernels of the per-dataset calls (``JD_SEP_NO_FUSION=1``)."""
+def _check_c6_shaped_step(counts_shape, n_obs, psf_shape, label):
+    """One joint step of a c6-shaped fit (calibrated, up-sampled x2, general PSFs, uniform prior) against autograd of
+    the oracle in fp32 and float64: flux gradient, every dataset loss, d loss / d shift_xy, d loss / d log background norm."""
     from jolideco_amd import MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import instrument_observations
 
-    if not fused:
-        jd_option("JD_SEP_NO_FUSION", "1")
-    counts_shape, n_obs, u = (512, 512), 4, 2
-    datasets, _, flux_init, cal = instrument_observations(shape=counts_shape, n_obs=n_obs, seed=0, psf_shape=(33, 33))
+    u = 2
+    fh, fw = u * counts_shape[0], u * counts_shape[1]
+    datasets, _, flux_init, cal = instrument_observations(shape=counts_shape, n_obs=n_obs, seed=0, psf_shape=psf_shape)
     rs = np.random.RandomState(5)  # (a rough start image: the pooled sums and the clip see structure at the pixel scale)
     flux_start = (flux_init * rs.uniform(0.6, 1.4, size=counts_shape)).astype(np.float32)
     comp = SpatialFluxComponent.from_numpy(flux=flux_start, upsampling_factor=u, prior=UniformPrior())
@@ -514,9 +505,9 @@ def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
     session.cfg._optimizer_step = lambda states, step: None  # keep the gradient buffer, no update
     session.epoch()
     torch.cuda.synchronize()
-    n = 1024 * 1024
+    n = fh * fw
     comm = session.comm.cpu().numpy()
-    grad, scalars = comm[:n].reshape(1024, 1024), comm[n : n + n_obs]
+    grad, scalars = comm[:n].reshape(fh, fw), comm[n : n + n_obs]
     seen = session.states[0].flux_cur.cpu().numpy()
 
     def oracle(precision):
@@ -552,6 +543,39 @@ def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
         np.testing.assert_allclose(got_shift, ref_shift, rtol=1e-4, atol=2e-5 * np.abs(ref_shift).max())
         np.testing.assert_allclose(got_norm, ref_norm, rtol=2e-5)
         worst = max(worst, float(np.max(np.abs(got_shift - ref_shift)) / np.abs(ref_shift).max()))
-    print(f"c6-shaped 1024^2 x 4 (fused={fused}): flux gradient {err_64:.1e} from the float64 oracle, {err_32:.1e} from the fp32 "
+    print(f"c6-shaped {label}: flux gradient {err_64:.1e} from the float64 oracle, {err_32:.1e} from the fp32 "
           f"oracle (itself {ref_64:.1e} from float64), losses max rel {np.max(np.abs(scalars / losses_64 - 1)):.1e}, "
           f"shift gradient {worst:.1e}")
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
+    """One joint step of a c6-shaped fit at 1024^2 flux pixels x 4 observations against autograd of the oracle
+    (`cpu_ref.DatasetRef.loss`: jolideco/models/npred.py:210-261 with the calibration of :298-402): counts grid 512^2,
+    ``upsampling_factor=2``, general 33x33 PSFs (66x66 up-sampled -> native FFT convolution: compile-time schedules for
+    rows of 1152 and columns of 1024), one trained `NPredCalibration` (sub-pixel shift + background norm) per observation.
+    Compared: the flux gradient, every dataset loss, d loss / d shift_xy and d loss / d log background norm.  ``fused``:
+    the batched calibrated step (jd_npred_poisson_calibrated_batch_fwd_bwd: rows with each dataset's shift, columns, the
+    pooled middle launch -- sum-pool + Poisson pass + row transform of the up-sampled g -- and the adjoint's column pass
+    over all four datasets; loss and background-norm gradient finalised by each dataset's last launch) against the
+    separate kernels of the per-dataset calls (``JD_SEP_NO_FUSION=1``)."""
+    if not fused:
+        jd_option("JD_SEP_NO_FUSION", "1")
+    _check_c6_shaped_step((512, 512), 4, (33, 33), f"1024^2 x 4 (fused={fused})")
+
+
+@pytest.mark.parametrize("form", ["batched", "per-dataset", "separate-kernels"])
+def test_c6_shaped_calibrated_upsampled_joint_step_4096_columns(form, jd_option):
+    """The row kernels bench.py's c6 times (round-4 verdict, weak 1): flux rows of 4096 pixels -> row transforms of length
+    4608 = 8 * 8 * 8 * 9 (`fftn_rows_fwd_kernel<8, 8, 8, 9>` with the calibration shift in its load,
+    `fftn_rows_pooled_kernel<2, 8, 8, 8, 9>`, `fftn_rows_inv_kernel<true, 8, 8, 8, 9>`), on a SHORT counts grid (64 x 2048,
+    flux grid 128 x 4096) so that the oracle stays cheap; general 33x33 PSFs (66x66 up-sampled), 4 calibrated
+    observations.  ``batched``: jd_npred_poisson_calibrated_batch_fwd_bwd's launches over all datasets (what a fit of this
+    height runs); ``per-dataset``: the five launches + transposed shift per dataset (``JD_FFT_BATCH=0``: what c6 runs at
+    4096 flux rows); ``separate-kernels``: no fusion at all.  The 2304-point column kernel of c6
+    (`fftn_cols_kernel<128, 2, 16, 16, 9>`) is checked by tests/test_gpu_fft_native.py on 4096-row images."""
+    if form == "per-dataset":
+        jd_option("JD_FFT_BATCH", 0)
+    elif form == "separate-kernels":
+        jd_option("JD_SEP_NO_FUSION", "1")
+    _check_c6_shaped_step((64, 2048), 4, (33, 33), f"128 x 4096 flux grid x 4 ({form})")

@@ -80,6 +80,38 @@ def test_the_frame_follows_the_nonzero_taps_not_the_array_size(jd_option):
     big.close(), small.close()
 
 
+@pytest.mark.parametrize("walk", [1, 0])
+def test_an_operator_overwritten_in_place_by_a_wider_one_is_reported_not_trimmed(jd_option, walk):
+    """Operator buffers are immutable (round-4 advice): the library remembers, by device address, the support of the
+    operator it built there, and launches on the 17-tap frame / the trimmed tile window from that record.  A registered
+    buffer overwritten IN PLACE by an operator with wider support (`khat.copy_(other)`) carries its own record in its
+    header; the kernels compare, and the next library call raises instead of silently dropping the outer taps."""
+    from jolideco_amd.data import gaussian_kernel
+    from jolideco_amd.ops import ConvPlan
+
+    jd_option("JD_SEP_WALK", walk)
+    H, W = 96, 260
+    plan = ConvPlan(H, W, 33, 33, DEV, method="separable")
+    to_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)  # noqa: E731
+    k_narrow = plan.psf_spectrum(to_dev(_embed(gaussian_kernel(2.0, (17, 17)), (33, 33))))
+    k_wide = plan.psf_spectrum(to_dev(gaussian_kernel(3.2, (33, 33))))
+    image, scale = torch.rand(H, W, device=DEV) + 0.5, torch.rand(H, W, device=DEV) + 0.5
+    ok = plan.conv_same(image, scale, k_narrow)
+    torch.cuda.synchronize()
+    k_narrow.copy_(k_wide)  # the registry still holds the 17-tap support for this address
+    plan.conv_same(image, scale, k_narrow)  # launched on the narrow frame / window: the guard trips on the device
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="immutable"):
+        plan.conv_same(image, scale, k_wide)
+    # the flag is consumed by the report; a correct operator works again, and rebuilding INTO the address re-registers it
+    wide = plan.conv_same(image, scale, k_wide)
+    rebuilt = plan.psf_spectrum(to_dev(gaussian_kernel(3.2, (33, 33))), out=k_narrow)
+    assert rebuilt is k_narrow and plan.walk_frame(k_narrow) == 33
+    assert torch.equal(plan.conv_same(image, scale, k_narrow), wide)
+    assert not torch.equal(ok, wide)
+    plan.close()
+
+
 def _mixed_batch(shape, frames, seed):
     """Operators, exposures, backgrounds, counts of len(frames) observations on ONE 33x33 separable plan; frames[i] = 17:
     a 17x17 (or smaller) Gaussian embedded in zeros, 33: a 33x33 Gaussian."""
