@@ -113,9 +113,56 @@ def build_session_c6(device, shape=(2048, 2048), n_obs=8, seed=0, K=128):
     return deconvolver.session(datasets, components=comp, calibrations=calibrations)
 
 
+def c6_roofline(plan, counts_shape, n_obs, u, kernel_ms):
+    """The likelihood step of ONE calibrated, up-sampled observation on the native FFT path against the HBM roof: six
+    launches -- rows (bilinear shift x exposure -> row spectra), columns (x kernel spectrum), pooled middle (rows^-1 x U,
+    sum-pool, Poisson pass, rows of the up-sampled g), columns (conjugate), rows^-1 + adjoint epilogue, transposed shift --
+    with the ALGORITHMIC bytes of each (every array counted once per launch that streams it) over the
+    launch durations the library's hipEvent pairs measured."""
+    H, W = u * counts_shape[0], u * counts_shape[1]
+    hh, kh, kw = H // 2, plan.kh, plan.kw
+
+    def fft_length(n, with_three=True):
+        best = None
+        for odd in (1, 3, 9) if with_three else (1, 9):
+            m = 8
+            while m * odd < max(n, 32):
+                m *= 2
+            best = m * odd if best is None or m * odd < best else best
+        return best
+
+    nx, ny = fft_length(W + max((kw - 1) // 2, kw - 1 - (kw - 1) // 2)), fft_length(hh + kh - 1, False)
+    img, cnt = 4.0 * H * W, 4.0 * counts_shape[0] * counts_shape[1]
+    spec, kept, khat = 8.0 * hh * nx, 8.0 * (hh + kh - 1) * nx, 8.0 * nx * ny
+    launches = {  # timer -> (what, algorithmic bytes per observation, launches per observation)
+        "fft_r2c": ("rows: flux (shifted) + exposure in, row spectra out", 2 * img + spec, 1),
+        "cmul": ("columns: spectra + kernel spectrum in, kept rows out (forward and adjoint)", 2 * (spec + khat + kept), 2),
+        "poisson_fused": ("pooled middle: kept rows + background + counts in, row spectra of g out", kept + 2 * cnt + spec, 1),
+        "fft_c2r": ("rows^-1 + adjoint epilogue: kept rows + exposure in, exposure x corr out", kept + 2 * img, 1),
+        "shift": ("transposed shift: exposure x corr + flux + gradient in, gradient out", 4 * img, 1),
+    }
+    rows, total_bytes, total_ms = {}, 0.0, 0.0
+    for name, (what, nbytes, per_obs) in launches.items():
+        ms = kernel_ms.get(name)
+        if not ms:
+            continue
+        ms_obs = ms / n_obs
+        rows[name] = {"what": what, "bytes_per_observation": nbytes, "ms_per_observation": ms_obs, "launches_per_observation": per_obs,
+                      "achieved": nbytes / (ms_obs * 1e-3) / 1e9, "frac": nbytes / (ms_obs * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        total_bytes += nbytes
+        total_ms += ms_obs
+    if not total_ms:
+        return None
+    achieved = total_bytes / (total_ms * 1e-3) / 1e9
+    return {"kernel": "native FFT likelihood step of one calibrated, up-sampled observation (6 launches)", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_observation": total_bytes, "ms_per_observation": total_ms, "padded_fft_grid": [ny, nx], "launches": rows,
+            "note": "PMC traffic of these kernels: profiles/r05/pmc_hbm_traffic.csv rows c6"}
+
+
 def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), n_obs=8):
-    """Time config c6 (see `build_session_c6`): it/s and the per-kernel table.  No roofline object: the step is a chain of
-    FFT launches, the transposed shift and the 4096^2 prior -- the table says where the time goes."""
+    """Time config c6 (see `build_session_c6`): it/s, the per-kernel table and `roofline_c6` (the six launches of one
+    observation's likelihood step against the HBM roof)."""
     session = build_session_c6(device, shape=shape, n_obs=n_obs)
     for _ in range(warmup):
         session.epoch()
@@ -144,6 +191,7 @@ def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), 
         "kernel_ms_per_step": {k: v[0] / 4 for k, v in prof.items() if v[1] and k not in nested},
         "launches_per_step": {k: v[1] / 4 for k, v in prof.items() if v[1] and k not in nested},
     }
+    out["roofline_c6"] = c6_roofline(plan, shape, n_obs, 2, out["kernel_ms_per_step"])
     del session
     return out
 
@@ -353,8 +401,10 @@ def main():
     ap.add_argument("--no-general-psf", action="store_true",
                     help="skip the extra run that convolves the PSFs as general (not separable) kernels")
     ap.add_argument("--shard-of", type=int, default=0,
-                    help="tuning only: time rank 0's share of an N-rank joint step in ONE process, without the "
-                         "collective (the printed value is NOT a benchmark result)")
+                    help="tuning only: time one rank's share (--rank, default 0) of an N-rank joint step in ONE process, "
+                         "without the collective (the printed value is NOT a benchmark result); tools/shard_table.py "
+                         "times every rank of N = 2 / 4 / 8 that way")
+    ap.add_argument("--rank", type=int, default=0, help="with --shard-of N: the rank whose share is timed")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -392,7 +442,9 @@ def main():
     if args.shard_of > 1:
         from jolideco_amd.distributed import DistContext
 
-        fake = DistContext(rank=0, world_size=args.shard_of, dry_run=True)
+        if not 0 <= args.rank < args.shard_of:
+            raise SystemExit(f"--rank {args.rank} is not a rank of --shard-of {args.shard_of}")
+        fake = DistContext(rank=args.rank, world_size=args.shard_of, dry_run=True)
     session = build_session(args.config, device, dist=fake)
     torch.cuda.synchronize(device)
     log("session ready; warm-up")
@@ -430,9 +482,10 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     n_py, n_px = (H - PATCH) // STRIDE + 1, (W - PATCH) // STRIDE + 1
-    rows = dist_ctx.shard_range(n_py) if world > 1 else (0, n_py)
+    shares = getattr(session, "prior_shares", None)  # (cost-aware placement: a rank with costly datasets takes fewer rows)
+    rows = dist_ctx.shard_range(n_py, shares) if world > 1 else (0, n_py)
     if fake is not None:
-        rows = fake.shard_range(n_py)
+        rows = fake.shard_range(n_py, shares)
     np_local = (rows[1] - rows[0]) * n_px
 
     def avg_ms(name):
@@ -560,7 +613,7 @@ def main():
     psf_sizes = " + ".join(f"{n} x {shp}" for shp, n in runs)
     out = {
         "metric": ("MAP iters/sec at 2048x2048, 8-obs joint fit" if args.config == "c3" else f"MAP iters/sec ({args.config})")
-        + (f" [TUNING: rank 0 of {args.shard_of}, no collective]" if args.shard_of > 1 else ""),
+        + (f" [TUNING: rank {args.rank} of {args.shard_of}, no collective]" if args.shard_of > 1 else ""),
         "value": args.steps / elapsed,
         "unit": "iters/s",
         "n_gpus": world,
@@ -588,10 +641,11 @@ def main():
                         f"varying exposure/background), GMM patch prior 8x8 stride 4 K={K}, joint fit, Adam lr 0.1",
             "psf_shapes": psf_shapes,
             "global_observations": n_obs,
-            "sharding": (f"observations round-robin over {world} rank(s), prior by patch rows; per step 1 all-reduce of the "
+            "sharding": (f"observations over {world} rank(s) by estimated cost (longest processing time first), prior by patch "
+                         "rows in shares that even the ranks out; per step 1 all-reduce of the "
                          "likelihood gradient started before the prior and overlapped with it + 1 all-gather of the prior "
                          "bands" if os.environ.get("JOLIDECO_DIST_OVERLAP", "1") != "0" else
-                         f"observations round-robin over {world} rank(s), prior by patch rows, 1 all-reduce/step")
+                         f"observations over {world} rank(s) by estimated cost, prior by patch rows, 1 all-reduce/step")
             if world > 1 else "single GPU",
         },
         # numerics of the run itself: the loss scalars of the last timed step [dataset losses | log-priors] -- the same

@@ -388,7 +388,8 @@ enum {
   JD_KERNEL_GMM_SORT = 13,       /*   stage 2: counting sort of the surviving (patch, component) records (inside GMM_FWD) */
   JD_KERNEL_GMM_EXACT = 14,      /*   stage 3: exact fp32 MFMA evaluation of the survivors (inside GMM_FWD) */
   JD_KERNEL_GMM_STAGE = 15,      /*   stage 0: patches -> mean-subtracted fp16 fragments, norms, scales (inside GMM_FWD) */
-  JD_KERNEL_COUNT = 16
+  JD_KERNEL_SHIFT = 16,          /* calibration: bilinear sub-pixel shift and its transpose (+ shift gradient partial sums) */
+  JD_KERNEL_COUNT = 17
 };
 int jd_profile_enable(int capacity);
 int jd_profile_disable(void);

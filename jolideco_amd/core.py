@@ -16,6 +16,7 @@ trace.  Two fit modes:
 All arithmetic of the step runs in libjolideco_hip.so; there is no CPU fallback.
 """
 import copy
+import os
 import logging
 from pathlib import Path
 
@@ -461,8 +462,29 @@ class FitSession:
         self.joint = deconvolver.fit_mode == "joint"
         names_all = list(datasets)
         # joint mode shards the datasets over the ranks; sequential mode runs full replicas
+        self.prior_shares = None
         if self.joint and dist.sharded:
-            local_names = dist.shard_items(names_all)
+            # cost-aware placement (identical on every rank): datasets by longest-processing-time-first on their estimated
+            # cost, then the prior's patch rows in shares that top every rank up to the same estimated load
+            from .distributed import balanced_shares, lpt_assignment
+            from .models.npred import COST_PRIOR_FIXED, COST_PRIOR_PER_128_COMPONENTS, estimate_dataset_cost
+
+            if os.environ.get("JOLIDECO_DIST_PLACEMENT", "cost") == "round-robin":
+                local_names = dist.shard_items(names_all)
+            else:
+                costs = [estimate_dataset_cost(datasets[n], components, bool(calibrations is not None and n in calibrations))
+                         for n in names_all]
+                owners, loads = lpt_assignment(costs, dist.world_size)
+                local_names = [n for n, owner in zip(names_all, owners) if owner == dist.rank]
+                prior_cost = 0.0
+                for comp in components.values():
+                    prior = getattr(comp, "prior", None)
+                    if getattr(prior, "shardable", False) and not comp.frozen:
+                        k = getattr(getattr(prior, "gmm", None), "n_components", 128)
+                        up = comp.upsampling_factor or 1
+                        prior_cost += (COST_PRIOR_FIXED + COST_PRIOR_PER_128_COMPONENTS * k / 128.0) * up * up
+                self.prior_shares = balanced_shares(loads, prior_cost)
+                self.rank_loads = loads
         else:
             local_names = names_all
         local_datasets = {n: datasets[n] for n in local_names}
@@ -591,10 +613,11 @@ class FitSession:
             n_rows = prior.n_patch_rows(st.shape)
             y_ranges = []
             for r in range(dist.world_size):
-                rows = DistContext(r, dist.world_size).shard_range(n_rows)
+                rows = DistContext(r, dist.world_size).shard_range(n_rows, self.prior_shares)
                 y_ranges.append(band_rows(rows, prior.stride, H))
             size = max(y1 - y0 for y0, y1 in y_ranges) * W
-            plan.append({"ci": ci, "offset": offset, "size": size, "y_ranges": y_ranges, "rows": dist.shard_range(n_rows)})
+            plan.append({"ci": ci, "offset": offset, "size": size, "y_ranges": y_ranges,
+                         "rows": dist.shard_range(n_rows, self.prior_shares)})
             offset += size
         if not plan:
             return
@@ -638,7 +661,7 @@ class FitSession:
 
     def _prior_rows(self, prior, state):
         if self.joint and self.dist.sharded and prior.shardable:
-            return self.dist.shard_range(prior.n_patch_rows(state.shape))
+            return self.dist.shard_range(prior.n_patch_rows(state.shape), self.prior_shares)
         return None
 
     def _apply_step(self, states, stepped):

@@ -113,30 +113,40 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, int N, const Ff
 
 // Compile-time radix schedule (R0, R1, R2[, R3]) of a row transform: N, every sub-transform length and every loop bound
 // are constants (the generic form dispatches on the radix inside the butterfly loop).  R0 = 0: generic.
+// T: threads of a row block.  4608 = 8 * 8 * 8 * 9 runs 576 threads (nine waves): ONE radix-8 butterfly per thread and pass
+// (576 of them; 512 radix-9 butterflies), and two blocks -- LDS holds no more: two padded sequences of 4608 are 78 KB --
+// are 18 waves per CU instead of 8.  MAXQ / PRE: 16-byte pieces of an image row / of a spectrum row per thread.
 template <int R0, int R1, int R2, int R3>
 struct RowSched {
   static constexpr bool STATIC = R0 > 0;
   static constexpr int N = STATIC ? R0 * R1 * R2 * (R3 ? R3 : 1) : 0;
+  static constexpr int T = (R0 == 8 && R1 == 8 && R2 == 8 && R3 == 9) ? 576 : ROW_THREADS;
+  static constexpr int WAVES_PER_SIMD = T == 576 ? 5 : 1;  // (two blocks of nine waves: five on one SIMD -> at most 96 registers)
+  static constexpr int MAXQ = STATIC ? (N + 4 * T - 1) / (4 * T) : 5;  // generic: Nx <= 4608 < 4 * 256 * 5
+  static constexpr int PRE = STATIC ? (N + 2 * T - 1) / (2 * T) : 9;   // generic: Nx <= 2 * 256 * 9
 };
 
-template <int R, int DIR, int N, int P>
+template <int R, int DIR, int N, int P, int T>
 __device__ __forceinline__ void pass_static(const float2* x, float2* y, const float2* tw, int tid) {
 #pragma unroll
-  for (int i0 = 0; i0 < N / R; i0 += ROW_THREADS) {
+  for (int i0 = 0; i0 < N / R; i0 += T) {
     const int i = i0 + tid;
-    if (i < N / R) pass_one<R, DIR>(x, y, N, P, tw, i);
+    // linear padded indices where the pass allows them and a thread runs ONE butterfly per pass (576 threads): with
+    // several, the compiler keeps them all in flight and the registers cost more waves than the instructions save
+    constexpr bool LIN = (T == 576 || JD_FFT_LIN) && pass_is_linear(N, R, P);
+    if (i < N / R) pass_one<R, DIR, LIN>(x, y, N, P, tw, i);
   }
   __syncthreads();
 }
 
 template <int DIR, int R0, int R1, int R2, int R3>
 __device__ __forceinline__ float2* fft_lds_static(float2* a, float2* b, const float2* tw, int tid) {
-  constexpr int N = RowSched<R0, R1, R2, R3>::N;
-  pass_static<R0, DIR, N, 1>(a, b, tw, tid);
-  pass_static<R1, DIR, N, R0>(b, a, tw, tid);
-  pass_static<R2, DIR, N, R0 * R1>(a, b, tw, tid);
+  constexpr int N = RowSched<R0, R1, R2, R3>::N, T = RowSched<R0, R1, R2, R3>::T;
+  pass_static<R0, DIR, N, 1, T>(a, b, tw, tid);
+  pass_static<R1, DIR, N, R0, T>(b, a, tw, tid);
+  pass_static<R2, DIR, N, R0 * R1, T>(a, b, tw, tid);
   if constexpr (R3 > 0) {
-    pass_static<R3, DIR, N, R0 * R1 * R2>(b, a, tw, tid);
+    pass_static<R3, DIR, N, R0 * R1 * R2, T>(b, a, tw, tid);
     return a;
   } else {
     return b;
@@ -172,17 +182,33 @@ __device__ __forceinline__ int mod_small(int b, int p, float inv_p) {
   return k >= p ? k - p : k;
 }
 
-template <int R, int DIR, int MAXB, int LANES, bool POW2>
-__device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, const float2* tw, int lane) {
+// LIN_IN / LIN_OUT (compile-time schedules only): the padded index is linear in t -- inputs when N / R is a multiple of 16
+// (lp(b + t nb) = lp(b) + t (nb + nb / 16)), outputs when p is a multiple of 16, or p = 1 and the R <= 16 outputs of a
+// butterfly share one group of 16 (R = 2, 4, 8, 16) -- one address per butterfly and compile-time offsets in the LDS
+// instructions instead of an add, a shift and an add per element (a third of the kernel's vector instructions).
+constexpr bool lin_in(int N, int R) { return ((N / R) & 15) == 0; }
+constexpr bool lin_out(int R, int p) { return (p & 15) == 0 || (p == 1 && (R == 2 || R == 4 || R == 8 || R == 16)); }
+
+template <int R, int DIR, int MAXB, int LANES, bool POW2, bool LIN_IN = false, bool LIN_OUT = false>
+__device__ __forceinline__ void column_pass_inplace(float2* x_, int N, int p, const float2* tw_, int lane) {
+  cf* x = reinterpret_cast<cf*>(x_);
+  const cf* tw = reinterpret_cast<const cf*>(tw_);
   const int nb = N / R;
   const float inv_p = 1.f / (float)p;
-  float2 u[MAXB][R];
+  cf u[MAXB][R];
 #pragma unroll
   for (int q = 0; q < MAXB; ++q) {
     const int b = lane + LANES * q;
     if (b < nb) {
+      if constexpr (LIN_IN) {
+        const cf* xb = x + lp(b);
+        const int step = nb + (nb >> 4);
 #pragma unroll
-      for (int t = 0; t < R; ++t) u[q][t] = x[lp(b + t * nb)];
+        for (int t = 0; t < R; ++t) u[q][t] = xb[t * step];
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) u[q][t] = x[lp(b + t * nb)];
+      }
     }
   }
   column_sync<LANES>();
@@ -192,7 +218,7 @@ __device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, con
     if (b < nb) {
       const int k = POW2 ? (b & (p - 1)) : mod_small(b, p, inv_p);
       if (p > 1) {
-        float2 w[R];
+        cf w[R];
         w[1] = tw[k * (nb / p)];
         if (DIR > 0) w[1].y = -w[1].y;
 #pragma unroll
@@ -202,8 +228,15 @@ __device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, con
       }
       Dft<R, DIR>::run(u[q]);
       const int j = (b - k) * R + k;
+      if constexpr (LIN_OUT) {
+        cf* xj = x + lp(j);
+        const int step = p == 1 ? 1 : p + (p >> 4);
 #pragma unroll
-      for (int t = 0; t < R; ++t) x[lp(j + t * p)] = u[q][t];
+        for (int t = 0; t < R; ++t) xj[t * step] = u[q][t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[lp(j + t * p)] = u[q][t];
+      }
     }
   }
   column_sync<LANES>();
@@ -214,16 +247,26 @@ __device__ __forceinline__ void column_pass_inplace(float2* x, int N, int p, con
 // spectrum, and the FIRST pass of the inverse transform, whose radices run in reverse order -- its first pass (radix R,
 // sub-transform length 1) reads exactly the elements b + t p the thread holds.  Two LDS exchanges and the separate pass
 // over the column for the product are gone.
-template <int R, int MAXB, int LANES>
-__device__ __forceinline__ void column_mid_inplace(float2* x, int N, const float2* tw, const float2* kcol, int conj, int lane) {
+template <int R, int MAXB, int LANES, bool LIN_IN = false>
+__device__ __forceinline__ void column_mid_inplace(float2* x_, int N, const float2* tw_, const float2* kcol_, int conj, int lane) {
+  cf* x = reinterpret_cast<cf*>(x_);
+  const cf* tw = reinterpret_cast<const cf*>(tw_);
+  const cf* kcol = reinterpret_cast<const cf*>(kcol_);
   const int nb = N / R;  // = p of the forward pass
-  float2 u[MAXB][R];
+  cf u[MAXB][R];
 #pragma unroll
   for (int q = 0; q < MAXB; ++q) {
     const int b = lane + LANES * q;
     if (b < nb) {
+      if constexpr (LIN_IN) {
+        const cf* xb = x + lp(b);
+        const int step = nb + (nb >> 4);
 #pragma unroll
-      for (int t = 0; t < R; ++t) u[q][t] = x[lp(b + t * nb)];
+        for (int t = 0; t < R; ++t) u[q][t] = xb[t * step];
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) u[q][t] = x[lp(b + t * nb)];
+      }
     }
   }
   column_sync<LANES>();
@@ -231,11 +274,11 @@ __device__ __forceinline__ void column_mid_inplace(float2* x, int N, const float
   for (int q = 0; q < MAXB; ++q) {
     const int b = lane + LANES * q;
     if (b < nb) {
-      float2 kh[R];
+      cf kh[R];
 #pragma unroll
       for (int t = 0; t < R; ++t) kh[t] = kcol[b + t * nb];
       {
-        float2 w[R];
+        cf w[R];
         w[1] = tw[b];  // k = b, nb / p = 1
 #pragma unroll
         for (int t = 2; t < R; ++t) w[t] = cmul(w[t / 2], w[t - t / 2]);
@@ -245,13 +288,19 @@ __device__ __forceinline__ void column_mid_inplace(float2* x, int N, const float
       Dft<R, -1>::run(u[q]);
 #pragma unroll
       for (int t = 0; t < R; ++t) {
-        float2 k = kh[t];
+        cf k = kh[t];
         if (conj) k.y = -k.y;
         u[q][t] = cmul(u[q][t], k);
       }
       Dft<R, 1>::run(u[q]);
+      if constexpr (LIN_IN && lin_out(R, 1)) {  // (compile-time schedules; the R outputs share a group of 16)
+        cf* xj = x + lp(b * R);
 #pragma unroll
-      for (int t = 0; t < R; ++t) x[lp(b * R + t)] = u[q][t];
+        for (int t = 0; t < R; ++t) xj[t] = u[q][t];
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[lp(b * R + t)] = u[q][t];
+      }
     }
   }
   column_sync<LANES>();
@@ -316,10 +365,6 @@ __device__ __forceinline__ void column_conv_inplace(float2* x, int N, const FftP
 // kernels.h) lives in device memory: as a by-value kernel argument, indexing it with the dataset number made the compiler
 // copy it to scratch in every kernel.
 
-struct __attribute__((packed, aligned(4))) F4U4 {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
-  float x, y, z, w;
-};
-
 struct RowsFwdArgs {
   const float* in;
   const float* shift_xy;  // nullable, device [2]: the input is the bilinearly shifted image (the calibration's shift_fwd)
@@ -335,7 +380,7 @@ struct RowsFwdArgs {
 
 // rows: z[x] = in[y][x] s[y][x] + i in[y + Hh][x] s[y + Hh][x], zero beyond W -> FFT -> spec[y][.]
 template <int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs a) {
+__global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2, R3>::WAVES_PER_SIMD)) void fftn_rows_fwd_kernel(RowsFwdArgs a) {
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
@@ -347,23 +392,26 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   const size_t ra = (size_t)y * a.W, rb = (size_t)(y + a.Hh) * a.W;
-  constexpr int MAXQ = 5;  // float4 pieces of a row per thread (Nx <= 4608 < 4 * 256 * MAXQ)
-  float4 su[MAXQ], sv[MAXQ];
+  constexpr int MAXQ = S::MAXQ;
+  float pu[MAXQ][4], pv[MAXQ][4];  // this thread's pieces of the two (shifted) input rows; zero beyond W
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pu[q][i] = pv[q][i] = 0.f;
   if (shift_xy) {  // (block-uniform)
     // the bilinearly shifted rows of both halves, straight from global memory: per piece the five source columns of the two
     // source rows (one 16-byte load at a 4-byte aligned address + one float each; element-wise with bounds checks where
     // the window leaves the image) -- the arithmetic of shift_fwd_kernel, whose launch and image this replaces
     const ShiftGeom g = shift_geom(shift_xy, a.shift_scale);
     const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int r0 = y + half * a.Hh + g.fy, r1 = r0 + 1;
+    auto shifted_row = [&](int yrow, float (&dst)[MAXQ][4]) {
+      const int r0 = yrow + g.fy, r1 = r0 + 1;
       const bool in_r0 = r0 >= 0 && r0 < a.H, in_r1 = r1 >= 0 && r1 < a.H;
       const float* row0 = a.in + (size_t)(in_r0 ? r0 : 0) * a.W;
       const float* row1 = a.in + (size_t)(in_r1 ? r1 : 0) * a.W;
 #pragma unroll
       for (int q = 0; q < MAXQ; ++q) {
-        const int x = 4 * (tid + q * ROW_THREADS);
+        const int x = 4 * (tid + q * S::T);
         float t0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, t1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
         if (x < a.W) {
           const int c0 = x + g.fx;
@@ -385,38 +433,40 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_fwd_kernel(RowsFwdArgs 
             }
           }
         }
-        float o[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = t0[i] * w00 + t0[i + 1] * w10 + t1[i] * w01 + t1[i + 1] * w11;
-        (half ? sv[q] : su[q]) = make_float4(o[0], o[1], o[2], o[3]);
+        for (int i = 0; i < 4; ++i) dst[q][i] = t0[i] * w00 + t0[i + 1] * w10 + t1[i] * w01 + t1[i + 1] * w11;
+      }
+    };
+    shifted_row(y, pu);
+    shifted_row(y + a.Hh, pv);
+  } else {
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int x = 4 * (tid + q * S::T);
+      if (x < a.W) {
+        const float4 u = *reinterpret_cast<const float4*>(a.in + ra + x), v = *reinterpret_cast<const float4*>(a.in + rb + x);
+        pu[q][0] = u.x, pu[q][1] = u.y, pu[q][2] = u.z, pu[q][3] = u.w;
+        pv[q][0] = v.x, pv[q][1] = v.y, pv[q][2] = v.z, pv[q][3] = v.w;
       }
     }
   }
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * ROW_THREADS);
+    const int x = 4 * (tid + q * S::T);
     if (x >= Nx) continue;
-    float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
-    if (x < a.W) {
-      if (shift_xy) {
-        u = su[q], v = sv[q];
-      } else {
-        u = *reinterpret_cast<const float4*>(a.in + ra + x);
-        v = *reinterpret_cast<const float4*>(a.in + rb + x);
-      }
-      if (scale) {
-        const float4 su_ = *reinterpret_cast<const float4*>(scale + ra + x), sv_ = *reinterpret_cast<const float4*>(scale + rb + x);
-        u.x *= su_.x, u.y *= su_.y, u.z *= su_.z, u.w *= su_.w;
-        v.x *= sv_.x, v.y *= sv_.y, v.z *= sv_.z, v.w *= sv_.w;
-      }
+    if (scale && x < a.W) {
+      const float4 su = *reinterpret_cast<const float4*>(scale + ra + x), sv = *reinterpret_cast<const float4*>(scale + rb + x);
+      pu[q][0] *= su.x, pu[q][1] *= su.y, pu[q][2] *= su.z, pu[q][3] *= su.w;
+      pv[q][0] *= sv.x, pv[q][1] *= sv.y, pv[q][2] *= sv.z, pv[q][3] *= sv.w;
     }
     const int e = lp(x);  // (x % 4 == 0: the four elements share a group of 16, consecutive in the padded layout)
-    bufa[e] = float2{u.x, v.x}, bufa[e + 1] = float2{u.y, v.y}, bufa[e + 2] = float2{u.z, v.z}, bufa[e + 3] = float2{u.w, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bufa[e + i] = float2{pu[q][i], pv[q][i]};
   }
   __syncthreads();
   const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   float2* out = spec + (size_t)y * Nx;
-  for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+  for (int x = 2 * tid; x < Nx; x += 2 * S::T) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
   }
@@ -444,11 +494,11 @@ template <int LANES, int R0, int R1, int R2>
 __device__ __forceinline__ void column_conv_static(float2* x, const float2* tw, const float2* kcol, int conj, int lane) {
   constexpr int N = R0 * R1 * R2;
   constexpr bool POW2 = (R2 & (R2 - 1)) == 0;
-  column_pass_inplace<R0, -1, ceil_div(N / R0, LANES), LANES, true>(x, N, 1, tw, lane);
-  column_pass_inplace<R1, -1, ceil_div(N / R1, LANES), LANES, true>(x, N, R0, tw, lane);
-  column_mid_inplace<R2, ceil_div(N / R2, LANES), LANES>(x, N, tw, kcol, conj, lane);
-  column_pass_inplace<R1, 1, ceil_div(N / R1, LANES), LANES, POW2>(x, N, R2, tw, lane);
-  column_pass_inplace<R0, 1, ceil_div(N / R0, LANES), LANES, POW2>(x, N, R2 * R1, tw, lane);
+  column_pass_inplace<R0, -1, ceil_div(N / R0, LANES), LANES, true, lin_in(N, R0), lin_out(R0, 1)>(x, N, 1, tw, lane);
+  column_pass_inplace<R1, -1, ceil_div(N / R1, LANES), LANES, true, lin_in(N, R1), lin_out(R1, R0)>(x, N, R0, tw, lane);
+  column_mid_inplace<R2, ceil_div(N / R2, LANES), LANES, lin_in(N, R2)>(x, N, tw, kcol, conj, lane);
+  column_pass_inplace<R1, 1, ceil_div(N / R1, LANES), LANES, POW2, lin_in(N, R1), lin_out(R1, R2)>(x, N, R2, tw, lane);
+  column_pass_inplace<R0, 1, ceil_div(N / R0, LANES), LANES, POW2, lin_in(N, R0), lin_out(R0, R2 * R1)>(x, N, R2 * R1, tw, lane);
 }
 
 template <int LANES, int CBS, int R0, int R1, int R2>
@@ -504,18 +554,19 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
 // -- and added to the block's own spectrum row (as a real part: + FFT(Im c_s); as an imaginary part: + i FFT(Re c_s)), so
 // that a seam block runs one transform like every other block: with two, the seam blocks set the duration of the whole
 // launch (every block of these launches is resident at once).
+template <int T>
 __device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* work, int Nx, int y, int Hh, int Ny, int ra, int rb,
                                                   int tid) {
   const bool spill_up = y >= Hh - ra, spill_down = y < rb;
   const float2* src = work + (size_t)y * Nx;
   if (!(spill_up || spill_down)) {  // (block-uniform)
-    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+    for (int x = 2 * tid; x < Nx; x += 2 * T) {
       const float4 v = *reinterpret_cast<const float4*>(src + x);
       buf[lp(x)] = float2{v.x, v.y}, buf[lp(x + 1)] = float2{v.z, v.w};
     }
   } else {
     const float2* sp = work + (size_t)(spill_up ? Ny - Hh + y : Hh + y) * Nx;
-    for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+    for (int x = 2 * tid; x < Nx; x += 2 * T) {
       const float4 v = *reinterpret_cast<const float4*>(src + x), c = *reinterpret_cast<const float4*>(sp + x);
       const float2 m0 = sp[x == 0 ? 0 : Nx - x], m1 = sp[Nx - x - 1];  // C[-x], C[-(x + 1)]
       float2 o0, o1;
@@ -534,7 +585,7 @@ __device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* wor
 
 // The same in two steps, for a block that runs several transforms in a row: the (combined) spectrum row into REGISTERS --
 // the loads of the next row are in flight while the block transforms the current one -- and from there into LDS.
-constexpr int ROW_PRE = 9;  // float4 pieces (two spectrum elements) of a row per thread: Nx <= 2 * 256 * 9
+template <int T, int ROW_PRE>  // ROW_PRE: float4 pieces (two spectrum elements) of a row per thread
 __device__ __forceinline__ void load_spectrum_row_regs(float4 (&pre)[ROW_PRE], const float2* work, int Nx, int y, int Hh, int Ny, int ra,
                                                        int rb, int tid) {
   const bool spill_up = y >= Hh - ra, spill_down = y < rb;
@@ -542,7 +593,7 @@ __device__ __forceinline__ void load_spectrum_row_regs(float4 (&pre)[ROW_PRE], c
   const float2* sp = work + (size_t)(spill_up ? Ny - Hh + y : Hh + y) * Nx;
 #pragma unroll
   for (int i = 0; i < ROW_PRE; ++i) {
-    const int x = 2 * (tid + i * ROW_THREADS);
+    const int x = 2 * (tid + i * T);
     if (x >= Nx) continue;
     float4 v = *reinterpret_cast<const float4*>(src + x);
     if (spill_up || spill_down) {  // (block-uniform; see load_spectrum_row)
@@ -558,10 +609,11 @@ __device__ __forceinline__ void load_spectrum_row_regs(float4 (&pre)[ROW_PRE], c
   }
 }
 
+template <int T, int ROW_PRE>
 __device__ __forceinline__ void store_spectrum_row_regs(float2* buf, const float4 (&pre)[ROW_PRE], int Nx, int tid) {
 #pragma unroll
   for (int i = 0; i < ROW_PRE; ++i) {
-    const int x = 2 * (tid + i * ROW_THREADS);
+    const int x = 2 * (tid + i * T);
     if (x >= Nx) continue;
     buf[lp(x)] = float2{pre[i].x, pre[i].y}, buf[lp(x + 1)] = float2{pre[i].z, pre[i].w};
   }
@@ -592,7 +644,7 @@ struct RowsInvArgs {
 
 // rows^-1 + epilogue.  ADJ = false: out = conv;  ADJ = true: out (+)= (coef * corr) * scale
 template <bool ADJ, int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs a) {
+__global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2, R3>::WAVES_PER_SIMD)) void fftn_rows_inv_kernel(RowsInvArgs a) {
 #pragma clang fp contract(off)  // (product, product, sum: the batched form below must give the same bits)
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
@@ -600,19 +652,19 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
   // n_batch > 0 (ADJ, calibrated batched step): block b = row pair b / n of dataset b % n; out = the dataset's gshift image
   // (overwritten), scale = its exposure, and the blocks of row pairs 0 / 1 finalise the dataset's loss / norm gradient
   const int tid = threadIdx.x, nb = ADJ ? a.n_batch : 0;
-  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
+  const int y = nb ? (int)blockIdx.x / (ADJ ? nb : 1) : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
   const float2* const work = nb ? a.batch->work[d] : a.work;
   const float* const scale = nb ? a.batch->exposure[d] : a.scale;
   float* const out = nb ? a.batch->gshift[d] : a.out;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
-  constexpr int MAXQ = 5;  // float4 pieces of a row per thread: W <= 4 * 256 * 5
-  load_spectrum_row(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  constexpr int MAXQ = S::MAXQ;
+  load_spectrum_row<S::T>(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
   const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * ROW_THREADS);
+    const int x = 4 * (tid + q * S::T);
     if (x >= a.W) continue;
     const int e = lp(x);
     const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
@@ -635,22 +687,22 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
     *reinterpret_cast<float4*>(out + o2 + x) = dn;
   }
   if (ADJ && a.fin_partials && y == 0) {  // (block-uniform)
-    __shared__ double red[ROW_THREADS / 64];
+    __shared__ double red[S::T / 64];
     const double* part = a.fin_partials + (size_t)d * a.fin_count;
     double acc = 0.0;
-    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
-    const double total = block_sum<ROW_THREADS>(acc, red);
+    for (int i = tid; i < a.fin_count; i += S::T) acc += part[i];
+    const double total = block_sum<S::T>(acc, red);
     if (tid == 0) {
       if (nb) a.batch->loss_out[d][0] = (float)(a.fin_scale * total + (double)a.batch->loss_offset[d]);
       else a.fin_out[0] = (float)(a.fin_scale * total + a.fin_offset);
     }
   }
   if (ADJ && a.fin2_partials && y == 1 && (!nb || a.batch->grad_log_bkg_norm[d])) {
-    __shared__ double red2[ROW_THREADS / 64];
+    __shared__ double red2[S::T / 64];
     const double* part = a.fin2_partials + (size_t)d * a.fin_count;
     double acc = 0.0;
-    for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
-    const double total = block_sum<ROW_THREADS>(acc, red2);
+    for (int i = tid; i < a.fin_count; i += S::T) acc += part[i];
+    const double total = block_sum<S::T>(acc, red2);
     if (tid == 0) (nb ? a.batch->grad_log_bkg_norm[d] : a.fin2_out)[0] = (float)(a.fin2_scale * total);
   }
 }
@@ -660,7 +712,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_kernel(RowsInvArgs 
 // each accumulates onto its predecessor, bit for bit -- and writes the two gradient rows once.  Blocks 0 .. n - 1
 // finalise the datasets' losses (fin_count partial sums each).
 template <int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_batch_kernel(RowsInvArgs a) {
+__global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2, R3>::WAVES_PER_SIMD)) void fftn_rows_inv_batch_kernel(RowsInvArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
@@ -668,23 +720,23 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_batch_kernel(RowsIn
   const int tid = threadIdx.x, y = blockIdx.x;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
-  constexpr int MAXQ = 5;
+  constexpr int MAXQ = S::MAXQ;
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
   float4 au[MAXQ], ad[MAXQ];
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) au[q] = ad[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 pre[ROW_PRE];
-  load_spectrum_row_regs(pre, a.batch->work[0], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  float4 pre[S::PRE];
+  load_spectrum_row_regs<S::T, S::PRE>(pre, a.batch->work[0], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
 #pragma unroll 1
   for (int d = 0; d < a.n_batch; ++d) {
-    store_spectrum_row_regs(bufa, pre, Nx, tid);
-    if (d + 1 < a.n_batch) load_spectrum_row_regs(pre, a.batch->work[d + 1], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+    store_spectrum_row_regs<S::T, S::PRE>(bufa, pre, Nx, tid);
+    if (d + 1 < a.n_batch) load_spectrum_row_regs<S::T, S::PRE>(pre, a.batch->work[d + 1], Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
     const float* scale = a.batch->exposure[d];
     const bool add = d > 0 || a.accumulate;
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-      const int x = 4 * (tid + q * ROW_THREADS);
+      const int x = 4 * (tid + q * S::T);
       if (x >= a.W) continue;
       const int e = lp(x);
       const float2 c0 = r[e], c1 = r[e + 1], c2 = r[e + 2], c3 = r[e + 3];
@@ -706,18 +758,18 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_inv_batch_kernel(RowsIn
   }
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * ROW_THREADS);
+    const int x = 4 * (tid + q * S::T);
     if (x >= a.W) continue;
     *reinterpret_cast<float4*>(a.out + o1 + x) = au[q];
     *reinterpret_cast<float4*>(a.out + o2 + x) = ad[q];
   }
   if (a.fin_partials) {
-    __shared__ double red[ROW_THREADS / 64];
+    __shared__ double red[S::T / 64];
     for (int d = blockIdx.x; d < a.n_batch; d += gridDim.x) {  // (block-uniform; more datasets than blocks: several per block)
       const double* part = a.fin_partials + (size_t)d * a.fin_count;
       double acc = 0.0;
-      for (int i = tid; i < a.fin_count; i += ROW_THREADS) acc += part[i];
-      const double total = block_sum<ROW_THREADS>(acc, red);
+      for (int i = tid; i < a.fin_count; i += S::T) acc += part[i];
+      const double total = block_sum<S::T>(acc, red);
       if (tid == 0) a.batch->loss_out[d][0] = (float)(a.fin_scale * total + (double)a.batch->loss_offset[d]);
       __syncthreads();
     }
@@ -743,10 +795,10 @@ struct RowsPoissonArgs {
 // arithmetic of every Poisson pass of the library), and at once the forward row transform of the g rows -- they ARE the
 // row pair the adjoint's first launch would read.  The convolution image and the g image never exist.
 template <int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPoissonArgs a) {
+__global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2, R3>::WAVES_PER_SIMD)) void fftn_rows_poisson_kernel(RowsPoissonArgs a) {
   extern __shared__ float2 lds[];
-  __shared__ double red[ROW_THREADS / 64];
   using S = RowSched<R0, R1, R2, R3>;
+  __shared__ double red[S::T / 64];
   const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, nb = a.n_batch;
   const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
@@ -756,15 +808,15 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   const float* const counts = nb ? a.batch->counts[d] : a.counts;
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
-  constexpr int MAXQ = 5;
-  load_spectrum_row(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  constexpr int MAXQ = S::MAXQ;
+  load_spectrum_row<S::T>(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
   const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
   float4 gu[MAXQ], gd[MAXQ];
   float local = 0.f;
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * ROW_THREADS);
+    const int x = 4 * (tid + q * S::T);
     gu[q] = gd[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (x >= a.W) continue;
     const int e = lp(x);
@@ -787,13 +839,13 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
     }
     gu[q] = make_float4(g1[0], g1[1], g1[2], g1[3]), gd[q] = make_float4(g2[0], g2[1], g2[2], g2[3]);
   }
-  const double total = block_sum<ROW_THREADS>((double)local, red);
+  const double total = block_sum<S::T>((double)local, red);
   if (tid == 0) a.partials[(size_t)d * a.Hh + y] = total;
   __syncthreads();  // every thread has read its part of the convolution row: the buffers are free
   // ---- z = g[y] + i g[y + Hh], zero padded: the adjoint's row transform ---------------------------------------------
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {  // (Nx <= 4608 < 4 * 256 * MAXQ)
-    const int x = 4 * (tid + q * ROW_THREADS), e = lp(x);
+    const int x = 4 * (tid + q * S::T), e = lp(x);
     if (x >= Nx) continue;
     float4 u = make_float4(0.f, 0.f, 0.f, 0.f), v = u;
     if (x < a.W) u = gu[q], v = gd[q];
@@ -802,7 +854,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_poisson_kernel(RowsPois
   __syncthreads();
   const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   float2* out = spec + (size_t)y * Nx;
-  for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+  for (int x = 2 * tid; x < Nx; x += 2 * S::T) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
   }
@@ -830,10 +882,10 @@ struct RowsPooledArgs {
 // transform of the up-sampled g rows -- the U flux rows of a counts row carry the same g, so their spectrum row is
 // computed once and stored U times.  Replaces rows^-1 -> convolution image -> pooled Poisson kernel -> g image -> rows.
 template <int U, int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPooledArgs a) {
+__global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2, R3>::WAVES_PER_SIMD)) void fftn_rows_pooled_kernel(RowsPooledArgs a) {
   extern __shared__ float2 lds[];
-  __shared__ double red[ROW_THREADS / 64];
   using S = RowSched<R0, R1, R2, R3>;
+  __shared__ double red[S::T / 64];
   const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, nb = a.n_batch;
   const int Y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - Y * nb : 0;
@@ -845,7 +897,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
   const size_t pbase = (size_t)d * (a.Hh / U);
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
-  constexpr int MAXQ = 5, PC = 4 / U;  // float4 pieces of a flux row per thread; counts pixels per piece
+  constexpr int MAXQ = S::MAXQ, PC = 4 / U;
   float pu[MAXQ][PC], pd[MAXQ][PC];    // pooled sums: counts row Y (upper half) and Y + H / (2 U) (lower half)
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q)
@@ -853,11 +905,11 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
     for (int c = 0; c < PC; ++c) pu[q][c] = pd[q][c] = 0.f;
 #pragma unroll 1
   for (int j = 0; j < U; ++j) {
-    load_spectrum_row(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+    load_spectrum_row<S::T>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-      const int x = 4 * (tid + q * ROW_THREADS);
+      const int x = 4 * (tid + q * S::T);
       if (x >= a.W) continue;
       const int e = lp(x);
       const float2 v[4] = {r[e], r[e + 1], r[e + 2], r[e + 3]};
@@ -872,7 +924,7 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
   double local = 0.0, local_b = 0.0;
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * ROW_THREADS);
+    const int x = 4 * (tid + q * S::T);
 #pragma unroll
     for (int c = 0; c < PC; ++c) gu[q][c] = gd[q][c] = 0.f;
     if (x >= a.W) continue;
@@ -890,24 +942,24 @@ __global__ __launch_bounds__(ROW_THREADS) void fftn_rows_pooled_kernel(RowsPoole
       gd[q][c] = pd[q][c] >= 0.f ? g : 0.f;
     }
   }
-  const double total = block_sum<ROW_THREADS>(local, red);
+  const double total = block_sum<S::T>(local, red);
   if (tid == 0) a.partials[pbase + Y] = total;
   if (a.partials_b) {
     __syncthreads();
-    const double total_b = block_sum<ROW_THREADS>(local_b, red);
+    const double total_b = block_sum<S::T>(local_b, red);
     if (tid == 0) a.partials_b[pbase + Y] = total_b;
   }
   // ---- z = g_up[y] + i g_up[y + Hh], zero padded: the adjoint's row transform, the same for the U flux rows ---------------
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * ROW_THREADS), e = lp(x);
+    const int x = 4 * (tid + q * S::T), e = lp(x);
     if (x >= Nx) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) bufa[e + i] = x < a.W ? float2{gu[q][i / U], gd[q][i / U]} : float2{0.f, 0.f};
   }
   __syncthreads();
   const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
-  for (int x = 2 * tid; x < Nx; x += 2 * ROW_THREADS) {
+  for (int x = 2 * tid; x < Nx; x += 2 * S::T) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     const float4 v = make_float4(c0.x, c0.y, c1.x, c1.y);
 #pragma unroll
@@ -1098,7 +1150,8 @@ int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), const FftNati
   int rc = lds_attr(reinterpret_cast<const void*>(kernels[sched]), lds_rows);
   if (rc) return rc;
   ProfScope prof(kernel_id, stream);
-  hipLaunchKernelGGL(kernels[sched], dim3(blocks ? blocks : n.Hh), dim3(ROW_THREADS), lds_rows, stream, a);
+  static constexpr int threads[N_ROW_SCHED] = {RowSched<0, 0, 0, 0>::T, RowSched<16, 16, 9, 0>::T, RowSched<8, 8, 8, 9>::T, RowSched<16, 8, 9, 0>::T};
+  hipLaunchKernelGGL(kernels[sched], dim3(blocks ? blocks : n.Hh), dim3(threads[sched]), lds_rows, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

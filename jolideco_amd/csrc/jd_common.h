@@ -106,6 +106,10 @@ __device__ __forceinline__ ShiftGeom shift_geom(const float* shift_xy, float sca
   return g;
 }
 
+struct __attribute__((packed, aligned(4))) F4U4 {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
+  float x, y, z, w;
+};
+
 // out = (accumulate ? out : 0) + scale * sum(partials[0..n)) + offset, summed in index order in fp64.
 int launch_finalize_sum(const double* partials, int n, double scale, double offset, float* out,
                         int accumulate, hipStream_t stream);

@@ -28,14 +28,94 @@ constexpr int MAX_PASSES = 6;
 JD_FFT_HD int lp(int e) { return e + (e >> 4); }
 JD_FFT_HD int lp_size(int n) { return n + (n >> 4) + 1; }
 
-JD_FFT_HD float2 cadd(float2 a, float2 b) { return float2{a.x + b.x, a.y + b.y}; }
-JD_FFT_HD float2 csub(float2 a, float2 b) { return float2{a.x - b.x, a.y - b.y}; }
-JD_FFT_HD float2 cmul(float2 a, float2 b) { return float2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-JD_FFT_HD float2 cconj(float2 a) { return float2{a.x, -a.y}; }
+// Complex arithmetic.  On the device a complex number is a PAIR of 32-bit registers and every operation below is one or
+// two PACKED fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on both halves of a register pair; their
+// op_sel / op_sel_hi modifiers pick, per result half, which half of each source is read, neg_lo / neg_hi negate a source
+// per result half): an addition is ONE instruction instead of two, a complex product TWO instead of four, and a
+// multiplication by +-i costs nothing (it is the operand swizzle of the addition that consumes it).  The transforms of
+// this library are bound by their vector-instruction count (fftnative.hip), so this halves their arithmetic.  On the
+// host (tests/native/fftcore_check.cpp) the same functions are plain scalar code.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define JD_FFT_PACKED 1
+typedef float cf __attribute__((ext_vector_type(2)));
+#else
+#define JD_FFT_PACKED 0
+typedef float2 cf;
+#endif
+
+JD_FFT_HD cf cadd(cf a, cf b) {
+#if JD_FFT_PACKED
+  return a + b;
+#else
+  return cf{a.x + b.x, a.y + b.y};
+#endif
+}
+JD_FFT_HD cf csub(cf a, cf b) {
+#if JD_FFT_PACKED
+  return a - b;
+#else
+  return cf{a.x - b.x, a.y - b.y};
+#endif
+}
+// a * b
+JD_FFT_HD cf cmul(cf a, cf b) {
+#if JD_FFT_PACKED
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));  // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));  // (-a.y b.y, a.y b.x) + t
+  return r;
+#else
+  return cf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+#endif
+}
+// a * (c + i s) for a compile-time constant: the constant lives in a scalar register pair
+JD_FFT_HD cf cmul_const(cf a, float c, float s) {
+#if JD_FFT_PACKED
+  const cf b = cf{c, s};
+  cf t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+  return r;
+#else
+  return cf{a.x * c - a.y * s, a.x * s + a.y * c};
+#endif
+}
+// a + c * b, c real
+JD_FFT_HD cf cfma_real(cf a, float c, cf b) {
+#if JD_FFT_PACKED
+  return a + b * cf{c, c};
+#else
+  return cf{a.x + c * b.x, a.y + c * b.y};
+#endif
+}
+JD_FFT_HD cf cscale(cf a, float c) {
+#if JD_FFT_PACKED
+  return a * cf{c, c};
+#else
+  return cf{a.x * c, a.y * c};
+#endif
+}
+JD_FFT_HD cf cconj(cf a) { return cf{a.x, -a.y}; }
 // multiplication by -i (DIR < 0: the forward transform's quarter turn) or +i (DIR > 0: the inverse's)
 template <int DIR>
-JD_FFT_HD float2 crot(float2 a) {
-  return DIR < 0 ? float2{a.y, -a.x} : float2{-a.y, a.x};
+JD_FFT_HD cf crot(cf a) {
+  return DIR < 0 ? cf{a.y, -a.x} : cf{-a.y, a.x};
+}
+// a + crot<DIR>(b) and a - crot<DIR>(b): the quarter turn is the operand swizzle of the addition
+template <int DIR>
+JD_FFT_HD cf cadd_rot(cf a, cf b) {
+#if JD_FFT_PACKED
+  cf r;
+  if (DIR < 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));  // (a.x + b.y, a.y - b.x)
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));         // (a.x - b.y, a.y + b.x)
+  return r;
+#else
+  return cadd(a, crot<DIR>(b));
+#endif
+}
+template <int DIR>
+JD_FFT_HD cf csub_rot(cf a, cf b) {
+  return cadd_rot<-DIR>(a, b);
 }
 
 // in-register DFTs, natural order in and out; DIR = -1: exp(-2 pi i jk / R) (forward), +1: inverse (unnormalised)
@@ -44,26 +124,26 @@ struct Dft;
 
 template <int DIR>
 struct Dft<2, DIR> {
-  static JD_FFT_HD void run(float2* u) {
-    const float2 a = u[0], b = u[1];
+  static JD_FFT_HD void run(cf* u) {
+    const cf a = u[0], b = u[1];
     u[0] = cadd(a, b), u[1] = csub(a, b);
   }
 };
 
 template <int DIR>
 struct Dft<4, DIR> {
-  static JD_FFT_HD void run(float2* u) {
-    const float2 t0 = cadd(u[0], u[2]), t1 = csub(u[0], u[2]), t2 = cadd(u[1], u[3]), t3 = crot<DIR>(csub(u[1], u[3]));
-    u[0] = cadd(t0, t2), u[1] = cadd(t1, t3), u[2] = csub(t0, t2), u[3] = csub(t1, t3);
+  static JD_FFT_HD void run(cf* u) {
+    const cf t0 = cadd(u[0], u[2]), t1 = csub(u[0], u[2]), t2 = cadd(u[1], u[3]), d = csub(u[1], u[3]);
+    u[0] = cadd(t0, t2), u[1] = cadd_rot<DIR>(t1, d), u[2] = csub(t0, t2), u[3] = csub_rot<DIR>(t1, d);
   }
 };
 
 // radix-2 decimation in time on top of two half-size transforms (R = 8, 16)
 template <int R, int DIR>
 struct Dft {
-  static JD_FFT_HD void run(float2* u) {
+  static JD_FFT_HD void run(cf* u) {
     constexpr int H = R / 2;
-    float2 e[H], o[H];
+    cf e[H], o[H];
 #pragma unroll
     for (int i = 0; i < H; ++i) e[i] = u[2 * i], o[i] = u[2 * i + 1];
     Dft<H, DIR>::run(e);
@@ -72,34 +152,36 @@ struct Dft {
     for (int k = 0; k < H; ++k) {
       // w = exp(DIR * 2 pi i k / R) (compile-time constants after unrolling)
       const double ang = (DIR < 0 ? -1.0 : 1.0) * 6.283185307179586476925286766559 * k / R;
-      float2 t;
-      if (k == 0) t = o[k];
-      else if (4 * k == R) t = crot<DIR>(o[k]);
-      else t = cmul(o[k], float2{(float)__builtin_cos(ang), (float)__builtin_sin(ang)});
-      u[k] = cadd(e[k], t), u[k + H] = csub(e[k], t);
+      if (k == 0) {
+        u[k] = cadd(e[k], o[k]), u[k + H] = csub(e[k], o[k]);
+      } else if (4 * k == R) {
+        u[k] = cadd_rot<DIR>(e[k], o[k]), u[k + H] = csub_rot<DIR>(e[k], o[k]);
+      } else {
+        const cf t = cmul_const(o[k], (float)__builtin_cos(ang), (float)__builtin_sin(ang));
+        u[k] = cadd(e[k], t), u[k + H] = csub(e[k], t);
+      }
     }
   }
 };
 
 template <int DIR>
 struct Dft<3, DIR> {
-  static JD_FFT_HD void run(float2* u) {
+  static JD_FFT_HD void run(cf* u) {
     const float c = 0.86602540378443864676f;  // sin(2 pi / 3)
-    const float2 s = cadd(u[1], u[2]), d = csub(u[1], u[2]);
-    const float2 m = float2{u[0].x - 0.5f * s.x, u[0].y - 0.5f * s.y};
-    const float2 r = crot<DIR>(float2{c * d.x, c * d.y});
-    u[0] = cadd(u[0], s), u[1] = cadd(m, r), u[2] = csub(m, r);
+    const cf s = cadd(u[1], u[2]), d = cscale(csub(u[1], u[2]), c);
+    const cf m = cfma_real(u[0], -0.5f, s);
+    u[0] = cadd(u[0], s), u[1] = cadd_rot<DIR>(m, d), u[2] = csub_rot<DIR>(m, d);
   }
 };
 
 template <int DIR>
 struct Dft<9, DIR> {
-  static JD_FFT_HD void run(float2* u) {
+  static JD_FFT_HD void run(cf* u) {
     // n = 3 n1 + n2, k = k1 + 3 k2:  X[k1 + 3 k2] = sum_n2 w9^(n2 k1) w3^(n2 k2) sum_n1 w3^(n1 k1) x[3 n1 + n2]
-    float2 a[3][3];
+    cf a[3][3];
 #pragma unroll
     for (int n2 = 0; n2 < 3; ++n2) {
-      float2 v[3] = {u[n2], u[3 + n2], u[6 + n2]};
+      cf v[3] = {u[n2], u[3 + n2], u[6 + n2]};
       Dft<3, DIR>::run(v);
 #pragma unroll
       for (int k1 = 0; k1 < 3; ++k1) {
@@ -107,13 +189,13 @@ struct Dft<9, DIR> {
           a[n2][k1] = v[k1];
         } else {
           const double ang = (DIR < 0 ? -1.0 : 1.0) * 6.283185307179586476925286766559 * (n2 * k1) / 9.0;
-          a[n2][k1] = cmul(v[k1], float2{(float)__builtin_cos(ang), (float)__builtin_sin(ang)});
+          a[n2][k1] = cmul_const(v[k1], (float)__builtin_cos(ang), (float)__builtin_sin(ang));
         }
       }
     }
 #pragma unroll
     for (int k1 = 0; k1 < 3; ++k1) {
-      float2 v[3] = {a[0][k1], a[1][k1], a[2][k1]};
+      cf v[3] = {a[0][k1], a[1][k1], a[2][k1]};
       Dft<3, DIR>::run(v);
 #pragma unroll
       for (int k2 = 0; k2 < 3; ++k2) u[k1 + 3 * k2] = v[k2];
@@ -129,15 +211,18 @@ struct Dft<9, DIR> {
 // t (nb + nb / 16)), outputs when p = 1 (the R <= 16 outputs of a butterfly share one group of 16) or p is a multiple
 // of 16 -- one base address each plus compile-time multiples of a uniform step instead of an add, a shift and an add per
 // element.
-JD_FFT_HD bool pass_is_linear(int N, int R, int p) { return ((N / R) & 15) == 0 && (p == 1 || (p & 15) == 0); }
+JD_FFT_HD constexpr bool pass_is_linear(int N, int R, int p) { return ((N / R) & 15) == 0 && (p == 1 || (p & 15) == 0); }
 
 template <int R, int DIR, bool LIN = false>
-JD_FFT_HD void pass_one(const float2* x, float2* y, int N, int p, const float2* tw, int b) {
+JD_FFT_HD void pass_one(const float2* x_, float2* y_, int N, int p, const float2* tw_, int b) {
+  const cf* x = reinterpret_cast<const cf*>(x_);
+  cf* y = reinterpret_cast<cf*>(y_);
+  const cf* tw = reinterpret_cast<const cf*>(tw_);
   const int nb = N / R;
   const int k = b & (p - 1);
-  float2 u[R];
+  cf u[R];
   if (LIN) {
-    const float2* xb = x + lp(b);
+    const cf* xb = x + lp(b);
     const int step = nb + (nb >> 4);
 #pragma unroll
     for (int t = 0; t < R; ++t) u[t] = xb[t * step];
@@ -147,7 +232,7 @@ JD_FFT_HD void pass_one(const float2* x, float2* y, int N, int p, const float2* 
   }
   if (p > 1) {
     // w^t built from one table entry by a product tree (depth <= 4: a few ulp), not by R - 1 dependent products
-    float2 w[R];
+    cf w[R];
     w[1] = tw[k * (nb / p)];
     if (DIR > 0) w[1].y = -w[1].y;
 #pragma unroll
@@ -158,7 +243,7 @@ JD_FFT_HD void pass_one(const float2* x, float2* y, int N, int p, const float2* 
   Dft<R, DIR>::run(u);
   const int j = (b - k) * R + k;
   if (LIN) {
-    float2* yb = y + lp(j);
+    cf* yb = y + lp(j);
     const int step = p == 1 ? 1 : p + (p >> 4);
 #pragma unroll
     for (int t = 0; t < R; ++t) yb[t * step] = u[t];

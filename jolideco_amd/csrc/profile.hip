@@ -156,6 +156,7 @@ extern "C" const char* jd_kernel_name(int kernel) {
     case JD_KERNEL_GMM_SORT: return "gmm_bucket_kernels";
     case JD_KERNEL_GMM_EXACT: return "gmm_exact_kernel";
     case JD_KERNEL_GMM_STAGE: return "gmm_stage_kernel";
+    case JD_KERNEL_SHIFT: return "shift_kernels";
     default: return "?";
   }
 }

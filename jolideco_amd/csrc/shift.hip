@@ -126,11 +126,138 @@ __global__ __launch_bounds__(256) void shift_bwd_batch_kernel(const float* __res
   }
 }
 
+
+// ---- the same two kernels on four pixels per thread (W % 4 == 0, 16-byte aligned images) -------------------------------
+// A block owns SHIFT_ROWS rows of 1024 columns and walks down them: per row a thread loads the five source columns of ONE
+// new row of gs (a 16-byte load at a 4-byte aligned address + one float) and of the flux -- the row above is the previous
+// step's -- instead of four bounds-checked scalar loads per pixel and image; the gradient row goes through float4.  The
+// per-pixel arithmetic (order of the four products and three sums, every operation rounded on its own) is that of the
+// scalar kernels above: the same v, bit for bit.  4096^2: 77 -> see profiles/r05.
+struct Row5 {
+  float v[5];
+};
+
+__device__ __forceinline__ Row5 load_row5(const float* img, int H, int W, int y, int x) {  // img[y][x .. x + 4], zero outside
+  Row5 r;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) r.v[i] = 0.f;
+  if (y < 0 || y >= H) return r;
+  const float* row = img + (size_t)y * W;
+  if (x >= 0 && x + 4 < W) {
+    const F4U4 q = *reinterpret_cast<const F4U4*>(row + x);
+    r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w, r.v[4] = row[x + 4];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (x + i >= 0 && x + i < W) r.v[i] = row[x + i];
+  }
+  return r;
+}
+
+// rows [y_begin, y_end) of one dataset for this thread's four columns x .. x + 3; dsx / dsy += the shift gradient terms
+__device__ __forceinline__ void shift_bwd_rows4(const float* __restrict__ in, const float* __restrict__ gs, float* __restrict__ grad_in,
+                                                bool add, int H, int W, const ShiftGeom& g, int x, int y_begin, int y_end,
+                                                double& dsx, double& dsy) {
+#pragma clang fp contract(off)
+  const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
+  // gs rows py - 1 (prev) and py (cur) at columns x - fx - 1 ..; flux rows y0 (north) and y0 + 1 (south) at columns x + fx ..
+  Row5 prev = load_row5(gs, H, W, y_begin - g.fy - 1, x - g.fx - 1);
+  Row5 north = load_row5(in, H, W, y_begin + g.fy, x + g.fx);
+  for (int y = y_begin; y < y_end; ++y) {
+    const Row5 cur = load_row5(gs, H, W, y - g.fy, x - g.fx - 1);
+    const Row5 south = load_row5(in, H, W, y + g.fy + 1, x + g.fx);
+    const size_t off = (size_t)y * W + x;
+    const float4 go = *reinterpret_cast<const float4*>(gs + off);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (add) acc = *reinterpret_cast<const float4*>(grad_in + off);
+    const float gov[4] = {go.x, go.y, go.z, go.w}, accv[4] = {acc.x, acc.y, acc.z, acc.w};
+    float out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = cur.v[i + 1] * w00 + cur.v[i] * w10 + prev.v[i + 1] * w01 + prev.v[i] * w11;
+      if (add) v += accv[i];
+      out[i] = v;
+      const float nw = north.v[i], ne = north.v[i + 1], sw = south.v[i], se = south.v[i + 1];
+      dsx += (double)(gov[i] * ((ne - nw) * g.wy0 + (se - sw) * g.wy1));
+      dsy += (double)(gov[i] * ((sw - nw) * g.wx0 + (se - ne) * g.wx1));
+    }
+    *reinterpret_cast<float4*>(grad_in + off) = make_float4(out[0], out[1], out[2], out[3]);
+    prev = cur, north = south;
+  }
+}
+
+__global__ __launch_bounds__(256) void shift_bwd4_kernel(const float* __restrict__ in, const float* __restrict__ gs,
+                                                         float* __restrict__ grad_in, int accumulate, int H, int W,
+                                                         const float* __restrict__ shift_xy, float scale,
+                                                         double* __restrict__ partials) {
+  __shared__ double smem[256 / 64];
+  const int x = 4 * (blockIdx.x * 256 + threadIdx.x);
+  const ShiftGeom g = shift_geom(shift_xy, scale);
+  double dsx = 0.0, dsy = 0.0;
+  if (x < W)
+    shift_bwd_rows4(in, gs, grad_in, accumulate != 0, H, W, g, x, blockIdx.y * SHIFT_ROWS, min((int)(blockIdx.y + 1) * SHIFT_ROWS, H), dsx, dsy);
+  const double tx = block_sum<256>(dsx, smem);
+  __syncthreads();
+  const double ty = block_sum<256>(dsy, smem);
+  if (threadIdx.x == 0) {
+    const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    partials[2 * b] = tx * (double)scale;
+    partials[2 * b + 1] = ty * (double)scale;
+  }
+}
+
+__global__ __launch_bounds__(256) void shift_bwd4_batch_kernel(const float* __restrict__ in, const FftBatch* __restrict__ batch,
+                                                               int n_datasets, float* __restrict__ grad_in, int accumulate, int H,
+                                                               int W, float scale, double* __restrict__ partials,
+                                                               size_t partials_stride) {
+#pragma clang fp contract(off)
+  __shared__ double smem[256 / 64];
+  const int x = 4 * (blockIdx.x * 256 + threadIdx.x);
+  const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  const int y_begin = blockIdx.y * SHIFT_ROWS, y_end = min((int)(blockIdx.y + 1) * SHIFT_ROWS, H);
+  for (int d = 0; d < n_datasets; ++d) {
+    const float* gs = batch->gshift[d];
+    const float* shift_xy = batch->shift_xy[d];
+    const bool add = accumulate || d > 0;
+    double dsx = 0.0, dsy = 0.0;
+    if (shift_xy) {
+      const ShiftGeom g = shift_geom(shift_xy, scale);
+      if (x < W) shift_bwd_rows4(in, gs, grad_in, add, H, W, g, x, y_begin, y_end, dsx, dsy);
+      const double tx = block_sum<256>(dsx, smem);
+      __syncthreads();
+      const double ty = block_sum<256>(dsy, smem);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        partials[(size_t)d * partials_stride + 2 * b] = tx * (double)scale;
+        partials[(size_t)d * partials_stride + 2 * b + 1] = ty * (double)scale;
+      }
+    } else if (x < W) {
+      for (int y = y_begin; y < y_end; ++y) {
+        const size_t off = (size_t)y * W + x;
+        float4 v = *reinterpret_cast<const float4*>(gs + off);
+        if (add) {
+          const float4 o = *reinterpret_cast<const float4*>(grad_in + off);
+          v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(grad_in + off) = v;
+      }
+    }
+  }
+}
+
+static bool shift_vec_ok(const void* a, const void* b, const void* c, int W) {
+  return W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 int launch_shift_bwd_batch(const float* in, const FftBatch* batch, int n_datasets, float* grad_in, int accumulate, int H, int W,
                            float scale, double* partials, size_t partials_stride, int* n_blocks, hipStream_t stream) {
-  dim3 grid((W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
+  // (the batch table's images are hipMalloc'ed by the plan: 256-byte aligned)
+  const bool vec = shift_vec_ok(in, grad_in, nullptr, W);
+  dim3 grid(vec ? (W + 1023) / 1024 : (W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
   *n_blocks = grid.x * grid.y;
-  shift_bwd_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
+  ProfScope prof(JD_KERNEL_SHIFT, stream);
+  if (vec) shift_bwd4_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
+  else shift_bwd_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -193,6 +320,7 @@ int launch_finalize_multi_batch(const double* partials, size_t stride, int n_blo
 
 int launch_shift_fwd(const float* in, float* out, int H, int W, const float* shift_xy, float scale, hipStream_t stream) {
   dim3 grid((W + 255) / 256, H);
+  ProfScope prof(JD_KERNEL_SHIFT, stream);
   shift_fwd_kernel<<<grid, 256, 0, stream>>>(in, out, H, W, shift_xy, scale);
   JD_LAUNCH_CHECK();
   return JD_OK;
@@ -202,9 +330,12 @@ int shift_bwd_max_blocks(int H, int W) { return ((W + 255) / 256) * ((H + SHIFT_
 
 int launch_shift_bwd(const float* in, const float* gs, float* grad_in, int accumulate, int H, int W,
                      const float* shift_xy, float scale, double* partials, int* n_blocks, hipStream_t stream) {
-  dim3 grid((W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
+  const bool vec = shift_vec_ok(in, gs, grad_in, W);
+  dim3 grid(vec ? (W + 1023) / 1024 : (W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
   *n_blocks = grid.x * grid.y;
-  shift_bwd_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
+  ProfScope prof(JD_KERNEL_SHIFT, stream);
+  if (vec) shift_bwd4_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
+  else shift_bwd_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

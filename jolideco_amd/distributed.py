@@ -2,8 +2,11 @@
 "nccl" backend (= RCCL over xGMI on ROCm).  The reference has no distributed code at all; this is
 new.
 
-Partitioning: rank r owns datasets {d : d mod R = r}; the GMM prior is split by contiguous patch
-rows; theta, optimizer state and GMM constants are replicated.  Per optimizer step: ONE sum all-reduce
+Partitioning: the datasets go to the ranks by longest-processing-time-first on an estimated cost per dataset
+(`lpt_assignment`; equal costs give the round-robin d mod R), the GMM prior is split by contiguous patch rows in
+shares that top every rank up to the same estimated load (`balanced_shares`, `split_range`: a rank that owns a
+dataset with a wide PSF evaluates fewer patch rows); theta, optimizer state and GMM constants are replicated.  Every
+rank computes the same partition from the same inputs.  Per optimizer step: ONE sum all-reduce
 of a flat buffer holding every component's likelihood gradient followed by the epoch's loss scalars
 (16.8 MB per component at 2048^2), started asynchronously, and -- while it is in flight -- the rank's
 band of the prior gradient, exchanged with ONE all-gather of the compact bands (`FitSession`,
@@ -15,7 +18,57 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["DistContext", "init_from_env"]
+__all__ = ["DistContext", "init_from_env", "lpt_assignment", "balanced_shares", "split_range"]
+
+
+def lpt_assignment(costs, world_size):
+    """Owner rank of every item by longest-processing-time-first: items in order of falling cost (ties: by index), each to
+    the least loaded rank (ties: the lowest rank).  Deterministic -- every rank computes the same table; equal costs give
+    the round-robin ``i mod world_size``.  Returns (owners, loads per rank)."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    loads, owners = [0.0] * world_size, [0] * len(costs)
+    for i in order:
+        rank = min(range(world_size), key=lambda r: (loads[r], r))
+        owners[i] = rank
+        loads[rank] += float(costs[i])
+    return owners, loads
+
+
+def balanced_shares(loads, divisible):
+    """Shares (sum 1) of a divisible piece of work of total cost ``divisible`` that top the ranks' fixed ``loads`` up to a
+    common level where that is possible (water filling: a rank already above the level gets nothing); None when every
+    rank gets the same share anyway."""
+    n = len(loads)
+    if n < 2 or divisible <= 0 or max(loads) - min(loads) <= 1e-12 * max(max(loads), 1.0):
+        return None
+    level_order = sorted(loads)
+    level = None
+    for k in range(n, 0, -1):  # the k least loaded ranks share the work
+        candidate = (sum(level_order[:k]) + divisible) / k
+        if candidate >= level_order[k - 1]:
+            level = candidate
+            break
+    shares = [max(level - load, 0.0) / divisible for load in loads]
+    total = sum(shares)
+    return [s / total for s in shares]
+
+
+def split_range(n, world_size, shares=None):
+    """Contiguous [begin, end) slices of range(n), one per rank.  ``shares`` None: balanced, the first n mod R ranks get one
+    extra element; else rank r gets about shares[r] * n elements (boundaries at the rounded cumulative shares)."""
+    if shares is None:
+        base, extra = divmod(n, world_size)
+        out, begin = [], 0
+        for r in range(world_size):
+            end = begin + base + (1 if r < extra else 0)
+            out.append((begin, end))
+            begin = end
+        return out
+    total, acc, bounds = float(sum(shares)), 0.0, [0]
+    for r in range(world_size):
+        acc += float(shares[r])
+        bounds.append(n if r == world_size - 1 else max(bounds[-1], min(n, int(round(n * acc / total)))))
+    return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
 
 class DistContext:
@@ -44,16 +97,18 @@ class DistContext:
             return cls(rank=dist.get_rank(), world_size=dist.get_world_size(), force_collectives=force_collectives_requested())
         return cls()
 
-    def shard_items(self, items):
-        """Round-robin ownership: item i belongs to rank i mod world_size."""
-        return [item for i, item in enumerate(items) if i % self.world_size == self.rank]
+    def shard_items(self, items, costs=None):
+        """This rank's items, in their original order.  Without ``costs`` round-robin (item i belongs to rank
+        i mod world_size); with an estimated cost per item the longest-processing-time-first table of `lpt_assignment`."""
+        if costs is None:
+            return [item for i, item in enumerate(items) if i % self.world_size == self.rank]
+        owners, _ = lpt_assignment(costs, self.world_size)
+        return [item for item, owner in zip(items, owners) if owner == self.rank]
 
-    def shard_range(self, n):
-        """Contiguous, balanced [begin, end) slice of range(n) for this rank (the first n mod R
-        ranks get one extra element)."""
-        base, extra = divmod(n, self.world_size)
-        begin = self.rank * base + min(self.rank, extra)
-        return begin, begin + base + (1 if self.rank < extra else 0)
+    def shard_range(self, n, shares=None):
+        """Contiguous [begin, end) slice of range(n) for this rank: balanced (the first n mod R ranks get one extra
+        element), or by ``shares`` per rank (`split_range`)."""
+        return split_range(n, self.world_size, shares)[self.rank]
 
     def all_reduce_sum(self, buffer):
         """In-place sum all-reduce of one flat tensor (a no-op for a single process)."""

@@ -148,6 +148,44 @@ def dataset_psfs(dataset, components):
 
 WALK_MAX_EDGE = 33  # widest frame of the strip-walk kernels (csrc/walkconv.hip)
 
+# Estimated cost of a likelihood step (forward model + Poisson pass + adjoint) per (dataset, component), in units of one
+# rank-1 PSF of up to 17 taps on the strip-walk kernels, from the per-kernel tables of profiles/r04 at 2048^2: 17-tap frame
+# 15 + 10.5 us; 33-tap frame 1.6 x the forward and 2.4 x the adjoint; MFMA Toeplitz 2 x 27 us at 17
+# taps, growing with the PSF area; native FFT 72 us per observation whatever the PSF size; separable tile kernel about 1.3
+# per rank.  Only the RATIOS between the datasets of one fit matter (`distributed.lpt_assignment`), and the ratio to the
+# prior below (`balanced_shares`).
+COST_WALK17, COST_WALK33, COST_TILE_PER_RANK, COST_DIRECT17, COST_FFT = 1.0, 1.9, 1.3, 2.1, 2.8
+# GMM patch prior of the whole image in the same units: screen 198 us (proportional to the number of components, K = 128)
+# + stage, sort, exact evaluation, arg-max, gather 170 us against the 25.5 us unit
+COST_PRIOR_FIXED, COST_PRIOR_PER_128_COMPONENTS = 6.7, 7.8
+
+
+def estimate_dataset_cost(dataset, components, calibrated=False):
+    """Estimated cost of one dataset's likelihood step in the units above: decides which rank owns the dataset and how
+    many patch rows of the prior that rank evaluates (jolideco_amd/core.py, sharded joint fits).  Host logic only: the
+    convolution method "auto" would choose, from the PSF shapes and their separable ranks."""
+    method = default_conv_method()
+    counts_shape = np.shape(dataset["counts"])
+    total = 0.0
+    for name, psf in dataset_psfs(dataset, components).items():
+        edge = max(psf.shape[-2:])
+        up = components[name].upsampling_factor or 1
+        edge *= up
+        if method == "fft" or calibrated or up > 1:
+            unit = COST_FFT if edge > DIRECT_FAST_EDGE or method == "fft" else COST_DIRECT17
+        else:
+            rank = psf_separable_rank(psf) if method == "auto" and psf.ndim == 2 else 0
+            if rank == 1 and edge <= WALK_MAX_EDGE:
+                unit = COST_WALK17 if edge <= 17 else COST_WALK33
+            elif rank >= 1 and (rank == 1 or edge > DIRECT_FAST_EDGE):
+                unit = COST_TILE_PER_RANK * rank * max(edge / 17.0, 1.0)
+            elif edge <= DIRECT_FAST_EDGE or counts_shape[0] * counts_shape[1] < 1 << 20 and edge <= 33:
+                unit = COST_DIRECT17 * (edge / 17.0) ** 2
+            else:
+                unit = COST_FFT
+        total += unit * up * up  # (the flux grid has up^2 pixels per counts pixel)
+    return total
+
 
 def common_kernel_shape(datasets, components, calibrations=None):
     """PSF array shape to embed every PSF of every dataset in, or None to leave each dataset its own.

@@ -200,6 +200,62 @@ def test_shard_rules():
     assert DistContext().all_reduce_sum(buf) is buf
 
 
+def test_cost_aware_placement_rules():
+    """Datasets by longest-processing-time-first, the prior's patch rows in shares that top every rank up to one level
+    (round-4 verdict: the 33x33 PSFs of SURVEY section 8(d) cost 1.9 x a 17x17 one and sat on ranks 6 and 7)."""
+    from jolideco_amd.distributed import DistContext, balanced_shares, lpt_assignment, split_range
+
+    # equal costs: the round-robin of before, on any number of ranks
+    for world in (1, 2, 3, 8):
+        owners, loads = lpt_assignment([1.0] * 11, world)
+        assert owners == [i % world for i in range(11)]
+        assert [DistContext(r, world).shard_items(list(range(11)), costs=[1.0] * 11) for r in range(world)] == \
+               [DistContext(r, world).shard_items(list(range(11))) for r in range(world)]
+        assert balanced_shares(loads if 11 % world == 0 else [1.0] * world, 5.0) is None
+    # the benchmark's eight observations (two of them 1.9 x): four ranks
+    costs = [1, 1, 1, 1, 1, 1, 1.9, 1.9]
+    owners, loads = lpt_assignment(costs, 4)
+    assert sorted(loads) == pytest.approx([2.0, 2.0, 2.9, 2.9]) and owners[6] != owners[7]
+    for rank in range(4):  # a rank's datasets keep their order
+        mine = DistContext(rank, 4).shard_items(list(range(8)), costs=costs)
+        assert mine == sorted(mine) and all(owners[i] == rank for i in mine)
+    # eight ranks, one observation each: the prior evens the ranks out
+    owners, loads = lpt_assignment(costs, 8)
+    shares = balanced_shares(loads, 14.5)
+    assert sum(shares) == pytest.approx(1.0)
+    totals = [load + 14.5 * share for load, share in zip(loads, shares)]
+    assert max(totals) - min(totals) < 1e-9
+    ranges = split_range(511, 8, shares)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 511 and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+    sizes = [b - a for a, b in ranges]
+    heavy = [r for r in range(8) if loads[r] > 1.5]
+    assert all(sizes[r] < min(sizes[q] for q in range(8) if q not in heavy) for r in heavy)
+    assert [DistContext(r, 8).shard_range(511, shares) for r in range(8)] == ranges
+    # a rank whose datasets alone exceed the common level gets no patch rows; the others share them
+    shares = balanced_shares([10.0, 1.0, 1.0], 3.0)
+    assert shares == pytest.approx([0.0, 0.5, 0.5])
+    assert split_range(81, 3, shares) == [(0, 0), (0, 40), (40, 81)]
+    # no shares: the balanced split
+    assert split_range(509, 8) == [DistContext(r, 8).shard_range(509) for r in range(8)]
+
+
+def test_dataset_cost_estimate_follows_the_psf():
+    """`estimate_dataset_cost`: host logic on the PSF shapes and ranks (no device)."""
+    import numpy as np
+
+    from jolideco_amd import FluxComponents, SpatialFluxComponent
+    from jolideco_amd.data import gaussian_kernel, instrument_like_psf
+    from jolideco_amd.models.npred import COST_FFT, COST_WALK17, COST_WALK33, estimate_dataset_cost
+
+    comps = FluxComponents()
+    comps["flux"] = SpatialFluxComponent.from_numpy(flux=np.ones((64, 64)))
+    data = lambda psf: {"counts": np.zeros((2048, 2048), dtype=np.float32), "psf": psf}  # noqa: E731
+    assert estimate_dataset_cost(data(gaussian_kernel(2.0, (17, 17))), comps) == COST_WALK17
+    assert estimate_dataset_cost(data(gaussian_kernel(3.2, (33, 33))), comps) == COST_WALK33
+    assert estimate_dataset_cost(data(instrument_like_psf(0, (65, 65))), comps) == COST_FFT
+    assert estimate_dataset_cost(data(gaussian_kernel(2.0, (17, 17))), comps, calibrated=True) > COST_WALK17
+
+
 def _helpers_worker(rank, world_size, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size),
                       LOCAL_RANK=str(rank))

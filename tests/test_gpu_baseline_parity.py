@@ -568,8 +568,8 @@ def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
 def test_c6_shaped_calibrated_upsampled_joint_step_4096_columns(form, jd_option):
     """The row kernels bench.py's c6 times (round-4 verdict, weak 1): flux rows of 4096 pixels -> row transforms of length
     4608 = 8 * 8 * 8 * 9 (`fftn_rows_fwd_kernel<8, 8, 8, 9>` with the calibration shift in its load,
-    `fftn_rows_pooled_kernel<2, 8, 8, 8, 9>`, `fftn_rows_inv_kernel<true, 8, 8, 8, 9>`), on a SHORT counts grid (64 x 2048,
-    flux grid 128 x 4096) so that the oracle stays cheap; general 33x33 PSFs (66x66 up-sampled), 4 calibrated
+    `fftn_rows_pooled_kernel<2, 8, 8, 8, 9>`, `fftn_rows_inv_kernel<true, 8, 8, 8, 9>`), on a SHORT counts grid (96 x 2048,
+    flux grid 192 x 4096: half the rows still hold the 66-row PSF) so that the oracle stays cheap; general 33x33 PSFs (66x66 up-sampled), 4 calibrated
     observations.  ``batched``: jd_npred_poisson_calibrated_batch_fwd_bwd's launches over all datasets (what a fit of this
     height runs); ``per-dataset``: the five launches + transposed shift per dataset (``JD_FFT_BATCH=0``: what c6 runs at
     4096 flux rows); ``separate-kernels``: no fusion at all.  The 2304-point column kernel of c6
@@ -578,4 +578,4 @@ def test_c6_shaped_calibrated_upsampled_joint_step_4096_columns(form, jd_option)
         jd_option("JD_FFT_BATCH", 0)
     elif form == "separate-kernels":
         jd_option("JD_SEP_NO_FUSION", "1")
-    _check_c6_shaped_step((64, 2048), 4, (33, 33), f"128 x 4096 flux grid x 4 ({form})")
+    _check_c6_shaped_step((96, 2048), 4, (33, 33), f"192 x 4096 flux grid x 4 ({form})")

@@ -192,7 +192,9 @@ def test_every_rank_of_a_sharded_joint_step_in_one_process(world_size):
     jd_add_rolled_bands -- everything but the transport), one rank after the other in this process on the bench's
     workload shape (8 observations, K = 128).  What the collectives would deliver, summed on the host in float64, must be
     the single-GPU step: gradient buffer and loss scalars.  (N = 8: one observation per rank, the driver's scaling run;
-    N = 3: uneven observation counts and band heights.)"""
+    N = 3: uneven observation counts and band heights.)  The workload is SURVEY section 8(d)'s mixed one (observations 6 and 7
+    carry 33x33 PSFs): the cost-aware placement gives their ranks fewer patch rows of the prior -- bands of different heights
+    in one all-gather -- and the sum must still be the single-GPU step."""
     from conftest import rel_linf
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
     from jolideco_amd.data import synthetic_gmm, synthetic_observations
@@ -211,19 +213,26 @@ def test_every_rank_of_a_sharded_joint_step_in_one_process(world_size):
         session.cfg._optimizer_step = lambda states, step: None  # keep the gradient buffer, no update
         session.epoch()
         torch.cuda.synchronize()
+        rows = session.band_plan[0]["rows"] if session.band_plan else None
         return (session.states[0].grad.double().cpu().numpy().copy(), session.scalars.double().cpu().numpy().copy(),
-                session.priors[0].last_shifts, len(session.local_idx))
+                session.priors[0].last_shifts, [g for g, _ in session.local_idx], rows)
 
-    grad_1, scalars_1, shifts_1, n_local = one_step(DistContext())
-    assert n_local == n_obs
-    grad_sum, scalars_sum, owned = np.zeros_like(grad_1), np.zeros_like(scalars_1), 0
+    grad_1, scalars_1, shifts_1, local, _ = one_step(DistContext())
+    assert local == list(range(n_obs))
+    grad_sum, scalars_sum, owned, band_rows = np.zeros_like(grad_1), np.zeros_like(scalars_1), [], []
     for rank in range(world_size):
-        grad_r, scalars_r, shifts_r, n_local = one_step(DistContext(rank=rank, world_size=world_size, dry_run=True))
+        grad_r, scalars_r, shifts_r, local, rows = one_step(DistContext(rank=rank, world_size=world_size, dry_run=True))
         assert shifts_r == shifts_1  # identically seeded generators: every rank rolls the image the same way
         grad_sum += grad_r
         scalars_sum += scalars_r
-        owned += n_local
-    assert owned == n_obs
+        owned += local
+        band_rows.append(rows)
+    assert sorted(owned) == list(range(n_obs))
+    # the bands tile the 81 patch rows; with one observation per rank the two ranks of the 33x33 PSFs take fewer of them
+    assert band_rows[0][0] == 0 and band_rows[-1][1] == 81 and all(a[1] == b[0] for a, b in zip(band_rows[:-1], band_rows[1:]))
+    if world_size == 8:
+        heights = [b - a for a, b in band_rows]
+        assert sorted(heights)[1] < sorted(heights)[2] and sum(heights) == 81
     err = rel_linf(grad_sum, grad_1)
     print(f"{world_size} emulated ranks: gradient rel Linf {err:.2e}, scalars", np.abs(scalars_sum / scalars_1 - 1).max())
     assert err < 2e-6

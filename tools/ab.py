@@ -24,7 +24,13 @@ for v in variants:
     parsed.append((name, env))
 all_keys = sorted({k for _, e in parsed for k in e})
 dev = torch.device("cuda:0")
-session = bench.build_session(cfg, dev)
+if cfg == "c6":  # calibrations + up-sampling x2 + general 65x65 PSFs (bench.build_session_c6)
+    session = bench.build_session_c6(dev)
+elif cfg.endswith("fft"):  # e.g. c3fft: the configuration through the FFT path
+    os.environ["JOLIDECO_CONV_METHOD"] = "fft"
+    session = bench.build_session(cfg[:-3], dev)
+else:
+    session = bench.build_session(cfg, dev)
 for _ in range(10):
     session.epoch()
 torch.cuda.synchronize()

@@ -5,6 +5,7 @@ R=$1; CFG=$2; shift 2
 for r in $(seq 1 $R); do
   for lib in "$@"; do
     if [ "$lib" = "default" ]; then unset JOLIDECO_HIP_LIBRARY; else export JOLIDECO_HIP_LIBRARY=jolideco_amd/libjolideco_hip_$lib.so; fi
-    python tools/ab.py $CFG 1 40 -- $lib: 2>&1 | grep "step"
+    python tools/ab.py $CFG 1 ${STEPS:-40} -- $lib: > /tmp/ab_one.log 2>&1 || { echo "$lib FAILED:"; tail -n 5 /tmp/ab_one.log; }
+    grep " step " /tmp/ab_one.log || true
   done
 done
