@@ -53,6 +53,7 @@ import torch  # noqa: E402
 
 CONFIGS = {
     # name: (H, W, n_obs, K)
+    "c1": (128, 128, 1, 0),  # BASELINE configs[0]: point source, Gaussian PSF, uniform prior, the reference's own loop (sequential)
     "c2": (1024, 1024, 1, 128),
     "c3": (2048, 2048, 8, 128),
     "c4": (4096, 4096, 1, 128),
@@ -72,6 +73,18 @@ def build_session(cfg_name, device, seed=0, dist=None, fit_mode="joint"):
     from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
 
     H, W, n_obs, K = CONFIGS[cfg_name]
+    if cfg_name == "c1":
+        # 128^2, delta source of 1000 counts, PSF sigma 3 on 17x17, exposure 1, background 2,
+        # uniform prior, seed 428723, flux_init ~ gamma(30) (examples/first-steps.py:53), the reference's sequential loop
+        from jolideco_amd import UniformPrior
+        from jolideco_amd.data import point_source_gauss_psf
+
+        rs = np.random.RandomState(428723)
+        data = point_source_gauss_psf(shape=(H, W), shape_psf=(17, 17), sigma_psf=3, source_level=1000, random_state=rs)
+        data.pop("flux")
+        comp = SpatialFluxComponent.from_numpy(flux=rs.gamma(30, size=(H, W)), prior=UniformPrior())
+        deconvolver = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="sequential")
+        return deconvolver.session({"obs-0": data}, components=comp, dist=dist)
     datasets, _, flux_init = synthetic_observations(shape=(H, W), n_obs=n_obs, seed=seed)
     means, covs, weights = synthetic_gmm(K, D, seed=0)
     gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=STRIDE))
@@ -196,6 +209,80 @@ def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), 
     return out
 
 
+def e0102_run(device, n_epochs=250, shape=(256, 256), n_obs=24, psf_shape=(128, 128), K=128):
+    """Time-to-solution of the fit the reference publishes a runtime for (examples/chandra-e0102-filament.py:91-93,178-222:
+    24 Chandra observations of one field, 128x128 MARX PSFs, ``upsampling_factor=2``, one `NPredCalibration` per
+    observation, GMM patch prior, ``n_epochs=250`` in the reference's own SEQUENTIAL mode -- "takes about 30 min on an M1
+    cpu"), end to end through `MAPDeconvolver.run()`: session set-up, 250 epochs x 24 optimizer steps (each with the full
+    prior) + the trace evaluation of every epoch, the trace read back at the end.  The tutorial's counts grid is not in the
+    reference tree: ASSUMED 256 x 256 (flux grid 512 x 512); synthetic counts, synthetic general PSFs and a synthetic
+    K = 128 mixture of the same shapes."""
+    from jolideco_amd import GMMPatchPrior, MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent
+    from jolideco_amd.data import instrument_observations, synthetic_gmm
+    from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureModelMeta
+
+    datasets, _, flux_init, cal = instrument_observations(shape=shape, n_obs=n_obs, seed=0, psf_shape=psf_shape)
+    means, covs, weights = synthetic_gmm(K, D, seed=0)
+
+    def build():
+        gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=STRIDE))
+        comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm), upsampling_factor=2)
+        calibrations = NPredCalibrations()
+        for name, (sx, sy, norm) in cal.items():
+            calibrations[name] = NPredCalibration(shift_x=sx, shift_y=sy, background_norm=norm)
+        return comp, calibrations
+
+    # a short run first: library load, kernel attributes, allocator warm-up (the timed run still builds its own session)
+    comp, calibrations = build()
+    MAPDeconvolver(n_epochs=2, display_progress=False, device=device, fit_mode="sequential").run(
+        datasets, components=comp, calibrations=calibrations)
+    torch.cuda.synchronize(device)
+    comp, calibrations = build()
+    deco = MAPDeconvolver(n_epochs=n_epochs, display_progress=False, device=device, fit_mode="sequential")
+    t0 = time.perf_counter()
+    result = deco.run(datasets, components=comp, calibrations=calibrations)
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    totals = np.asarray(result.trace_loss["total"], dtype=np.float64)
+    if not np.all(np.isfinite(totals)) or not np.all(np.isfinite(result.flux_total)):
+        raise SystemExit("e0102: non-finite trace or flux")
+    # the epochs alone (no set-up), eagerly enqueued against replayed: a session of the same fit
+    comp, calibrations = build()
+    session = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="sequential").session(
+        datasets, components=comp, calibrations=calibrations)
+    for _ in range(6):
+        session.epoch()
+    torch.cuda.synchronize(device)
+    gc.collect()
+    gc.disable()
+    try:
+        n = 30
+        t0 = time.perf_counter()
+        for _ in range(n):
+            session.epoch()
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize(device)
+        t_epoch = (time.perf_counter() - t0) / n
+    finally:
+        gc.enable()
+    steps = n_epochs * n_obs
+    return {
+        "metric": "time to solution, reference example chandra-e0102-filament (sequential MAP fit)", "unit": "s", "value": wall,
+        "higher_is_better": False, "n_gpus": 1, "dtype": "f32", "data": "synthetic", "scaling": "strong", "vs_baseline": None,
+        "steps": steps, "warmup": 0, "ms_per_step": 1e3 * wall / steps, "epochs": n_epochs,
+        "config": {"workload": f"e0102: {n_obs} observations, counts grid {shape[0]}x{shape[1]} (ASSUMED: the tutorial's size is not in "
+                               f"the reference tree), {psf_shape[0]}x{psf_shape[1]} general PSFs, upsampling_factor 2 (flux grid "
+                               f"{2 * shape[0]}x{2 * shape[1]}), one NPredCalibration per observation, GMM patch prior K={K}, "
+                               f"fit_mode sequential, {n_epochs} epochs = {steps} optimizer steps + {n_epochs} trace evaluations, "
+                               "MAPDeconvolver.run() end to end"},
+        "reference_runtime": "about 30 min on an M1 cpu (examples/chandra-e0102-filament.py:216-222; real data, other hardware: "
+                             "quoted for scale, not a measured baseline)",
+        "epoch_ms": 1e3 * t_epoch, "host_enqueue_ms_per_step": 1e3 * t_enq / (n * n_obs),
+        "epochs_replayed_from_graphs": bool(session._graphs),
+        "check": {"total_first": float(totals[0]), "total_last": float(totals[-1]), "decreasing": bool(totals[-1] < totals[0])},
+    }
+
+
 PMC_TRAFFIC_FILES = ("profiles/r04/pmc_hbm_traffic.csv", "profiles/r03/pmc_hbm_traffic.csv", "profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
 _TRAFFIC_USED = {}  # kernel -> file its traffic figure came from
 
@@ -265,6 +352,27 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def cpu_baseline_c1(n_epochs=200):
+    """BASELINE configs[0] is the reference's own CPU-runnable case: the oracle's sequential loop on the full workload."""
+    from jolideco_amd.data import point_source_gauss_psf
+    from oracle import cpu_ref
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    rs = np.random.RandomState(428723)
+    data = point_source_gauss_psf(shape=(128, 128), shape_psf=(17, 17), sigma_psf=3, source_level=1000, random_state=rs)
+    data.pop("flux")
+    flux_init = rs.gamma(30, size=(128, 128))
+    cpu_ref.map_fit_sequential({"obs-0": data}, {"flux": flux_init}, {"flux": cpu_ref.UniformPriorRef()}, n_epochs=5)  # warm-up
+    t0 = time.perf_counter()
+    cpu_ref.map_fit_sequential({"obs-0": data}, {"flux": flux_init}, {"flux": cpu_ref.UniformPriorRef()}, n_epochs=n_epochs)
+    dt = (time.perf_counter() - t0) / n_epochs
+    return {"value": 1.0 / dt, "unit": "iters/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/cpu_ref.py map_fit_sequential (autograd, torch {torch.__version__} CPU, {cores} threads), the full "
+                      f"128x128 workload, {n_epochs} epochs (1 step + 1 trace evaluation each): {1e3 * dt:.2f} ms per epoch",
+            "sample_seconds_per_step": dt}
+
+
 def cpu_baseline(cfg_name, sample_edge=1024, max_steps=10, budget_s=15.0):
     """Time the CPU oracle (the PyTorch-CPU restatement of the reference's joint step) on a
     `sample_edge`^2 crop of the same workload (same number of observations, same PSFs, same GMM)
@@ -272,6 +380,8 @@ def cpu_baseline(cfg_name, sample_edge=1024, max_steps=10, budget_s=15.0):
     from jolideco_amd.data import synthetic_gmm, synthetic_observations
     from oracle import cpu_ref
 
+    if cfg_name == "c1":
+        return cpu_baseline_c1()
     H, W, n_obs, K = CONFIGS[cfg_name]
     cores = host_cores()
     torch.set_num_threads(cores)
@@ -395,7 +505,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--settle-seconds", type=float, default=SETTLE_SECONDS,
                     help="steps run for at least this long between the warm-up and the timed regions (0: none)")
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c6"])
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c6", "e0102"])
+    ap.add_argument("--epochs", type=int, default=250, help="--config e0102: epochs of the sequential fit")
     ap.add_argument("--no-c6", action="store_true", help="skip the c6 side run (calibrations + up-sampling + general 65x65 PSFs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-general-psf", action="store_true",
@@ -427,6 +538,12 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    if args.config == "e0102":
+        if world != 1:
+            raise SystemExit("--config e0102 is a single-GPU run (sequential mode: replicas only)")
+        log("e0102: time to solution of the reference's Chandra example shape")
+        print(json.dumps(e0102_run(device, n_epochs=args.epochs)))
+        return
     if args.config == "c6":
         if world != 1:
             raise SystemExit("--config c6 is a single-GPU side run")
@@ -437,6 +554,8 @@ def main():
         print(json.dumps(out))
         return
     H, W, n_obs, K = CONFIGS[args.config]
+    if args.config == "c1":
+        args.no_general_psf = True  # (the side runs are variants of the joint GMM fits)
     log(f"building {args.config}: {H}x{W}, {n_obs} obs, K={K} on {device}")
     fake = None
     if args.shard_of > 1:
@@ -627,6 +746,8 @@ def main():
         # region, MAX over the ranks.  A step cannot be faster than this: where it approaches ms_per_step the run is
         # host bound (tools/hosttime.py's method)
         "host_enqueue_ms_per_step": host_enqueue_ms,
+        # the timed steps were replayed from captured hipGraphs (device-resident step scalars, jolideco_amd/core.py)
+        "epochs_replayed_from_graphs": bool(getattr(session, "_graphs", None)),
         "repeats": len(times), "timing": "median of `repeats` regions of `steps` steps, each bracketed by barrier + synchronize",
         "settle": settled,
         "clock_mhz": clock_mhz,
@@ -637,8 +758,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.config}: {H}x{W}, {n_obs} observations (Gaussian PSFs sigma = 1.5 + 0.25 i on {psf_sizes}, "
-                        f"varying exposure/background), GMM patch prior 8x8 stride 4 K={K}, joint fit, Adam lr 0.1",
+            "workload": ("c1: 128x128, one point-source observation (1000 counts at the centre, Gaussian PSF sigma 3 on 17x17, "
+                         "exposure 1, background 2), uniform prior, the reference's sequential loop (one step + one trace "
+                         "evaluation per epoch), Adam lr 0.1" if args.config == "c1" else
+                         f"{args.config}: {H}x{W}, {n_obs} observations (Gaussian PSFs sigma = 1.5 + 0.25 i on {psf_sizes}, "
+                         f"varying exposure/background), GMM patch prior 8x8 stride 4 K={K}, joint fit, Adam lr 0.1"),
             "psf_shapes": psf_shapes,
             "global_observations": n_obs,
             "sharding": (f"observations over {world} rank(s) by estimated cost (longest processing time first), prior by patch "

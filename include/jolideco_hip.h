@@ -211,9 +211,9 @@ int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* plan, int n_comp, const fl
  * `for dataset: jd_npred_poisson_calibrated_fwd_bwd(..., accumulate = dataset > 0)` -- same results, bit for bit.  On a
  * plan of the native FFT convolution with up-sampling 2 or 4 every launch covers all datasets: rows (with the dataset's
  * shift), columns, the pooled Poisson launch, the adjoint's column pass, rows^-1 + adjoint epilogue into one image per
- * dataset, a transposed shift that adds the datasets up in dataset order, and the finalize of the shift gradients (flux
- * grids up to 2048 rows: beyond, a dataset's own launches already run in several rounds of blocks and the per-dataset
- * calls do as well; option JD_FFT_BATCH=2 batches regardless).  Every other case runs the per-dataset calls.
+ * dataset, a transposed shift that adds the datasets up in dataset order, and the finalize of the shift gradients (at
+ * every size since round 5; option JD_FFT_BATCH=0 runs the per-dataset calls, 3 / 4 the intermediate forms measured in
+ * csrc/fftconv.hip).  Every other case runs the per-dataset calls.
  *   exposure, khat, background, counts, loss_out : host arrays of n_datasets device pointers
  *   shift_xy, log_background_norm, grad_shift_xy, grad_log_background_norm : NULL, or host arrays of n_datasets device
  *                                                  pointers with NULL entries where a dataset has none (see above) */
@@ -269,11 +269,16 @@ int jd_gmm_is_triangular(const jd_gmm* gmm);
  *   grad_flux_accum += grad_coef * d(sum_{patches in shard} v_patch)/d flux   (NULL: forward only)
  *   argmax_out      optional int32 per patch (global patch index order), max mode only
  * Only patch rows [patch_row_begin, patch_row_end) are evaluated (multi-GPU shard of the prior;
- * pass 0 and -1 for all rows). */
+ * pass 0 and -1 for all rows).
+ * DEVICE-RESIDENT STEP SCALARS (new: what lets a whole epoch be captured in a hipGraph and replayed): with
+ * shift_dev != NULL the kernels read the roll from device memory -- shift_dev[0] = shift_y in [0, H), shift_dev[1] =
+ * shift_x in [0, W), the residues the host would have passed -- and ignore the two by-value arguments; every launch
+ * argument of the pass is then the same from step to step (the caller uploads the shifts of the coming steps with one
+ * small copy, jolideco_amd/core.py StepScalars).  Same results as the by-value form, bit for bit. */
 int jd_gmm_prior_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int stride, int shift_y,
                          int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                          float value_scale, float* value_out, int accumulate_value, float grad_coef,
-                         float* grad_flux_accum, int32_t* argmax_out, void* stream);
+                         float* grad_flux_accum, int32_t* argmax_out, const int* shift_dev, void* stream);
 
 /* The same evaluation with the OPTIMIZER STEP of the component in the epilogue of its last kernel (new: one pass over
  * the gradient image and one launch less per step; jolideco/core.py:229 is the step it folds in).  Where
@@ -293,10 +298,12 @@ typedef struct {
   float step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps; /* as jd_adam_step */
   float lr;               /* sgd */
   int use_log_flux, sgd;
+  const float* bias_dev;  /* nullable, device [2] = {step_size, bias2_sqrt}: read by the kernel instead of the two members
+                             above (the step count of a captured graph's optimizer step lives in device memory) */
 } jd_step;
 int jd_gmm_prior_fwd_bwd_step(jd_gmm* gmm, const float* flux, int H, int W, int stride, int shift_y, int shift_x,
                               int marginalize, float value_scale, float* value_out, int accumulate_value,
-                              float grad_coef, const jd_step* step, void* stream);
+                              float grad_coef, const jd_step* step, const int* shift_dev, void* stream);
 
 /* Diagnostics of the screened arg-max path, read without synchronisation from host-mapped memory the last block of a
  * pass writes: out[0..4] = {generation of the last finished pass, it fell back to the dense fp32 kernel (0 / 1), bucket
@@ -349,18 +356,22 @@ int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_
  * buffer so the caller can keep the pre-step flux for the loss trace, core.py:247) and zeroes
  * grad_flux when zero_grad != 0.  step_size = lr / (1 - beta1^t), bias2_sqrt = sqrt(1 - beta2^t),
  * one_minus_beta1 = 1 - beta1 and one_minus_beta2 = 1 - beta2 are computed by the caller in double
- * precision and rounded once, as torch does (fp32(1 - 0.999) != 1 - fp32(0.999)). */
+ * precision and rounded once, as torch does (fp32(1 - 0.999) != 1 - fp32(0.999)).
+ * bias_dev != NULL: device [2] = {step_size, bias2_sqrt}, read by the kernel instead of the two by-value arguments (see
+ * jd_gmm_prior_fwd_bwd: device-resident step scalars). */
 int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux, float* exp_avg,
                  float* exp_avg_sq, const float* mask, size_t n, float step_size, float beta1,
                  float beta2, float one_minus_beta1, float one_minus_beta2, float bias2_sqrt, float eps,
-                 int zero_grad, int use_log_flux, void* stream);
+                 int zero_grad, int use_log_flux, const float* bias_dev, void* stream);
 /* jd_adam_step with use_log_flux = 0 for MANY small parameter vectors in ONE launch (the calibration parameters of the
  * datasets of a joint step, jolideco/core.py:197-204,229): tensor i (sizes[i] floats) takes its own step_size[i] /
  * bias2_sqrt[i] (its own step count, as torch.optim.Adam keeps one per parameter).  Host arrays of n_tensors <= 64
- * entries.  Same bits as n_tensors calls of jd_adam_step. */
+ * entries.  Same bits as n_tensors calls of jd_adam_step.  bias_dev != NULL: device [2 n_tensors], {step_size,
+ * bias2_sqrt} of tensor i at [2 i], read by the kernel instead of the two host arrays (which may then be NULL). */
 int jd_adam_step_multi(int n_tensors, float* const* theta, const float* const* grad, float* const* exp_avg,
                        float* const* exp_avg_sq, const int* sizes, const float* step_size, const float* bias2_sqrt,
-                       float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps, void* stream);
+                       float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps,
+                       const float* bias_dev, void* stream);
 /* plain SGD (core.py:41): theta -= lr * grad_flux * flux_in */
 int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
                 const float* mask, size_t n, float lr, int zero_grad, int use_log_flux, void* stream);

@@ -75,11 +75,12 @@ EXPORTS = {
     "jd_gmm_prior_fwd_bwd": (
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
-         c_float, c_void_p, c_void_p, c_void_p],
+         c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "jd_gmm_prior_fwd_bwd_step": (
         c_int,
-        [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p,
+         c_void_p],
     ),
     "jd_gmm_screen_stats": (c_int, [c_void_p, POINTER(c_int)]),
     "jd_gmm_prior_band_fwd_bwd": (
@@ -102,11 +103,11 @@ EXPORTS = {
     "jd_adam_step": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float,
-         c_float, c_float, c_float, c_float, c_int, c_int, c_void_p],
+         c_float, c_float, c_float, c_float, c_int, c_int, c_void_p, c_void_p],
     ),
     "jd_adam_step_multi": (
         c_int,
-        [c_int, fpp, fpp, fpp, fpp, POINTER(c_int), fp, fp, c_float, c_float, c_float, c_float, c_float, c_void_p],
+        [c_int, fpp, fpp, fpp, fpp, POINTER(c_int), fp, fp, c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
     ),
     "jd_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_int, c_int, c_void_p]),
     "jd_profile_enable": (c_int, [c_int]),
@@ -125,7 +126,7 @@ class Step(ctypes.Structure):
         ("exp_avg_sq", c_void_p), ("mask", c_void_p),
         ("step_size", c_float), ("beta1", c_float), ("beta2", c_float), ("one_minus_beta1", c_float),
         ("one_minus_beta2", c_float), ("bias2_sqrt", c_float), ("eps", c_float), ("lr", c_float),
-        ("use_log_flux", c_int), ("sgd", c_int),
+        ("use_log_flux", c_int), ("sgd", c_int), ("bias_dev", c_void_p),
     ]
 
 
@@ -157,10 +158,15 @@ def lib():
     return _lib
 
 
+OPTION_GENERATION = 0  # bumped by every set_option: captured epochs (core.FitSession) are valid for one generation
+
+
 def set_option(key, value=None):
     """Set a tuning / test switch of the library (`JD_*`, csrc/options.hip); None returns it to its default.  The library
     reads the environment only once, when it is loaded."""
+    global OPTION_GENERATION
     check(lib().jd_set_option(key.encode(), None if value is None else str(value).encode()))
+    OPTION_GENERATION += 1
 
 
 def get_option(key):
@@ -196,9 +202,19 @@ def clock_probe(milliseconds=2.0, device=None):
     return mhz.value
 
 
+_PROFILE_ACTIVE = False
+
+
+def profile_active():
+    """True between `profile_enable` and `profile_read`: launches are bracketed by event pairs (no graph capture / replay)."""
+    return _PROFILE_ACTIVE
+
+
 def profile_enable(capacity=8192):
     """Start timing the library's kernels with hipEvent pairs on their launch stream."""
+    global _PROFILE_ACTIVE
     check(lib().jd_profile_enable(int(capacity)))
+    _PROFILE_ACTIVE = True
 
 
 def profile_pause(paused=True):
@@ -217,6 +233,8 @@ def profile_read():
         check(status)
         out[name] = (total.value, count.value)
     lib().jd_profile_disable()
+    global _PROFILE_ACTIVE
+    _PROFILE_ACTIVE = False
     return out
 
 

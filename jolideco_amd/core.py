@@ -177,9 +177,10 @@ class MAPDeconvolver:
         return "\n".join(lines)
 
     # ------------------------------------------------------------------------------------------
-    def _step_args(self, st, step):
+    def _step_args(self, st, step, bias_dev=None):
         """`_hip.Step` of component state ``st`` for optimizer step number ``step``: what a prior needs to apply the
-        update in the epilogue of its own last kernel (`device_fwd_bwd_step`)."""
+        update in the epilogue of its own last kernel (`device_fwd_bwd_step`).  ``bias_dev``: device tensor [step_size,
+        bias2_sqrt] the kernel reads instead of the by-value terms (planned epochs)."""
         lr = self.optimizer_kwargs["lr"]
         args = _hip.Step()
         args.theta, args.flux_in, args.flux_out = st.theta.data_ptr(), st.flux_cur.data_ptr(), st.flux[1 - st.cur].data_ptr()
@@ -193,6 +194,7 @@ class MAPDeconvolver:
             args.eps = self.optimizer_kwargs.get("eps", 1e-8)
             args.exp_avg, args.exp_avg_sq = st.exp_avg.data_ptr(), st.exp_avg_sq.data_ptr()
             args.sgd = 0
+            args.bias_dev = None if bias_dev is None else bias_dev.data_ptr()
         else:
             args.lr, args.sgd = lr, 1
         return args
@@ -220,7 +222,7 @@ class MAPDeconvolver:
                         ptr(st.theta), ptr(st.flux_cur), ptr(st.flux[1 - st.cur]), ptr(st.grad), ptr(st.exp_avg),
                         ptr(st.exp_avg_sq), ptr(st.mask), n, step_size, beta1, beta2, 1 - beta1, 1 - beta2, bias2_sqrt, eps,
                         0,  # no zeroing pass: the first gradient term of every step OVERWRITES the buffer (FitSession.epoch)
-                        int(st.use_log_flux), stream,
+                        int(st.use_log_flux), ptr(getattr(st, "bias_dev", None)), stream,
                     )
                 )
             else:
@@ -368,9 +370,11 @@ class MAPDeconvolver:
             total_loss.poisson_loss.names_all = local
 
 
-def _adam_step_many(cfg, items, cache):
+def _adam_step_many(cfg, items, cache, bias_dev=None):
     """ONE launch for the Adam steps of the small parameter tensors `items` = [(parameter, state)] that have a gradient
-    (jd_adam_step_multi: each tensor with its own step count); `cache`: pointer arrays by tensor set."""
+    (jd_adam_step_multi: each tensor with its own step count); `cache`: pointer arrays by tensor set.
+    ``bias_dev`` (planned epochs, `FitSession._epoch_planned`): device tensor of 2 floats per item holding the bias terms
+    of this step -- every item steps, and the kernel reads its terms from there."""
     import ctypes
 
     lr = cfg.optimizer_kwargs["lr"]
@@ -378,6 +382,8 @@ def _adam_step_many(cfg, items, cache):
     todo = []
     for p, st in items:
         if p.grad is None:
+            if bias_dev is not None:
+                raise RuntimeError("planned epoch: a calibration parameter without a gradient")
             continue
         st["step"] += 1
         todo.append((p, st, adam_bias_terms(st["step"], lr, beta1, beta2)))
@@ -398,7 +404,8 @@ def _adam_step_many(cfg, items, cache):
             )
         check(lib.jd_adam_step_multi(
             n, *arrays, (ctypes.c_float * n)(*[b[0] for _, _, b in part]), (ctypes.c_float * n)(*[b[1] for _, _, b in part]),
-            beta1, beta2, 1 - beta1, 1 - beta2, cfg.optimizer_kwargs.get("eps", 1e-8), stream_ptr(part[0][0].device),
+            beta1, beta2, 1 - beta1, 1 - beta2, cfg.optimizer_kwargs.get("eps", 1e-8),
+            None if bias_dev is None else ptr(bias_dev[2 * start : 2 * (start + n)]), stream_ptr(part[0][0].device),
         ))
 
 
@@ -423,10 +430,10 @@ class _CalibrationStepper:
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def step(self):
+    def step(self, bias_dev=None):
         lib, cfg = _hip.lib(), self.cfg
         if cfg.optimizer_type == "adam":  # both parameters of the dataset in one launch
-            _adam_step_many(cfg, list(zip(self.params, self.state)), self.__dict__.setdefault("_arrays", {}))
+            _adam_step_many(cfg, list(zip(self.params, self.state)), self.__dict__.setdefault("_arrays", {}), bias_dev)
             return
         lr = cfg.optimizer_kwargs["lr"]
         for p, st in zip(self.params, self.state):
@@ -435,6 +442,52 @@ class _CalibrationStepper:
             st["step"] += 1
             data, n, stream = p.data, p.numel(), stream_ptr(p.device)
             check(lib.jd_sgd_step(ptr(data), ptr(data), ptr(data), ptr(p.grad), None, n, lr, 0, 0, stream))
+
+
+class StepScalars:
+    """The per-step scalars of an epoch in DEVICE memory: the cycle-spin shifts of every prior evaluation and the Adam bias
+    terms of every optimizer step (include/jolideco_hip.h: device-resident step scalars).  The launch arguments of an
+    epoch are then the same from epoch to epoch -- the values travel in ONE small host-to-device copy per epoch, enqueued
+    in front of the epoch's launches -- which is what lets `FitSession` capture an epoch in a hipGraph and replay it.
+
+    One int32 device buffer [shifts: 2 per slot | bias terms: 2 floats per slot, as bit patterns]; a ring of pinned host
+    rows so that a row is not overwritten before its copy has run (an event per row, waited for only when the ring
+    wraps around a copy that has not finished)."""
+
+    RING = 64
+
+    def __init__(self, device, n_shift, n_bias):
+        self.n_shift, self.n_bias = n_shift, n_bias
+        n = max(2 * (n_shift + n_bias), 4)
+        self.dev = torch.zeros(n, dtype=torch.int32, device=device)
+        self.dev_f = self.dev.view(torch.float32)
+        self.host = torch.zeros((self.RING, n), dtype=torch.int32).pin_memory()
+        self.host_i = self.host.numpy()
+        self.host_f = self.host.view(torch.float32).numpy()
+        self.events = [None] * self.RING
+        self.slot = 0
+        self.shift_slots = [self.dev[2 * k : 2 * k + 2] for k in range(n_shift)]
+        self.bias_slots = [self.dev_f[2 * (n_shift + k) : 2 * (n_shift + k) + 2] for k in range(n_bias)]
+
+    def bias_range(self, k, n):
+        """Device view of the bias slots k .. k + n - 1 (2 n floats)."""
+        return self.dev_f[2 * (self.n_shift + k) : 2 * (self.n_shift + k + n)]
+
+    def upload(self, shifts, biases):
+        """shifts: [(y, x)] residues per slot; biases: [(step_size, bias2_sqrt)] per slot -> device (asynchronous)."""
+        slot = self.slot
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        if shifts:
+            self.host_i[slot, : 2 * len(shifts)] = np.asarray(shifts, dtype=np.int32).reshape(-1)
+        if biases:
+            base = 2 * self.n_shift
+            self.host_f[slot, base : base + 2 * len(biases)] = np.asarray(biases, dtype=np.float32).reshape(-1)
+        self.dev.copy_(self.host[slot], non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self.events[slot] = event
+        self.slot = (slot + 1) % self.RING
 
 
 class FitSession:
@@ -530,7 +583,6 @@ class FitSession:
         # comm_events = []: a sharded step brackets its collectives with event pairs on the compute stream (bench.py reads
         # them after an untimed phase: how long the stream waited for the all-reduce it overlapped, and for the all-gather)
         self.comm_events = None
-        import os
 
         # The optimizer step inside the last kernel of a component's gradient (the prior's gather kernel, or the band sum of
         # a sharded prior): decided ONCE here -- the deconvolver's own `_optimizer_step` (a subclass or an instance that
@@ -554,6 +606,15 @@ class FitSession:
         )
         # sequential mode: the per-epoch trace evaluates every dataset on the same stale flux -- one batched launch
         self.batch_trace = (not self.joint) and batchable
+        # Planned epochs (single process, the session's own optimizer step): the per-step scalars live in device memory
+        # (`StepScalars`), so an epoch's launch arguments never change -- and after `GRAPH_WARMUP` epochs the epoch is
+        # captured in a hipGraph per flux-buffer parity and replayed (JOLIDECO_GRAPH=0: planned epochs without capture;
+        # JOLIDECO_STEP_SCALARS=host: the by-value form of rounds 1-4 throughout)
+        self.use_graph = os.environ.get("JOLIDECO_GRAPH", "1") != "0" and getattr(deconvolver, "use_graph", True)
+        self.step_scalars = None
+        self._graphs = {}
+        self._epochs_done = 0
+        self._planned_ok = os.environ.get("JOLIDECO_STEP_SCALARS", "device") != "host"
 
     def gather_calibrations(self):
         """Sharded joint fit: every rank receives the current calibration parameters of the datasets the other ranks
@@ -711,7 +772,231 @@ class FitSession:
             counts[name] = counts.get(name, 0) + 1
         return {name: sums[name] / counts[name] for name in sums}
 
+    # ---- planned epochs: device-resident step scalars, hipGraph capture -------------------------------------------
+    GRAPH_WARMUP = 3  # eager epochs before an epoch is captured (lazy allocations, table uploads, kernel attributes)
+
+    def reset_graphs(self):
+        """Forget the captured epochs (a library option that changes what an epoch launches was set: `_hip.set_option`
+        bumps `_hip.OPTION_GENERATION`, and `epoch` compares)."""
+        self._graphs = {}
+        self._epochs_done = 0
+        self._option_generation = _hip.OPTION_GENERATION
+
+    def _planned_capable(self):
+        """Planned epochs apply: one process, the session's own optimizer step (a hook sees every gradient through the
+        by-value path), no event brackets around collectives, no kernel timers."""
+        cfg = self.cfg
+        own = getattr(type(cfg), "_optimizer_step", None) is MAPDeconvolver._optimizer_step and "_optimizer_step" not in vars(cfg)
+        return (self._planned_ok and own and not self.dist.sharded and self.comm_events is None and not self.n_val
+                and cfg.optimizer_type in ("adam", "sgd"))
+
+    def _plan_slots(self):
+        """How many shift / bias slots an epoch needs, and the calibration steppers of every optimizer step."""
+        drawing = [ci for ci, prior in enumerate(self.priors) if hasattr(prior, "draw_shifts")]
+        n_local = len(self.local_idx)
+        if self.joint:
+            n_shift = len(drawing)
+            cal_groups = [[self.cal_optimizers[li] for _, li in self.local_idx if self.cal_optimizers[li] is not None]]
+            n_flux = 1
+        else:
+            n_shift = len(drawing) * (n_local + 1)  # every step + the trace
+            cal_groups = [[self.cal_optimizers[li]] if self.cal_optimizers[li] is not None else [] for _, li in self.local_idx]
+            n_flux = n_local
+        n_cal = sum(len(opt.params) for group in cal_groups for opt in group)
+        return drawing, n_shift, n_flux, cal_groups, n_cal
+
+    def _plan_epoch(self):
+        """Host side of an epoch: draw the cycle-spin shifts of every prior evaluation IN THE ORDER the evaluations run
+        (the generators advance exactly as in the by-value path), compute the bias terms of every optimizer step, and
+        send both to the device.  Returns the plan the launches read: DeviceShifts per (step, prior), bias slots."""
+        from .ops import DeviceShifts
+
+        cfg = self.cfg
+        drawing, n_shift, n_flux, cal_groups, n_cal = self._plan_slots()
+        if self.step_scalars is None:
+            self.step_scalars = StepScalars(self.comm.device, n_shift, n_flux + n_cal)
+        sc = self.step_scalars
+        lr = cfg.optimizer_kwargs["lr"]
+        beta1, beta2 = cfg.optimizer_kwargs.get("betas", (0.9, 0.999))
+        adam = cfg.optimizer_type == "adam"
+        n_eval = 1 if self.joint else len(self.local_idx) + 1
+        shifts_host, shifts = [], []
+        for _ in range(n_eval):
+            row = {}
+            for ci in drawing:
+                prior, (H, W) = self.priors[ci], self.states[ci].shape
+                drawn = prior.draw_shifts()
+                if drawn is None:
+                    row[ci] = None
+                    shifts_host.append((0, 0))
+                else:
+                    row[ci] = DeviceShifts(sc.shift_slots[len(shifts_host)], drawn)
+                    shifts_host.append((drawn[0] % H, drawn[1] % W))
+            shifts.append(row)
+        biases = [adam_bias_terms(self.step + j + 1, lr, beta1, beta2) if adam else (0.0, 1.0) for j in range(n_flux)]
+        flux_bias = [sc.bias_slots[j] if adam else None for j in range(n_flux)]
+        cal_bias, k = [], n_flux
+        for group in cal_groups:
+            n = sum(len(opt.params) for opt in group)
+            for opt in group:
+                for st in opt.state:
+                    biases.append(adam_bias_terms(st["step"] + 1, lr, beta1, beta2) if adam else (0.0, 1.0))
+            cal_bias.append(sc.bias_range(k, n) if (adam and n) else None)
+            k += n
+        sc.upload(shifts_host, biases)
+        return {"shifts": shifts, "flux_bias": flux_bias, "cal_bias": cal_bias, "cal_groups": cal_groups, "n_steps": n_flux}
+
+    def _commit_replay(self, plan):
+        """The host state an eagerly enqueued epoch leaves behind, after a REPLAYED one: step counts, flux buffer parity."""
+        self.step += plan["n_steps"]
+        if plan["n_steps"] % 2:
+            for st in self.states:
+                st.cur = 1 - st.cur
+        for group in plan["cal_groups"]:
+            for opt in group:
+                for st in opt.state:
+                    st["step"] += 1
+
+    def _epoch_planned(self):
+        plan = self._plan_epoch()
+        parity = tuple(st.cur for st in self.states)
+        graph = self._graphs.get(parity) if self.use_graph else None
+        if graph is not None:
+            graph.replay()
+            self._commit_replay(plan)
+        elif self.use_graph and self._epochs_done >= self.GRAPH_WARMUP and not _hip.profile_active():
+            # capture this epoch's launches (nothing runs during the capture), then run them
+            snapshot = (self.step, [st.cur for st in self.states],
+                        [[s["step"] for s in opt.state] for group in plan["cal_groups"] for opt in group])
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    self._enqueue_epoch(plan)
+            except Exception:
+                # (something in this fit cannot be captured: planned epochs without graphs from here on; the host state the
+                # aborted enqueue changed is put back and the epoch runs eagerly)
+                log.warning("hipGraph capture of an epoch failed; continuing without graphs", exc_info=True)
+                self.use_graph = False
+                self.step = snapshot[0]
+                for st, cur in zip(self.states, snapshot[1]):
+                    st.cur = cur
+                steps = iter(snapshot[2])
+                for group in plan["cal_groups"]:
+                    for opt in group:
+                        for s, value in zip(opt.state, next(steps)):
+                            s["step"] = value
+                torch.cuda.synchronize()
+                self._enqueue_epoch(plan)
+            else:
+                self._graphs[parity] = graph
+                graph.replay()
+        else:
+            self._enqueue_epoch(plan)
+        self._epochs_done += 1
+
+    def _enqueue_epoch(self, plan):
+        """The launches of one epoch of a single-process fit, reading the step scalars of `plan` from device memory: the
+        body of `_epoch_by_value` without its sharded branches (same kernels, same order, same results bit for bit)."""
+        cfg, states, priors, total_loss = self.cfg, self.states, self.priors, self.total_loss
+        n_d, n_c = self.n_d, self.n_c
+        slot = self._slot
+        beta = -float(cfg.beta)
+
+        def flux_step(stepped, bias):
+            self.step += 1
+            for st in states:
+                st.bias_dev = bias
+            try:
+                self._apply_step(states, stepped)
+            finally:
+                for st in states:
+                    st.bias_dev = None
+
+        def cal_steps(group, bias):
+            if not group:
+                return
+            if cfg.optimizer_type != "adam":
+                for opt in group:
+                    opt.step()
+                return
+            items = [(p, st) for opt in group for p, st in zip(opt.params, opt.state)]
+            _adam_step_many(cfg, items, self.__dict__.setdefault("_cal_step_cache", {}), bias)
+
+        def priors_and_step(j, coef, shifts):
+            stepped = set()
+            for ci, (st, prior) in enumerate(zip(states, priors)):
+                kwargs = {"shifts": shifts[ci]} if ci in shifts else {}
+                if self._fuse_step(st, prior):
+                    prior.device_fwd_bwd_step(st.flux_cur, slot(n_d + ci), coef,
+                                              cfg._step_args(st, self.step + 1, plan["flux_bias"][j]), **kwargs)
+                    stepped.add(ci)
+                else:
+                    prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef, **kwargs)
+            flux_step(stepped, plan["flux_bias"][j])
+
+        if self.joint:
+            fluxes = [st.flux_cur for st in states]
+            grads = [st.grad for st in states]
+            first = True
+            if self.batch_joint:
+                total_loss.poisson_loss.fwd_bwd_batch(
+                    [li for _, li in self.local_idx], fluxes if n_c > 1 else fluxes[0],
+                    [slot(gslot) for gslot, _ in self.local_idx], grad=grads if n_c > 1 else grads[0], accumulate=False,
+                )
+                first = False
+            elif self.batch_joint_calibrated:
+                for _, li in self.local_idx:
+                    self._cal_zero_grad(li)
+                total_loss.poisson_loss.fwd_bwd_batch_calibrated(
+                    [li for _, li in self.local_idx], fluxes[0], [slot(gslot) for gslot, _ in self.local_idx], grad=grads[0],
+                    accumulate=False,
+                )
+                first = False
+            else:
+                for gslot, li in self.local_idx:
+                    self._cal_zero_grad(li)
+                    total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
+                    first = False
+            if first:
+                for g in grads:
+                    g.zero_()
+            priors_and_step(0, beta, plan["shifts"][0])
+            cal_steps(plan["cal_groups"][0], plan["cal_bias"][0])
+        else:
+            coef = beta / total_loss.prior_weight
+            for j, (gslot, li) in enumerate(self.local_idx):
+                fluxes = [st.flux_cur for st in states]
+                grads = [st.grad for st in states]
+                self._cal_zero_grad(li)
+                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
+                priors_and_step(j, coef, plan["shifts"][j])
+                cal_steps(plan["cal_groups"][j], plan["cal_bias"][j])
+            stale = [st.flux_trace for st in states]
+            if self.batch_trace:
+                total_loss.poisson_loss.fwd_bwd_batch(
+                    [li for _, li in self.local_idx], stale if n_c > 1 else stale[0],
+                    [slot(gslot) for gslot, _ in self.local_idx],
+                )
+            else:
+                for gslot, li in self.local_idx:
+                    total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
+            trace_shifts = plan["shifts"][-1]
+            for ci, (st, prior) in enumerate(zip(states, priors)):
+                kwargs = {"shifts": trace_shifts[ci]} if ci in trace_shifts else {}
+                prior.device_fwd_bwd(st.flux_trace, slot(n_d + ci), **kwargs)
+
     def epoch(self):
+        """One epoch of the fit, enqueued without any host synchronisation: planned (device-resident step scalars, replayed
+        from a captured hipGraph once warm) where `_planned_capable` holds, else the by-value form."""
+        if getattr(self, "_option_generation", None) != _hip.OPTION_GENERATION:
+            self.reset_graphs()
+        if self._planned_capable() and not _hip.profile_active():
+            return self._epoch_planned()
+        if self._graphs:
+            self.reset_graphs()
+        return self._epoch_by_value()
+
+    def _epoch_by_value(self):
         cfg, dist, states, priors, total_loss = self.cfg, self.dist, self.states, self.priors, self.total_loss
         n_d, n_c = self.n_d, self.n_c
         slot = self._slot

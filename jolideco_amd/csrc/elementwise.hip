@@ -434,6 +434,7 @@ __global__ __launch_bounds__(BLOCK) void poisson_nll_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(BLOCK) void adam_kernel(AdamArgs a) {
+  use_device_bias(a);
   const size_t stride = (size_t)gridDim.x * BLOCK * VEC;
   for (size_t i = ((size_t)blockIdx.x * BLOCK + threadIdx.x) * VEC; i < a.n; i += stride) {
     float th[VEC], f[VEC], gf[VEC], m[VEC], v[VEC], mk[VEC];
@@ -596,12 +597,13 @@ extern "C" int jd_flux_from_theta(const float* theta, const float* mask, float* 
 extern "C" int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
                             float* exp_avg, float* exp_avg_sq, const float* mask, size_t n, float step_size,
                             float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,
-                            float bias2_sqrt, float eps, int zero_grad, int use_log_flux, void* stream) {
+                            float bias2_sqrt, float eps, int zero_grad, int use_log_flux, const float* bias_dev,
+                            void* stream) {
   JD_REQUIRE(theta && flux_in && flux_out && grad_flux && exp_avg && exp_avg_sq && n > 0,
              "jd_adam_step: null argument or n == 0");
   AdamArgs a{theta, flux_in, flux_out, grad_flux, exp_avg, exp_avg_sq, mask, n,
              step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, 0.f, zero_grad, 0,
-             use_log_flux ? 0 : 1};
+             use_log_flux ? 0 : 1, bias_dev};
   return launch_adam(a, as_stream(stream));
 }
 
@@ -617,6 +619,7 @@ struct AdamMultiArgs {
   int size[ADAM_MULTI_MAX];
   float step_size[ADAM_MULTI_MAX], bias2_sqrt[ADAM_MULTI_MAX];
   float beta1, beta2, one_minus_beta1, one_minus_beta2, eps;
+  const float* bias_dev;  // nullable, device [2 n]: {step_size, bias2_sqrt} of tensor i at [2 i], read instead of the arrays above
 };
 
 __global__ __launch_bounds__(64) void adam_multi_kernel(AdamMultiArgs a) {
@@ -633,6 +636,7 @@ __global__ __launch_bounds__(64) void adam_multi_kernel(AdamMultiArgs a) {
       theta = a.theta[i], grad = a.grad[i], m = a.m[i], v = a.v[i], size = a.size[i];
       s.step_size = a.step_size[i], s.bias2_sqrt = a.bias2_sqrt[i];
     }
+  if (a.bias_dev) s.step_size = a.bias_dev[2 * blockIdx.x], s.bias2_sqrt = a.bias_dev[2 * blockIdx.x + 1];
   for (int j = threadIdx.x; j < size; j += 64) {
     float th = theta[j], mj = m[j], vj = v[j];
     adam_update(th, mj, vj, grad[j], s);
@@ -643,16 +647,18 @@ __global__ __launch_bounds__(64) void adam_multi_kernel(AdamMultiArgs a) {
 extern "C" int jd_adam_step_multi(int n_tensors, float* const* theta, const float* const* grad, float* const* exp_avg,
                                   float* const* exp_avg_sq, const int* sizes, const float* step_size,
                                   const float* bias2_sqrt, float beta1, float beta2, float one_minus_beta1,
-                                  float one_minus_beta2, float eps, void* stream) {
-  JD_REQUIRE(theta && grad && exp_avg && exp_avg_sq && sizes && step_size && bias2_sqrt, "jd_adam_step_multi: null argument");
+                                  float one_minus_beta2, float eps, const float* bias_dev, void* stream) {
+  JD_REQUIRE(theta && grad && exp_avg && exp_avg_sq && sizes && (bias_dev || (step_size && bias2_sqrt)),
+             "jd_adam_step_multi: null argument");
   JD_REQUIRE(n_tensors >= 1 && n_tensors <= ADAM_MULTI_MAX, "jd_adam_step_multi: n_tensors = %d not in [1, %d]", n_tensors,
              ADAM_MULTI_MAX);
   AdamMultiArgs a{};
   for (int i = 0; i < n_tensors; ++i) {
     JD_REQUIRE(theta[i] && grad[i] && exp_avg[i] && exp_avg_sq[i] && sizes[i] > 0, "jd_adam_step_multi: null tensor %d", i);
     a.theta[i] = theta[i], a.grad[i] = grad[i], a.m[i] = exp_avg[i], a.v[i] = exp_avg_sq[i], a.size[i] = sizes[i];
-    a.step_size[i] = step_size[i], a.bias2_sqrt[i] = bias2_sqrt[i];
+    if (!bias_dev) a.step_size[i] = step_size[i], a.bias2_sqrt[i] = bias2_sqrt[i];
   }
+  a.bias_dev = bias_dev;
   a.beta1 = beta1, a.beta2 = beta2, a.one_minus_beta1 = one_minus_beta1, a.one_minus_beta2 = one_minus_beta2, a.eps = eps;
   ProfScope prof(JD_KERNEL_ADAM, as_stream(stream));
   adam_multi_kernel<<<n_tensors, 64, 0, as_stream(stream)>>>(a);
@@ -664,7 +670,7 @@ extern "C" int jd_sgd_step(float* theta, const float* flux_in, float* flux_out, 
                            const float* mask, size_t n, float lr, int zero_grad, int use_log_flux, void* stream) {
   JD_REQUIRE(theta && flux_in && flux_out && grad_flux && n > 0, "jd_sgd_step: null argument or n == 0");
   AdamArgs a{theta, flux_in, flux_out, grad_flux, nullptr, nullptr, mask, n,
-             0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, lr, zero_grad, 1, use_log_flux ? 0 : 1};
+             0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, lr, zero_grad, 1, use_log_flux ? 0 : 1, nullptr};
   return launch_adam(a, as_stream(stream));
 }
 

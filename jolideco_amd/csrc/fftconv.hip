@@ -810,13 +810,18 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
     JD_REQUIRE(exposure[d] && khat[d] && background[d] && counts[d] && loss_out[d], "%s: null pointer for dataset %d", who, d);
   hipStream_t s = as_stream(stream);
   const bool any_cal = shift_xy || log_background_norm;
-  // Measured (tools/gpu/cb1024.py, 8 calibrated observations, up-sampling x2, batched against per-dataset calls): flux grid
-  // 512^2 204 against 499 us per step, 1024^2 330 against 590, 2048^2 855 against 1071; at 4096^2 (bench config c6), where a
-  // dataset's launches already run in several rounds of blocks, the two tie (5.5 ms).  So: batched up to 2048 rows
-  // (JD_FFT_BATCH=2: always).
+  // Measured, 8 calibrated observations, up-sampling x2, launches over all datasets against per-dataset calls
+  // (tools/gpu/cb1024.py): flux grid 512^2 204 against 499 us per step, 1024^2 330 against 590, 2048^2 855 against 1071.  At
+  // 4096^2 (bench config c6) the round-4 kernels tied; with the round-5 kernels (tools/ab.py c6, one process): launches over
+  // all datasets 4.33 ms per step, per-dataset calls 4.63, the FFT launches dataset by dataset on one set of work arrays with
+  // only the tail over all datasets 4.63 (the tail alone: 383 us against 8 x 54).  So: every launch over all datasets, at
+  // every size (JD_FFT_BATCH = 0: per-dataset calls; 3: per-dataset calls beyond 2048 rows, the round-4 rule; 4: beyond
+  // 2048 rows the FFT launches dataset by dataset, the tail over all datasets).
+  const int mode = opt_value(OPT_FFT_BATCH, 1);
   const bool batched = p->native && grad_flux && n_datasets >= 2 && n_datasets <= FFT_MAX_BATCH &&
-                       fftn_pooled_supported(p->fftn, upsampling) && !opt_is_set(OPT_SEP_NO_FUSION) &&
-                       opt_value(OPT_FFT_BATCH, 1) != 0 && (p->fftn.Hh <= 1024 || opt_value(OPT_FFT_BATCH, 1) == 2);
+                       fftn_pooled_supported(p->fftn, upsampling) && !opt_is_set(OPT_SEP_NO_FUSION) && mode != 0 &&
+                       (p->fftn.Hh <= 1024 || mode != 3);
+  const bool sequential = batched && p->fftn.Hh > 1024 && mode == 4;
   if (!batched) {
     const float* fluxes[1] = {flux};
     float* grads[1] = {grad_flux};
@@ -839,7 +844,7 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
   for (int d = 0; d < n_datasets; ++d) any_shift = any_shift || (shift_xy && shift_xy[d]);
   if (any_cal && (rc = ensure_calibration_buffers(p, 1, any_shift))) return rc;
   const FftNative& fn = p->fftn;
-  for (int d = 0; d + 1 < n_datasets; ++d) {
+  for (int d = 0; d + 1 < n_datasets && !sequential; ++d) {
     if (!p->fft_extra_spec[d]) JD_HIP(hipMalloc(&p->fft_extra_spec[d], (size_t)fn.Hh * fn.Nx * sizeof(float2)));
     if (!p->fft_extra_work[d]) JD_HIP(hipMalloc(&p->fft_extra_work[d], (size_t)fn.Ny * fn.Nx * sizeof(float2)));
   }
@@ -865,7 +870,8 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
     batch.exposure[d] = exposure[d], batch.khat[d] = reinterpret_cast<const float2*>(khat[d]);
     batch.background[d] = background[d], batch.counts[d] = counts[d];
     batch.loss_out[d] = loss_out[d], batch.loss_offset[d] = stirling_mean[d];
-    batch.spec[d] = d ? p->fft_extra_spec[d - 1] : fn.spec, batch.work[d] = d ? p->fft_extra_work[d - 1] : fn.work;
+    batch.spec[d] = d && !sequential ? p->fft_extra_spec[d - 1] : fn.spec;
+    batch.work[d] = d && !sequential ? p->fft_extra_work[d - 1] : fn.work;
     batch.shift_xy[d] = shift_xy ? shift_xy[d] : nullptr;
     batch.log_bkg_norm[d] = log_background_norm ? log_background_norm[d] : nullptr;
     batch.grad_shift_xy[d] = grad_shift_xy ? grad_shift_xy[d] : nullptr;
@@ -877,7 +883,8 @@ extern "C" int jd_npred_poisson_calibrated_batch_fwd_bwd(jd_conv_plan* p, int n_
   const double n_pix = (double)(p->H / upsampling) * (double)(p->W / upsampling);
   return fftn_poisson_step_pooled_batch(fn, upsampling, n_datasets, p->fft_batch_dev[slot], p->fft_batch_host[slot], flux, p->partials_batch,
                                         p->partials_batch + (size_t)n_datasets * per, eps, (float)(1.0 / n_pix), grad_flux,
-                                        p->partials_shift_batch, grad_scale, accumulate, s, 1.0 / n_pix, (double)grad_scale);
+                                        p->partials_shift_batch, grad_scale, accumulate, s, 1.0 / n_pix, (double)grad_scale,
+                                        sequential ? 1 : 0);
 }
 
 extern "C" int jd_npred_poisson_calibrated_fwd_bwd(jd_conv_plan* p, int n_comp, const float* const* flux,

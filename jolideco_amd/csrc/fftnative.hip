@@ -58,6 +58,10 @@ __device__ __forceinline__ void lds_wave_fence() {
 #ifndef JD_FFT_LOOP_OUTSIDE
 #define JD_FFT_LOOP_OUTSIDE 0  // 1: one butterfly loop per radix (switch outside): more registers, fewer instructions
 #endif
+#ifndef JD_FFT_POOLED_PREFETCH
+#define JD_FFT_POOLED_PREFETCH 0  // 1: the pooled middle launch of 576-thread blocks loads the next spectrum row while it transforms
+                                  // (measured, c6: 68 -> 88 us per launch -- 96 registers are not enough for it: 92 bytes of scratch)
+#endif
 #ifndef JD_FFT_LIN
 #define JD_FFT_LIN 0           // 1: linear padded indices where a pass allows them (jd_fftcore.h)
 #endif
@@ -369,8 +373,8 @@ struct RowsFwdArgs {
   const float* in;
   const float* shift_xy;  // nullable, device [2]: the input is the bilinearly shifted image (the calibration's shift_fwd)
   float shift_scale;
-  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = row pair b / n of dataset b % n (scale, spec from the table)
-  int n_batch;
+  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = row pair b / n of dataset d0 + b % n (scale, spec from the table)
+  int n_batch, d0;
   const float* scale;  // nullable
   float2* spec;        // [Hh][Nx]
   const float2* tw;
@@ -385,7 +389,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   using S = RowSched<R0, R1, R2, R3>;
   const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, nb = a.n_batch;
-  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
+  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? a.d0 + (int)blockIdx.x - y * nb : 0;
   const float* const scale = nb ? a.batch->exposure[d] : a.scale;
   float2* const spec = nb ? a.batch->spec[d] : a.spec;
   const float* const shift_xy = nb ? a.batch->shift_xy[d] : a.shift_xy;
@@ -479,8 +483,8 @@ struct ColsArgs {
   const float2* tw;
   int Hh, Nx, Ny, conj, groups;
   int keep_lo, keep_hi;  // rows [0, keep_lo) and [keep_hi, Ny) of the result are written (the others are never read)
-  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = column group b / n of dataset b % n (spec, work, khat from the table)
-  int n_batch;
+  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = column group b / n of dataset d0 + b % n (spec, work, khat from the table)
+  int n_batch, d0;
   FftPasses f;
 };
 
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(512, 3) void fftn_cols_kernel(ColsArgs a) {
   // neighbouring column groups (the same 128-byte lines of every spectrum row) go to the same XCD (blockIdx % 8), one
   // after the other: the partial lines they read and write meet in that XCD's L2
   const int nb = a.n_batch;
-  const int bq = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - bq * nb : 0;
+  const int bq = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? a.d0 + (int)blockIdx.x - bq * nb : 0;
   const float2* const spec_in = nb ? a.batch->spec[d] : a.spec;
   float2* const work_out = nb ? a.batch->work[d] : a.work;
   const float2* const khat = nb ? a.batch->khat[d] : a.khat;
@@ -638,7 +642,7 @@ struct RowsInvArgs {
   double fin2_scale;
   float* fin2_out;
   const FftBatch* batch;        // fftn_rows_inv_batch_kernel (device memory): the n_batch datasets whose adjoints one block adds up, in order
-  int n_batch;
+  int n_batch, d0;              // (fftn_rows_inv_kernel: block b = row pair b / n of dataset d0 + b % n)
   FftPasses f;
 };
 
@@ -652,7 +656,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   // n_batch > 0 (ADJ, calibrated batched step): block b = row pair b / n of dataset b % n; out = the dataset's gshift image
   // (overwritten), scale = its exposure, and the blocks of row pairs 0 / 1 finalise the dataset's loss / norm gradient
   const int tid = threadIdx.x, nb = ADJ ? a.n_batch : 0;
-  const int y = nb ? (int)blockIdx.x / (ADJ ? nb : 1) : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
+  const int y = nb ? (int)blockIdx.x / (ADJ ? nb : 1) : (int)blockIdx.x, d = nb ? a.d0 + (int)blockIdx.x - y * nb : 0;
   const float2* const work = nb ? a.batch->work[d] : a.work;
   const float* const scale = nb ? a.batch->exposure[d] : a.scale;
   float* const out = nb ? a.batch->gshift[d] : a.out;
@@ -785,8 +789,8 @@ struct RowsPoissonArgs {
   double* partials;    // [Hh] ([n][Hh] for a batch)
   int H, W, Hh, Nx, Ny, ra, rb;
   float eps, inv_n;
-  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = row pair b / n of dataset b % n
-  int n_batch;
+  const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = row pair b / n of dataset d0 + b % n
+  int n_batch, d0;
   FftPasses f;
 };
 
@@ -801,7 +805,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   __shared__ double red[S::T / 64];
   const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, nb = a.n_batch;
-  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - y * nb : 0;
+  const int y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? a.d0 + (int)blockIdx.x - y * nb : 0;
   const float2* const work = nb ? a.batch->work[d] : a.work;
   float2* const spec = nb ? a.batch->spec[d] : a.spec;
   const float* const background = nb ? a.batch->background[d] : a.background;
@@ -871,8 +875,8 @@ struct RowsPooledArgs {
   double* partials_b;         // nullable [Hh / U]: block sums of g * background (d loss / d log norm up to the scale)
   int H, W, Hh, Nx, Ny, ra, rb;
   float eps, inv_n;
-  const FftBatch* batch;      // device memory, nullable; n_batch > 0: block b = counts-row pair b / n of dataset b % n
-  int n_batch;
+  const FftBatch* batch;      // device memory, nullable; n_batch > 0: block b = counts-row pair b / n of dataset d0 + b % n
+  int n_batch, d0;
   FftPasses f;
 };
 
@@ -888,7 +892,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   __shared__ double red[S::T / 64];
   const int Nx = S::STATIC ? S::N : a.Nx;
   const int tid = threadIdx.x, nb = a.n_batch;
-  const int Y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? (int)blockIdx.x - Y * nb : 0;
+  const int Y = nb ? (int)blockIdx.x / nb : (int)blockIdx.x, d = nb ? a.d0 + (int)blockIdx.x - Y * nb : 0;
   const float2* const work = nb ? a.batch->work[d] : a.work;
   float2* const spec = nb ? a.batch->spec[d] : a.spec;
   const float* const background = nb ? a.batch->background[d] : a.background;
@@ -903,9 +907,19 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   for (int q = 0; q < MAXQ; ++q)
 #pragma unroll
     for (int c = 0; c < PC; ++c) pu[q][c] = pd[q][c] = 0.f;
+  // 576-thread blocks (two per CU): the spectrum row of flux row j + 1 is loaded into registers while the block transforms
+  // row j (a block with a single round of loads per transform leaves the memory system idle while it computes)
+  constexpr bool PREFETCH = S::T == 576 && JD_FFT_POOLED_PREFETCH;
+  float4 pre[S::PRE];
+  if constexpr (PREFETCH) load_spectrum_row_regs<S::T, S::PRE>(pre, work, Nx, U * Y, a.Hh, a.Ny, a.ra, a.rb, tid);
 #pragma unroll 1
   for (int j = 0; j < U; ++j) {
-    load_spectrum_row<S::T>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+    if constexpr (PREFETCH) {
+      store_spectrum_row_regs<S::T, S::PRE>(bufa, pre, Nx, tid);
+      if (j + 1 < U) load_spectrum_row_regs<S::T, S::PRE>(pre, work, Nx, U * Y + j + 1, a.Hh, a.Ny, a.ra, a.rb, tid);
+    } else {
+      load_spectrum_row<S::T>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+    }
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
@@ -1080,20 +1094,25 @@ int lds_attr(const void* kernel, size_t bytes) {
   return JD_OK;
 }
 
-int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream, const FftBatch* batch = nullptr, int n_batch = 0) {
+int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream, const FftBatch* batch = nullptr, int n_batch = 0,
+                int d0 = 0) {
   const FftPasses fy = passes_of(n.Ny);
   const int ra = adjoint ? n.kh - 1 - n.oy : n.oy, rb = adjoint ? n.oy : n.kh - 1 - n.oy;
   ColsArgs a{};
   a.spec = n.spec, a.work = n.work, a.khat = khat, a.tw = n.tw_y, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.conj = adjoint ? 1 : 0;
   a.keep_lo = n.Hh + rb, a.keep_hi = n.Ny - ra, a.f = fy;
-  a.batch = batch, a.n_batch = n_batch;
+  a.batch = batch, a.n_batch = n_batch, a.d0 = d0;
   const size_t per_col = (size_t)lp_size(n.Ny) * sizeof(float2);
   const int lanes = column_lanes(n.Ny, fy);
   if (!lanes) return fail(JD_ERR_INVALID, "native FFT: no column kernel for length %d", n.Ny);
-  // columns per block: 4 one-wave columns (32 contiguous bytes of every spectrum row), 2 two-wave columns for the long
-  // ones.  Measured at 2048^2, Ny = 1152 (round 4, compile-time schedules): 4 columns 24.2 us, 3 columns (768 blocks = 3 per
-  // CU, 24-byte pieces) 26.7, 9 columns (one block per CU) 25.9; at 4096^2, Ny = 2304: 2 two-wave columns 91 us, 4: 104
-  int cb = lanes == 64 ? 4 : 2;
+  // columns per block: 4 (32 contiguous bytes of every spectrum row).  Measured at 2048^2, Ny = 1152 (round 4, one-wave
+  // columns): 4 columns 24.2 us, 3 columns (768 blocks = 3 per CU, 24-byte pieces) 26.7, 9 columns (one block per CU) 25.9.
+  // Two-wave columns (Ny = 2304: 4096-row images): with the round-5 kernels (packed arithmetic, linear LDS indices: 110
+  // registers, two blocks of 512 threads per CU) 4 columns 74.8 against 87.0 us for 2 (c6; round 4, 139 registers: 104
+  // against 91).  The generic two-wave kernel (168 registers) keeps 2.
+  const bool static_two_wave = lanes == 128 && fy.n == 3 && fy.r[0] == 16 && fy.r[1] == 16 && (fy.r[2] == 9 || fy.r[2] == 8);
+  int cb = lanes == 64 || static_two_wave ? 4 : 2;
+  if (n.Nx % cb != 0) cb = 2;
   const int ocb = opt_value(OPT_FFT_NATIVE, 1);  // (tuning: JD_FFT_NATIVE = 2 / 4 / 8 forces the columns per block)
   if ((ocb == 2 || ocb == 4 || ocb == 8) && (size_t)ocb * per_col <= 160 * 1024 && n.Nx % ocb == 0 && ocb * lanes <= 512) cb = ocb;
   a.groups = n.Nx / cb;
@@ -1107,8 +1126,10 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
   static Entry table[] = {
       {64, 4, 16, 8, 9, fftn_cols_kernel<64, 4, 16, 8, 9>},    // 1152: 2048-row images, PSFs up to 129 rows
       {128, 2, 16, 16, 9, fftn_cols_kernel<128, 2, 16, 16, 9>},  // 2304: 4096-row images
+      {128, 4, 16, 16, 9, fftn_cols_kernel<128, 4, 16, 16, 9>},  // (default: four columns per block, 32-byte pieces)
       {64, 4, 16, 8, 8, fftn_cols_kernel<64, 4, 16, 8, 8>},    // 1024
       {128, 2, 16, 16, 8, fftn_cols_kernel<128, 2, 16, 16, 8>},  // 2048
+      {128, 4, 16, 16, 8, fftn_cols_kernel<128, 4, 16, 16, 8>},
       {64, 4, 8, 8, 9, fftn_cols_kernel<64, 4, 8, 8, 9>},      // 576: 1024-row images
       {64, 4, 8, 8, 8, fftn_cols_kernel<64, 4, 8, 8, 8>},      // 512
       {64, 0, 0, 0, 0, fftn_cols_kernel<64, 0, 0, 0, 0>},      // generic
@@ -1157,12 +1178,12 @@ int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), const FftNati
 }
 
 int launch_rows_fwd(const FftNative& n, const float* in, const float* in_scale, hipStream_t stream, const float* shift_xy = nullptr,
-                    float shift_scale = 1.f, const FftBatch* batch = nullptr, int n_batch = 0) {
+                    float shift_scale = 1.f, const FftBatch* batch = nullptr, int n_batch = 0, int d0 = 0) {
   static void (*const kernels[N_ROW_SCHED])(RowsFwdArgs) = JD_ROW_KERNELS(fftn_rows_fwd_kernel, );
   RowsFwdArgs a{};
   a.in = in, a.scale = in_scale, a.spec = n.spec, a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.f = passes_of(n.Nx);
   a.shift_xy = shift_xy, a.shift_scale = shift_scale;
-  a.batch = batch, a.n_batch = n_batch;
+  a.batch = batch, a.n_batch = n_batch, a.d0 = d0;
   return launch_row_kernel(kernels, n, a, JD_KERNEL_FFT_R2C, stream, n_batch ? n.Hh * n_batch : 0);
 }
 
@@ -1291,38 +1312,47 @@ int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_de
 int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, const FftBatch* batch_dev, const FftBatch& host,
                                    const float* flux, double* partials, double* partials_b, float eps, float inv_n, float* grad,
                                    double* partials_shift, float coef, int accumulate, hipStream_t stream, double loss_scale,
-                                   double norm_grad_scale) {
+                                   double norm_grad_scale, int sequential) {
   if (nd < 1 || nd > FFT_MAX_BATCH) return fail(JD_ERR_INVALID, "native FFT batch: %d datasets not in [1, %d]", nd, FFT_MAX_BATCH);
   if (!fftn_pooled_supported(n, upsampling)) return fail(JD_ERR_INVALID, "native FFT batch: up-sampling %d not supported", upsampling);
-  int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, (float)upsampling, batch_dev, nd);
-  if (rc) return rc;
-  if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, nd))) return rc;
   const int per = n.Hh / upsampling;
-  {
-    static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
-    static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
-    RowsPooledArgs a{};
-    a.tw = n.tw_x, a.partials = partials, a.partials_b = partials_b;
-    a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
-    a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
-    rc = upsampling == 2 ? launch_row_kernel(kernels2, n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd)
-                         : launch_row_kernel(kernels4, n, a, JD_KERNEL_POISSON_FUSED, stream, per * nd);
+  // sequential (large images, where a dataset's launches already fill the chip in several rounds of blocks and its 160 MB
+  // of work arrays stay in the 256 MB last-level cache from launch to launch): the five FFT launches dataset by dataset
+  // (blocks of dataset d0 only; the table may give every dataset the SAME work arrays), then the tail over all datasets
+  const int groups = sequential ? nd : 1, per_launch = sequential ? 1 : nd;
+  for (int gi = 0; gi < groups; ++gi) {
+    const int d0 = sequential ? gi : 0;
+    int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, (float)upsampling, batch_dev, per_launch, d0);
     if (rc) return rc;
+    if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, per_launch, d0))) return rc;
+    {
+      static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
+      static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
+      RowsPooledArgs a{};
+      a.tw = n.tw_x, a.partials = partials, a.partials_b = partials_b;
+      a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
+      a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = per_launch, a.d0 = d0;
+      rc = upsampling == 2 ? launch_row_kernel(kernels2, n, a, JD_KERNEL_POISSON_FUSED, stream, per * per_launch)
+                           : launch_row_kernel(kernels4, n, a, JD_KERNEL_POISSON_FUSED, stream, per * per_launch);
+      if (rc) return rc;
+    }
+    if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, per_launch, d0))) return rc;
+    // rows^-1 + adjoint epilogue into every dataset's own image (the blocks of row pairs 0 / 1 finalise its loss / norm
+    // gradient)
+    {
+      static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
+      RowsInvArgs a{};
+      a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
+      a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
+      a.coef = coef, a.accumulate = 0, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = per_launch, a.d0 = d0;
+      a.fin_partials = partials, a.fin_count = per, a.fin_scale = loss_scale;
+      a.fin2_partials = partials_b, a.fin2_scale = norm_grad_scale;
+      if ((rc = launch_row_kernel(kernels_adj, n, a, JD_KERNEL_FFT_C2R, stream, n.Hh * per_launch))) return rc;
+    }
   }
-  if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
-  // the tail over all datasets: rows^-1 + adjoint epilogue into every dataset's own image (blocks of row pairs 0 / 1
-  // finalise its loss / norm gradient), ONE transposed-shift launch that adds the datasets up in order (a dataset without
-  // a shift: its image as it is), one launch for the shift gradients
-  {
-    static void (*const kernels_adj[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_kernel, true, );
-    RowsInvArgs a{};
-    a.tw = n.tw_x, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
-    a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
-    a.coef = coef, a.accumulate = 0, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = nd;
-    a.fin_partials = partials, a.fin_count = per, a.fin_scale = loss_scale;
-    a.fin2_partials = partials_b, a.fin2_scale = norm_grad_scale;
-    if ((rc = launch_row_kernel(kernels_adj, n, a, JD_KERNEL_FFT_C2R, stream, n.Hh * nd))) return rc;
-  }
+  // the tail over all datasets: ONE transposed-shift launch that adds the datasets up in order (a dataset without a shift:
+  // its image as it is), one launch for the shift gradients
+  int rc;
   const size_t shift_stride = (size_t)2 * shift_bwd_max_blocks(n.H, n.W);
   int shift_blocks = 0;
   if ((rc = launch_shift_bwd_batch(flux, batch_dev, nd, grad, accumulate, n.H, n.W, (float)upsampling, partials_shift, shift_stride,

@@ -66,6 +66,7 @@ struct GmmFwdArgs {
   const float* mfrag;    // K * 64: [jb 4][g 4][r 4] = -m'[16 jb + 4 g + r]
   const float* const_k;  // K
   int K, H, W, stride, nPx, shift_y, shift_x;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
   int n_begin, n_end;    // linear patch index range (row-major over the patch grid)
   int32_t* argmax_out;   // nullable (MODE_MAX)
   float* value_patch;    // nullable: per patch v | MODE_DENSE: (n, K) out
@@ -78,6 +79,14 @@ struct GmmFwdArgs {
 // v mod n for -n <= v < 2 n: the host normalises the cycle-spin shifts to [0, n), so every coordinate
 // (pixel inside the image) - shift is in (-n, n); an integer division here costs ~20 instructions per pixel and
 // made the gather the bottleneck of the bucketed kernels.
+// The cycle-spin shift of a pass from DEVICE memory (captured hipGraphs replay with the shifts of the step they run for:
+// the host uploads them, the launch arguments never change): overwrites the by-value members of the kernel's own copy
+// of its arguments.
+template <class A>
+__device__ __forceinline__ void use_device_shift(A& a) {
+  if (a.shift_dev) a.shift_y = a.shift_dev[0], a.shift_x = a.shift_dev[1];
+}
+
 __device__ __forceinline__ int wrap(int v, int n) {
   v = v < 0 ? v + n : v;
   return v >= n ? v - n : v;
@@ -261,6 +270,7 @@ __device__ __forceinline__ int xs_index(int t, int c, int p) {
 
 template <int TB, int MODE, bool TRI>
 __global__ __launch_bounds__(256, 1) void gmm_fwd_kernel(GmmFwdArgs a) {
+  use_device_shift(a);
   if (a.run_flag && *a.run_flag != a.run_gen) return;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                                          // TB * 2048 floats
@@ -640,10 +650,12 @@ struct GmmBwdArgs {
   const int* counts;   // elements of bucket k: the slots behind them up to offsets[k + 1] are padding
   float* gpatch;       // (n_end - n_begin) * 64
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
 };
 
 template <bool TRI>
 __global__ __launch_bounds__(256) void gmm_bwd_max_kernel(GmmBwdArgs a) {
+  use_device_shift(a);
   const int lane = threadIdx.x & 63;
   const int g = lane >> 4, n16 = lane & 15;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -697,6 +709,7 @@ struct GmmBwdFallbackArgs {
   const int* flag;
   int gen;
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
 };
 
 // the groups grp_begin, grp_begin + grp_step, ... < grp_end of 32 patches (group 0 starts at a.n_begin), one wave each
@@ -770,6 +783,7 @@ struct GmmBwdLseArgs {
   double* partials;          // one per block: the sum of the logsumexp values of its patches
   float* gpatch;             // (n_end - n_begin) * 64
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
   // Behind the logsumexp screen (mark != nullptr): the kernel evaluates the 32-patch groups that hold a marked patch
   // (more candidates than a patch may keep: smooth patches, where most components are within the margin) -- or, after a
   // fallback of the pass (*run_flag == run_gen), all of them -- and leaves v per patch in vpatch (0 for a filtered
@@ -849,6 +863,7 @@ __device__ __forceinline__ void lse_component(const FragBuf& f, const GFrag& gfr
 // component instead of two.)
 template <bool TRI, int GRP>
 __global__ __launch_bounds__(256, 1) void gmm_bwd_lse_kernel(GmmBwdLseArgs a) {
+  use_device_shift(a);
   const bool everything = !a.mark || *a.run_flag == a.run_gen;
   __shared__ double red[4];
   const int lane = threadIdx.x & 63;
@@ -1002,6 +1017,7 @@ struct GmmScreenArgs {
   const float* sk2_k;    // K: s_k^2, the squared power-of-two scale of the fp16 fragments
   const float* mnorm_k;  // K: 1.001 |m'_k| (0 for a zero-mean component)
   int K, H, W, stride, nPx, shift_y, shift_x, n_begin, n_end;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
   const int* korder;         // K: the order in which the components are visited (most popular first)
   const uint4* xfrag;        // staged patches (gmm_stage_kernel): fp16 B fragments [tile][pixel step][lane],
   const float* xn;           //   1.0001 |xbar|, s_x^2 and validity per [tile * 32 + c]
@@ -1033,6 +1049,7 @@ struct __attribute__((packed, aligned(4))) F4U {  // 16 bytes at a 4-byte aligne
 struct GmmStageArgs {
   const float* flux;
   int H, W, stride, nPx, shift_y, shift_x, n_begin, n_end, n_tiles;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
   uint4* xfrag;              // [tile][pixel step 4][lane 64] = 8 fp16 of xbar / s_x (B fragment of the 32x32x16 MFMA)
   float* xn;                 // [tile * 32 + c] 1.0001 |xbar|
   float* xs2;                // s_x^2
@@ -1044,6 +1061,7 @@ struct GmmStageArgs {
 };
 
 __global__ __launch_bounds__(256) void gmm_stage_kernel(GmmStageArgs a) {
+  use_device_shift(a);
   if (a.pcount && blockIdx.x == 0 && threadIdx.x == 0) *a.dense_count = 0;
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1488,6 +1506,7 @@ struct GmmExactArgs {
   int gen;                // the pass has fallen back to the dense kernel when *flag == gen
   unsigned long long* best;
   int K, H, W, stride, nPx, shift_y, shift_x;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
   // fused backward pass (grec != nullptr): the gradient row of EVERY surviving record is written to grec[bucket slot]
   // and the key carries the bucket slot instead of the component (slots ascend with the component, so ties still go
   // to the lowest component); gmm_best_kernel turns the winning key into the row the gather kernel reads
@@ -1524,6 +1543,7 @@ constexpr int EXACT_OFF_LDS = 1025;        // bucket offsets kept in LDS up to K
 // backward kernel costs 4x the memory instructions) and read back in B-operand order.
 template <bool TRI>
 __global__ __launch_bounds__(256) void gmm_exact_kernel(GmmExactArgs a) {
+  use_device_shift(a);
   if (*a.flag == a.gen) return;  // the dense kernel takes over
   __shared__ __attribute__((aligned(16))) float stage[4][32 * EXACT_PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1707,6 +1727,7 @@ struct GmmBestArgs {
 constexpr int BEST_CHUNK = 1024;
 
 __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
+  use_device_shift(a.fb);
   __shared__ double red[4];
   const int base = a.n_begin + blockIdx.x * BEST_CHUNK;
   const bool slots = a.winner && *a.flag != a.gen;
@@ -1942,6 +1963,7 @@ struct GmmGatherArgs {
   const float* gpatch;
   float* grad;
   int H, W, stride, nPx, nPy, shift_y, shift_x, row_begin, row_end;  // patch-row shard
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
   int y_begin, y_end;                                                // rolled-frame pixel rows covered
   float coef;
   // fused backward pass (winner != nullptr and no fallback): the row of patch n is grec[winner[n]] (none if < 0)
@@ -1965,6 +1987,7 @@ struct GmmGatherArgs {
 
 __global__ __launch_bounds__(256) void gmm_gather_kernel(GmmGatherArgs a) {
 #pragma clang fp contract(off)
+  use_device_shift(a);
   const int Y = a.y_begin + blockIdx.y;
   const int X = blockIdx.x * 256 + threadIdx.x;
   if (X >= a.W || Y >= a.y_end) return;
@@ -2023,6 +2046,8 @@ constexpr int GATHER_T = 32, GATHER_MAX_P = JD_GATHER_MAX_P, GATHER_MAX_PX = JD_
 
 __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
 #pragma clang fp contract(off)
+  use_device_shift(a);
+  use_device_bias(a.step);
   __shared__ __attribute__((aligned(16))) float rows[GATHER_MAX_P * GATHER_MAX_PX][D];
   const int tid = threadIdx.x;
   const int xoff = a.vec ? ((a.shift_x % 4) + 4) & 3 : 0;
@@ -2163,10 +2188,12 @@ struct AddBandsArgs {
   const float* bands;
   size_t chunk;
   int H, W, shift_y, shift_x, n_bands, y_lo, y_hi;
+  const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
   int y_begin[BANDS_MAX], y_end[BANDS_MAX];
 };
 
 __global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
+  use_device_shift(a);
   const int Y = a.y_lo + blockIdx.y;
   const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (X >= a.W || Y >= a.y_hi) return;
@@ -2202,6 +2229,8 @@ __global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
 // pixels of the un-rolled image (16-byte accesses to the optimizer state; W % 4 == 0) and reads the four rolled-frame
 // band values of every band that holds its row one by one.
 __global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgs a, AdamArgs st) {
+  use_device_shift(a);
+  use_device_bias(st);
   const int yy = blockIdx.y;
   const int xx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (xx >= a.W) return;
@@ -2642,6 +2671,9 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   float* rec_ub = reinterpret_cast<float*>(g->rec + 2 * slots);
   int* flag = g->screen_ctl;
   g->gen = g->gen % (1 << 30) + 1;
+  // a pass whose shifts come from device memory may be REPLAYED from a captured graph with this very generation number:
+  // a fallback flag left by an earlier replay must not be taken for this pass's (a node of the graph clears it)
+  if (a.shift_dev) JD_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
   // rows of the record-gradient buffer: 1.0-1.3 records per patch survive on the seeded mixtures of the benchmark, up
   // to 1.9 on noise under an image-like mixture (condition numbers 1e5: wider bounds); beyond 4 per patch (+ bucket
   // padding; 1 KB per patch) the scan kernel raises the fallback flag and the dense kernel takes the pass
@@ -2686,7 +2718,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   ProfScope prof(JD_KERNEL_GMM_FWD, s);
   GmmStageArgs stg{};
-  stg.flux = a.flux, stg.H = a.H, stg.W = a.W, stg.stride = a.stride, stg.nPx = a.nPx, stg.shift_y = a.shift_y, stg.shift_x = a.shift_x;
+  stg.flux = a.flux, stg.H = a.H, stg.W = a.W, stg.stride = a.stride, stg.nPx = a.nPx, stg.shift_y = a.shift_y, stg.shift_x = a.shift_x, stg.shift_dev = a.shift_dev;
   stg.n_begin = a.n_begin, stg.n_end = a.n_end, stg.n_tiles = (int)n_tiles;
   stg.pcount = lse ? g->pcount : nullptr, stg.dense_mark = lse ? g->dense_mark : nullptr;
   stg.dense_count = lse ? reinterpret_cast<int*>(g->dense_list) : nullptr;
@@ -2694,7 +2726,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   GmmScreenArgs sc{};
   sc.xfrag = g->xfrag, sc.xn = stg.xn, sc.xs2 = stg.xs2, sc.ok = g->xok;
   sc.flux = a.flux, sc.afrag16 = g->afrag16, sc.const_k = g->const_k, sc.efro_k = g->efro_k, sc.sk2_k = g->sk2_k, sc.mnorm_k = g->mnorm_k, sc.korder = g->korder;
-  sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x;
+  sc.K = a.K, sc.H = a.H, sc.W = a.W, sc.stride = a.stride, sc.nPx = a.nPx, sc.shift_y = a.shift_y, sc.shift_x = a.shift_x, sc.shift_dev = a.shift_dev;
   sc.n_begin = a.n_begin, sc.n_end = a.n_end;
   sc.lfinal = g->lfinal, sc.rec_n = rec_n, sc.rec_k = rec_k, sc.rec_ub = rec_ub;
   sc.seg_cnt = g->seg_cnt, sc.flag = flag, sc.gen = g->gen, sc.dense_mark = lse ? g->dense_mark : nullptr;
@@ -2747,7 +2779,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   ex.order_n = g->rec_order_n, ex.counts = bk.counts, ex.offsets = bk.offsets, ex.flag = flag, ex.gen = g->gen;
   ex.gfrag = g->gfrag, ex.grec = fused ? g->grec : nullptr, ex.lrec = lse ? g->lrec : nullptr;
   ex.best = g->best, ex.K = g->K, ex.H = a.H, ex.W = a.W, ex.stride = a.stride, ex.nPx = a.nPx;
-  ex.shift_y = a.shift_y, ex.shift_x = a.shift_x;
+  ex.shift_y = a.shift_y, ex.shift_x = a.shift_x, ex.shift_dev = a.shift_dev;
 #ifdef JD_EXACT_STAMPS
   static unsigned long long* stamps_dev = nullptr;
   static size_t stamps_cap = 0;
@@ -2807,7 +2839,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     GmmBwdLseArgs b{};
     b.flux = a.flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
     b.partials = g->partials, b.gpatch = g->gpatch, b.K = g->K;
-    b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x;
+    b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x, b.shift_dev = a.shift_dev;
     b.n_begin = a.n_begin, b.n_end = a.n_end, b.run_flag = flag, b.run_gen = g->gen;
     b.mark = g->dense_mark, b.vpatch = g->vpatch;
     b.list = g->dense_list + 1, b.list_count = reinterpret_cast<const int*>(g->dense_list);
@@ -2856,7 +2888,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
     GmmBwdFallbackArgs& b = be.fb;
     b.flux = a.flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = fallback_argmax, b.gpatch = g->gpatch;
     b.flag = flag, b.gen = g->gen, b.K = g->K;
-    b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x;
+    b.H = a.H, b.W = a.W, b.stride = a.stride, b.nPx = a.nPx, b.shift_y = a.shift_y, b.shift_x = a.shift_x, b.shift_dev = a.shift_dev;
     b.n_begin = a.n_begin, b.n_end = a.n_end;
   }
   const unsigned best_blocks = (unsigned)((n + BEST_CHUNK - 1) / BEST_CHUNK);
@@ -2883,7 +2915,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
                           int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                           float value_scale, float* value_out, int accumulate_value, float grad_coef,
                           float* grad_flux_accum, int32_t* argmax_out, float* band_out, void* stream,
-                          const AdamArgs* step = nullptr) {
+                          const AdamArgs* step = nullptr, const int* shift_dev = nullptr) {
   JD_REQUIRE(g && flux && value_out, "jd_gmm_prior_fwd_bwd: null argument");
   JD_REQUIRE(H >= P && W >= P, "jd_gmm_prior_fwd_bwd: image (%d, %d) smaller than a patch", H, W);
   JD_REQUIRE(stride >= 1 && stride <= P, "jd_gmm_prior_fwd_bwd: stride = %d not in [1, 8]", stride);
@@ -2934,7 +2966,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   }
   GmmFwdArgs a{};
   a.flux = flux, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
-  a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x;
+  a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x, a.shift_dev = shift_dev;
   a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = fused ? argmax_out : arg, a.value_patch = nullptr, a.partials = g->partials;
   if (grad_flux_accum && (rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;  // (the fused fallback writes it)
   int n_waves = 0;
@@ -2945,7 +2977,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     GmmBwdLseArgs b{};
     b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
     b.partials = g->partials, b.gpatch = g->gpatch, b.K = g->K;
-    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
+    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x, b.shift_dev = shift_dev;
     b.n_begin = n_begin, b.n_end = n_end;
     const long groups = (n + 31) / 32;
     long blocks = (groups + 2 * 4 - 1) / (2 * 4);  // 2 groups per wave, 4 waves per block
@@ -3002,7 +3034,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     GmmBwdArgs b{};
     b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
     b.offsets = bk.offsets, b.counts = bk.counts, b.gpatch = g->gpatch, b.K = g->K;
-    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x;
+    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x, b.shift_dev = shift_dev;
     b.n_begin = n_begin, b.n_end = n_end;
     long bwd_blocks = ((long)(slots_cap / 32) + 3) / 4;
     const long cap = (long)g->n_cu * 3;  // 3 blocks of 4 waves per CU: one wave per SIMD x 3
@@ -3017,7 +3049,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
 
   GmmGatherArgs ga{};
   ga.gpatch = g->gpatch, ga.grad = grad_flux_accum, ga.H = H, ga.W = W, ga.stride = stride, ga.nPx = nPx, ga.nPy = nPy;
-  ga.shift_y = shift_y, ga.shift_x = shift_x, ga.row_begin = patch_row_begin, ga.row_end = patch_row_end;
+  ga.shift_y = shift_y, ga.shift_x = shift_x, ga.shift_dev = shift_dev, ga.row_begin = patch_row_begin, ga.row_end = patch_row_end;
   ga.y_begin = patch_row_begin * stride;
   ga.y_end = (patch_row_end - 1) * stride + P;
   ga.coef = grad_coef;
@@ -3049,9 +3081,9 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
 extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
                                     int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                                     float value_scale, float* value_out, int accumulate_value, float grad_coef,
-                                    float* grad_flux_accum, int32_t* argmax_out, void* stream) {
+                                    float* grad_flux_accum, int32_t* argmax_out, const int* shift_dev, void* stream) {
   return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, patch_row_begin, patch_row_end, marginalize, value_scale,
-                        value_out, accumulate_value, grad_coef, grad_flux_accum, argmax_out, nullptr, stream);
+                        value_out, accumulate_value, grad_coef, grad_flux_accum, argmax_out, nullptr, stream, nullptr, shift_dev);
 }
 
 // Diagnostics of the screened arg-max path (no synchronisation: whatever pass has landed in the host-mapped block):
@@ -3066,7 +3098,7 @@ extern "C" int jd_gmm_screen_stats(const jd_gmm* g, int* out) {
 
 extern "C" int jd_gmm_prior_fwd_bwd_step(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y, int shift_x,
                                          int marginalize, float value_scale, float* value_out, int accumulate_value,
-                                         float grad_coef, const jd_step* step, void* stream) {
+                                         float grad_coef, const jd_step* step, const int* shift_dev, void* stream) {
   JD_REQUIRE(step && step->theta && step->flux_in && step->flux_out && step->grad_flux, "jd_gmm_prior_fwd_bwd_step: null argument");
   JD_REQUIRE(step->sgd || (step->exp_avg && step->exp_avg_sq), "jd_gmm_prior_fwd_bwd_step: Adam needs its moment images");
   AdamArgs a{};
@@ -3074,9 +3106,9 @@ extern "C" int jd_gmm_prior_fwd_bwd_step(jd_gmm* g, const float* flux, int H, in
   a.m = step->exp_avg, a.v = step->exp_avg_sq, a.mask = step->mask, a.n = (size_t)H * W;
   a.step_size = step->step_size, a.beta1 = step->beta1, a.beta2 = step->beta2, a.one_minus_beta1 = step->one_minus_beta1;
   a.one_minus_beta2 = step->one_minus_beta2, a.bias2_sqrt = step->bias2_sqrt, a.eps = step->eps, a.lr = step->lr;
-  a.zero_grad = 0, a.sgd = step->sgd ? 1 : 0, a.linear = step->use_log_flux ? 0 : 1;
+  a.zero_grad = 0, a.sgd = step->sgd ? 1 : 0, a.linear = step->use_log_flux ? 0 : 1, a.bias_dev = step->bias_dev;
   return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, 0, -1, marginalize, value_scale, value_out, accumulate_value,
-                        grad_coef, nullptr, nullptr, nullptr, stream, &a);
+                        grad_coef, nullptr, nullptr, nullptr, stream, &a, shift_dev);
 }
 
 extern "C" int jd_gmm_prior_band_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
@@ -3132,7 +3164,7 @@ extern "C" int jd_add_rolled_bands_step(int H, int W, int shift_y, int shift_x, 
   st.m = step->exp_avg, st.v = step->exp_avg_sq, st.mask = step->mask, st.n = (size_t)H * W;
   st.step_size = step->step_size, st.beta1 = step->beta1, st.beta2 = step->beta2, st.one_minus_beta1 = step->one_minus_beta1;
   st.one_minus_beta2 = step->one_minus_beta2, st.bias2_sqrt = step->bias2_sqrt, st.eps = step->eps, st.lr = step->lr;
-  st.zero_grad = 0, st.sgd = step->sgd ? 1 : 0, st.linear = step->use_log_flux ? 0 : 1;
+  st.zero_grad = 0, st.sgd = step->sgd ? 1 : 0, st.linear = step->use_log_flux ? 0 : 1, st.bias_dev = step->bias_dev;
   dim3 grid((W + 1023) / 1024, H);
   ProfScope prof(JD_KERNEL_ADAM, as_stream(stream));
   add_rolled_bands_step_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, st);

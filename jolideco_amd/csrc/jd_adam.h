@@ -17,7 +17,14 @@ struct AdamArgs {
   float step_size, beta1, beta2, one_minus_beta1, one_minus_beta2, bias2_sqrt, eps, lr;
   int zero_grad, sgd;
   int linear;  // use_log_flux=False: theta IS the flux (models/core.py:586-594), no exp / chain rule
+  // nullable, device [2] = {step_size, bias2_sqrt}: read instead of the two members above (use_device_bias) -- the step
+  // count of a captured graph's optimizer step lives in device memory, its launch arguments never change
+  const float* bias_dev;
 };
+
+__device__ __forceinline__ void use_device_bias(AdamArgs& a) {
+  if (a.bias_dev) a.step_size = a.bias_dev[0], a.bias2_sqrt = a.bias_dev[1];
+}
 
 __device__ inline void adam_update(float& th, float& m, float& v, float g, const AdamArgs& a) {
   // every product and sum rounded on its own: whether the compiler fuses a multiply-add depends on the kernel around it

@@ -265,7 +265,7 @@ int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_de
 int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, const FftBatch* batch_dev, const FftBatch& host,
                                    const float* flux, double* partials, double* partials_b, float eps, float inv_n, float* grad,
                                    double* partials_shift, float coef, int accumulate, hipStream_t stream, double loss_scale,
-                                   double norm_grad_scale);
+                                   double norm_grad_scale, int sequential);
 bool fftn_pooled_supported(const FftNative& n, int upsampling);
 int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,

@@ -30,9 +30,9 @@ OptionSlot g_options[OPT_COUNT] = {
     {"JD_SEP_JOINT_CHUNK", {INT_MIN}},   {"JD_SEP_WALK_ADJ_ALL", {INT_MIN}}, {"JD_SEP_WALK_COST33", {INT_MIN}},
     {"JD_SEP_WALK_ROWS33", {INT_MIN}},   {"JD_SEP_NO_TRIM", {INT_MIN}},      {"JD_SEP_WALK_ADJ_ROWS33", {INT_MIN}},
     {"JD_SEP_WALK_ADJ33", {INT_MIN}},    {"JD_FFT_NATIVE", {INT_MIN}},
-    {"JD_DIRECT_AUTO_ALL", {INT_MIN}},
-    {"JD_FFT_BATCH", {INT_MIN}},  // 0: the batched joint steps of a native FFT plan run their per-dataset calls; 2: the
-                                  // calibrated one batches images beyond 2048 rows too  // "auto" takes the MFMA Toeplitz kernel up to 33 taps (as before round 4)
+    {"JD_DIRECT_AUTO_ALL", {INT_MIN}},  // "auto" takes the MFMA Toeplitz kernel up to 33 taps (as before round 4)
+    {"JD_FFT_BATCH", {INT_MIN}},  // 0: the batched joint steps of a native FFT plan run their per-dataset calls; the calibrated
+                                  // one beyond 2048 flux rows: 3 per-dataset calls, 4 per-dataset FFT launches + one tail
 };
 
 int parse(const char* text) {

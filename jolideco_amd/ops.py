@@ -308,6 +308,16 @@ class ConvPlan:
             )
 
 
+class DeviceShifts:
+    """Cycle-spin shifts of one prior evaluation held in DEVICE memory: ``dev`` = int32 tensor [shift_y mod H, shift_x mod W]
+    the kernels read (jd_gmm_prior_fwd_bwd: device-resident step scalars), ``host`` = the same pair as the host drew it."""
+
+    __slots__ = ("dev", "host")
+
+    def __init__(self, dev, host):
+        self.dev, self.host = dev, host
+
+
 class GmmHandle:
     """GMM constants in MFMA fragment order on the device (jd_gmm)."""
 
@@ -353,6 +363,11 @@ class GmmHandle:
         H, W = flux.shape[-2:]
         if flux.numel() != H * W:
             raise ValueError("flux must be a single (H, W) image")
+        shift_dev = None
+        if isinstance(shifts, DeviceShifts):  # the kernels read the roll from device memory (captured graphs)
+            if band_out is not None:
+                raise ValueError("device-resident shifts are not available for the band form")
+            shift_dev, shifts = ptr(shifts.dev), shifts.host
         sy, sx = (0, 0) if shifts is None else shifts
         if band_out is not None:
             if grad is not None or argmax_out is not None:
@@ -372,7 +387,7 @@ class GmmHandle:
             _hip.lib().jd_gmm_prior_fwd_bwd(
                 self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(patch_rows[0]), int(patch_rows[1]),
                 int(bool(marginalize)), c_float(value_scale), ptr(value_out), int(accumulate_value),
-                c_float(grad_coef), ptr(grad), ptr(argmax_out), stream_ptr(flux.device),
+                c_float(grad_coef), ptr(grad), ptr(argmax_out), shift_dev, stream_ptr(flux.device),
             )
         )
 
@@ -383,11 +398,15 @@ class GmmHandle:
         support it (stride < 4): the caller then evaluates the prior and steps separately."""
         flux = require_hip_tensor(flux, "flux")
         H, W = flux.shape[-2:]
+        shift_dev = None
+        if isinstance(shifts, DeviceShifts):
+            shift_dev, shifts = ptr(shifts.dev), shifts.host
         sy, sx = (0, 0) if shifts is None else shifts
         check(
             _hip.lib().jd_gmm_prior_fwd_bwd_step(
                 self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(bool(marginalize)), c_float(value_scale),
-                ptr(value_out), int(accumulate_value), c_float(grad_coef), ctypes.byref(step), stream_ptr(flux.device),
+                ptr(value_out), int(accumulate_value), c_float(grad_coef), ctypes.byref(step), shift_dev,
+                stream_ptr(flux.device),
             )
         )
 

@@ -67,7 +67,7 @@ def test_argument_validation_reports_errors(lib):
     assert lib.jd_gmm_create(4, 16, fp, fp, fp, fp, ctypes.byref(handle)) == -1
     assert b"D = 64" in lib.jd_last_error()
     assert lib.jd_poisson_nll(None, None, 0, 0.0, 1e-25, None, None, None) == -1
-    assert lib.jd_adam_step(None, None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, None) == -1
+    assert lib.jd_adam_step(None, None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, None, None) == -1
     assert lib.jd_elementwise_prior_fwd_bwd(7, None, 0, 0, 0, 0, None, 0, None, None) == -1
     assert lib.jd_profile_enable(0) == -1
     total, count = ctypes.c_double(), ctypes.c_longlong()

@@ -256,7 +256,7 @@ def test_adam_step_matches_torch_optim():
         grad = torch.from_numpy(g).to(DEV)
         ss, b2 = adam_bias_terms(step, 0.1, 0.9, 0.999)
         check(_hip.lib().jd_adam_step(ptr(theta), ptr(flux), ptr(flux2), ptr(grad), ptr(m), ptr(v), None, n, ss, 0.9,
-                                      0.999, 1 - 0.9, 1 - 0.999, b2, 1e-8, 1, 1, stream_ptr()))
+                                      0.999, 1 - 0.9, 1 - 0.999, b2, 1e-8, 1, 1, None, stream_ptr()))
         flux, flux2 = flux2, flux
         assert float(grad.abs().max()) == 0.0
         np.testing.assert_allclose(theta.cpu().numpy(), ref_p.detach().numpy(), rtol=2e-6, atol=2e-6)
@@ -1135,13 +1135,13 @@ def test_adam_step_multi_equals_the_single_tensor_steps_bit_for_bit():
             terms[i] = adam_bias_terms(steps[i], lr, beta1, beta2)
         for i in active:
             check(_hip.lib().jd_adam_step(ptr(ta[i]), ptr(ta[i]), ptr(ta[i]), ptr(grads[i]), ptr(ma[i]), ptr(va[i]), None, sizes[i],
-                                          terms[i][0], beta1, beta2, 1 - beta1, 1 - beta2, terms[i][1], eps, 0, 0, stream_ptr(ta[i].device)))
+                                          terms[i][0], beta1, beta2, 1 - beta1, 1 - beta2, terms[i][1], eps, 0, 0, None, stream_ptr(ta[i].device)))
         n = len(active)
         check(_hip.lib().jd_adam_step_multi(
             n, ptr_array([tb[i] for i in active]), ptr_array([grads[i] for i in active]), ptr_array([mb[i] for i in active]),
             ptr_array([vb[i] for i in active]), (ctypes.c_int * n)(*[sizes[i] for i in active]),
             (ctypes.c_float * n)(*[terms[i][0] for i in active]), (ctypes.c_float * n)(*[terms[i][1] for i in active]),
-            beta1, beta2, 1 - beta1, 1 - beta2, eps, stream_ptr(tb[0].device)))
+            beta1, beta2, 1 - beta1, 1 - beta2, eps, None, stream_ptr(tb[0].device)))
     torch.cuda.synchronize()
     for i in range(len(sizes)):
         np.testing.assert_array_equal(ta[i].cpu().numpy(), tb[i].cpu().numpy())
