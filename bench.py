@@ -589,6 +589,17 @@ def main():
     prof = profile_phase(session, device, n_obs)
     comm_ms = session.comm_times_ms() if world > 1 else None
     session.comm_events = None
+    # the shader clock INSIDE the screen kernel (round-4 verdict item 6): an untimed phase on the stamped instantiation of
+    # the kernel (jd_gmm_screen_clock) -- s_memtime / s_memrealtime ticks of up to 4096 blocks per launch
+    screen_clock = None
+    handles = [p.gmm.handle(device) for p in session.priors if hasattr(p, "gmm")]
+    if handles and world == 1 and args.shard_of <= 1:
+        handles[0].screen_clock()  # arms the handle
+        session.reset_graphs()
+        for _ in range(max(args.warmup, 8)):
+            session.epoch()
+        mhz, samples = handles[0].screen_clock()
+        screen_clock = {"mhz": mhz, "blocks_sampled": samples} if samples else None
 
     # sanity: the fit must have produced finite numbers
     if not np.all(np.isfinite(scal)):
@@ -638,6 +649,12 @@ def main():
             "algorithmic_fp32_flop": gmm_flop,
             "algorithmic_fp32_equivalent_tflops": gmm_flop / (gmm_ms * 1e-3) / 1e12,
             "traffic_source": pmc_traffic_source("gmm_screen_kernel"),
+            # `frac` prices the kernel against the roof at the NOMINAL 2400 MHz; the board does not hold that clock inside
+            # this kernel (power): in_kernel_clock_mhz is what its own blocks measured (s_memtime against the 100 MHz
+            # reference clock, jd_gmm_screen_clock), frac_at_in_kernel_clock the fraction of the roof at THAT clock
+            "in_kernel_clock_mhz": screen_clock["mhz"] if screen_clock else None,
+            "in_kernel_clock_blocks_sampled": screen_clock["blocks_sampled"] if screen_clock else None,
+            "frac_at_in_kernel_clock": (achieved / (F16_MATRIX_PEAK_TFLOPS * screen_clock["mhz"] / 2400.0)) if screen_clock else None,
             "note": "results are bit-identical to the fp32 MFMA kernel; the fp16 product only decides which "
                     "components can NOT be the arg-max; gmm_exact also writes the gradient rows of the survivors "
                     "(the backward pass of the arg-max prior has no kernel of its own)",

@@ -310,6 +310,12 @@ int jd_gmm_prior_fwd_bwd_step(jd_gmm* gmm, const float* flux, int H, int W, int 
  * slots its surviving records used, patches it covered, gradient rows per patch the record buffer has room for now}.
  * The library uses the same numbers to double that room (4 -> 32) after a pass that ran out of it. */
 int jd_gmm_screen_stats(const jd_gmm* gmm, int* out);
+/* The shader clock the board holds INSIDE the screen kernel (a measurement tool of bench.py: the matrix roof the kernel
+ * is priced against scales with it).  The first call arms the handle: its default screen launch then runs an instantiation
+ * whose blocks leave s_memtime / s_memrealtime tick counts between their first and last instruction.  Later calls
+ * synchronise the device, return the mean of 100 MHz x (shader ticks / reference ticks) over the blocks stamped since the
+ * previous call (samples_out of them, at most 4096 per launch) and clear the stamps. */
+int jd_gmm_screen_clock(jd_gmm* gmm, double* mhz_out, int* samples_out);
 
 /* The same evaluation for ONE RANK OF A SHARDED PRIOR (joint fit over several GPUs; the
  * reference has no distributed code): instead of accumulating into the gradient image, the gradient of the shard's

@@ -382,8 +382,8 @@ def _adam_step_many(cfg, items, cache, bias_dev=None):
     todo = []
     for p, st in items:
         if p.grad is None:
-            if bias_dev is not None:
-                raise RuntimeError("planned epoch: a calibration parameter without a gradient")
+            if bias_dev is not None:  # (the plan listed the parameters that had a gradient after the previous epoch)
+                raise RuntimeError("planned epoch: a calibration parameter lost its gradient between two epochs")
             continue
         st["step"] += 1
         todo.append((p, st, adam_bias_terms(st["step"], lr, beta1, beta2)))
@@ -464,7 +464,8 @@ class StepScalars:
         self.host = torch.zeros((self.RING, n), dtype=torch.int32).pin_memory()
         self.host_i = self.host.numpy()
         self.host_f = self.host.view(torch.float32).numpy()
-        self.events = [None] * self.RING
+        self.events = [torch.cuda.Event() for _ in range(self.RING)]
+        self.used = [False] * self.RING
         self.slot = 0
         self.shift_slots = [self.dev[2 * k : 2 * k + 2] for k in range(n_shift)]
         self.bias_slots = [self.dev_f[2 * (n_shift + k) : 2 * (n_shift + k) + 2] for k in range(n_bias)]
@@ -476,7 +477,7 @@ class StepScalars:
     def upload(self, shifts, biases):
         """shifts: [(y, x)] residues per slot; biases: [(step_size, bias2_sqrt)] per slot -> device (asynchronous)."""
         slot = self.slot
-        if self.events[slot] is not None:
+        if self.used[slot]:
             self.events[slot].synchronize()
         if shifts:
             self.host_i[slot, : 2 * len(shifts)] = np.asarray(shifts, dtype=np.int32).reshape(-1)
@@ -484,9 +485,8 @@ class StepScalars:
             base = 2 * self.n_shift
             self.host_f[slot, base : base + 2 * len(biases)] = np.asarray(biases, dtype=np.float32).reshape(-1)
         self.dev.copy_(self.host[slot], non_blocking=True)
-        event = torch.cuda.Event()
-        event.record()
-        self.events[slot] = event
+        self.events[slot].record()
+        self.used[slot] = True
         self.slot = (slot + 1) % self.RING
 
 
@@ -614,6 +614,7 @@ class FitSession:
         self.step_scalars = None
         self._graphs = {}
         self._epochs_done = 0
+        self._total_epochs = 0
         self._planned_ok = os.environ.get("JOLIDECO_STEP_SCALARS", "device") != "host"
 
     def gather_calibrations(self):
@@ -791,7 +792,10 @@ class FitSession:
                 and cfg.optimizer_type in ("adam", "sgd"))
 
     def _plan_slots(self):
-        """How many shift / bias slots an epoch needs, and the calibration steppers of every optimizer step."""
+        """Shift / bias slots of an epoch (fixed for the session) and the calibration steppers of every optimizer step."""
+        cached = getattr(self, "_plan_slots_cache", None)
+        if cached is not None:
+            return cached
         drawing = [ci for ci, prior in enumerate(self.priors) if hasattr(prior, "draw_shifts")]
         n_local = len(self.local_idx)
         if self.joint:
@@ -803,12 +807,15 @@ class FitSession:
             cal_groups = [[self.cal_optimizers[li]] if self.cal_optimizers[li] is not None else [] for _, li in self.local_idx]
             n_flux = n_local
         n_cal = sum(len(opt.params) for group in cal_groups for opt in group)
-        return drawing, n_shift, n_flux, cal_groups, n_cal
+        self._plan_slots_cache = (drawing, n_shift, n_flux, cal_groups, n_cal)
+        return self._plan_slots_cache
 
     def _plan_epoch(self):
         """Host side of an epoch: draw the cycle-spin shifts of every prior evaluation IN THE ORDER the evaluations run
         (the generators advance exactly as in the by-value path), compute the bias terms of every optimizer step, and
-        send both to the device.  Returns the plan the launches read: DeviceShifts per (step, prior), bias slots."""
+        send both to the device.  Returns the plan the launches read: DeviceShifts per (step, prior), bias slots, and per
+        optimizer step the calibration parameters that take it -- those that had a gradient after the previous epoch (a
+        shift that is exactly zero never gets one: jolideco/models/npred.py:225-232; torch.optim.Adam skips it)."""
         from .ops import DeviceShifts
 
         cfg = self.cfg
@@ -821,30 +828,42 @@ class FitSession:
         adam = cfg.optimizer_type == "adam"
         n_eval = 1 if self.joint else len(self.local_idx) + 1
         shifts_host, shifts = [], []
-        for _ in range(n_eval):
-            row = {}
-            for ci in drawing:
-                prior, (H, W) = self.priors[ci], self.states[ci].shape
-                drawn = prior.draw_shifts()
+        if len(drawing) == 1:  # one drawing prior: all draws of the epoch in one call (same numbers, same generator state)
+            ci = drawing[0]
+            prior, (H, W) = self.priors[ci], self.states[ci].shape
+            for drawn in prior.draw_shifts_many(n_eval):
                 if drawn is None:
-                    row[ci] = None
+                    shifts.append({ci: None})
                     shifts_host.append((0, 0))
                 else:
-                    row[ci] = DeviceShifts(sc.shift_slots[len(shifts_host)], drawn)
+                    shifts.append({ci: DeviceShifts(sc.shift_slots[len(shifts_host)], drawn)})
                     shifts_host.append((drawn[0] % H, drawn[1] % W))
-            shifts.append(row)
+        else:
+            for _ in range(n_eval):
+                row = {}
+                for ci in drawing:
+                    prior, (H, W) = self.priors[ci], self.states[ci].shape
+                    drawn = prior.draw_shifts()
+                    if drawn is None:
+                        row[ci] = None
+                        shifts_host.append((0, 0))
+                    else:
+                        row[ci] = DeviceShifts(sc.shift_slots[len(shifts_host)], drawn)
+                        shifts_host.append((drawn[0] % H, drawn[1] % W))
+                shifts.append(row)
         biases = [adam_bias_terms(self.step + j + 1, lr, beta1, beta2) if adam else (0.0, 1.0) for j in range(n_flux)]
         flux_bias = [sc.bias_slots[j] if adam else None for j in range(n_flux)]
-        cal_bias, k = [], n_flux
+        cal_bias, cal_items, k = [], [], n_flux
         for group in cal_groups:
-            n = sum(len(opt.params) for opt in group)
-            for opt in group:
-                for st in opt.state:
-                    biases.append(adam_bias_terms(st["step"] + 1, lr, beta1, beta2) if adam else (0.0, 1.0))
-            cal_bias.append(sc.bias_range(k, n) if (adam and n) else None)
-            k += n
+            items = [(p, st) for opt in group for p, st in zip(opt.params, opt.state) if p.grad is not None]
+            for _, st in items:
+                biases.append(adam_bias_terms(st["step"] + 1, lr, beta1, beta2) if adam else (0.0, 1.0))
+            cal_bias.append(sc.bias_range(k, len(items)) if (adam and items) else None)
+            cal_items.append(items)
+            k += len(items)
         sc.upload(shifts_host, biases)
-        return {"shifts": shifts, "flux_bias": flux_bias, "cal_bias": cal_bias, "cal_groups": cal_groups, "n_steps": n_flux}
+        return {"shifts": shifts, "flux_bias": flux_bias, "cal_bias": cal_bias, "cal_items": cal_items, "n_steps": n_flux,
+                "signature": tuple(len(items) for items in cal_items)}
 
     def _commit_replay(self, plan):
         """The host state an eagerly enqueued epoch leaves behind, after a REPLAYED one: step counts, flux buffer parity."""
@@ -852,22 +871,20 @@ class FitSession:
         if plan["n_steps"] % 2:
             for st in self.states:
                 st.cur = 1 - st.cur
-        for group in plan["cal_groups"]:
-            for opt in group:
-                for st in opt.state:
-                    st["step"] += 1
+        for items in plan["cal_items"]:
+            for _, st in items:
+                st["step"] += 1
 
     def _epoch_planned(self):
         plan = self._plan_epoch()
-        parity = tuple(st.cur for st in self.states)
+        parity = tuple(st.cur for st in self.states) + plan["signature"]
         graph = self._graphs.get(parity) if self.use_graph else None
         if graph is not None:
             graph.replay()
             self._commit_replay(plan)
         elif self.use_graph and self._epochs_done >= self.GRAPH_WARMUP and not _hip.profile_active():
             # capture this epoch's launches (nothing runs during the capture), then run them
-            snapshot = (self.step, [st.cur for st in self.states],
-                        [[s["step"] for s in opt.state] for group in plan["cal_groups"] for opt in group])
+            snapshot = (self.step, [st.cur for st in self.states], [[st["step"] for _, st in items] for items in plan["cal_items"]])
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph):
@@ -880,11 +897,9 @@ class FitSession:
                 self.step = snapshot[0]
                 for st, cur in zip(self.states, snapshot[1]):
                     st.cur = cur
-                steps = iter(snapshot[2])
-                for group in plan["cal_groups"]:
-                    for opt in group:
-                        for s, value in zip(opt.state, next(steps)):
-                            s["step"] = value
+                for items, values in zip(plan["cal_items"], snapshot[2]):
+                    for (_, st), value in zip(items, values):
+                        st["step"] = value
                 torch.cuda.synchronize()
                 self._enqueue_epoch(plan)
             else:
@@ -912,14 +927,16 @@ class FitSession:
                 for st in states:
                     st.bias_dev = None
 
-        def cal_steps(group, bias):
-            if not group:
+        def cal_steps(items, bias):
+            if not items:
                 return
             if cfg.optimizer_type != "adam":
-                for opt in group:
-                    opt.step()
+                lr = cfg.optimizer_kwargs["lr"]
+                for p, st in items:
+                    st["step"] += 1
+                    check(_hip.lib().jd_sgd_step(ptr(p.data), ptr(p.data), ptr(p.data), ptr(p.grad), None, p.numel(), lr, 0, 0,
+                                                 stream_ptr(p.device)))
                 return
-            items = [(p, st) for opt in group for p, st in zip(opt.params, opt.state)]
             _adam_step_many(cfg, items, self.__dict__.setdefault("_cal_step_cache", {}), bias)
 
         def priors_and_step(j, coef, shifts):
@@ -961,7 +978,7 @@ class FitSession:
                 for g in grads:
                     g.zero_()
             priors_and_step(0, beta, plan["shifts"][0])
-            cal_steps(plan["cal_groups"][0], plan["cal_bias"][0])
+            cal_steps(plan["cal_items"][0], plan["cal_bias"][0])
         else:
             coef = beta / total_loss.prior_weight
             for j, (gslot, li) in enumerate(self.local_idx):
@@ -970,7 +987,7 @@ class FitSession:
                 self._cal_zero_grad(li)
                 total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
                 priors_and_step(j, coef, plan["shifts"][j])
-                cal_steps(plan["cal_groups"][j], plan["cal_bias"][j])
+                cal_steps(plan["cal_items"][j], plan["cal_bias"][j])
             stale = [st.flux_trace for st in states]
             if self.batch_trace:
                 total_loss.poisson_loss.fwd_bwd_batch(
@@ -990,8 +1007,11 @@ class FitSession:
         from a captured hipGraph once warm) where `_planned_capable` holds, else the by-value form."""
         if getattr(self, "_option_generation", None) != _hip.OPTION_GENERATION:
             self.reset_graphs()
-        if self._planned_capable() and not _hip.profile_active():
+        # (the first epoch runs by value: it shows which calibration parameters receive a gradient at all)
+        if self._total_epochs > 0 and self._planned_capable() and not _hip.profile_active():
+            self._total_epochs += 1
             return self._epoch_planned()
+        self._total_epochs += 1
         if self._graphs:
             self.reset_graphs()
         return self._epoch_by_value()

@@ -410,6 +410,13 @@ class GmmHandle:
             )
         )
 
+    def screen_clock(self):
+        """(MHz, samples): the shader clock inside the screen kernel since the last call (jd_gmm_screen_clock; the first call
+        arms the handle and returns (0.0, 0); synchronises the device)."""
+        mhz, samples = ctypes.c_double(0.0), c_int(0)
+        check(_hip.lib().jd_gmm_screen_clock(self._handle, ctypes.byref(mhz), ctypes.byref(samples)))
+        return float(mhz.value), int(samples.value)
+
     def screen_stats(self):
         """(generation, fell_back, bucket_slots, patches, rows_per_patch) of the last screened pass that has finished
         (jd_gmm_screen_stats; no synchronisation)."""

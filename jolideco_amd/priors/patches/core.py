@@ -4,7 +4,7 @@ import logging
 import torch
 
 from ...utils.norms import IdentityImageNorm, ImageNorm, PatchNorm, SubtractMeanPatchNorm
-from ...utils.torch import TORCH_DEFAULT_DEVICE, cycle_spin_shifts, get_default_generator
+from ...utils.torch import TORCH_DEFAULT_DEVICE, cycle_spin_shifts, cycle_spin_shifts_many, get_default_generator
 from ..core import Prior
 from .gmm import GaussianMixtureModel
 
@@ -83,6 +83,15 @@ class GMMPatchPrior(Prior):
         """One pair of cycle-spin draws (None when cycle_spin is off)."""
         shifts = cycle_spin_shifts(self.patch_shape, self.generator) if self.cycle_spin else None
         self.last_shifts = shifts
+        return shifts
+
+    def draw_shifts_many(self, n):
+        """The next `n` pairs of cycle-spin draws, in order (an epoch's worth, `FitSession._plan_epoch`)."""
+        if not self.cycle_spin:
+            self.last_shifts = None
+            return [None] * n
+        shifts = cycle_spin_shifts_many(self.patch_shape, self.generator, n)
+        self.last_shifts = shifts[-1]
         return shifts
 
     def __call__(self, flux, mask=None):

@@ -48,6 +48,17 @@ def cycle_spin_shifts(patch_shape, generator):
     return int(first), int(second)
 
 
+def cycle_spin_shifts_many(patch_shape, generator, n):
+    """`n` consecutive draws of `cycle_spin_shifts`, in one `randint` call where both directions share a range (square
+    patches): the CPU generator hands out one number per element in order, so `randint(size=(2 n,))` returns the numbers of
+    2 n single draws and leaves the generator in the same state (tests/test_host_logic.py holds torch to that)."""
+    wy, wx = patch_shape[0] // 4, patch_shape[1] // 4
+    if wy != wx or n > 4096:
+        return [cycle_spin_shifts(patch_shape, generator) for _ in range(n)]
+    values = torch.randint(-wy, wy + 1, (2 * n,), generator=generator).tolist()
+    return [(values[2 * i], values[2 * i + 1]) for i in range(n)]
+
+
 def cycle_spin(image, patch_shape, generator):
     """Rolled copy of ``image`` (jolideco/utils/torch.py:91-119).  The accelerated prior never
     materialises this: the roll is folded into the kernel's addressing."""

@@ -49,6 +49,26 @@ def test_cycle_spin_shift_draws_follow_the_reference_order(golden):
     assert np.array_equal(mine, golden("rng_draws")["shifts"])
 
 
+def test_an_epoch_worth_of_cycle_spin_draws_is_the_same_as_single_draws(golden):
+    """`cycle_spin_shifts_many` (planned epochs draw all shifts of an epoch at once): the reference's draw sequence -- the
+    live-reference fixture -- and the generator left in the state n single draws leave it in, for every batch size."""
+    import torch
+
+    from jolideco_amd.utils.torch import cycle_spin_shifts, cycle_spin_shifts_many, get_default_generator
+
+    gen = get_default_generator("cpu")
+    many = cycle_spin_shifts_many((8, 8), gen, 32)
+    assert np.array_equal(np.array(many), golden("rng_draws")["shifts"])
+    for n in (1, 2, 7, 16, 25, 64, 501):
+        a, b = torch.Generator().manual_seed(n), torch.Generator().manual_seed(n)
+        single = [cycle_spin_shifts((8, 8), a) for _ in range(n)]
+        assert cycle_spin_shifts_many((8, 8), b, n) == single
+        assert torch.equal(a.get_state(), b.get_state())
+    # patches that are not square draw from two ranges: single draws
+    a, b = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
+    assert cycle_spin_shifts_many((8, 16), b, 5) == [cycle_spin_shifts((8, 16), a) for _ in range(5)]
+
+
 def test_adam_scalars_match_torch():
     """step_size / sqrt(bias2) as torch.optim.Adam computes them in python floats."""
     from jolideco_amd.ops import adam_bias_terms
