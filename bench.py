@@ -58,6 +58,9 @@ CONFIGS = {
     "c3": (2048, 2048, 8, 128),
     "c4": (4096, 4096, 1, 128),
     "c5": (2048, 2048, 16, 128),  # two flux components: "extended" (GMM prior) + "points" (inverse-gamma prior)
+    # c3's workload on an image with an odd number of rows and a width that is no multiple of 4 (side run `odd_size_fft`:
+    # until round 5 such sizes left the native FFT path for un-batched rocFFT plans)
+    "c3odd": (2047, 2050, 8, 128),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector rate
@@ -177,11 +180,12 @@ def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), 
     """Time config c6 (see `build_session_c6`): it/s, the per-kernel table and `roofline_c6` (the six launches of one
     observation's likelihood step against the HBM roof)."""
     session = build_session_c6(device, shape=shape, n_obs=n_obs)
-    for _ in range(warmup):
+    for _ in range(max(warmup, 10)):  # (incl. the "auto" policy's probe epochs)
         session.epoch()
     torch.cuda.synchronize(device)
     stats = region_stats(timed_regions(session, steps, repeats, device, dist_ctx), steps)
     host_ms = 1e3 * float(np.median(HOST_ENQUEUE[-1])) / steps
+    replayed = bool(getattr(session, "_graphs", None))
     prof = profile_phase(session, device, n_obs, steps=4)
     nested = ("gmm_stage", "gmm_screen", "gmm_sort", "gmm_exact")
     models = session.total_loss.poisson_loss.npred_models_all
@@ -201,6 +205,7 @@ def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), 
         # the calibrated batched entry (jd_npred_poisson_calibrated_batch_fwd_bwd) is called; beyond 2048 flux rows the
         # library runs its per-dataset launches (measured faster there)
         "batched_calibrated_entry": bool(getattr(session, "batch_joint_calibrated", False)),
+        "graph_policy": getattr(session, "graph_policy", None), "epochs_replayed_from_graphs": replayed,
         "kernel_ms_per_step": {k: v[0] / 4 for k, v in prof.items() if v[1] and k not in nested},
         "launches_per_step": {k: v[1] / 4 for k, v in prof.items() if v[1] and k not in nested},
     }
@@ -250,7 +255,7 @@ def e0102_run(device, n_epochs=250, shape=(256, 256), n_obs=24, psf_shape=(128, 
     comp, calibrations = build()
     session = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="sequential").session(
         datasets, components=comp, calibrations=calibrations)
-    for _ in range(6):
+    for _ in range(16):  # (the "auto" policy's probe epochs, then warm-up and capture)
         session.epoch()
     torch.cuda.synchronize(device)
     gc.collect()
@@ -278,7 +283,7 @@ def e0102_run(device, n_epochs=250, shape=(256, 256), n_obs=24, psf_shape=(128, 
         "reference_runtime": "about 30 min on an M1 cpu (examples/chandra-e0102-filament.py:216-222; real data, other hardware: "
                              "quoted for scale, not a measured baseline)",
         "epoch_ms": 1e3 * t_epoch, "host_enqueue_ms_per_step": 1e3 * t_enq / (n * n_obs),
-        "epochs_replayed_from_graphs": bool(session._graphs),
+        "epochs_replayed_from_graphs": bool(session._graphs), "graph_policy": session.graph_policy,
         "check": {"total_first": float(totals[0]), "total_last": float(totals[-1]), "decreasing": bool(totals[-1] < totals[0])},
     }
 
@@ -445,7 +450,11 @@ def settle(session, device, dist_ctx, seconds=SETTLE_SECONDS, chunk=20):
     return {"seconds": time.perf_counter() - t0, "steps": n}
 
 
-HOST_ENQUEUE = []  # per call of timed_regions: seconds the host took to enqueue each region (MAX over the ranks)
+HOST_ENQUEUE = []  # per call of timed_regions: seconds the host needs to enqueue a region's steps (MAX over the ranks)
+# The host's own cost of a step is measured on the first steps of a region, issued into an EMPTY queue: once a few dozen
+# captured epochs are in flight hipGraphLaunch waits for the device, and the time until "everything is enqueued" becomes
+# the device's time (200 replayed steps: 0.44 ms per step "to enqueue" against 0.04 for the first 16).
+ENQUEUE_BURST = 16
 
 
 def timed_regions(session, steps, repeats, device, dist_ctx):
@@ -462,14 +471,17 @@ def timed_regions(session, steps, repeats, device, dist_ctx):
             dist_ctx.barrier()
             torch.cuda.synchronize(device)
             t0 = time.perf_counter()
-            for _ in range(steps):
+            burst = min(steps, ENQUEUE_BURST)
+            for _ in range(burst):
                 session.epoch()
-            t_enqueued = time.perf_counter()  # the host has issued every launch and collective of the region
+            t_enqueued = time.perf_counter()  # the host has issued the first `burst` steps into an empty queue
+            for _ in range(steps - burst):
+                session.epoch()
             torch.cuda.synchronize(device)
             dist_ctx.barrier()
             torch.cuda.synchronize(device)
             times.append(time.perf_counter() - t0)
-            enqueue.append(t_enqueued - t0)
+            enqueue.append((t_enqueued - t0) * steps / burst)  # (scaled to the region: callers divide by `steps`)
     finally:
         gc.enable()
     if dist_ctx.world_size > 1:
@@ -505,7 +517,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=9, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--settle-seconds", type=float, default=SETTLE_SECONDS,
                     help="steps run for at least this long between the warm-up and the timed regions (0: none)")
-    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c6", "e0102"])
+    ap.add_argument("--config", default="c3", choices=sorted(c for c in CONFIGS if c != "c3odd") + ["c6", "e0102"])
     ap.add_argument("--epochs", type=int, default=250, help="--config e0102: epochs of the sequential fit")
     ap.add_argument("--no-c6", action="store_true", help="skip the c6 side run (calibrations + up-sampling + general 65x65 PSFs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -576,6 +588,7 @@ def main():
     times = timed_regions(session, args.steps, max(args.repeats, 1), device, dist_ctx)
     stats = region_stats(times, args.steps)
     host_enqueue_ms = 1e3 * float(np.median(HOST_ENQUEUE[-1])) / args.steps
+    replayed, graph_policy = bool(getattr(session, "_graphs", None)), getattr(session, "graph_policy", None)
     elapsed = args.steps / stats["value"]  # the median region
     log(f"timed regions done: {stats['ms_per_step']:.4f} ms/step (median of {len(times)}; "
         f"{stats['ms_per_step_min']:.4f} .. {stats['ms_per_step_max']:.4f})")
@@ -758,13 +771,16 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "ms_per_step_min": stats["ms_per_step_min"], "ms_per_step_max": stats["ms_per_step_max"],
-        # time the HOST needs to issue one step (python + ctypes + hipLaunch, and at N > 1 the torch.distributed calls):
-        # from the start of a timed region until its last step has been enqueued, before the synchronisation; median
-        # region, MAX over the ranks.  A step cannot be faster than this: where it approaches ms_per_step the run is
-        # host bound (tools/hosttime.py's method)
+        # time the HOST needs to issue one step (python + ctypes + hipLaunch / hipGraphLaunch, and at N > 1 the
+        # torch.distributed calls): over the first ENQUEUE_BURST steps of a timed region, issued into an empty queue;
+        # median region, MAX over the ranks.  A step cannot be faster than this: where it approaches ms_per_step the run
+        # is host bound
         "host_enqueue_ms_per_step": host_enqueue_ms,
         # the timed steps were replayed from captured hipGraphs (device-resident step scalars, jolideco_amd/core.py)
-        "epochs_replayed_from_graphs": bool(getattr(session, "_graphs", None)),
+        "epochs_replayed_from_graphs": replayed,
+        # what the session's "auto" policy decided after its probe epochs (jolideco_amd/core.py: captured epochs only
+        # where the host bounds the fit)
+        "graph_policy": graph_policy,
         "repeats": len(times), "timing": "median of `repeats` regions of `steps` steps, each bracketed by barrier + synchronize",
         "settle": settled,
         "clock_mhz": clock_mhz,
@@ -943,6 +959,43 @@ def main():
                 "launch_ms_per_step": {name: k.get(name) for name in ("fft_r2c", "cmul", "poisson_fused", "fft_c2r")},
                 "note": "PMC traffic of these kernels: profiles/r04/pmc_hbm_traffic.csv rows c3fft",
             }
+    if world == 1 and fake is None and args.config == "c3" and not args.no_general_psf:
+        # any image size takes the native FFT path since round 5 (odd H: a lower half one row short; W % 4 != 0: rows at
+        # 4-byte alignment): c3's workload at 2047 x 2050 through the FFT path, native against rocFFT (JD_FFT_NATIVE=0:
+        # the fallback such sizes took until round 4 -- un-batched plans, one observation after the other)
+        log("odd-size FFT run (2047 x 2050)")
+        odd = {}
+        previous = os.environ.get("JOLIDECO_CONV_METHOD")
+        os.environ["JOLIDECO_CONV_METHOD"] = "fft"
+        try:
+            from jolideco_amd.ops import ConvPlan
+
+            for label, native in (("native", None), ("rocfft", 0)):
+                # (plans are cached by geometry and the switch is read when a plan is created: a cache of its own per run;
+                # the plans of the sessions that are still alive stay where they are)
+                saved_cache, ConvPlan._cache = ConvPlan._cache, {}
+                with _hip.options(JD_FFT_NATIVE=native):
+                    other = build_session("c3odd", device)
+                    for _ in range(max(args.warmup, 6)):
+                        other.epoch()
+                    torch.cuda.synchronize(device)
+                    side = region_stats(timed_regions(other, args.steps, side_repeats, device, dist_ctx), args.steps)
+                    plans = {m.plan for mm in other.total_loss.poisson_loss.npred_models_all for m in mm.values()}
+                    odd[label] = {"value": side["value"], "unit": "iters/s", "ms_per_step": side["ms_per_step"],
+                                  "native_fft": all(bool(p.native_fft) for p in plans), "batched_joint_step": bool(other.batch_joint)}
+                    del other, plans
+                gc.collect()
+                for plan in ConvPlan._cache.values():
+                    plan.close()
+                ConvPlan._cache = saved_cache
+                torch.cuda.empty_cache()
+        finally:
+            if previous is None:
+                os.environ.pop("JOLIDECO_CONV_METHOD", None)
+            else:
+                os.environ["JOLIDECO_CONV_METHOD"] = previous
+        odd["workload"] = "c3's observations and prior on a 2047 x 2050 image (odd rows, width % 4 == 2), JOLIDECO_CONV_METHOD=fft"
+        out["odd_size_fft"] = odd
     # The same fit with the GMM arg-max evaluated by the dense fp32 MFMA kernel for every (patch, component) pair
     # (JD_GMM_SCREEN=0; bit-identical results): reported next to the headline for whoever wants the number without the
     # fp16 screen.
@@ -974,6 +1027,31 @@ def main():
                     "evaluation of every observation per epoch",
         }
         del seq
+    if world == 1 and fake is None and not args.no_general_psf:
+        # the same steps REPLAYED from captured hipGraphs (JOLIDECO_GRAPH=1; device-resident step scalars): what the host
+        # then pays per step, and what the device pays for the replay
+        log("graph-replay run (JOLIDECO_GRAPH=1)")
+        previous = os.environ.get("JOLIDECO_GRAPH")
+        os.environ["JOLIDECO_GRAPH"] = "1"
+        try:
+            other = build_session(args.config, device, fit_mode="sequential" if args.config == "c1" else "joint")
+            for _ in range(max(args.warmup, 10)):
+                other.epoch()
+            torch.cuda.synchronize(device)
+            side = region_stats(timed_regions(other, args.steps, side_repeats, device, dist_ctx), args.steps)
+            out["graph_replay"] = {
+                "value": side["value"], "unit": "iters/s", "ms_per_step": side["ms_per_step"],
+                "host_enqueue_ms_per_step": 1e3 * float(np.median(HOST_ENQUEUE[-1])) / args.steps,
+                "epochs_replayed_from_graphs": bool(other._graphs),
+                "note": "same workload, every epoch replayed from a captured hipGraph (the default policy captures only fits the "
+                        "host bounds)",
+            }
+            del other
+        finally:
+            if previous is None:
+                os.environ.pop("JOLIDECO_GRAPH", None)
+            else:
+                os.environ["JOLIDECO_GRAPH"] = previous
     if world == 1 and fake is None and args.config == "c3" and not args.no_general_psf and not args.no_c6:
         log("c6 side run (calibrations + up-sampling x2 + general 65x65 PSFs)")
         del session

@@ -356,6 +356,12 @@ int jd_elementwise_prior_fwd_bwd(int kind, const float* flux, size_t n, float al
  * use_log_flux == 0: flux = theta [* mask] (the parameter is the flux itself, no positivity). */
 int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, int use_log_flux, void* stream);
 
+/* Device-resident step scalars (see jd_gmm_prior_fwd_bwd): dst[0 .. n) <- host_row[0 .. n), read by ONE small block
+ * straight from PINNED host memory (hipHostMalloc'ed, e.g. a torch tensor after pin_memory(): device-accessible) -- the
+ * epoch's shifts and bias terms reach the device without a copy-engine hand-over on the stream.  The caller keeps the row
+ * untouched until the launch has run (jolideco_amd/core.py StepScalars: a ring of rows guarded by events). */
+int jd_step_scalars_fetch(const int32_t* host_row, int32_t* dst, int n, void* stream);
+
 /* One torch.optim.Adam step (jolideco/core.py:39-42,229) on theta with the chain rule of
  * models/core.py:588-592 fused in: g_theta = grad_flux * flux_in.  Writes theta, exp_avg,
  * exp_avg_sq in place, writes flux_out = exp(theta_new) [* mask] (may alias flux_in or be a second

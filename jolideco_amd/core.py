@@ -16,6 +16,7 @@ trace.  Two fit modes:
 All arithmetic of the step runs in libjolideco_hip.so; there is no CPU fallback.
 """
 import copy
+import ctypes
 import os
 import logging
 from pathlib import Path
@@ -462,6 +463,7 @@ class StepScalars:
         self.dev = torch.zeros(n, dtype=torch.int32, device=device)
         self.dev_f = self.dev.view(torch.float32)
         self.host = torch.zeros((self.RING, n), dtype=torch.int32).pin_memory()
+        self.host_ptr, self.row_bytes = self.host.data_ptr(), 4 * n
         self.host_i = self.host.numpy()
         self.host_f = self.host.view(torch.float32).numpy()
         self.events = [torch.cuda.Event() for _ in range(self.RING)]
@@ -484,7 +486,9 @@ class StepScalars:
         if biases:
             base = 2 * self.n_shift
             self.host_f[slot, base : base + 2 * len(biases)] = np.asarray(biases, dtype=np.float32).reshape(-1)
-        self.dev.copy_(self.host[slot], non_blocking=True)
+        # (one small block reads the pinned row over the host link: cheaper on the stream than a copy-engine transfer)
+        check(_hip.lib().jd_step_scalars_fetch(ctypes.c_void_p(self.host_ptr + slot * self.row_bytes), ptr(self.dev),
+                                               self.dev.numel(), stream_ptr(self.dev.device)))
         self.events[slot].record()
         self.used[slot] = True
         self.slot = (slot + 1) % self.RING
@@ -610,7 +614,19 @@ class FitSession:
         # (`StepScalars`), so an epoch's launch arguments never change -- and after `GRAPH_WARMUP` epochs the epoch is
         # captured in a hipGraph per flux-buffer parity and replayed (JOLIDECO_GRAPH=0: planned epochs without capture;
         # JOLIDECO_STEP_SCALARS=host: the by-value form of rounds 1-4 throughout)
-        self.use_graph = os.environ.get("JOLIDECO_GRAPH", "1") != "0" and getattr(deconvolver, "use_graph", True)
+        # JOLIDECO_GRAPH: "1" capture always, "0" never (planned epochs enqueued eagerly), unset / "auto": the first
+        # AUTO_PROBE epochs run by value and are timed -- host time to enqueue an epoch against the device's time for it --,
+        # and only a fit the HOST bounds goes on to planned, captured epochs: a replayed epoch costs the device a few
+        # microseconds more per step than eagerly launched kernels (a fetch of the step scalars, the graph's own
+        # hand-overs: +1.3 % on the 0.62 ms step of the benchmark, +4 % on a 0.26 ms step), which is a loss wherever the
+        # host already keeps the queue full (tools/gpu/small_fits.py, profiles/r05/small_fits.txt)
+        mode = os.environ.get("JOLIDECO_GRAPH", "auto").lower()
+        self.graph_mode = {"1": "always", "on": "always", "0": "never", "off": "never"}.get(mode, "auto")
+        if getattr(deconvolver, "use_graph", None) is not None:
+            self.graph_mode = "always" if deconvolver.use_graph else "never"
+        self.use_graph = self.graph_mode == "always"
+        self.graph_policy = {"always": "captured epochs (forced)", "never": "no capture (forced)"}.get(self.graph_mode, "undecided")
+        self._probe = []  # (host seconds, start event, end event) of the by-value probe epochs
         self.step_scalars = None
         self._graphs = {}
         self._epochs_done = 0
@@ -778,10 +794,12 @@ class FitSession:
 
     def reset_graphs(self):
         """Forget the captured epochs (a library option that changes what an epoch launches was set: `_hip.set_option`
-        bumps `_hip.OPTION_GENERATION`, and `epoch` compares)."""
+        bumps `_hip.OPTION_GENERATION`, and `epoch` compares); the "auto" policy decides anew."""
         self._graphs = {}
         self._epochs_done = 0
         self._option_generation = _hip.OPTION_GENERATION
+        if self.graph_mode == "auto":
+            self.use_graph, self.graph_policy, self._probe = False, "undecided", []
 
     def _planned_capable(self):
         """Planned epochs apply: one process, the session's own optimizer step (a hook sees every gradient through the
@@ -1009,12 +1027,47 @@ class FitSession:
             self.reset_graphs()
         # (the first epoch runs by value: it shows which calibration parameters receive a gradient at all)
         if self._total_epochs > 0 and self._planned_capable() and not _hip.profile_active():
-            self._total_epochs += 1
-            return self._epoch_planned()
+            if self.graph_mode != "auto" or self.use_graph:
+                self._total_epochs += 1
+                return self._epoch_planned()
+            if self.graph_policy == "undecided":
+                return self._epoch_probe()
         self._total_epochs += 1
         if self._graphs:
             self.reset_graphs()
         return self._epoch_by_value()
+
+    AUTO_PROBE = 8  # by-value epochs timed before the "auto" policy decides
+    AUTO_HOST_BOUND = 0.75  # host enqueue time / device time of an epoch beyond which the fit counts as host bound
+
+    def _epoch_probe(self):
+        """A by-value epoch of the "auto" policy's probe phase: timed on the host and, by an event pair, on the device.
+        After AUTO_PROBE of them (one wait for the last event) the session goes on by value (the device bounds the fit: the
+        events are as far apart as the device needs) or to planned, captured epochs (the host bounds it: the device ran
+        every epoch as fast as it was enqueued)."""
+        import time
+
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        t0 = time.perf_counter()
+        self._epoch_by_value()
+        host = time.perf_counter() - t0
+        end.record()
+        self._total_epochs += 1
+        self._probe.append((host, start, end))
+        if len(self._probe) < self.AUTO_PROBE:
+            return
+        end.synchronize()
+        probe = self._probe[2:]  # (the first two still pay for lazy allocations and table uploads)
+        host_s = float(np.median([h for h, _, _ in probe]))
+        device_s = 1e-3 * float(np.median([a.elapsed_time(b) for _, a, b in probe]))
+        ratio = host_s / max(device_s, 1e-9)
+        self._probe = []
+        if ratio > self.AUTO_HOST_BOUND:
+            self.use_graph = True
+            self.graph_policy = f"captured epochs (host bound: enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us per epoch)"
+        else:
+            self.graph_policy = f"by value (device bound: enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us per epoch)"
 
     def _epoch_by_value(self):
         cfg, dist, states, priors, total_loss = self.cfg, self.dist, self.states, self.priors, self.total_loss

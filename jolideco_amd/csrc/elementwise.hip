@@ -594,6 +594,20 @@ extern "C" int jd_flux_from_theta(const float* theta, const float* mask, float* 
   return JD_OK;
 }
 
+// The step scalars of an epoch from a pinned host row (device-accessible: zero-copy reads over the host link) into their
+// device buffer: one small block instead of a hipMemcpyAsync, whose copy engine hand-over costs a stream 6-8 us between two
+// epochs (tools/gpu/small_fits.py).
+__global__ __launch_bounds__(256) void fetch_scalars_kernel(const int* __restrict__ src, int* __restrict__ dst, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+extern "C" int jd_step_scalars_fetch(const int32_t* host_row, int32_t* dst, int n, void* stream) {
+  JD_REQUIRE(host_row && dst && n > 0 && n <= (1 << 20), "jd_step_scalars_fetch: null argument or bad n");
+  fetch_scalars_kernel<<<1, 256, 0, as_stream(stream)>>>(host_row, dst, n);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
 extern "C" int jd_adam_step(float* theta, const float* flux_in, float* flux_out, float* grad_flux,
                             float* exp_avg, float* exp_avg_sq, const float* mask, size_t n, float step_size,
                             float beta1, float beta2, float one_minus_beta1, float one_minus_beta2,

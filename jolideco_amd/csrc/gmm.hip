@@ -2207,14 +2207,22 @@ struct AddBandsArgs {
 
 __global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
   use_device_shift(a);
+  // the band ranges into LDS through COMPILE-TIME indices: indexing the by-value argument arrays with the runtime band number
+  // made the compiler copy the whole argument block to scratch in every thread (584 bytes per lane; the band sum + step of a
+  // 2048^2 image took 147 us instead of 35: round 5, rank share of an 8-way split)
+  __shared__ int s_yb[BANDS_MAX], s_ye[BANDS_MAX];
+#pragma unroll
+  for (int b = 0; b < BANDS_MAX; ++b)
+    if ((int)threadIdx.x == b) s_yb[b] = a.y_begin[b], s_ye[b] = a.y_end[b];
+  __syncthreads();
   const int Y = a.y_lo + blockIdx.y;
   const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (X >= a.W || Y >= a.y_hi) return;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   bool any = false;
   const bool vec = (a.W & 3) == 0 && (a.chunk & 3) == 0;
-  for (int b = 0; b < a.n_bands; ++b) {  // (constant indices would need an unrolled loop: n_bands is small)
-    const int yb = a.y_begin[b], ye = a.y_end[b];
+  for (int b = 0; b < a.n_bands; ++b) {
+    const int yb = s_yb[b], ye = s_ye[b];
     if (Y < yb || Y >= ye) continue;
     const float* row = a.bands + (size_t)b * a.chunk + (size_t)(Y - yb) * a.W + X;
     if (vec) {
@@ -2244,6 +2252,12 @@ __global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
 __global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgs a, AdamArgs st) {
   use_device_shift(a);
   use_device_bias(st);
+  // (band ranges through LDS: see add_rolled_bands_kernel)
+  __shared__ int s_yb[BANDS_MAX], s_ye[BANDS_MAX];
+#pragma unroll
+  for (int b = 0; b < BANDS_MAX; ++b)
+    if ((int)threadIdx.x == b) s_yb[b] = a.y_begin[b], s_ye[b] = a.y_end[b];
+  __syncthreads();
   const int yy = blockIdx.y;
   const int xx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (xx >= a.W) return;
@@ -2254,7 +2268,7 @@ __global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgs
 #pragma unroll
   for (int i = 0; i < 4; ++i) X[i] = wrap(xx + i + a.shift_x, a.W);
   for (int b = 0; b < a.n_bands; ++b) {
-    const int yb = a.y_begin[b], ye = a.y_end[b];
+    const int yb = s_yb[b], ye = s_ye[b];
     if (Y < yb || Y >= ye) continue;
     const float* row = a.bands + (size_t)b * a.chunk + (size_t)(Y - yb) * a.W;
 #pragma unroll

@@ -144,7 +144,7 @@ class ConvPlan:
     @property
     def native_fft(self):
         """True when an "fft" plan runs on the hand-written transforms of csrc/fftnative.hip (no padded grid) instead of
-        rocFFT (sizes 2^a * {1, 3, 9} reach; even H, W % 4 == 0; option JD_FFT_NATIVE=0 switches it off)."""
+        rocFFT (padded sizes 2^a * {1, 3, 9} up to 4608 columns x 2304 row pairs; any H, W since round 5; option JD_FFT_NATIVE=0 switches it off)."""
         return self.method == "fft" and (self.Hp, self.Wp) == (self.H, self.W)
 
     def takes_walk(self, n_datasets=1):

@@ -564,6 +564,13 @@ def test_c6_shaped_calibrated_upsampled_joint_step_1024_4obs(fused, jd_option):
     _check_c6_shaped_step((512, 512), 4, (33, 33), f"1024^2 x 4 (fused={fused})")
 
 
+def test_c6_shaped_calibrated_upsampled_joint_step_ragged_width():
+    """The same step on a flux grid whose width is not a multiple of 4 (counts grid 80 x 97 -> flux grid 160 x 194): rows read
+    and written at 4-byte alignment, the last piece of a counts row holds one pixel of the pooled Poisson pass (round 5:
+    every image size takes the native FFT path and its batched steps)."""
+    _check_c6_shaped_step((80, 97), 3, (33, 33), "160 x 194 flux grid x 3 (ragged width)")
+
+
 @pytest.mark.parametrize("form", ["batched", "per-dataset", "separate-kernels"])
 def test_c6_shaped_calibrated_upsampled_joint_step_4096_columns(form, jd_option):
     """The row kernels bench.py's c6 times (round-4 verdict, weak 1): flux rows of 4096 pixels -> row transforms of length

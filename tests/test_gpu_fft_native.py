@@ -20,7 +20,10 @@ CASES = [((64, 128), (5, 7)), ((200, 328), (17, 17)), ((130, 516), (33, 17)), ((
          # rows of 4096 pixels -> row transforms of length 4608 = 8 * 8 * 8 * 9, the compile-time schedule bench.py's c6 and a
          # 4096^2 FFT fit time (round-4 verdict): on a short image with a wide general PSF, and at full size (rows 4608,
          # columns 2304 = 16 * 16 * 9 on two waves)
-         ((256, 4096), (65, 65)), ((4096, 4096), (17, 17)), ((4096, 4096), (130, 130))]
+         ((256, 4096), (65, 65)), ((4096, 4096), (17, 17)), ((4096, 4096), (130, 130)),
+         # any image size (round 5): an odd number of rows (the lower half of the row pairs is one row short), widths that
+         # are not multiples of 4 (rows read and written at 4-byte alignment, the last piece element by element)
+         ((65, 131), (5, 7)), ((201, 330), (17, 17)), ((127, 513), (33, 17)), ((64, 67), (9, 9)), ((2047, 2050), (33, 33))]
 
 
 def _psf(kshape, seed):
@@ -78,14 +81,15 @@ def test_native_fft_convolution_and_adjoint_match_float64_and_rocfft(jd_option, 
     assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
 
 
-def test_native_fft_fit_matches_the_oracle(monkeypatch):
+@pytest.mark.parametrize("shape", [(96, 132), (97, 131)], ids=["96x132", "97x131-odd-rows-ragged-width"])
+def test_native_fft_fit_matches_the_oracle(monkeypatch, shape):
     """A joint fit through the native FFT path (general PSFs of two sizes, conv_method = fft) against the oracle."""
     from jolideco_amd import MAPDeconvolver, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import synthetic_observations
     from oracle import cpu_ref
 
     monkeypatch.setenv("JOLIDECO_CONV_METHOD", "fft")
-    datasets, _, flux_init = synthetic_observations(shape=(96, 132), n_obs=8, seed=2)
+    datasets, _, flux_init = synthetic_observations(shape=shape, n_obs=8, seed=2)
     comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=UniformPrior())
     deco = MAPDeconvolver(n_epochs=5, display_progress=False, device=DEV, fit_mode="joint")
     session = deco.session(datasets, components=comp)

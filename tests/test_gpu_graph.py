@@ -110,9 +110,10 @@ def test_planned_and_replayed_epochs_equal_the_by_value_epochs_bit_for_bit(monke
     _assert_same(replayed, by_value)
 
 
-def test_run_goes_through_the_graph_and_matches_the_oracle(monkeypatch):
-    """`MAPDeconvolver.run` (the reference's entry point) replays captured epochs by default; the result is the fit the
-    oracle computes (the anchor-B shape: sequential mode, GMM prior, three observations)."""
+def test_run_under_the_auto_policy_matches_the_oracle(monkeypatch):
+    """`MAPDeconvolver.run` (the reference's entry point) under the default policy -- eight timed by-value epochs, then by
+    value or planned + captured, whichever the fit's host / device balance asks for -- gives the fit the oracle computes (the
+    anchor-B shape: sequential mode, GMM prior, three observations; 16 epochs: the switch lies inside the fit)."""
     from conftest import rel_linf
     from jolideco_amd import GMMPatchPrior, MAPDeconvolver, SpatialFluxComponent
     from jolideco_amd.data import point_source_gauss_psf, synthetic_gmm
@@ -129,13 +130,10 @@ def test_run_goes_through_the_graph_and_matches_the_oracle(monkeypatch):
     means, covs, weights = synthetic_gmm(4, 64, seed=2)
     gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
     comp = SpatialFluxComponent.from_numpy(flux=flux_init, prior=GMMPatchPrior(gmm=gmm))
-    deco = MAPDeconvolver(n_epochs=8, display_progress=False, device=DEV)
-    captured = []
-    original = deco.session
-
+    deco = MAPDeconvolver(n_epochs=16, display_progress=False, device=DEV)
     res = deco.run(datasets, components=comp)
     gmm_o = cpu_ref.GMM.from_numpy(means, covs, weights, stride=4)
-    final, trace = cpu_ref.map_fit_sequential(datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o)}, n_epochs=8)
+    final, trace = cpu_ref.map_fit_sequential(datasets, {"flux": flux_init}, {"flux": cpu_ref.GMMPatchPriorRef(gmm_o)}, n_epochs=16)
     assert rel_linf(res.flux_total, final["flux"]) < 1e-5
     np.testing.assert_allclose(res.trace_loss["total"], [row["total"] for row in trace], rtol=1e-4)
 
@@ -145,7 +143,7 @@ def test_an_option_set_between_epochs_invalidates_the_captured_epochs(monkeypatc
     counter and the session captures anew (bench.py times the dense-GMM side run on the session of the headline run)."""
     from jolideco_amd import MAPDeconvolver
 
-    monkeypatch.delenv("JOLIDECO_GRAPH", raising=False)
+    monkeypatch.setenv("JOLIDECO_GRAPH", "1")
     datasets, comp, _ = _build_joint()
     session = MAPDeconvolver(n_epochs=1, display_progress=False, device=DEV, fit_mode="joint").session(datasets, components=comp)
     for _ in range(6):
@@ -158,3 +156,26 @@ def test_an_option_set_between_epochs_invalidates_the_captured_epochs(monkeypatc
         session.epoch()
     torch.cuda.synchronize()
     assert len(session._graphs) == 2
+
+
+def test_the_auto_policy_decides_after_its_probe_epochs(monkeypatch):
+    """Default policy: epochs 1 .. 8 by value and timed, then ONE decision from the host's enqueue time against the device's
+    time per epoch; whichever way it goes the fit is the by-value fit bit for bit."""
+    from jolideco_amd import MAPDeconvolver
+
+    by_value = _fit(monkeypatch, "host", _build_joint, 14, "joint")
+    monkeypatch.delenv("JOLIDECO_GRAPH", raising=False)
+    monkeypatch.delenv("JOLIDECO_STEP_SCALARS", raising=False)
+    datasets, comp, _ = _build_joint()
+    session = MAPDeconvolver(n_epochs=1, display_progress=False, device=DEV, fit_mode="joint").session(datasets, components=comp)
+    rows = []
+    for i in range(14):
+        session.epoch()
+        rows.append(session.scalars.clone())
+        assert (session.graph_policy == "undecided") == (i < 8), (i, session.graph_policy)
+    torch.cuda.synchronize()
+    assert session.graph_policy.startswith(("by value", "captured epochs"))
+    assert bool(session._graphs) == session.graph_policy.startswith("captured")
+    print("auto policy on the 96 x 132 joint fit:", session.graph_policy)
+    np.testing.assert_array_equal(torch.stack(rows).cpu().numpy(), by_value[1])
+    np.testing.assert_array_equal(session.states[0].flux_cur.cpu().numpy(), by_value[0][0])
