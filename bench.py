@@ -288,7 +288,7 @@ def e0102_run(device, n_epochs=250, shape=(256, 256), n_obs=24, psf_shape=(128, 
     }
 
 
-PMC_TRAFFIC_FILES = ("profiles/r04/pmc_hbm_traffic.csv", "profiles/r03/pmc_hbm_traffic.csv", "profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
+PMC_TRAFFIC_FILES = ("profiles/r05/pmc_hbm_traffic.csv", "profiles/r04/pmc_hbm_traffic.csv", "profiles/r03/pmc_hbm_traffic.csv", "profiles/r02/pmc_hbm_traffic.csv", "profiles/r01/pmc_hbm_traffic.csv")
 _TRAFFIC_USED = {}  # kernel -> file its traffic figure came from
 
 
@@ -957,7 +957,7 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "ms_per_observation": ms_obs,
                 "bytes_per_observation": per_obs_bytes,
                 "launch_ms_per_step": {name: k.get(name) for name in ("fft_r2c", "cmul", "poisson_fused", "fft_c2r")},
-                "note": "PMC traffic of these kernels: profiles/r04/pmc_hbm_traffic.csv rows c3fft",
+                "note": "PMC traffic of these kernels: profiles/r05/pmc_hbm_traffic.csv rows c3fft",
             }
     if world == 1 and fake is None and args.config == "c3" and not args.no_general_psf:
         # any image size takes the native FFT path since round 5 (odd H: a lower half one row short; W % 4 != 0: rows at

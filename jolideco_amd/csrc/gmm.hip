@@ -2196,33 +2196,42 @@ __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
 // (band b = rows [y_begin[b], y_end[b]) of the rolled frame, at bands + b * chunk) put back into the gradient image.
 // Every rank adds the same numbers in the same order: replicas stay bit-identical.
 constexpr int BANDS_MAX = 64;
-struct AddBandsArgs {
+template <int NB>  // band ranges a launch carries: 8, 16 or BANDS_MAX
+struct AddBandsArgsT {
   float* grad;
   const float* bands;
   size_t chunk;
   int H, W, shift_y, shift_x, n_bands, y_lo, y_hi;
   const int* shift_dev;  // nullable, device [2] = {shift_y, shift_x} residues: read instead of the two members above (use_device_shift)
-  int y_begin[BANDS_MAX], y_end[BANDS_MAX];
+  int y_begin[NB], y_end[NB];
 };
+using AddBandsArgs = AddBandsArgsT<BANDS_MAX>;  // (what the host fills; launches copy the ranges into the size they take)
 
-__global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
+template <int NB>
+static AddBandsArgsT<NB> narrow_bands(const AddBandsArgs& a) {
+  AddBandsArgsT<NB> n{};
+  n.grad = a.grad, n.bands = a.bands, n.chunk = a.chunk, n.H = a.H, n.W = a.W, n.shift_y = a.shift_y, n.shift_x = a.shift_x;
+  n.n_bands = a.n_bands, n.y_lo = a.y_lo, n.y_hi = a.y_hi, n.shift_dev = a.shift_dev;
+  for (int b = 0; b < NB; ++b) n.y_begin[b] = a.y_begin[b], n.y_end[b] = a.y_end[b];
+  return n;
+}
+
+// The loop over the bands is UNROLLED over the NB ranges of the launch: indexing the by-value argument arrays with a runtime
+// band number made the compiler copy the whole argument block to scratch in every thread (584 bytes per lane: the band sum +
+// optimizer step of a 2048^2 image took 147 us, 46 % of a rank's share of an 8-way step; round 5), and staging the ranges in
+// LDS by 64 compile-time compares compiled to 30 000 instructions (204 us).  Launches carry 8, 16 or 64 ranges.
+template <int NB>
+__global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgsT<NB> a) {
   use_device_shift(a);
-  // the band ranges into LDS through COMPILE-TIME indices: indexing the by-value argument arrays with the runtime band number
-  // made the compiler copy the whole argument block to scratch in every thread (584 bytes per lane; the band sum + step of a
-  // 2048^2 image took 147 us instead of 35: round 5, rank share of an 8-way split)
-  __shared__ int s_yb[BANDS_MAX], s_ye[BANDS_MAX];
-#pragma unroll
-  for (int b = 0; b < BANDS_MAX; ++b)
-    if ((int)threadIdx.x == b) s_yb[b] = a.y_begin[b], s_ye[b] = a.y_end[b];
-  __syncthreads();
   const int Y = a.y_lo + blockIdx.y;
   const int X = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (X >= a.W || Y >= a.y_hi) return;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   bool any = false;
   const bool vec = (a.W & 3) == 0 && (a.chunk & 3) == 0;
-  for (int b = 0; b < a.n_bands; ++b) {
-    const int yb = s_yb[b], ye = s_ye[b];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int yb = a.y_begin[b], ye = a.y_end[b];  // (unused ranges are empty: y_begin = y_end = 0)
     if (Y < yb || Y >= ye) continue;
     const float* row = a.bands + (size_t)b * a.chunk + (size_t)(Y - yb) * a.W + X;
     if (vec) {
@@ -2249,15 +2258,10 @@ __global__ __launch_bounds__(256) void add_rolled_bands_kernel(AddBandsArgs a) {
 // adam_pixel -- one pass over the gradient image and one launch less per step.  A thread owns an ALIGNED group of four
 // pixels of the un-rolled image (16-byte accesses to the optimizer state; W % 4 == 0) and reads the four rolled-frame
 // band values of every band that holds its row one by one.
-__global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgs a, AdamArgs st) {
+template <int NB>
+__global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgsT<NB> a, AdamArgs st) {
   use_device_shift(a);
   use_device_bias(st);
-  // (band ranges through LDS: see add_rolled_bands_kernel)
-  __shared__ int s_yb[BANDS_MAX], s_ye[BANDS_MAX];
-#pragma unroll
-  for (int b = 0; b < BANDS_MAX; ++b)
-    if ((int)threadIdx.x == b) s_yb[b] = a.y_begin[b], s_ye[b] = a.y_end[b];
-  __syncthreads();
   const int yy = blockIdx.y;
   const int xx = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (xx >= a.W) return;
@@ -2267,8 +2271,9 @@ __global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgs
   int X[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) X[i] = wrap(xx + i + a.shift_x, a.W);
-  for (int b = 0; b < a.n_bands; ++b) {
-    const int yb = s_yb[b], ye = s_ye[b];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int yb = a.y_begin[b], ye = a.y_end[b];
     if (Y < yb || Y >= ye) continue;
     const float* row = a.bands + (size_t)b * a.chunk + (size_t)(Y - yb) * a.W;
 #pragma unroll
@@ -3196,7 +3201,9 @@ extern "C" int jd_add_rolled_bands(float* grad, int H, int W, int shift_y, int s
   }
   if (a.y_lo >= a.y_hi) return JD_OK;
   dim3 grid((W + 1023) / 1024, a.y_hi - a.y_lo);
-  add_rolled_bands_kernel<<<grid, 256, 0, as_stream(stream)>>>(a);
+  if (n_bands <= 8) add_rolled_bands_kernel<8><<<grid, 256, 0, as_stream(stream)>>>(narrow_bands<8>(a));
+  else if (n_bands <= 16) add_rolled_bands_kernel<16><<<grid, 256, 0, as_stream(stream)>>>(narrow_bands<16>(a));
+  else add_rolled_bands_kernel<BANDS_MAX><<<grid, 256, 0, as_stream(stream)>>>(a);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -3227,7 +3234,9 @@ extern "C" int jd_add_rolled_bands_step(int H, int W, int shift_y, int shift_x, 
   st.zero_grad = 0, st.sgd = step->sgd ? 1 : 0, st.linear = step->use_log_flux ? 0 : 1, st.bias_dev = step->bias_dev;
   dim3 grid((W + 1023) / 1024, H);
   ProfScope prof(JD_KERNEL_ADAM, as_stream(stream));
-  add_rolled_bands_step_kernel<<<grid, 256, 0, as_stream(stream)>>>(a, st);
+  if (n_bands <= 8) add_rolled_bands_step_kernel<8><<<grid, 256, 0, as_stream(stream)>>>(narrow_bands<8>(a), st);
+  else if (n_bands <= 16) add_rolled_bands_step_kernel<16><<<grid, 256, 0, as_stream(stream)>>>(narrow_bands<16>(a), st);
+  else add_rolled_bands_step_kernel<BANDS_MAX><<<grid, 256, 0, as_stream(stream)>>>(a, st);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void shift_bwd4_batch_kernel(const float* __re
   }
 }
 
+
 static bool shift_vec_ok(const void* a, const void* b, const void* c, int W) {
   return W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
@@ -256,6 +257,9 @@ int launch_shift_bwd_batch(const float* in, const FftBatch* batch, int n_dataset
   dim3 grid(vec ? (W + 1023) / 1024 : (W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
   *n_blocks = grid.x * grid.y;
   ProfScope prof(JD_KERNEL_SHIFT, stream);
+  // (measured, not kept -- round 5: rows outside / datasets inside, the pixel's gradient in registers and written once, the
+  // per-dataset partial sums in LDS: 458 against 390 us for 8 datasets at 4096^2 -- the loop over the datasets then runs its
+  // 24 loads per dataset and row one dataset after the other)
   if (vec) shift_bwd4_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
   else shift_bwd_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
   JD_LAUNCH_CHECK();

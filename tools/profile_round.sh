@@ -4,7 +4,7 @@
 # The PMC passes collect FETCH_SIZE and WRITE_SIZE in SEPARATE runs (MI355X_MICROARCH.md: they do not fit one pass), the
 # SQ counters of the GMM screen kernel in two more; every rocprofv3 call has python3 right behind "--".
 set -euo pipefail  # a failed bench or profiler run stops the script: no partial profile round gets copied
-R=${1:-r04}
+R=${1:-r05}
 OUT=gpurun_out/profile_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
@@ -14,6 +14,12 @@ for cfg in c2 c4 c5; do
   python3 bench.py --config $cfg --steps 100 --warmup 10 > $OUT/${cfg}_n1_bench.json 2> $OUT/${cfg}_n1_bench.err
 done
 python3 bench.py --config c6 > $OUT/c6_n1_bench.json 2> $OUT/c6_n1_bench.err
+python3 bench.py --config c1 --steps 200 --warmup 20 > $OUT/c1_n1_bench.json 2> $OUT/c1_n1_bench.err
+python3 bench.py --config e0102 > $OUT/e0102_bench.json 2> $OUT/e0102_bench.err
+python3 tools/gpu/small_fits.py > $OUT/small_fits.txt 2>&1
+python3 tools/rccl_probe.py > $OUT/rccl_probe.json 2> $OUT/rccl_probe.err
+# (the profiler runs below time the by-value epochs: the same kernels, no graph replay under the tracer)
+export JOLIDECO_GRAPH=0 JOLIDECO_STEP_SCALARS=host
 kernel_stats() {  # <label> <bench args...>: rocprofv3 kernel statistics of one bench command
   local label=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$label -o $label -- \
@@ -35,6 +41,7 @@ traffic() {  # <label> <bench args...>: FETCH_SIZE and WRITE_SIZE per kernel, se
 for cfg in c3 c4 c5 c6; do kernel_stats $cfg --config $cfg; done
 traffic c3 --config c3
 traffic c4 --config c4
+traffic c6 --config c6
 # the same fit through the FFT path (the native FFT convolution on these sizes)
 export JOLIDECO_CONV_METHOD=fft
 kernel_stats c3fft --config c3
