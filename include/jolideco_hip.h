@@ -274,11 +274,17 @@ int jd_gmm_is_triangular(const jd_gmm* gmm);
  * shift_dev != NULL the kernels read the roll from device memory -- shift_dev[0] = shift_y in [0, H), shift_dev[1] =
  * shift_x in [0, W), the residues the host would have passed -- and ignore the two by-value arguments; every launch
  * argument of the pass is then the same from step to step (the caller uploads the shifts of the coming steps with one
- * small copy, jolideco_amd/core.py StepScalars).  Same results as the by-value form, bit for bit. */
+ * small copy, jolideco_amd/core.py StepScalars).  Same results as the by-value form, bit for bit.
+ * TWO PHASES (new: the prior beside the likelihood): `phases` = 3 runs the whole pass; 1 runs everything up to the
+ * per-patch gradient rows -- value, arg-max, rows: it reads the flux and writes value_out and the handle's work buffers
+ * only --, 2 the gather of those rows into grad_flux_accum (for _step: + the optimizer step).  A caller enqueues phase 1
+ * on a second stream next to the likelihood launches of the step, joins the streams and calls phase 2 with the same
+ * arguments (JD_ERR_INVALID if they differ or another pass of the handle ran in between); a handle has one pass in
+ * flight at a time. */
 int jd_gmm_prior_fwd_bwd(jd_gmm* gmm, const float* flux, int H, int W, int stride, int shift_y,
                          int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                          float value_scale, float* value_out, int accumulate_value, float grad_coef,
-                         float* grad_flux_accum, int32_t* argmax_out, const int* shift_dev, void* stream);
+                         float* grad_flux_accum, int32_t* argmax_out, const int* shift_dev, int phases, void* stream);
 
 /* The same evaluation with the OPTIMIZER STEP of the component in the epilogue of its last kernel (new: one pass over
  * the gradient image and one launch less per step; jolideco/core.py:229 is the step it folds in).  Where
@@ -303,7 +309,7 @@ typedef struct {
 } jd_step;
 int jd_gmm_prior_fwd_bwd_step(jd_gmm* gmm, const float* flux, int H, int W, int stride, int shift_y, int shift_x,
                               int marginalize, float value_scale, float* value_out, int accumulate_value,
-                              float grad_coef, const jd_step* step, const int* shift_dev, void* stream);
+                              float grad_coef, const jd_step* step, const int* shift_dev, int phases, void* stream);
 
 /* Diagnostics of the screened arg-max path, read without synchronisation from host-mapped memory the last block of a
  * pass writes: out[0..4] = {generation of the last finished pass, it fell back to the dense fp32 kernel (0 / 1), bucket

@@ -75,12 +75,12 @@ EXPORTS = {
     "jd_gmm_prior_fwd_bwd": (
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
-         c_float, c_void_p, c_void_p, c_void_p, c_void_p],
+         c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     ),
     "jd_gmm_prior_fwd_bwd_step": (
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_float, c_void_p, c_void_p,
-         c_void_p],
+         c_int, c_void_p],
     ),
     "jd_gmm_screen_stats": (c_int, [c_void_p, POINTER(c_int)]),
     "jd_gmm_screen_clock": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),

@@ -627,6 +627,9 @@ class FitSession:
         self.use_graph = self.graph_mode == "always"
         self.graph_policy = {"always": "captured epochs (forced)", "never": "no capture (forced)"}.get(self.graph_mode, "undecided")
         self._probe = []  # (host seconds, start event, end event) of the by-value probe epochs
+        # the GMM prior's first phase on a second stream beside the likelihood launches (`_start_priors`)
+        self.overlap_prior = os.environ.get("JOLIDECO_PRIOR_OVERLAP", "1") != "0"
+        self._side_stream = torch.cuda.Stream(device=device)
         self.step_scalars = None
         self._graphs = {}
         self._epochs_done = 0
@@ -883,6 +886,81 @@ class FitSession:
         return {"shifts": shifts, "flux_bias": flux_bias, "cal_bias": cal_bias, "cal_items": cal_items, "n_steps": n_flux,
                 "signature": tuple(len(items) for items in cal_items)}
 
+    def _plan_by_value(self):
+        """The same plan with HOST scalars: the shifts as drawn (in evaluation order), no device slots -- the kernels take
+        them by value.  The single-process epochs of the default policy (device bound fits) run through `_enqueue_epoch`
+        with this plan: one launch sequence for both forms."""
+        drawing, _, n_flux, cal_groups, _ = self._plan_slots()
+        n_eval = 1 if self.joint else len(self.local_idx) + 1
+        shifts = [{ci: self.priors[ci].draw_shifts() for ci in drawing} for _ in range(n_eval)]
+        cal_items = [[(p, st) for opt in group for p, st in zip(opt.params, opt.state)] for group in cal_groups]
+        return {"shifts": shifts, "flux_bias": [None] * n_flux, "cal_bias": [None] * len(cal_groups), "cal_items": cal_items,
+                "n_steps": n_flux, "signature": ()}
+
+    # ---- the prior beside the likelihood ------------------------------------------------------------------------------
+    def _overlap_active(self):
+        """Phase 1 of a GMM prior (value + gradient rows: it reads the flux only) runs on a second stream while the main
+        stream runs the likelihood launches of the step; the streams join in front of the gather (+ optimizer step).  Not
+        while the kernel timers run (a kernel timed beside another one is not the kernel's time); JOLIDECO_PRIOR_OVERLAP=0:
+        one stream."""
+        return self.overlap_prior and not self.dist.sharded and not _hip.profile_active()
+
+    def _prior_calls(self, coef, shifts, bias):
+        """The prior evaluations of ONE optimizer step as callables `call(phases)` (3: the whole pass): [(ci, call, steps)],
+        `steps`: the prior's gather kernel applies the component's optimizer step."""
+        cfg, n_d, slot, step_no = self.cfg, self.n_d, self._slot, self.step + 1
+        calls = []
+        for ci, (st, prior) in enumerate(zip(self.states, self.priors)):
+            kwargs = {"shifts": shifts[ci]} if ci in shifts else {}
+            flux, value = st.flux_cur, slot(n_d + ci)
+            if self._fuse_step(st, prior):
+                args = cfg._step_args(st, step_no, bias)
+
+                def call(phases=3, prior=prior, flux=flux, value=value, args=args, kwargs=kwargs):
+                    prior.device_fwd_bwd_step(flux, value, coef, args, **(dict(kwargs, phases=phases) if phases != 3 else kwargs))
+
+                calls.append((ci, call, True))
+            else:
+
+                def call(phases=3, prior=prior, flux=flux, value=value, grad=st.grad, kwargs=kwargs):
+                    prior.device_fwd_bwd(flux, value, grad=grad, coef=coef, **(dict(kwargs, phases=phases) if phases != 3 else kwargs))
+
+                calls.append((ci, call, False))
+        return calls
+
+    def _start_priors(self, calls):
+        """Phase 1 of every prior that has one (at most one per GMM handle: a handle holds one pass at a time) on the side
+        stream, behind everything the main stream has been given so far.  Returns the components started."""
+        if not self._overlap_active():
+            return set()
+        eligible, seen = [], set()
+        for ci, call, _ in calls:
+            prior = self.priors[ci]
+            key = id(getattr(prior, "gmm", prior))
+            if getattr(prior, "supports_phases", False) and key not in seen:
+                seen.add(key)
+                eligible.append((ci, call))
+        if not eligible:
+            return set()
+        main = torch.cuda.current_stream(self.comm.device)
+        self._side_stream.wait_stream(main)
+        with torch.cuda.stream(self._side_stream):
+            for _, call in eligible:
+                call(1)
+        return {ci for ci, _ in eligible}
+
+    def _finish_priors(self, calls, early):
+        """Join the side stream, then phase 2 of the priors started early and the whole pass of the others, in component
+        order.  Returns the components whose optimizer step the prior applied."""
+        if early:
+            torch.cuda.current_stream(self.comm.device).wait_stream(self._side_stream)
+        stepped = set()
+        for ci, call, steps in calls:
+            call(2 if ci in early else 3)
+            if steps:
+                stepped.add(ci)
+        return stepped
+
     def _commit_replay(self, plan):
         """The host state an eagerly enqueued epoch leaves behind, after a REPLAYED one: step counts, flux buffer parity."""
         self.step += plan["n_steps"]
@@ -951,27 +1029,19 @@ class FitSession:
             if cfg.optimizer_type != "adam":
                 lr = cfg.optimizer_kwargs["lr"]
                 for p, st in items:
+                    if p.grad is None:
+                        continue
                     st["step"] += 1
                     check(_hip.lib().jd_sgd_step(ptr(p.data), ptr(p.data), ptr(p.data), ptr(p.grad), None, p.numel(), lr, 0, 0,
                                                  stream_ptr(p.device)))
                 return
             _adam_step_many(cfg, items, self.__dict__.setdefault("_cal_step_cache", {}), bias)
 
-        def priors_and_step(j, coef, shifts):
-            stepped = set()
-            for ci, (st, prior) in enumerate(zip(states, priors)):
-                kwargs = {"shifts": shifts[ci]} if ci in shifts else {}
-                if self._fuse_step(st, prior):
-                    prior.device_fwd_bwd_step(st.flux_cur, slot(n_d + ci), coef,
-                                              cfg._step_args(st, self.step + 1, plan["flux_bias"][j]), **kwargs)
-                    stepped.add(ci)
-                else:
-                    prior.device_fwd_bwd(st.flux_cur, slot(n_d + ci), grad=st.grad, coef=coef, **kwargs)
-            flux_step(stepped, plan["flux_bias"][j])
-
         if self.joint:
             fluxes = [st.flux_cur for st in states]
             grads = [st.grad for st in states]
+            calls = self._prior_calls(beta, plan["shifts"][0], plan["flux_bias"][0])
+            early = self._start_priors(calls)  # (the priors' first phase beside the likelihood launches below)
             first = True
             if self.batch_joint:
                 total_loss.poisson_loss.fwd_bwd_batch(
@@ -995,16 +1065,18 @@ class FitSession:
             if first:
                 for g in grads:
                     g.zero_()
-            priors_and_step(0, beta, plan["shifts"][0])
+            flux_step(self._finish_priors(calls, early), plan["flux_bias"][0])
             cal_steps(plan["cal_items"][0], plan["cal_bias"][0])
         else:
             coef = beta / total_loss.prior_weight
             for j, (gslot, li) in enumerate(self.local_idx):
                 fluxes = [st.flux_cur for st in states]
                 grads = [st.grad for st in states]
+                calls = self._prior_calls(coef, plan["shifts"][j], plan["flux_bias"][j])
+                early = self._start_priors(calls)
                 self._cal_zero_grad(li)
                 total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
-                priors_and_step(j, coef, plan["shifts"][j])
+                flux_step(self._finish_priors(calls, early), plan["flux_bias"][j])
                 cal_steps(plan["cal_items"][j], plan["cal_bias"][j])
             stale = [st.flux_trace for st in states]
             if self.batch_trace:
@@ -1032,6 +1104,8 @@ class FitSession:
                 return self._epoch_planned()
             if self.graph_policy == "undecided":
                 return self._epoch_probe()
+            self._total_epochs += 1
+            return self._enqueue_epoch(self._plan_by_value())
         self._total_epochs += 1
         if self._graphs:
             self.reset_graphs()
@@ -1050,7 +1124,7 @@ class FitSession:
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         t0 = time.perf_counter()
-        self._epoch_by_value()
+        self._enqueue_epoch(self._plan_by_value())
         host = time.perf_counter() - t0
         end.record()
         self._total_epochs += 1

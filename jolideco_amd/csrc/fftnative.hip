@@ -120,14 +120,19 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, int N, const Ff
 // T: threads of a row block.  4608 = 8 * 8 * 8 * 9 runs 576 threads (nine waves): ONE radix-8 butterfly per thread and pass
 // (576 of them; 512 radix-9 butterflies), and two blocks -- LDS holds no more: two padded sequences of 4608 are 78 KB --
 // are 18 waves per CU instead of 8.  MAXQ / PRE: 16-byte pieces of an image row / of a spectrum row per thread.
+// The generic (runtime-radix) form comes in two sizes: <0, 0, 0, 1> for rows of at most GENERIC_SMALL points (image and padded
+// length: the per-thread arrays of a row's pieces are a third as long -- the small images of the reference's own examples)
+// and <0, 0, 0, 0> for everything else.
+constexpr int GENERIC_SMALL = 1536, GENERIC_LARGE = 5120;
 template <int R0, int R1, int R2, int R3>
 struct RowSched {
   static constexpr bool STATIC = R0 > 0;
   static constexpr int N = STATIC ? R0 * R1 * R2 * (R3 ? R3 : 1) : 0;
+  static constexpr int LIMIT = STATIC ? N : R3 == 1 ? GENERIC_SMALL : GENERIC_LARGE;  // longest row (pixels or points) the kernel takes
   static constexpr int T = (R0 == 8 && R1 == 8 && R2 == 8 && R3 == 9) ? 576 : ROW_THREADS;
   static constexpr int WAVES_PER_SIMD = T == 576 ? 5 : 1;  // (two blocks of nine waves: five on one SIMD -> at most 96 registers)
-  static constexpr int MAXQ = STATIC ? (N + 4 * T - 1) / (4 * T) : 5;  // generic: Nx <= 4608 < 4 * 256 * 5
-  static constexpr int PRE = STATIC ? (N + 2 * T - 1) / (2 * T) : 9;   // generic: Nx <= 2 * 256 * 9
+  static constexpr int MAXQ = (LIMIT + 4 * T - 1) / (4 * T);  // 16-byte pieces of an image row per thread
+  static constexpr int PRE = (LIMIT + 2 * T - 1) / (2 * T);   // 16-byte pieces of a spectrum row per thread
 };
 
 template <int R, int DIR, int N, int P, int T>
@@ -933,7 +938,7 @@ struct RowsPooledArgs {
 // transform of the up-sampled g rows -- the U flux rows of a counts row carry the same g, so their spectrum row is
 // computed once and stored U times.  Replaces rows^-1 -> convolution image -> pooled Poisson kernel -> g image -> rows.
 template <int U, int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2, R3>::WAVES_PER_SIMD)) void fftn_rows_pooled_kernel(RowsPooledArgs a) {
+__global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2, R3>::T == 576 ? 5 : RowSched<R0, R1, R2, R3>::STATIC ? 4 : 1)) void fftn_rows_pooled_kernel(RowsPooledArgs a) {
   extern __shared__ float2 lds[];
   using S = RowSched<R0, R1, R2, R3>;
   __shared__ double red[S::T / 64];
@@ -948,12 +953,17 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   const size_t pbase = (size_t)d * (a.Hh / U);
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
-  constexpr int MAXQ = S::MAXQ, PC = 4 / U;
-  float pu[MAXQ][PC], pd[MAXQ][PC];    // pooled sums: counts row Y (upper half) and Y + H / (2 U) (lower half)
+  // A thread owns PIECES of PX = lcm(4, U) flux pixels = G counts pixels of the block's two counts rows (round 5: any
+  // up-sampling factor; U = 2: 4 flux pixels / 2 counts pixels, U = 4: 4 / 1, U = 3: 12 / 4).  The flux pixels of a piece
+  // are read from the transform's result in groups of four (one group of 16 in the padded layout: contiguous).
+  constexpr int PX = U % 4 == 0 ? U : U % 2 == 0 ? 2 * U : 4 * U, G = PX / U, SUB = PX / 4;
+  constexpr int MAXP = (S::LIMIT + PX * S::T - 1) / (PX * S::T);
+  float pu[MAXP][G], pd[MAXP][G];  // pooled sums: counts row Y (upper half) and Y + H / (2 U) (lower half)
 #pragma unroll
-  for (int q = 0; q < MAXQ; ++q)
+  for (int q = 0; q < MAXP; ++q)
 #pragma unroll
-    for (int c = 0; c < PC; ++c) pu[q][c] = pd[q][c] = 0.f;
+    for (int c = 0; c < G; ++c) pu[q][c] = pd[q][c] = 0.f;
+  const int Wd = a.W / U, Hdh = a.Hh / U;
   // 576-thread blocks (two per CU): the spectrum row of flux row j + 1 is loaded into registers while the block transforms
   // row j (a block with a single round of loads per transform leaves the memory system idle while it computes)
   constexpr bool PREFETCH = S::T == 576 && JD_FFT_POOLED_PREFETCH;
@@ -969,29 +979,31 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
     }
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int x = 4 * (tid + q * S::T);
+    for (int q = 0; q < MAXP; ++q) {
+      const int x = PX * (tid + q * S::T);
       if (x >= a.W) continue;
-      const int e = lp(x);
-      const float2 v[4] = {r[e], r[e + 1], r[e + 2], r[e + 3]};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) pu[q][i / U] += v[i].x, pd[q][i / U] += v[i].y;  // (row by row, left to right)
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int e = lp(x + 4 * sub);
+        const float2 v[4] = {r[e], r[e + 1], r[e + 2], r[e + 3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pu[q][(4 * sub + i) / U] += v[i].x, pd[q][(4 * sub + i) / U] += v[i].y;  // (row by row, left to right)
+      }
     }
     __syncthreads();  // the result buffer is the next transform's work space
   }
-  const int Wd = a.W / U, Hdh = a.Hh / U;
   const float norm = log_bkg_norm ? expf(log_bkg_norm[0]) : 1.f;
-  float gu[MAXQ][PC], gd[MAXQ][PC];
+  float gu[MAXP][G], gd[MAXP][G];
   double local = 0.0, local_b = 0.0;
 #pragma unroll
-  for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * S::T);
+  for (int q = 0; q < MAXP; ++q) {
+    const int x = PX * (tid + q * S::T);
 #pragma unroll
-    for (int c = 0; c < PC; ++c) gu[q][c] = gd[q][c] = 0.f;
+    for (int c = 0; c < G; ++c) gu[q][c] = gd[q][c] = 0.f;
     if (x >= a.W) continue;
 #pragma unroll
-    for (int c = 0; c < PC; ++c) {
-      if (x / U + c >= Wd) continue;  // (W % 4 == 2 at U = 2: the last piece of a row holds one counts pixel)
+    for (int c = 0; c < G; ++c) {
+      if (x / U + c >= Wd) continue;  // (the last piece of a row may hold fewer counts pixels)
       const size_t o1 = (size_t)Y * Wd + x / U + c, o2 = (size_t)(Y + Hdh) * Wd + x / U + c;
       const float b1 = log_bkg_norm ? background[o1] * norm : background[o1];
       const float b2 = log_bkg_norm ? background[o2] * norm : background[o2];
@@ -1013,11 +1025,16 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   }
   // ---- z = g_up[y] + i g_up[y + Hh], zero padded: the adjoint's row transform, the same for the U flux rows ---------------
 #pragma unroll
-  for (int q = 0; q < MAXQ; ++q) {
-    const int x = 4 * (tid + q * S::T), e = lp(x);
-    if (x >= Nx) continue;
+  for (int q = 0; q < MAXP; ++q) {
+    const int x = PX * (tid + q * S::T);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bufa[e + i] = x + i < a.W ? float2{gu[q][i / U], gd[q][i / U]} : float2{0.f, 0.f};
+    for (int sub = 0; sub < SUB; ++sub) {
+      if (x + 4 * sub >= Nx) continue;
+      const int e = lp(x + 4 * sub);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        bufa[e + i] = x + 4 * sub + i < a.W ? float2{gu[q][(4 * sub + i) / U], gd[q][(4 * sub + i) / U]} : float2{0.f, 0.f};
+    }
   }
   __syncthreads();
   const float2* res = row_fft<-1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
@@ -1206,28 +1223,30 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
 
 // The row kernels by schedule: compile-time forms for the row lengths of the usual image sizes, the generic form
 // otherwise.  Index into every table: row_schedule(f).
-constexpr int N_ROW_SCHED = 4;
-int row_schedule(const FftPasses& f) {
+constexpr int N_ROW_SCHED = 5;
+int row_schedule(const FftPasses& f, int Nx, int W) {
   auto is = [&](int r0, int r1, int r2, int r3) {
     return f.n == (r3 ? 4 : 3) && f.r[0] == r0 && f.r[1] == r1 && f.r[2] == r2 && (!r3 || f.r[3] == r3);
   };
   if (is(16, 16, 9, 0)) return 1;  // 2304: 2048-column images
   if (is(8, 8, 8, 9)) return 2;    // 4608: 4096-column images
   if (is(16, 8, 9, 0)) return 3;   // 1152: 1024-column images
-  return 0;
+  return Nx <= GENERIC_SMALL && W <= GENERIC_SMALL ? 4 : 0;
 }
 #define JD_ROW_KERNELS(NAME, ...)                                                                          \
-  {NAME<__VA_ARGS__ 0, 0, 0, 0>, NAME<__VA_ARGS__ 16, 16, 9, 0>, NAME<__VA_ARGS__ 8, 8, 8, 9>, NAME<__VA_ARGS__ 16, 8, 9, 0>}
+  {NAME<__VA_ARGS__ 0, 0, 0, 0>, NAME<__VA_ARGS__ 16, 16, 9, 0>, NAME<__VA_ARGS__ 8, 8, 8, 9>, NAME<__VA_ARGS__ 16, 8, 9, 0>, \
+   NAME<__VA_ARGS__ 0, 0, 0, 1>}
 
 template <class Args>
 int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), const FftNative& n, const Args& a,
                       int kernel_id, hipStream_t stream, int blocks = 0) {
-  const int sched = row_schedule(a.f);
+  const int sched = row_schedule(a.f, n.Nx, n.W);
   const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
   int rc = lds_attr(reinterpret_cast<const void*>(kernels[sched]), lds_rows);
   if (rc) return rc;
   ProfScope prof(kernel_id, stream);
-  static constexpr int threads[N_ROW_SCHED] = {RowSched<0, 0, 0, 0>::T, RowSched<16, 16, 9, 0>::T, RowSched<8, 8, 8, 9>::T, RowSched<16, 8, 9, 0>::T};
+  static constexpr int threads[N_ROW_SCHED] = {RowSched<0, 0, 0, 0>::T, RowSched<16, 16, 9, 0>::T, RowSched<8, 8, 8, 9>::T, RowSched<16, 8, 9, 0>::T,
+                                               RowSched<0, 0, 0, 1>::T};
   hipLaunchKernelGGL(kernels[sched], dim3(blocks ? blocks : n.Hh), dim3(threads[sched]), lds_rows, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;
@@ -1299,9 +1318,20 @@ int fftn_poisson_step(const FftNative& n, const float* flux, const float* exposu
 // into `target` (= coef * exposure * corr, overwritten or accumulated).  The loss and, if wanted, d loss / d log norm =
 // norm_grad_scale * sum(g * background) are finalised by blocks 0 and 1 of the last launch.
 bool fftn_pooled_supported(const FftNative& n, int upsampling) {
-  return (upsampling == 2 || upsampling == 4) && n.W % upsampling == 0 && n.H % (2 * upsampling) == 0 && n.Hh / upsampling >= 2 &&
+  return upsampling >= 2 && upsampling <= 4 && n.W % upsampling == 0 && n.H % (2 * upsampling) == 0 && n.Hh / upsampling >= 2 &&
          n.W <= 4 * ROW_THREADS * 5;
 }
+
+namespace {
+int launch_rows_pooled(const FftNative& n, int upsampling, const RowsPooledArgs& a, hipStream_t stream, int blocks) {
+  static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
+  static void (*const kernels3[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 3, );
+  static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
+  return upsampling == 2   ? launch_row_kernel(kernels2, n, a, JD_KERNEL_POISSON_FUSED, stream, blocks)
+         : upsampling == 3 ? launch_row_kernel(kernels3, n, a, JD_KERNEL_POISSON_FUSED, stream, blocks)
+                           : launch_row_kernel(kernels4, n, a, JD_KERNEL_POISSON_FUSED, stream, blocks);
+}
+}  // namespace
 
 int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* flux, const float* exposure, const float2* khat,
                              const float* background, const float* counts, const float* log_bkg_norm, double* partials,
@@ -1312,15 +1342,12 @@ int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* fl
   if (rc) return rc;
   if ((rc = launch_cols(n, khat, 0, stream))) return rc;
   {
-    static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
-    static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
     RowsPooledArgs a{};
     a.work = n.work, a.spec = n.spec, a.tw = n.tw_x, a.background = background, a.counts = counts, a.log_bkg_norm = log_bkg_norm;
     a.partials = partials, a.partials_b = norm_grad_out ? partials_b : nullptr;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
     a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx);
-    rc = upsampling == 2 ? launch_row_kernel(kernels2, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 2)
-                         : launch_row_kernel(kernels4, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh / 4);
+    rc = launch_rows_pooled(n, upsampling, a, stream, n.Hh / upsampling);
     if (rc) return rc;
   }
   if ((rc = launch_cols(n, khat, 1, stream))) return rc;
@@ -1348,8 +1375,7 @@ int fftn_poisson_step_batch(const FftNative& n, int nd, const FftBatch* batch_de
     if ((rc = launch_row_kernel(kernels, n, a, JD_KERNEL_POISSON_FUSED, stream, n.Hh * nd))) return rc;
   }
   if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, nd))) return rc;
-  static void (*const kernels[N_ROW_SCHED])(RowsInvArgs) = {fftn_rows_inv_batch_kernel<0, 0, 0, 0>, fftn_rows_inv_batch_kernel<16, 16, 9, 0>,
-                                                            fftn_rows_inv_batch_kernel<8, 8, 8, 9>, fftn_rows_inv_batch_kernel<16, 8, 9, 0>};
+  static void (*const kernels[N_ROW_SCHED])(RowsInvArgs) = JD_ROW_KERNELS(fftn_rows_inv_batch_kernel, );
   RowsInvArgs a{};
   a.tw = n.tw_x, a.out = grad, a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny;
   a.ra = n.kh - 1 - n.oy, a.rb = n.oy;
@@ -1382,14 +1408,11 @@ int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, c
     if (rc) return rc;
     if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, per_launch, d0))) return rc;
     {
-      static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
-      static void (*const kernels4[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 4, );
       RowsPooledArgs a{};
       a.tw = n.tw_x, a.partials = partials, a.partials_b = partials_b;
       a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
       a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = per_launch, a.d0 = d0;
-      rc = upsampling == 2 ? launch_row_kernel(kernels2, n, a, JD_KERNEL_POISSON_FUSED, stream, per * per_launch)
-                           : launch_row_kernel(kernels4, n, a, JD_KERNEL_POISSON_FUSED, stream, per * per_launch);
+      rc = launch_rows_pooled(n, upsampling, a, stream, per * per_launch);
       if (rc) return rc;
     }
     if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, per_launch, d0))) return rc;

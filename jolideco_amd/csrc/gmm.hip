@@ -2312,7 +2312,16 @@ __global__ __launch_bounds__(256) void add_rolled_bands_step_kernel(AddBandsArgs
 // ==========================================================================================
 constexpr int SCREEN_CLOCK_CAP = 4096;  // blocks of a screen launch that leave clock stamps
 
+struct GmmPass {  // a pass between its two phases (gmm_prior_impl): what the gather must find unchanged
+  bool valid = false;
+  int H = 0, W = 0, stride = 0, shift_y = 0, shift_x = 0, row_begin = 0, row_end = 0, marginalize = 0;
+  bool fused = false, lse_screened = false;
+  int gen = 0;
+  const int* shift_dev = nullptr;
+};
+
 struct jd_gmm {
+  GmmPass pass;
   unsigned long long* clock_stamps = nullptr;  // jd_gmm_screen_clock: 2 x SCREEN_CLOCK_CAP ticks, zero = not written
   int K = 0;
   bool triangular = true;  // every P_k upper triangular -> zero blocks are skipped
@@ -2954,8 +2963,9 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
                           int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                           float value_scale, float* value_out, int accumulate_value, float grad_coef,
                           float* grad_flux_accum, int32_t* argmax_out, float* band_out, void* stream,
-                          const AdamArgs* step = nullptr, const int* shift_dev = nullptr) {
+                          const AdamArgs* step = nullptr, const int* shift_dev = nullptr, int phases = 3) {
   JD_REQUIRE(g && flux && value_out, "jd_gmm_prior_fwd_bwd: null argument");
+  JD_REQUIRE(phases >= 1 && phases <= 3, "jd_gmm_prior_fwd_bwd: phases = %d not in [1, 3]", phases);
   JD_REQUIRE(H >= P && W >= P, "jd_gmm_prior_fwd_bwd: image (%d, %d) smaller than a patch", H, W);
   JD_REQUIRE(stride >= 1 && stride <= P, "jd_gmm_prior_fwd_bwd: stride = %d not in [1, 8]", stride);
   const int nPy = (H - P) / stride + 1, nPx = (W - P) / stride + 1;
@@ -2979,113 +2989,130 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
   }
   const long n = n_end - n_begin;
   int rc;
-  if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
-  // option JD_GMM_SCREEN = 0 forces the dense fp32 kernel (testing / tuning)
-  const bool screened = !marginalize && g->screen_ok && opt_value(OPT_GMM_SCREEN, 1) != 0 && !opt_is_set(OPT_GMM_DENSE);
-  // screened arg-max with a gradient: the exact kernel also produces the gradient rows (no second sort, no separate
-  // backward kernel); JD_GMM_FUSED_BWD=0 keeps the bucketed backward pass (testing / tuning)
-  const bool fused = screened && grad_flux_accum && g->triangular && opt_value(OPT_GMM_FUSED_BWD, 1) != 0;
-  // logsumexp mode with a gradient: through the screen as well (option JD_GMM_LSE_SCREEN = 0: the dense kernels)
-  bool lse_screened = marginalize && grad_flux_accum && g->screen_ok && g->triangular && g->K <= SCREEN_KC_MAX &&
-                      opt_value(OPT_GMM_LSE_SCREEN, 1) != 0 && !opt_is_set(OPT_GMM_DENSE);
-  if (lse_screened && g->host_stats && opt_value(OPT_GMM_LSE_SCREEN, 1) != 2) {  // (2: always, for tests and timing)
-    volatile int* hs = g->host_stats;
-    const int seen = hs[0];
-    if (g->last_pass_lse && seen == g->gen && seen != g->lse_seen_gen) {  // the previous pass has landed and was screened
-      g->lse_seen_gen = seen;
-      if (hs[1] == 2 || (hs[1] == 1 && g->rows_per_patch >= 32)) g->lse_skip = 32;
+  // phases: bit 0 = everything up to the per-patch gradient rows (value, arg-max, rows: reads the flux only), bit 1 = the
+  // gather (+ optimizer step) of those rows into the gradient image.  Called with 1 and later with 2 -- the same arguments --
+  // the two halves may sit on different streams: the caller runs the first beside the likelihood launches of the step (it
+  // does not touch the gradient image) and joins the streams in front of the second (jolideco_amd/core.py).
+  bool screened = false, fused = false, lse_screened = false;
+  if (phases & 1) {
+    if ((rc = grow(&g->partials, &g->partials_cap, (size_t)((n + 31) / 32 + 4)))) return rc;
+    // option JD_GMM_SCREEN = 0 forces the dense fp32 kernel (testing / tuning)
+    screened = !marginalize && g->screen_ok && opt_value(OPT_GMM_SCREEN, 1) != 0 && !opt_is_set(OPT_GMM_DENSE);
+    // screened arg-max with a gradient: the exact kernel also produces the gradient rows (no second sort, no separate
+    // backward kernel); JD_GMM_FUSED_BWD=0 keeps the bucketed backward pass (testing / tuning)
+    fused = screened && grad_flux_accum && g->triangular && opt_value(OPT_GMM_FUSED_BWD, 1) != 0;
+    // logsumexp mode with a gradient: through the screen as well (option JD_GMM_LSE_SCREEN = 0: the dense kernels)
+    lse_screened = marginalize && grad_flux_accum && g->screen_ok && g->triangular && g->K <= SCREEN_KC_MAX &&
+                        opt_value(OPT_GMM_LSE_SCREEN, 1) != 0 && !opt_is_set(OPT_GMM_DENSE);
+    if (lse_screened && g->host_stats && opt_value(OPT_GMM_LSE_SCREEN, 1) != 2) {  // (2: always, for tests and timing)
+      volatile int* hs = g->host_stats;
+      const int seen = hs[0];
+      if (g->last_pass_lse && seen == g->gen && seen != g->lse_seen_gen) {  // the previous pass has landed and was screened
+        g->lse_seen_gen = seen;
+        if (hs[1] == 2 || (hs[1] == 1 && g->rows_per_patch >= 32)) g->lse_skip = 32;
+      }
+      if (g->lse_skip > 0) --g->lse_skip, lse_screened = false;
     }
-    if (g->lse_skip > 0) --g->lse_skip, lse_screened = false;
-  }
-  g->last_pass_lse = lse_screened;
-  int32_t* arg = argmax_out;
-  if (grad_flux_accum && (!arg || fused)) {  // fused: the internal buffer holds the components after a fallback
-    if ((rc = grow(&g->argmax, &g->argmax_cap, (size_t)nPy * nPx))) return rc;
-    if (!arg) arg = g->argmax;
-  }
-  GmmFwdArgs a{};
-  a.flux = flux, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
-  a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x, a.shift_dev = shift_dev;
-  a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = fused ? argmax_out : arg, a.value_patch = nullptr, a.partials = g->partials;
-  if (grad_flux_accum && (rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;  // (the fused fallback writes it)
-  int n_waves = 0;
-  if (lse_screened)
-    rc = screened_forward(g, a, s, &n_waves, true, nullptr, (double)value_scale, value_out, accumulate_value, true);
-  else if (marginalize && grad_flux_accum) {
-    // value and gradient rows in one pass over the components (gmm_bwd_lse_kernel)
-    GmmBwdLseArgs b{};
-    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
-    b.partials = g->partials, b.gpatch = g->gpatch, b.K = g->K;
-    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x, b.shift_dev = shift_dev;
-    b.n_begin = n_begin, b.n_end = n_end;
-    const long groups = (n + 31) / 32;
-    long blocks = (groups + 2 * 4 - 1) / (2 * 4);  // 2 groups per wave, 4 waves per block
-    if (blocks > g->n_cu) blocks = g->n_cu;       // one block per CU (one wave per SIMD), grid-stride over the rest
-    if ((rc = grow(&g->partials, &g->partials_cap, (size_t)blocks))) return rc;
-    b.partials = g->partials;
-    n_waves = (int)blocks;
-    ProfScope prof(JD_KERNEL_GMM_BWD, s);
-    if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
-      gmm_bwd_lse_kernel<true, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+    g->last_pass_lse = lse_screened;
+    int32_t* arg = argmax_out;
+    if (grad_flux_accum && (!arg || fused)) {  // fused: the internal buffer holds the components after a fallback
+      if ((rc = grow(&g->argmax, &g->argmax_cap, (size_t)nPy * nPx))) return rc;
+      if (!arg) arg = g->argmax;
+    }
+    GmmFwdArgs a{};
+    a.flux = flux, a.afrag = g->afrag, a.mfrag = g->mfrag, a.const_k = g->const_k;
+    a.K = g->K, a.H = H, a.W = W, a.stride = stride, a.nPx = nPx, a.shift_y = shift_y, a.shift_x = shift_x, a.shift_dev = shift_dev;
+    a.n_begin = n_begin, a.n_end = n_end, a.argmax_out = fused ? argmax_out : arg, a.value_patch = nullptr, a.partials = g->partials;
+    if (grad_flux_accum && (rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;  // (the fused fallback writes it)
+    int n_waves = 0;
+    if (lse_screened)
+      rc = screened_forward(g, a, s, &n_waves, true, nullptr, (double)value_scale, value_out, accumulate_value, true);
+    else if (marginalize && grad_flux_accum) {
+      // value and gradient rows in one pass over the components (gmm_bwd_lse_kernel)
+      GmmBwdLseArgs b{};
+      b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.const_k = g->const_k;
+      b.partials = g->partials, b.gpatch = g->gpatch, b.K = g->K;
+      b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x, b.shift_dev = shift_dev;
+      b.n_begin = n_begin, b.n_end = n_end;
+      const long groups = (n + 31) / 32;
+      long blocks = (groups + 2 * 4 - 1) / (2 * 4);  // 2 groups per wave, 4 waves per block
+      if (blocks > g->n_cu) blocks = g->n_cu;       // one block per CU (one wave per SIMD), grid-stride over the rest
+      if ((rc = grow(&g->partials, &g->partials_cap, (size_t)blocks))) return rc;
+      b.partials = g->partials;
+      n_waves = (int)blocks;
+      ProfScope prof(JD_KERNEL_GMM_BWD, s);
+      if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
+        gmm_bwd_lse_kernel<true, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+      else
+        gmm_bwd_lse_kernel<false, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+      JD_LAUNCH_CHECK();
+    } else if (marginalize)
+      rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
+    else if (screened)
+      rc = screened_forward(g, a, s, &n_waves, fused, fused ? g->argmax : nullptr, (double)value_scale, value_out, accumulate_value);
     else
-      gmm_bwd_lse_kernel<false, 2><<<(unsigned)blocks, 256, 0, s>>>(b);
+      rc = launch_fwd<MODE_MAX>(a, g->triangular, g->n_cu, s, &n_waves);
+    if (rc) return rc;
+    // (screened path: the last block of gmm_best_kernel has written the value already)
+    if (!screened && !lse_screened &&
+        (rc = launch_finalize_sum(g->partials, n_waves, (double)value_scale, 0.0, value_out, accumulate_value, s)))
+      return rc;
+    if (!grad_flux_accum) return JD_OK;
+
+    if ((rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;
+    if (lse_screened) {
+      // the combine kernel (or, after a fallback, the gated dense backward kernel) has written g->gpatch
+    } else if (marginalize) {
+      // gmm_bwd_lse_kernel has written the rows together with the value
+    } else if (fused) {
+      // the rows are in g->grec already (after a fallback: in g->gpatch, written by gmm_best_kernel's blocks)
+    } else {
+    const size_t slots_cap = (size_t)n + 32 * (size_t)g->K;
+    if ((rc = grow(&g->order, &g->order_cap, slots_cap))) return rc;
+    // ---- bucket the patches by arg-max component -------------------------------------------------
+    GmmBucketArgs bk{};
+    bk.argmax = arg, bk.n_begin = n_begin, bk.n_end = n_end, bk.K = g->K;
+    bk.counts = g->bucket, bk.offsets = g->bucket + 2 * g->K;
+    bk.order = g->order, bk.gpatch = g->gpatch;
+    bk.chunk = BUCKET_CHUNK;
+    unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
+    const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
+    if (chunks > max_blocks) chunks = max_blocks;
+    if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
+    bk.blk_counts = g->blk_counts;
+    const size_t hist_bytes = (size_t)g->K * sizeof(int);
+    {
+      ProfScope prof(JD_KERNEL_GMM_BWD, s);
+      gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
+      gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
+      gmm_bucket_scatter_kernel<<<chunks, 256, 3 * hist_bytes + sizeof(int), s>>>(bk);
+      GmmBwdArgs b{};
+      b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
+      b.offsets = bk.offsets, b.counts = bk.counts, b.gpatch = g->gpatch, b.K = g->K;
+      b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x, b.shift_dev = shift_dev;
+      b.n_begin = n_begin, b.n_end = n_end;
+      long bwd_blocks = ((long)(slots_cap / 32) + 3) / 4;
+      const long cap = (long)g->n_cu * 3;  // 3 blocks of 4 waves per CU: one wave per SIMD x 3
+      if (bwd_blocks > cap) bwd_blocks = cap;
+      if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
+        gmm_bwd_max_kernel<true><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
+      else
+        gmm_bwd_max_kernel<false><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
+    }
     JD_LAUNCH_CHECK();
-  } else if (marginalize)
-    rc = launch_fwd<MODE_LSE>(a, g->triangular, g->n_cu, s, &n_waves);
-  else if (screened)
-    rc = screened_forward(g, a, s, &n_waves, fused, fused ? g->argmax : nullptr, (double)value_scale, value_out, accumulate_value);
-  else
-    rc = launch_fwd<MODE_MAX>(a, g->triangular, g->n_cu, s, &n_waves);
-  if (rc) return rc;
-  // (screened path: the last block of gmm_best_kernel has written the value already)
-  if (!screened && !lse_screened &&
-      (rc = launch_finalize_sum(g->partials, n_waves, (double)value_scale, 0.0, value_out, accumulate_value, s)))
-    return rc;
-  if (!grad_flux_accum) return JD_OK;
+    }
 
-  if ((rc = grow(&g->gpatch, &g->gpatch_cap, (size_t)n * D))) return rc;
-  if (lse_screened) {
-    // the combine kernel (or, after a fallback, the gated dense backward kernel) has written g->gpatch
-  } else if (marginalize) {
-    // gmm_bwd_lse_kernel has written the rows together with the value
-  } else if (fused) {
-    // the rows are in g->grec already (after a fallback: in g->gpatch, written by gmm_best_kernel's blocks)
+    g->pass = GmmPass{true, H, W, stride, shift_y, shift_x, patch_row_begin, patch_row_end, marginalize, fused, lse_screened, g->gen, shift_dev};
+    if (!(phases & 2)) return JD_OK;
   } else {
-  const size_t slots_cap = (size_t)n + 32 * (size_t)g->K;
-  if ((rc = grow(&g->order, &g->order_cap, slots_cap))) return rc;
-  // ---- bucket the patches by arg-max component -------------------------------------------------
-  GmmBucketArgs bk{};
-  bk.argmax = arg, bk.n_begin = n_begin, bk.n_end = n_end, bk.K = g->K;
-  bk.counts = g->bucket, bk.offsets = g->bucket + 2 * g->K;
-  bk.order = g->order, bk.gpatch = g->gpatch;
-  bk.chunk = BUCKET_CHUNK;
-  unsigned chunks = (unsigned)((n + BUCKET_CHUNK - 1) / BUCKET_CHUNK);
-  const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
-  if (chunks > max_blocks) chunks = max_blocks;
-  if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
-  bk.blk_counts = g->blk_counts;
-  const size_t hist_bytes = (size_t)g->K * sizeof(int);
-  {
-    ProfScope prof(JD_KERNEL_GMM_BWD, s);
-    gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
-    gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
-    gmm_bucket_scatter_kernel<<<chunks, 256, 3 * hist_bytes + sizeof(int), s>>>(bk);
-    GmmBwdArgs b{};
-    b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
-    b.offsets = bk.offsets, b.counts = bk.counts, b.gpatch = g->gpatch, b.K = g->K;
-    b.H = H, b.W = W, b.stride = stride, b.nPx = nPx, b.shift_y = shift_y, b.shift_x = shift_x, b.shift_dev = shift_dev;
-    b.n_begin = n_begin, b.n_end = n_end;
-    long bwd_blocks = ((long)(slots_cap / 32) + 3) / 4;
-    const long cap = (long)g->n_cu * 3;  // 3 blocks of 4 waves per CU: one wave per SIMD x 3
-    if (bwd_blocks > cap) bwd_blocks = cap;
-    if (g->triangular && !opt_is_set(OPT_GMM_DENSE))
-      gmm_bwd_max_kernel<true><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
-    else
-      gmm_bwd_max_kernel<false><<<(unsigned)bwd_blocks, 256, 0, s>>>(b);
+    const GmmPass& ps = g->pass;
+    JD_REQUIRE(ps.valid && ps.H == H && ps.W == W && ps.stride == stride && ps.shift_y == shift_y && ps.shift_x == shift_x &&
+                   ps.row_begin == patch_row_begin && ps.row_end == patch_row_end && ps.marginalize == marginalize &&
+                   ps.gen == g->gen && ps.shift_dev == shift_dev && grad_flux_accum,
+               "jd_gmm_prior_fwd_bwd: phase 2 (gather) without the matching phase 1 of the same pass");
+    fused = ps.fused, lse_screened = ps.lse_screened;
   }
-  JD_LAUNCH_CHECK();
-  }
-
+  g->pass.valid = false;
   GmmGatherArgs ga{};
   ga.gpatch = g->gpatch, ga.grad = grad_flux_accum, ga.H = H, ga.W = W, ga.stride = stride, ga.nPx = nPx, ga.nPy = nPy;
   ga.shift_y = shift_y, ga.shift_x = shift_x, ga.shift_dev = shift_dev, ga.row_begin = patch_row_begin, ga.row_end = patch_row_end;
@@ -3120,9 +3147,11 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
 extern "C" int jd_gmm_prior_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,
                                     int shift_x, int patch_row_begin, int patch_row_end, int marginalize,
                                     float value_scale, float* value_out, int accumulate_value, float grad_coef,
-                                    float* grad_flux_accum, int32_t* argmax_out, const int* shift_dev, void* stream) {
+                                    float* grad_flux_accum, int32_t* argmax_out, const int* shift_dev, int phases,
+                                    void* stream) {
   return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, patch_row_begin, patch_row_end, marginalize, value_scale,
-                        value_out, accumulate_value, grad_coef, grad_flux_accum, argmax_out, nullptr, stream, nullptr, shift_dev);
+                        value_out, accumulate_value, grad_coef, grad_flux_accum, argmax_out, nullptr, stream, nullptr, shift_dev,
+                        phases);
 }
 
 // Diagnostics of the screened arg-max path (no synchronisation: whatever pass has landed in the host-mapped block):
@@ -3163,7 +3192,8 @@ extern "C" int jd_gmm_screen_clock(jd_gmm* g, double* mhz_out, int* samples_out)
 
 extern "C" int jd_gmm_prior_fwd_bwd_step(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y, int shift_x,
                                          int marginalize, float value_scale, float* value_out, int accumulate_value,
-                                         float grad_coef, const jd_step* step, const int* shift_dev, void* stream) {
+                                         float grad_coef, const jd_step* step, const int* shift_dev, int phases,
+                                         void* stream) {
   JD_REQUIRE(step && step->theta && step->flux_in && step->flux_out && step->grad_flux, "jd_gmm_prior_fwd_bwd_step: null argument");
   JD_REQUIRE(step->sgd || (step->exp_avg && step->exp_avg_sq), "jd_gmm_prior_fwd_bwd_step: Adam needs its moment images");
   AdamArgs a{};
@@ -3173,7 +3203,7 @@ extern "C" int jd_gmm_prior_fwd_bwd_step(jd_gmm* g, const float* flux, int H, in
   a.one_minus_beta2 = step->one_minus_beta2, a.bias2_sqrt = step->bias2_sqrt, a.eps = step->eps, a.lr = step->lr;
   a.zero_grad = 0, a.sgd = step->sgd ? 1 : 0, a.linear = step->use_log_flux ? 0 : 1, a.bias_dev = step->bias_dev;
   return gmm_prior_impl(g, flux, H, W, stride, shift_y, shift_x, 0, -1, marginalize, value_scale, value_out, accumulate_value,
-                        grad_coef, nullptr, nullptr, nullptr, stream, &a, shift_dev);
+                        grad_coef, nullptr, nullptr, nullptr, stream, &a, shift_dev, phases);
 }
 
 extern "C" int jd_gmm_prior_band_fwd_bwd(jd_gmm* g, const float* flux, int H, int W, int stride, int shift_y,

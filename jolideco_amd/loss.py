@@ -107,13 +107,13 @@ class PoissonLoss:
     def batchable_calibrated(self, indices):
         """True if the datasets `indices` can take the batched CALIBRATED / UP-SAMPLED joint step
         (`fwd_bwd_batch_calibrated`): one flux component, ONE plan of the native FFT convolution shared by all datasets,
-        one up-sampling factor (2 or 4), each dataset with or without a calibration."""
+        one up-sampling factor (2, 3 or 4), each dataset with or without a calibration."""
         models_all = [self.npred_models_all[i] for i in indices]
         if len(models_all) < 2 or any(len(models) != 1 for models in models_all):
             return False
         first = next(iter(models_all[0].values()))
         u = first.upsampling_factor or 1
-        if u not in (2, 4) or first.plan.method != "fft" or not first.plan.native_fft:
+        if u not in (2, 3, 4) or first.plan.method != "fft" or not first.plan.native_fft:
             return False
         return all(
             (m.upsampling_factor or 1) == u and m.plan is first.plan for models in models_all for m in models.values()

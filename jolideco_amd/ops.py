@@ -356,7 +356,7 @@ class GmmHandle:
             pass
 
     def prior_fwd_bwd(self, flux, stride, shifts, value_out, value_scale, grad=None, grad_coef=0.0,
-                      marginalize=False, patch_rows=(0, -1), accumulate_value=False, argmax_out=None, band_out=None):
+                      marginalize=False, patch_rows=(0, -1), accumulate_value=False, argmax_out=None, band_out=None, phases=3):
         """``band_out``: instead of accumulating into ``grad``, write the gradient of the patch rows ``patch_rows`` as the
         band of the rolled frame they cover (jd_gmm_prior_band_fwd_bwd; `band_rows` gives its extent)."""
         flux = require_hip_tensor(flux, "flux")
@@ -387,12 +387,12 @@ class GmmHandle:
             _hip.lib().jd_gmm_prior_fwd_bwd(
                 self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(patch_rows[0]), int(patch_rows[1]),
                 int(bool(marginalize)), c_float(value_scale), ptr(value_out), int(accumulate_value),
-                c_float(grad_coef), ptr(grad), ptr(argmax_out), shift_dev, stream_ptr(flux.device),
+                c_float(grad_coef), ptr(grad), ptr(argmax_out), shift_dev, int(phases), stream_ptr(flux.device),
             )
         )
 
     def prior_fwd_bwd_step(self, flux, stride, shifts, value_out, value_scale, grad_coef, step, marginalize=False,
-                           accumulate_value=False):
+                           accumulate_value=False, phases=3):
         """The whole prior with the component's optimizer step in the epilogue of its gather kernel
         (jd_gmm_prior_fwd_bwd_step; ``step``: a filled `_hip.Step`).  Raises RuntimeError where the library does not
         support it (stride < 4): the caller then evaluates the prior and steps separately."""
@@ -405,7 +405,7 @@ class GmmHandle:
         check(
             _hip.lib().jd_gmm_prior_fwd_bwd_step(
                 self._handle, ptr(flux), H, W, int(stride), int(sy), int(sx), int(bool(marginalize)), c_float(value_scale),
-                ptr(value_out), int(accumulate_value), c_float(grad_coef), ctypes.byref(step), shift_dev,
+                ptr(value_out), int(accumulate_value), c_float(grad_coef), ctypes.byref(step), shift_dev, int(phases),
                 stream_ptr(flux.device),
             )
         )

@@ -104,7 +104,7 @@ class GMMPatchPrior(Prior):
             flux, self.gmm.handle(flux.device), self.stride, shifts, self.marginalize, scale
         )
 
-    def device_fwd_bwd(self, flux, value_out, grad=None, coef=0.0, patch_rows=None, shifts="draw", band_out=None):
+    def device_fwd_bwd(self, flux, value_out, grad=None, coef=0.0, patch_rows=None, shifts="draw", band_out=None, phases=3):
         """Fused path: value -> device scalar, ``grad += coef * d logprior / d flux``; with ``band_out`` the gradient of
         the shard ``patch_rows`` goes, un-accumulated, to the band of the rolled frame it covers (sharded joint fit)."""
         if isinstance(shifts, str):
@@ -112,13 +112,16 @@ class GMMPatchPrior(Prior):
         scale = self.log_like_weight / flux.numel()
         self.gmm.handle(flux.device).prior_fwd_bwd(
             flux.reshape(flux.shape[-2:]), self.stride, shifts, value_out, scale, grad=grad, grad_coef=coef * scale,
-            marginalize=self.marginalize, patch_rows=patch_rows or (0, -1), band_out=band_out,
+            marginalize=self.marginalize, patch_rows=patch_rows or (0, -1), band_out=band_out, phases=phases,
         )
 
     # the optimizer step of the component can ride in the epilogue of this prior's last kernel (`device_fwd_bwd_step`)
     supports_fused_step = True
+    # the pass splits into phase 1 (value + gradient rows: reads the flux only) and phase 2 (gather [+ step]): phase 1 may run
+    # on a second stream beside the likelihood launches (`phases` of device_fwd_bwd[_step]; FitSession)
+    supports_phases = True
 
-    def device_fwd_bwd_step(self, flux, value_out, coef, step, shifts="draw"):
+    def device_fwd_bwd_step(self, flux, value_out, coef, step, shifts="draw", phases=3):
         """`device_fwd_bwd` of the WHOLE prior with the component's optimizer step applied by its gather kernel:
         ``step.grad_flux`` holds every other gradient term; theta, the moments and the new flux are written in place
         (jd_gmm_prior_fwd_bwd_step).  Same numbers as `device_fwd_bwd` followed by the stand-alone step."""
@@ -127,7 +130,7 @@ class GMMPatchPrior(Prior):
         scale = self.log_like_weight / flux.numel()
         self.gmm.handle(flux.device).prior_fwd_bwd_step(
             flux.reshape(flux.shape[-2:]), self.stride, shifts, value_out, scale, coef * scale, step,
-            marginalize=self.marginalize,
+            marginalize=self.marginalize, phases=phases,
         )
 
     def hessian_ones(self, flux):

@@ -483,13 +483,12 @@ def test_c5_shaped_two_component_joint_step_1024_4obs():
 # ---------------------------------------------------------------------------------------------------------
 # config 6 shape (bench.py c6, the reference's Chandra example): calibrations + up-sampling + general PSFs
 # ---------------------------------------------------------------------------------------------------------
-def _check_c6_shaped_step(counts_shape, n_obs, psf_shape, label):
+def _check_c6_shaped_step(counts_shape, n_obs, psf_shape, label, u=2):
     """One joint step of a c6-shaped fit (calibrated, up-sampled x2, general PSFs, uniform prior) against autograd of
     the oracle in fp32 and float64: flux gradient, every dataset loss, d loss / d shift_xy, d loss / d log background norm."""
     from jolideco_amd import MAPDeconvolver, NPredCalibration, NPredCalibrations, SpatialFluxComponent, UniformPrior
     from jolideco_amd.data import instrument_observations
 
-    u = 2
     fh, fw = u * counts_shape[0], u * counts_shape[1]
     datasets, _, flux_init, cal = instrument_observations(shape=counts_shape, n_obs=n_obs, seed=0, psf_shape=psf_shape)
     rs = np.random.RandomState(5)  # (a rough start image: the pooled sums and the clip see structure at the pixel scale)
@@ -502,6 +501,7 @@ def _check_c6_shaped_step(counts_shape, n_obs, psf_shape, label):
     session = deco.session(datasets, components=comp, calibrations=cals)
     plans = {m.plan for m in session.total_loss.poisson_loss.npred_models_all}
     assert all(p.method == "fft" and p.native_fft for p in plans)
+    assert session.batch_joint_calibrated  # (the batched calibrated entry: the library runs its launches over all datasets)
     session.cfg._optimizer_step = lambda states, step: None  # keep the gradient buffer, no update
     session.epoch()
     torch.cuda.synchronize()
@@ -569,6 +569,13 @@ def test_c6_shaped_calibrated_upsampled_joint_step_ragged_width():
     and written at 4-byte alignment, the last piece of a counts row holds one pixel of the pooled Poisson pass (round 5:
     every image size takes the native FFT path and its batched steps)."""
     _check_c6_shaped_step((80, 97), 3, (33, 33), "160 x 194 flux grid x 3 (ragged width)")
+
+
+def test_c6_shaped_calibrated_upsampled_joint_step_factor_3():
+    """``upsampling_factor=3`` through the fused launches (round 5: the pooled middle launch owns COUNTS pixels and sums any
+    U x U block; until round 4 factors other than 2 and 4 ran the stand-alone kernels): counts grid 64 x 80, flux grid
+    192 x 240, general 17x17 PSFs (51x51 up-sampled), 3 calibrated observations, batched."""
+    _check_c6_shaped_step((64, 80), 3, (17, 17), "192 x 240 flux grid x 3, up-sampling factor 3", u=3)
 
 
 @pytest.mark.parametrize("form", ["batched", "per-dataset", "separate-kernels"])
