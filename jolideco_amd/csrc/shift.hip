@@ -128,11 +128,15 @@ __global__ __launch_bounds__(256) void shift_bwd_batch_kernel(const float* __res
 
 
 // ---- the same two kernels on four pixels per thread (W % 4 == 0, 16-byte aligned images) -------------------------------
-// A block owns SHIFT_ROWS rows of 1024 columns and walks down them: per row a thread loads the five source columns of ONE
-// new row of gs (a 16-byte load at a 4-byte aligned address + one float) and of the flux -- the row above is the previous
-// step's -- instead of four bounds-checked scalar loads per pixel and image; the gradient row goes through float4.  The
-// per-pixel arithmetic (order of the four products and three sums, every operation rounded on its own) is that of the
-// scalar kernels above: the same v, bit for bit.  4096^2: 77 -> see profiles/r05.
+// A thread owns R rows of four columns and keeps their gradient in REGISTERS over the datasets of the launch: per dataset
+// it loads R + 1 rows of five source columns of gs and of the flux (a 16-byte load at a 4-byte aligned address + one float
+// each -- independent loads, all in flight together) and the R centre rows of gs; the gradient is read once (if the launch
+// accumulates) and written once, where rounds 4-5 sent it through memory per dataset (a read-modify-write chain: 8
+// calibrated observations at 4096^2 390 us, and at 512^2 -- 32 blocks walking 16 rows x 8 datasets each -- 137 of the step's
+// 253 us).  The per-pixel arithmetic (order of the four products and three sums, v = t_d + v in dataset order, every
+// operation rounded on its own) is that of the scalar kernels above: the same v, bit for bit; the shift-gradient partial
+// sums are per block and dataset (wave sums by xor-butterfly, waves in index order: `block_sum`'s order), so their
+// grouping -- not their terms -- follows the tiling below.
 struct Row5 {
   float v[5];
 };
@@ -154,97 +158,146 @@ __device__ __forceinline__ Row5 load_row5(const float* img, int H, int W, int y,
   return r;
 }
 
-// rows [y_begin, y_end) of one dataset for this thread's four columns x .. x + 3; dsx / dsy += the shift gradient terms
-__device__ __forceinline__ void shift_bwd_rows4(const float* __restrict__ in, const float* __restrict__ gs, float* __restrict__ grad_in,
-                                                bool add, int H, int W, const ShiftGeom& g, int x, int y_begin, int y_end,
-                                                double& dsx, double& dsy) {
-#pragma clang fp contract(off)
-  const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
-  // gs rows py - 1 (prev) and py (cur) at columns x - fx - 1 ..; flux rows y0 (north) and y0 + 1 (south) at columns x + fx ..
-  Row5 prev = load_row5(gs, H, W, y_begin - g.fy - 1, x - g.fx - 1);
-  Row5 north = load_row5(in, H, W, y_begin + g.fy, x + g.fx);
-  for (int y = y_begin; y < y_end; ++y) {
-    const Row5 cur = load_row5(gs, H, W, y - g.fy, x - g.fx - 1);
-    const Row5 south = load_row5(in, H, W, y + g.fy + 1, x + g.fx);
-    const size_t off = (size_t)y * W + x;
-    const float4 go = *reinterpret_cast<const float4*>(gs + off);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (add) acc = *reinterpret_cast<const float4*>(grad_in + off);
-    const float gov[4] = {go.x, go.y, go.z, go.w}, accv[4] = {acc.x, acc.y, acc.z, acc.w};
-    float out[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = cur.v[i + 1] * w00 + cur.v[i] * w10 + prev.v[i + 1] * w01 + prev.v[i] * w11;
-      if (add) v += accv[i];
-      out[i] = v;
-      const float nw = north.v[i], ne = north.v[i + 1], sw = south.v[i], se = south.v[i + 1];
-      dsx += (double)(gov[i] * ((ne - nw) * g.wy0 + (se - sw) * g.wy1));
-      dsy += (double)(gov[i] * ((sw - nw) * g.wx0 + (se - ne) * g.wx1));
-    }
-    *reinterpret_cast<float4*>(grad_in + off) = make_float4(out[0], out[1], out[2], out[3]);
-    prev = cur, north = south;
-  }
+// Tiling of an H x W image: a block's 256 threads are `segs` row segments of `tpr` threads (a power of two <= 256: narrow
+// images put several row segments into a block instead of idle threads), a thread owns R rows: the block covers
+// segs * R rows of 4 * tpr columns.  R: 4 while that leaves >= 4 blocks per CU, else 2, else 1 (a 512^2 image: 256 blocks).
+struct ShiftTiling {
+  int tpr_log2, segs, R;
+  dim3 grid;
+};
+
+static ShiftTiling shift_tiling(int H, int W) {
+  ShiftTiling t;
+  t.tpr_log2 = 4;
+  while (t.tpr_log2 < 8 && (4 << t.tpr_log2) < W) ++t.tpr_log2;
+  const int tpr = 1 << t.tpr_log2;
+  t.segs = 256 / tpr;
+  const int gx = (W + 4 * tpr - 1) / (4 * tpr);
+  auto blocks = [&](int r) { return gx * ((H + t.segs * r - 1) / (t.segs * r)); };
+  t.R = blocks(4) >= 1024 ? 4 : blocks(2) >= 1024 ? 2 : 1;
+  t.grid = dim3(gx, (H + t.segs * t.R - 1) / (t.segs * t.R));
+  return t;
 }
 
-__global__ __launch_bounds__(256) void shift_bwd4_kernel(const float* __restrict__ in, const float* __restrict__ gs,
-                                                         float* __restrict__ grad_in, int accumulate, int H, int W,
-                                                         const float* __restrict__ shift_xy, float scale,
-                                                         double* __restrict__ partials) {
-  __shared__ double smem[256 / 64];
-  const int x = 4 * (blockIdx.x * 256 + threadIdx.x);
-  const ShiftGeom g = shift_geom(shift_xy, scale);
-  double dsx = 0.0, dsy = 0.0;
-  if (x < W)
-    shift_bwd_rows4(in, gs, grad_in, accumulate != 0, H, W, g, x, blockIdx.y * SHIFT_ROWS, min((int)(blockIdx.y + 1) * SHIFT_ROWS, H), dsx, dsy);
-  const double tx = block_sum<256>(dsx, smem);
-  __syncthreads();
-  const double ty = block_sum<256>(dsy, smem);
-  if (threadIdx.x == 0) {
-    const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    partials[2 * b] = tx * (double)scale;
-    partials[2 * b + 1] = ty * (double)scale;
-  }
-}
+struct ShiftBwdArgs {
+  const float* in;
+  const FftBatch* batch;  // the datasets' images and shifts (device table), or nullptr: the ONE dataset below
+  const float* gs0;
+  const float* shift0;
+  int n_datasets;
+  float* grad_in;
+  int accumulate, H, W, tpr_log2;
+  float scale;
+  double* partials;
+  size_t partials_stride;
+};
 
-__global__ __launch_bounds__(256) void shift_bwd4_batch_kernel(const float* __restrict__ in, const FftBatch* __restrict__ batch,
-                                                               int n_datasets, float* __restrict__ grad_in, int accumulate, int H,
-                                                               int W, float scale, double* __restrict__ partials,
-                                                               size_t partials_stride) {
+constexpr int SHIFT_CHUNK = 16;  // datasets between two barriers (their wave sums wait in LDS)
+
+template <int R>
+__global__ __launch_bounds__(256) void shift_bwd4_kernel(ShiftBwdArgs a) {
 #pragma clang fp contract(off)
-  __shared__ double smem[256 / 64];
-  const int x = 4 * (blockIdx.x * 256 + threadIdx.x);
+  __shared__ double wsum[SHIFT_CHUNK][256 / 64][2];
+  const int H = a.H, W = a.W;
+  const int tpr = 1 << a.tpr_log2, seg = threadIdx.x >> a.tpr_log2, segs = 256 >> a.tpr_log2;
+  const int x = 4 * (blockIdx.x * tpr + (threadIdx.x & (tpr - 1)));
+  const int y0 = ((int)blockIdx.y * segs + seg) * R;
+  const bool live = x < W && y0 < H;
   const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-  const int y_begin = blockIdx.y * SHIFT_ROWS, y_end = min((int)(blockIdx.y + 1) * SHIFT_ROWS, H);
-  for (int d = 0; d < n_datasets; ++d) {
-    const float* gs = batch->gshift[d];
-    const float* shift_xy = batch->shift_xy[d];
-    const bool add = accumulate || d > 0;
-    double dsx = 0.0, dsy = 0.0;
-    if (shift_xy) {
-      const ShiftGeom g = shift_geom(shift_xy, scale);
-      if (x < W) shift_bwd_rows4(in, gs, grad_in, add, H, W, g, x, y_begin, y_end, dsx, dsy);
-      const double tx = block_sum<256>(dsx, smem);
-      __syncthreads();
-      const double ty = block_sum<256>(dsy, smem);
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        partials[(size_t)d * partials_stride + 2 * b] = tx * (double)scale;
-        partials[(size_t)d * partials_stride + 2 * b + 1] = ty * (double)scale;
-      }
-    } else if (x < W) {
-      for (int y = y_begin; y < y_end; ++y) {
-        const size_t off = (size_t)y * W + x;
-        float4 v = *reinterpret_cast<const float4*>(gs + off);
-        if (add) {
-          const float4 o = *reinterpret_cast<const float4*>(grad_in + off);
-          v.x += o.x, v.y += o.y, v.z += o.z, v.w += o.w;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float acc[R][4];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.accumulate && live && y0 + k < H) q = *reinterpret_cast<const float4*>(a.grad_in + (size_t)(y0 + k) * W + x);
+    acc[k][0] = q.x, acc[k][1] = q.y, acc[k][2] = q.z, acc[k][3] = q.w;
+  }
+  for (int d0 = 0; d0 < a.n_datasets; d0 += SHIFT_CHUNK) {
+    const int dn = min(SHIFT_CHUNK, a.n_datasets - d0);
+    for (int dd = 0; dd < dn; ++dd) {
+      const int d = d0 + dd;
+      const float* gs = a.batch ? a.batch->gshift[d] : a.gs0;
+      const float* shift_xy = a.batch ? a.batch->shift_xy[d] : a.shift0;
+      const bool add = a.accumulate || d > 0;
+      if (shift_xy) {  // (uniform)
+        double dsx = 0.0, dsy = 0.0;
+        if (live) {
+          const ShiftGeom g = shift_geom(shift_xy, a.scale);
+          const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
+          // gs rows y - fy - 1 (prev) and y - fy (cur) at columns x - fx - 1 ..; flux rows y + fy (north), y + fy + 1 (south)
+          Row5 gr[R + 1], fl[R + 1];
+          float4 go[R];
+#pragma unroll
+          for (int k = 0; k <= R; ++k) {
+            gr[k] = load_row5(gs, H, W, y0 + k - g.fy - 1, x - g.fx - 1);
+            fl[k] = load_row5(a.in, H, W, y0 + k + g.fy, x + g.fx);
+          }
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            go[k] = y0 + k < H ? *reinterpret_cast<const float4*>(gs + (size_t)(y0 + k) * W + x) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int k = 0; k < R; ++k) {
+            const float gov[4] = {go[k].x, go[k].y, go[k].z, go[k].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float v = gr[k + 1].v[i + 1] * w00 + gr[k + 1].v[i] * w10 + gr[k].v[i + 1] * w01 + gr[k].v[i] * w11;
+              if (add) v += acc[k][i];
+              acc[k][i] = v;
+              const float nw = fl[k].v[i], ne = fl[k].v[i + 1], sw = fl[k + 1].v[i], se = fl[k + 1].v[i + 1];
+              dsx += (double)(gov[i] * ((ne - nw) * g.wy0 + (se - sw) * g.wy1));
+              dsy += (double)(gov[i] * ((sw - nw) * g.wx0 + (se - ne) * g.wx1));
+            }
+          }
         }
-        *reinterpret_cast<float4*>(grad_in + off) = v;
+        dsx = wave_sum(dsx), dsy = wave_sum(dsy);
+        if (lane == 0) wsum[dd][wave][0] = dsx, wsum[dd][wave][1] = dsy;
+      } else if (live) {  // a dataset without a shift contributes its image as it is
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          if (y0 + k >= H) continue;
+          const float4 q = *reinterpret_cast<const float4*>(gs + (size_t)(y0 + k) * W + x);
+          const float qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = qv[i];
+            if (add) v += acc[k][i];
+            acc[k][i] = v;
+          }
+        }
       }
     }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * dn) {  // thread 2 dd + i: sum i of dataset d0 + dd over the waves, in wave order
+      const int dd = threadIdx.x >> 1, i = threadIdx.x & 1, d = d0 + dd;
+      const float* shift_xy = a.batch ? a.batch->shift_xy[d] : a.shift0;
+      if (shift_xy) {
+        double total = 0.0;
+#pragma unroll
+        for (int w = 0; w < 256 / 64; ++w) total += wsum[dd][w][i];
+        a.partials[(size_t)d * a.partials_stride + 2 * b + i] = total * (double)a.scale;
+      }
+    }
+    __syncthreads();
+  }
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+      if (y0 + k < H)
+        *reinterpret_cast<float4*>(a.grad_in + (size_t)(y0 + k) * W + x) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
   }
 }
 
+static int launch_shift_bwd4(const ShiftBwdArgs& base, int* n_blocks, hipStream_t stream) {
+  ShiftBwdArgs a = base;
+  const ShiftTiling t = shift_tiling(a.H, a.W);
+  a.tpr_log2 = t.tpr_log2;
+  *n_blocks = t.grid.x * t.grid.y;
+  if (t.R == 4) shift_bwd4_kernel<4><<<t.grid, 256, 0, stream>>>(a);
+  else if (t.R == 2) shift_bwd4_kernel<2><<<t.grid, 256, 0, stream>>>(a);
+  else shift_bwd4_kernel<1><<<t.grid, 256, 0, stream>>>(a);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
 
 static bool shift_vec_ok(const void* a, const void* b, const void* c, int W) {
   return W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
@@ -253,15 +306,14 @@ static bool shift_vec_ok(const void* a, const void* b, const void* c, int W) {
 int launch_shift_bwd_batch(const float* in, const FftBatch* batch, int n_datasets, float* grad_in, int accumulate, int H, int W,
                            float scale, double* partials, size_t partials_stride, int* n_blocks, hipStream_t stream) {
   // (the batch table's images are hipMalloc'ed by the plan: 256-byte aligned)
-  const bool vec = shift_vec_ok(in, grad_in, nullptr, W);
-  dim3 grid(vec ? (W + 1023) / 1024 : (W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
-  *n_blocks = grid.x * grid.y;
   ProfScope prof(JD_KERNEL_SHIFT, stream);
-  // (measured, not kept -- round 5: rows outside / datasets inside, the pixel's gradient in registers and written once, the
-  // per-dataset partial sums in LDS: 458 against 390 us for 8 datasets at 4096^2 -- the loop over the datasets then runs its
-  // 24 loads per dataset and row one dataset after the other)
-  if (vec) shift_bwd4_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
-  else shift_bwd_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
+  if (shift_vec_ok(in, grad_in, nullptr, W)) {
+    ShiftBwdArgs a{in, batch, nullptr, nullptr, n_datasets, grad_in, accumulate, H, W, 0, scale, partials, partials_stride};
+    return launch_shift_bwd4(a, n_blocks, stream);
+  }
+  dim3 grid((W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
+  *n_blocks = grid.x * grid.y;
+  shift_bwd_batch_kernel<<<grid, 256, 0, stream>>>(in, batch, n_datasets, grad_in, accumulate, H, W, scale, partials, partials_stride);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }
@@ -330,16 +382,22 @@ int launch_shift_fwd(const float* in, float* out, int H, int W, const float* shi
   return JD_OK;
 }
 
-int shift_bwd_max_blocks(int H, int W) { return ((W + 255) / 256) * ((H + SHIFT_ROWS - 1) / SHIFT_ROWS); }
+int shift_bwd_max_blocks(int H, int W) {  // partial-sum pairs a launch may write: the larger of the two tilings
+  const ShiftTiling t = shift_tiling(H, W);
+  const int scalar = ((W + 255) / 256) * ((H + SHIFT_ROWS - 1) / SHIFT_ROWS), vec = (int)(t.grid.x * t.grid.y);
+  return scalar > vec ? scalar : vec;
+}
 
 int launch_shift_bwd(const float* in, const float* gs, float* grad_in, int accumulate, int H, int W,
                      const float* shift_xy, float scale, double* partials, int* n_blocks, hipStream_t stream) {
-  const bool vec = shift_vec_ok(in, gs, grad_in, W);
-  dim3 grid(vec ? (W + 1023) / 1024 : (W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
-  *n_blocks = grid.x * grid.y;
   ProfScope prof(JD_KERNEL_SHIFT, stream);
-  if (vec) shift_bwd4_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
-  else shift_bwd_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
+  if (shift_vec_ok(in, gs, grad_in, W)) {
+    ShiftBwdArgs a{in, nullptr, gs, shift_xy, 1, grad_in, accumulate, H, W, 0, scale, partials, 0};
+    return launch_shift_bwd4(a, n_blocks, stream);
+  }
+  dim3 grid((W + 255) / 256, (H + SHIFT_ROWS - 1) / SHIFT_ROWS);
+  *n_blocks = grid.x * grid.y;
+  shift_bwd_kernel<<<grid, 256, 0, stream>>>(in, gs, grad_in, accumulate, H, W, shift_xy, scale, partials);
   JD_LAUNCH_CHECK();
   return JD_OK;
 }

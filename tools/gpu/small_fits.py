@@ -11,10 +11,15 @@ from jolideco_amd.priors.patches import GaussianMixtureModel, GaussianMixtureMod
 
 DEV = "cuda:0"
 means, covs, weights = synthetic_gmm(128, 64, seed=0)
+ONLY = os.environ.get("SMALL_FITS_ONLY")  # e.g. "256:uniform:by-value" (a profiler run of one case)
 for counts_shape, n_obs in (((256, 256), 8), ((512, 512), 8), ((1024, 1024), 8)):
+    if ONLY and int(ONLY.split(":")[0]) != counts_shape[0]:
+        continue
     datasets, _, flux_init, cal = instrument_observations(shape=counts_shape, n_obs=n_obs, seed=0, psf_shape=(33, 33))
     for prior_name in ("uniform", "gmm"):
         for mode in ("by-value", "planned", "graph"):
+            if ONLY and ONLY.split(":")[1:] != [prior_name, mode]:
+                continue
             os.environ["JOLIDECO_STEP_SCALARS"] = "host" if mode == "by-value" else "device"
             os.environ["JOLIDECO_GRAPH"] = "1" if mode == "graph" else "0"
             gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
