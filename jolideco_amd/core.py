@@ -615,11 +615,13 @@ class FitSession:
         # captured in a hipGraph per flux-buffer parity and replayed (JOLIDECO_GRAPH=0: planned epochs without capture;
         # JOLIDECO_STEP_SCALARS=host: the by-value form of rounds 1-4 throughout)
         # JOLIDECO_GRAPH: "1" capture always, "0" never (planned epochs enqueued eagerly), unset / "auto": the first
-        # AUTO_PROBE epochs run by value and are timed -- host time to enqueue an epoch against the device's time for it --,
-        # and only a fit the HOST bounds goes on to planned, captured epochs: a replayed epoch costs the device a few
-        # microseconds more per step than eagerly launched kernels (a fetch of the step scalars, the graph's own
-        # hand-overs: +1.3 % on the 0.62 ms step of the benchmark, +4 % on a 0.26 ms step), which is a loss wherever the
-        # host already keeps the queue full (tools/gpu/small_fits.py, profiles/r05/small_fits.txt)
+        # AUTO_PROBE epochs run by value and are timed -- host time to enqueue an epoch against the device's time for it.
+        # Where the host needs less than AUTO_CLEAR of the device's time the fit stays by value (a replayed epoch costs the
+        # device a few microseconds more per step than eagerly launched kernels -- a fetch of the step scalars, the graph's
+        # own hand-overs: +1.3 % on the 0.62 ms step of the benchmark); otherwise the epoch is captured, AUTO_PROBE replays
+        # are timed the same way, and the faster form stays (tools/gpu/small_fits.py, profiles/r05/small_fits.txt: the
+        # host/device ratio alone misjudges fits in between -- 1024^2 x 8 with the GMM prior, ratio 0.64: 343 us by value,
+        # 311 replayed; with the uniform prior, ratio 0.75: 194 by value, 205 replayed)
         mode = os.environ.get("JOLIDECO_GRAPH", "auto").lower()
         self.graph_mode = {"1": "always", "on": "always", "0": "never", "off": "never"}.get(mode, "auto")
         if getattr(deconvolver, "use_graph", None) is not None:
@@ -627,6 +629,7 @@ class FitSession:
         self.use_graph = self.graph_mode == "always"
         self.graph_policy = {"always": "captured epochs (forced)", "never": "no capture (forced)"}.get(self.graph_mode, "undecided")
         self._probe = []  # (host seconds, start event, end event) of the by-value probe epochs
+        self._trial = None  # the replayed epochs being timed against them
         # the GMM prior's first phase on a second stream beside the likelihood launches (`_start_priors`)
         self.overlap_prior = os.environ.get("JOLIDECO_PRIOR_OVERLAP", "1") != "0"
         self._side_stream = torch.cuda.Stream(device=device)
@@ -801,6 +804,7 @@ class FitSession:
         self._graphs = {}
         self._epochs_done = 0
         self._option_generation = _hip.OPTION_GENERATION
+        self._trial = None
         if self.graph_mode == "auto":
             self.use_graph, self.graph_policy, self._probe = False, "undecided", []
 
@@ -911,6 +915,8 @@ class FitSession:
         cfg, n_d, slot, step_no = self.cfg, self.n_d, self._slot, self.step + 1
         calls = []
         for ci, (st, prior) in enumerate(zip(self.states, self.priors)):
+            if getattr(prior, "value_is_zero", False):
+                continue  # (a uniform prior: its slot holds the 0 the first epoch wrote -- no fill launch per step)
             kwargs = {"shifts": shifts[ci]} if ci in shifts else {}
             flux, value = st.flux_cur, slot(n_d + ci)
             if self._fuse_step(st, prior):
@@ -976,7 +982,10 @@ class FitSession:
         parity = tuple(st.cur for st in self.states) + plan["signature"]
         graph = self._graphs.get(parity) if self.use_graph else None
         if graph is not None:
-            graph.replay()
+            if self._trial is not None:
+                self._trial_replay(graph)
+            else:
+                graph.replay()
             self._commit_replay(plan)
         elif self.use_graph and self._epochs_done >= self.GRAPH_WARMUP and not _hip.profile_active():
             # capture this epoch's launches (nothing runs during the capture), then run them
@@ -1089,6 +1098,8 @@ class FitSession:
                     total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
             trace_shifts = plan["shifts"][-1]
             for ci, (st, prior) in enumerate(zip(states, priors)):
+                if getattr(prior, "value_is_zero", False):
+                    continue
                 kwargs = {"shifts": trace_shifts[ci]} if ci in trace_shifts else {}
                 prior.device_fwd_bwd(st.flux_trace, slot(n_d + ci), **kwargs)
 
@@ -1112,13 +1123,12 @@ class FitSession:
         return self._epoch_by_value()
 
     AUTO_PROBE = 8  # by-value epochs timed before the "auto" policy decides
-    AUTO_HOST_BOUND = 0.75  # host enqueue time / device time of an epoch beyond which the fit counts as host bound
+    AUTO_CLEAR = 0.4  # host enqueue time / device time of an epoch below which the device bounds the fit for certain
 
     def _epoch_probe(self):
         """A by-value epoch of the "auto" policy's probe phase: timed on the host and, by an event pair, on the device.
-        After AUTO_PROBE of them (one wait for the last event) the session goes on by value (the device bounds the fit: the
-        events are as far apart as the device needs) or to planned, captured epochs (the host bounds it: the device ran
-        every epoch as fast as it was enqueued)."""
+        After AUTO_PROBE of them (one wait for the last event) the session goes on by value (the device clearly bounds the
+        fit: the events are as far apart as the device needs) or captures the epoch and times replays (`_trial_replay`)."""
         import time
 
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1137,11 +1147,36 @@ class FitSession:
         device_s = 1e-3 * float(np.median([a.elapsed_time(b) for _, a, b in probe]))
         ratio = host_s / max(device_s, 1e-9)
         self._probe = []
-        if ratio > self.AUTO_HOST_BOUND:
-            self.use_graph = True
-            self.graph_policy = f"captured epochs (host bound: enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us per epoch)"
-        else:
+        if ratio < self.AUTO_CLEAR:
             self.graph_policy = f"by value (device bound: enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us per epoch)"
+        else:
+            # the host takes a good part of the epoch's time: capture, time AUTO_PROBE replays the same way, keep the faster
+            self.use_graph = True
+            self._trial = {"by_value": device_s, "host": host_s, "events": []}
+            self.graph_policy = (f"captured epochs (on trial: by value enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us "
+                                 "per epoch)")
+
+    def _trial_replay(self, graph):
+        """A replayed epoch of the trial: timed like the probe epochs; after AUTO_PROBE of them the faster form stays."""
+        trial = self._trial
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        graph.replay()
+        end.record()
+        trial["events"].append((start, end))
+        if len(trial["events"]) < self.AUTO_PROBE:
+            return
+        end.synchronize()
+        replay_s = 1e-3 * float(np.median([a.elapsed_time(b) for a, b in trial["events"][2:]]))
+        by_value_s = trial["by_value"]
+        self._trial = None
+        numbers = f"replayed {1e6 * replay_s:.0f} us / by value {1e6 * by_value_s:.0f} us per epoch, enqueue {1e6 * trial['host']:.0f} us"
+        if replay_s <= by_value_s:
+            self.graph_policy = f"captured epochs (measured: {numbers})"
+        else:
+            self.use_graph = False
+            self._graphs = {}
+            self.graph_policy = f"by value (measured: {numbers})"
 
     def _epoch_by_value(self):
         cfg, dist, states, priors, total_loss = self.cfg, self.dist, self.states, self.priors, self.total_loss

@@ -123,13 +123,15 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, int N, const Ff
 // The generic (runtime-radix) form comes in two sizes: <0, 0, 0, 1> for rows of at most GENERIC_SMALL points (image and padded
 // length: the per-thread arrays of a row's pieces are a third as long -- the small images of the reference's own examples)
 // and <0, 0, 0, 0> for everything else.
-constexpr int GENERIC_SMALL = 1536, GENERIC_LARGE = 5120;
+// <0, 0, 0, 2>: rows of at most GENERIC_TINY points on ONE wave (round 5: a 768-point row is 48 radix-16 butterflies per pass --
+// a 256-thread block idles through them and pays block barriers between the passes; one wave per row pair fences instead).
+constexpr int GENERIC_TINY = 1024, GENERIC_SMALL = 1536, GENERIC_LARGE = 5120;
 template <int R0, int R1, int R2, int R3>
 struct RowSched {
   static constexpr bool STATIC = R0 > 0;
   static constexpr int N = STATIC ? R0 * R1 * R2 * (R3 ? R3 : 1) : 0;
-  static constexpr int LIMIT = STATIC ? N : R3 == 1 ? GENERIC_SMALL : GENERIC_LARGE;  // longest row (pixels or points) the kernel takes
-  static constexpr int T = (R0 == 8 && R1 == 8 && R2 == 8 && R3 == 9) ? 576 : ROW_THREADS;
+  static constexpr int LIMIT = STATIC ? N : R3 == 2 ? GENERIC_TINY : R3 == 1 ? GENERIC_SMALL : GENERIC_LARGE;  // longest row (pixels or points) the kernel takes
+  static constexpr int T = (R0 == 8 && R1 == 8 && R2 == 8 && R3 == 9) ? 576 : (!STATIC && R3 == 2) ? 64 : ROW_THREADS;
   static constexpr int WAVES_PER_SIMD = T == 576 ? 5 : 1;  // (two blocks of nine waves: five on one SIMD -> at most 96 registers)
   static constexpr int MAXQ = (LIMIT + 4 * T - 1) / (4 * T);  // 16-byte pieces of an image row per thread
   static constexpr int PRE = (LIMIT + 2 * T - 1) / (2 * T);   // 16-byte pieces of a spectrum row per thread
@@ -166,7 +168,7 @@ __device__ __forceinline__ float2* fft_lds_static(float2* a, float2* b, const fl
 template <int DIR, class S, int R0, int R1, int R2, int R3>
 __device__ __forceinline__ float2* row_fft(float2* a, float2* b, int Nx, const FftPasses& f, const float2* tw, int tid) {
   if constexpr (S::STATIC) return fft_lds_static<DIR, R0, R1, R2, R3>(a, b, tw, tid);
-  else return fft_lds<DIR, true>(a, b, Nx, f, tw, tid, ROW_THREADS);
+  else return fft_lds<DIR, (S::T > 64)>(a, b, Nx, f, tw, tid, S::T);
 }
 
 // The same transform IN PLACE by the LANES threads of one column (the column kernel: one buffer per column instead of
@@ -1223,30 +1225,44 @@ int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t
 
 // The row kernels by schedule: compile-time forms for the row lengths of the usual image sizes, the generic form
 // otherwise.  Index into every table: row_schedule(f).
-constexpr int N_ROW_SCHED = 5;
-int row_schedule(const FftPasses& f, int Nx, int W) {
+constexpr int N_ROW_SCHED = 6;
+int fftn_cus() {  // compute units of the current device
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+int row_schedule(const FftPasses& f, int Nx, int W, int blocks) {
   auto is = [&](int r0, int r1, int r2, int r3) {
     return f.n == (r3 ? 4 : 3) && f.r[0] == r0 && f.r[1] == r1 && f.r[2] == r2 && (!r3 || f.r[3] == r3);
   };
   if (is(16, 16, 9, 0)) return 1;  // 2304: 2048-column images
   if (is(8, 8, 8, 9)) return 2;    // 4608: 4096-column images
   if (is(16, 8, 9, 0)) return 3;   // 1152: 1024-column images
+  // one wave per row where the launch has rows enough to fill the chip with waves (8 batched datasets at 512^2: 2592 row
+  // pairs, 150 -> 126 us per step); a launch of few rows (one dataset: 384) is done sooner with four waves on each
+  // (e0102, sequential: 0.240 against 0.263 ms per step)
+  const int tiny = opt_value(OPT_FFT_TINY, GENERIC_TINY);
+  if (Nx <= tiny && Nx <= GENERIC_TINY && W <= GENERIC_TINY && (blocks >= 3 * fftn_cus() || opt_is_set(OPT_FFT_TINY))) return 5;
   return Nx <= GENERIC_SMALL && W <= GENERIC_SMALL ? 4 : 0;
 }
 #define JD_ROW_KERNELS(NAME, ...)                                                                          \
   {NAME<__VA_ARGS__ 0, 0, 0, 0>, NAME<__VA_ARGS__ 16, 16, 9, 0>, NAME<__VA_ARGS__ 8, 8, 8, 9>, NAME<__VA_ARGS__ 16, 8, 9, 0>, \
-   NAME<__VA_ARGS__ 0, 0, 0, 1>}
+   NAME<__VA_ARGS__ 0, 0, 0, 1>, NAME<__VA_ARGS__ 0, 0, 0, 2>}
 
 template <class Args>
 int launch_row_kernel(void (*const (&kernels)[N_ROW_SCHED])(Args), const FftNative& n, const Args& a,
                       int kernel_id, hipStream_t stream, int blocks = 0) {
-  const int sched = row_schedule(a.f, n.Nx, n.W);
+  const int sched = row_schedule(a.f, n.Nx, n.W, blocks ? blocks : n.Hh);
   const size_t lds_rows = (size_t)2 * lp_size(n.Nx) * sizeof(float2);
   int rc = lds_attr(reinterpret_cast<const void*>(kernels[sched]), lds_rows);
   if (rc) return rc;
   ProfScope prof(kernel_id, stream);
   static constexpr int threads[N_ROW_SCHED] = {RowSched<0, 0, 0, 0>::T, RowSched<16, 16, 9, 0>::T, RowSched<8, 8, 8, 9>::T, RowSched<16, 8, 9, 0>::T,
-                                               RowSched<0, 0, 0, 1>::T};
+                                               RowSched<0, 0, 0, 1>::T, RowSched<0, 0, 0, 2>::T};
   hipLaunchKernelGGL(kernels[sched], dim3(blocks ? blocks : n.Hh), dim3(threads[sched]), lds_rows, stream, a);
   JD_LAUNCH_CHECK();
   return JD_OK;

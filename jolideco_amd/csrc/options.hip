@@ -33,6 +33,7 @@ OptionSlot g_options[OPT_COUNT] = {
     {"JD_DIRECT_AUTO_ALL", {INT_MIN}},  // "auto" takes the MFMA Toeplitz kernel up to 33 taps (as before round 4)
     {"JD_FFT_BATCH", {INT_MIN}},  // 0: the batched joint steps of a native FFT plan run their per-dataset calls; the calibrated
                                   // one beyond 2048 flux rows: 3 per-dataset calls, 4 per-dataset FFT launches + one tail
+    {"JD_FFT_TINY", {INT_MIN}},   // longest row (points) of the one-wave generic row kernels; 0: off (default 1024)
 };
 
 int parse(const char* text) {

@@ -91,6 +91,8 @@ class UniformPrior(Prior):
     def __call__(self, flux):
         return torch.tensor(0)
 
+    value_is_zero = True  # log-prior 0, gradient 0: a session whose slot for the value already holds 0 skips the call
+
     def device_fwd_bwd(self, flux, value_out, grad=None, coef=0.0, patch_rows=None):
         value_out.zero_()
 

@@ -159,23 +159,28 @@ def test_an_option_set_between_epochs_invalidates_the_captured_epochs(monkeypatc
 
 
 def test_the_auto_policy_decides_after_its_probe_epochs(monkeypatch):
-    """Default policy: epochs 1 .. 8 by value and timed, then ONE decision from the host's enqueue time against the device's
-    time per epoch; whichever way it goes the fit is the by-value fit bit for bit."""
+    """Default policy: epochs 1 .. 8 by value and timed; a fit whose host time is a good part of the device's is then
+    captured and 8 replays are timed against them, the faster form stays.  Whichever way it goes the fit is the by-value fit
+    bit for bit."""
     from jolideco_amd import MAPDeconvolver
 
-    by_value = _fit(monkeypatch, "host", _build_joint, 14, "joint")
+    n_epochs = 26  # first epoch, 8 probe epochs, 3 eager planned epochs, 2 captures, 8 timed replays, 4 more
+    by_value = _fit(monkeypatch, "host", _build_joint, n_epochs, "joint")
     monkeypatch.delenv("JOLIDECO_GRAPH", raising=False)
     monkeypatch.delenv("JOLIDECO_STEP_SCALARS", raising=False)
     datasets, comp, _ = _build_joint()
     session = MAPDeconvolver(n_epochs=1, display_progress=False, device=DEV, fit_mode="joint").session(datasets, components=comp)
-    rows = []
-    for i in range(14):
+    rows, policies = [], []
+    for i in range(n_epochs):
         session.epoch()
         rows.append(session.scalars.clone())
+        policies.append(session.graph_policy)
         assert (session.graph_policy == "undecided") == (i < 8), (i, session.graph_policy)
     torch.cuda.synchronize()
+    print("auto policy on the 96 x 132 joint fit:", policies[8], "->", session.graph_policy)
     assert session.graph_policy.startswith(("by value", "captured epochs"))
+    if "on trial" in policies[8]:
+        assert "measured" in session.graph_policy and session._trial is None
     assert bool(session._graphs) == session.graph_policy.startswith("captured")
-    print("auto policy on the 96 x 132 joint fit:", session.graph_policy)
     np.testing.assert_array_equal(torch.stack(rows).cpu().numpy(), by_value[1])
     np.testing.assert_array_equal(session.states[0].flux_cur.cpu().numpy(), by_value[0][0])

@@ -17,11 +17,13 @@ for counts_shape, n_obs in (((256, 256), 8), ((512, 512), 8), ((1024, 1024), 8))
         continue
     datasets, _, flux_init, cal = instrument_observations(shape=counts_shape, n_obs=n_obs, seed=0, psf_shape=(33, 33))
     for prior_name in ("uniform", "gmm"):
-        for mode in ("by-value", "planned", "graph"):
+        for mode in ("by-value", "planned", "graph", "auto"):
             if ONLY and ONLY.split(":")[1:] != [prior_name, mode]:
                 continue
             os.environ["JOLIDECO_STEP_SCALARS"] = "host" if mode == "by-value" else "device"
             os.environ["JOLIDECO_GRAPH"] = "1" if mode == "graph" else "0"
+            if mode == "auto":  # the default policy: probe epochs, then captured epochs where the host bounds the fit
+                del os.environ["JOLIDECO_GRAPH"]
             gmm = GaussianMixtureModel.from_numpy(means, covs, weights, meta=GaussianMixtureModelMeta(stride=4))
             prior = UniformPrior() if prior_name == "uniform" else GMMPatchPrior(gmm=gmm)
             comp = SpatialFluxComponent.from_numpy(flux=flux_init, upsampling_factor=2, prior=prior)
@@ -30,7 +32,7 @@ for counts_shape, n_obs in (((256, 256), 8), ((512, 512), 8), ((1024, 1024), 8))
                 cals[name] = NPredCalibration(shift_x=sx, shift_y=sy, background_norm=norm)
             session = MAPDeconvolver(n_epochs=1, display_progress=False, device=DEV, fit_mode="joint").session(
                 datasets, components=comp, calibrations=cals)
-            for _ in range(10):
+            for _ in range(12):
                 session.epoch()
             torch.cuda.synchronize()
             walls, hosts = [], []
@@ -47,5 +49,6 @@ for counts_shape, n_obs in (((256, 256), 8), ((512, 512), 8), ((1024, 1024), 8))
                 walls.append((t2 - t0) / 200)
                 hosts.append((t1 - t0) / 16)
             print(f"flux grid {2 * counts_shape[0]}^2 x {n_obs} calibrated obs, {prior_name:7s} prior, {mode:8s}: "
-                  f"{np.median(walls) * 1e6:7.1f} us/step, host {np.median(hosts) * 1e6:6.1f} us/step, graphs {len(session._graphs)}", flush=True)
+                  f"{np.median(walls) * 1e6:7.1f} us/step, host {np.median(hosts) * 1e6:6.1f} us/step, graphs {len(session._graphs)}"
+                  + (f" [{session.graph_policy}]" if mode == "auto" else ""), flush=True)
             del session
