@@ -631,7 +631,10 @@ class FitSession:
         self._probe = []  # (host seconds, start event, end event) of the by-value probe epochs
         self._trial = None  # the replayed epochs being timed against them
         # the GMM prior's first phase on a second stream beside the likelihood launches (`_start_priors`)
-        self.overlap_prior = os.environ.get("JOLIDECO_PRIOR_OVERLAP", "1") != "0"
+        # JOLIDECO_PRIOR_OVERLAP: "1" / "0" forced; unset: the "auto" policy times both and keeps the faster (the two sides
+        # compete for the same CUs: +6-9 % at 2048^2 x 8 and 4096^2, -10 % at 1024^2 x 4 -- profiles/r05/ab_prior_overlap.txt)
+        self.overlap_mode = {"1": "on", "0": "off"}.get(os.environ.get("JOLIDECO_PRIOR_OVERLAP", ""), "auto")
+        self.overlap_prior = self.overlap_mode != "off"
         self._side_stream = torch.cuda.Stream(device=device)
         self.step_scalars = None
         self._graphs = {}
@@ -807,6 +810,8 @@ class FitSession:
         self._trial = None
         if self.graph_mode == "auto":
             self.use_graph, self.graph_policy, self._probe = False, "undecided", []
+            if self.overlap_mode == "auto":
+                self.overlap_prior = True
 
     def _planned_capable(self):
         """Planned epochs apply: one process, the session's own optimizer step (a hook sees every gradient through the
@@ -1127,10 +1132,17 @@ class FitSession:
 
     def _epoch_probe(self):
         """A by-value epoch of the "auto" policy's probe phase: timed on the host and, by an event pair, on the device.
-        After AUTO_PROBE of them (one wait for the last event) the session goes on by value (the device clearly bounds the
-        fit: the events are as far apart as the device needs) or captures the epoch and times replays (`_trial_replay`)."""
+        Where the prior can run beside the likelihood the probe is twice as long and ALTERNATES between two streams and one
+        (early epochs run on clocks and caches that are still settling: a drift must hit both forms alike).  After the
+        last one (one wait for its event) the faster stream form stays, and the session goes on by value (the device
+        clearly bounds the fit: the events are as far apart as the device needs) or captures the epoch and times replays
+        (`_trial_replay`)."""
         import time
 
+        two_forms = (self.overlap_mode == "auto" and not self.dist.sharded
+                     and any(getattr(p, "supports_phases", False) for p in self.priors))
+        if two_forms:
+            self.overlap_prior = len(self._probe) % 2 == 0
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
         t0 = time.perf_counter()
@@ -1139,22 +1151,34 @@ class FitSession:
         end.record()
         self._total_epochs += 1
         self._probe.append((host, start, end))
-        if len(self._probe) < self.AUTO_PROBE:
+        if len(self._probe) < self.AUTO_PROBE * (2 if two_forms else 1):
             return
         end.synchronize()
-        probe = self._probe[2:]  # (the first two still pay for lazy allocations and table uploads)
-        host_s = float(np.median([h for h, _, _ in probe]))
-        device_s = 1e-3 * float(np.median([a.elapsed_time(b) for _, a, b in probe]))
-        ratio = host_s / max(device_s, 1e-9)
+
+        def medians(probe):  # (the first two of a form still pay for lazy allocations and table uploads)
+            return (float(np.median([h for h, _, _ in probe[2:]])),
+                    1e-3 * float(np.median([a.elapsed_time(b) for _, a, b in probe[2:]])))
+
+        streams = ""
+        if two_forms:
+            both, single = medians(self._probe[0::2]), medians(self._probe[1::2])
+            self.overlap_prior = both[1] <= single[1]
+            host_s, device_s = both if self.overlap_prior else single
+            streams = (f"; prior {'beside the likelihood' if self.overlap_prior else 'behind the likelihood'}: "
+                       f"{1e6 * both[1]:.0f} us on two streams / {1e6 * single[1]:.0f} us on one")
+        else:
+            host_s, device_s = medians(self._probe)
         self._probe = []
+        ratio = host_s / max(device_s, 1e-9)
         if ratio < self.AUTO_CLEAR:
-            self.graph_policy = f"by value (device bound: enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us per epoch)"
+            self.graph_policy = (f"by value (device bound: enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us per epoch"
+                                 f"{streams})")
         else:
             # the host takes a good part of the epoch's time: capture, time AUTO_PROBE replays the same way, keep the faster
             self.use_graph = True
-            self._trial = {"by_value": device_s, "host": host_s, "events": []}
+            self._trial = {"by_value": device_s, "host": host_s, "events": [], "streams": streams}
             self.graph_policy = (f"captured epochs (on trial: by value enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us "
-                                 "per epoch)")
+                                 f"per epoch{streams})")
 
     def _trial_replay(self, graph):
         """A replayed epoch of the trial: timed like the probe epochs; after AUTO_PROBE of them the faster form stays."""
@@ -1170,7 +1194,8 @@ class FitSession:
         replay_s = 1e-3 * float(np.median([a.elapsed_time(b) for a, b in trial["events"][2:]]))
         by_value_s = trial["by_value"]
         self._trial = None
-        numbers = f"replayed {1e6 * replay_s:.0f} us / by value {1e6 * by_value_s:.0f} us per epoch, enqueue {1e6 * trial['host']:.0f} us"
+        numbers = (f"replayed {1e6 * replay_s:.0f} us / by value {1e6 * by_value_s:.0f} us per epoch, enqueue {1e6 * trial['host']:.0f} us"
+                   f"{trial['streams']}")
         if replay_s <= by_value_s:
             self.graph_policy = f"captured epochs (measured: {numbers})"
         else:

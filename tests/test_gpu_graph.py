@@ -159,12 +159,13 @@ def test_an_option_set_between_epochs_invalidates_the_captured_epochs(monkeypatc
 
 
 def test_the_auto_policy_decides_after_its_probe_epochs(monkeypatch):
-    """Default policy: epochs 1 .. 8 by value and timed; a fit whose host time is a good part of the device's is then
-    captured and 8 replays are timed against them, the faster form stays.  Whichever way it goes the fit is the by-value fit
-    bit for bit."""
+    """Default policy: epochs 1 .. 8 by value with the GMM prior's first phase beside the likelihood, epochs 9 .. 16 on one
+    stream, both timed: the faster stays; a fit whose host time is a good part of the device's is then captured and 8
+    replays are timed against them, the faster form stays.  Whichever way it goes the fit is the by-value fit bit for bit."""
     from jolideco_amd import MAPDeconvolver
 
-    n_epochs = 26  # first epoch, 8 probe epochs, 3 eager planned epochs, 2 captures, 8 timed replays, 4 more
+    n_epochs = 34  # first epoch, 2 x 8 probe epochs, 3 eager planned epochs, 2 captures, 8 timed replays, 4 more
+    monkeypatch.delenv("JOLIDECO_PRIOR_OVERLAP", raising=False)
     by_value = _fit(monkeypatch, "host", _build_joint, n_epochs, "joint")
     monkeypatch.delenv("JOLIDECO_GRAPH", raising=False)
     monkeypatch.delenv("JOLIDECO_STEP_SCALARS", raising=False)
@@ -175,11 +176,11 @@ def test_the_auto_policy_decides_after_its_probe_epochs(monkeypatch):
         session.epoch()
         rows.append(session.scalars.clone())
         policies.append(session.graph_policy)
-        assert (session.graph_policy == "undecided") == (i < 8), (i, session.graph_policy)
+        assert (session.graph_policy == "undecided") == (i < 16), (i, session.graph_policy)
     torch.cuda.synchronize()
-    print("auto policy on the 96 x 132 joint fit:", policies[8], "->", session.graph_policy)
-    assert session.graph_policy.startswith(("by value", "captured epochs"))
-    if "on trial" in policies[8]:
+    print("auto policy on the 96 x 132 joint fit:", policies[16], "->", session.graph_policy)
+    assert session.graph_policy.startswith(("by value", "captured epochs")) and "on two streams" in session.graph_policy
+    if "on trial" in policies[16]:
         assert "measured" in session.graph_policy and session._trial is None
     assert bool(session._graphs) == session.graph_policy.startswith("captured")
     np.testing.assert_array_equal(torch.stack(rows).cpu().numpy(), by_value[1])
