@@ -325,6 +325,8 @@ def pmc_traffic_bytes(cfg_name, kernel):
         fetch = write = None
         with open(REPO / rel) as fh:
             rows = list(csv.DictReader(fh))
+        if not rows or not {"config", "kernel", "counter", "avg_per_launch_KB"} <= set(rows[0]):
+            continue  # (a malformed profile file must not stop the benchmark: traffic is reported as null)
         # "<config>s" / "<config>f" / "<config>g" rows: the same workload profiled on later builds -- the last one
         # found wins (the .commit sidecar names the build of the newest rows)
         for label in (cfg_name, cfg_name + "s", cfg_name + "f", cfg_name + "g", cfg_name + "h"):

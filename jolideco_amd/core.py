@@ -635,7 +635,7 @@ class FitSession:
         # compete for the same CUs: +6-9 % at 2048^2 x 8 and 4096^2, -10 % at 1024^2 x 4 -- profiles/r05/ab_prior_overlap.txt)
         self.overlap_mode = {"1": "on", "0": "off"}.get(os.environ.get("JOLIDECO_PRIOR_OVERLAP", ""), "auto")
         self.overlap_prior = self.overlap_mode != "off"
-        self._side_stream = torch.cuda.Stream(device=device)
+        self._side_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.step_scalars = None
         self._graphs = {}
         self._epochs_done = 0
@@ -912,7 +912,7 @@ class FitSession:
         stream runs the likelihood launches of the step; the streams join in front of the gather (+ optimizer step).  Not
         while the kernel timers run (a kernel timed beside another one is not the kernel's time); JOLIDECO_PRIOR_OVERLAP=0:
         one stream."""
-        return self.overlap_prior and not self.dist.sharded and not _hip.profile_active()
+        return self.overlap_prior and self._side_stream is not None and not self.dist.sharded and not _hip.profile_active()
 
     def _prior_calls(self, coef, shifts, bias):
         """The prior evaluations of ONE optimizer step as callables `call(phases)` (3: the whole pass): [(ci, call, steps)],
