@@ -155,7 +155,10 @@ def c6_roofline(plan, counts_shape, n_obs, u, kernel_ms):
         "cmul": ("columns: spectra + kernel spectrum in, kept rows out (forward and adjoint)", 2 * (spec + khat + kept), 2),
         "poisson_fused": ("pooled middle: kept rows + background + counts in, row spectra of g out", kept + 2 * cnt + spec, 1),
         "fft_c2r": ("rows^-1 + adjoint epilogue: kept rows + exposure in, exposure x corr out", kept + 2 * img, 1),
-        "shift": ("transposed shift: exposure x corr + flux + gradient in, gradient out", 4 * img, 1),
+        # (one launch over all observations: each reads its own exposure x corr image; the flux and the gradient -- read and
+        # written ONCE by the launch since round 5, in registers over the datasets -- are shared: counted once per launch)
+        "shift": ("transposed shift: exposure x corr in; flux in + gradient out shared by the observations of the launch",
+                  img + 2 * img / n_obs, 1),
     }
     rows, total_bytes, total_ms = {}, 0.0, 0.0
     for name, (what, nbytes, per_obs) in launches.items():
@@ -180,8 +183,9 @@ def c6_run(device, dist_ctx, steps=20, warmup=3, repeats=3, shape=(2048, 2048), 
     """Time config c6 (see `build_session_c6`): it/s, the per-kernel table and `roofline_c6` (the six launches of one
     observation's likelihood step against the HBM roof)."""
     session = build_session_c6(device, shape=shape, n_obs=n_obs)
-    for _ in range(max(warmup, 10)):  # (incl. the "auto" policy's probe epochs)
+    for _ in range(max(warmup, 10)):
         session.epoch()
+    warm_policy(session)  # (the "auto" policy's probe and trial epochs)
     torch.cuda.synchronize(device)
     stats = region_stats(timed_regions(session, steps, repeats, device, dist_ctx), steps)
     host_ms = 1e3 * float(np.median(HOST_ENQUEUE[-1])) / steps
@@ -255,8 +259,9 @@ def e0102_run(device, n_epochs=250, shape=(256, 256), n_obs=24, psf_shape=(128, 
     comp, calibrations = build()
     session = MAPDeconvolver(n_epochs=1, display_progress=False, device=device, fit_mode="sequential").session(
         datasets, components=comp, calibrations=calibrations)
-    for _ in range(16):  # (the "auto" policy's probe epochs, then warm-up and capture)
+    for _ in range(16):
         session.epoch()
+    warm_policy(session)  # (the "auto" policy's probe and trial epochs)
     torch.cuda.synchronize(device)
     gc.collect()
     gc.disable()
@@ -431,6 +436,16 @@ def cpu_baseline(cfg_name, sample_edge=1024, max_steps=10, budget_s=15.0):
     }
 
 
+def warm_policy(session, cap=96):
+    """Epochs until the session's "auto" policy has decided (probe epochs on two streams / one, a trial of replayed
+    epochs where the host weighs in): nothing of that belongs into a timed region."""
+    n = 0
+    while n < cap and (getattr(session, "graph_policy", "") == "undecided" or getattr(session, "_trial", None) is not None):
+        session.epoch()
+        n += 1
+    return n
+
+
 def settle(session, device, dist_ctx, seconds=SETTLE_SECONDS, chunk=20):
     """Steps for at least `seconds` before the timed regions (chunks of `chunk` steps; every rank runs the same number:
     the ranks agree after each chunk whether all of them have had enough)."""
@@ -584,6 +599,8 @@ def main():
 
     for _ in range(args.warmup):
         session.epoch()
+    if dist_ctx.world_size == 1:
+        warm_policy(session)  # (a single-process fit's "auto" policy: its probe and trial epochs are not timed)
     torch.cuda.synchronize(device)
     settled = settle(session, device, dist_ctx, args.settle_seconds) if args.settle_seconds > 0 else {"seconds": 0.0, "steps": 0}
     log(f"settled: {settled['steps']} steps in {settled['seconds']:.3f} s; timed regions")
@@ -890,6 +907,7 @@ def main():
             other = build_session(args.config, device)
             for _ in range(args.warmup):
                 other.epoch()
+            warm_policy(other)
             torch.cuda.synchronize(device)
             side = region_stats(timed_regions(other, args.steps, side_repeats, device, dist_ctx), args.steps)
             prof_other = profile_phase(other, device, n_obs)
@@ -980,6 +998,7 @@ def main():
                     other = build_session("c3odd", device)
                     for _ in range(max(args.warmup, 6)):
                         other.epoch()
+                    warm_policy(other)
                     torch.cuda.synchronize(device)
                     side = region_stats(timed_regions(other, args.steps, side_repeats, device, dist_ctx), args.steps)
                     plans = {m.plan for mm in other.total_loss.poisson_loss.npred_models_all for m in mm.values()}
@@ -1006,6 +1025,7 @@ def main():
         with _hip.options(JD_GMM_SCREEN=0):
             for _ in range(args.warmup):
                 session.epoch()
+            warm_policy(session)
             torch.cuda.synchronize(device)
             side = region_stats(timed_regions(session, args.steps, side_repeats, device, dist_ctx), args.steps)
             out["dense_fp32_gmm"] = {
@@ -1039,6 +1059,7 @@ def main():
             other = build_session(args.config, device, fit_mode="sequential" if args.config == "c1" else "joint")
             for _ in range(max(args.warmup, 10)):
                 other.epoch()
+            warm_policy(other)
             torch.cuda.synchronize(device)
             side = region_stats(timed_regions(other, args.steps, side_repeats, device, dist_ctx), args.steps)
             out["graph_replay"] = {

@@ -1161,11 +1161,12 @@ class FitSession:
 
         streams = ""
         if two_forms:
+            # (an epoch enqueued by value takes the longer of the host's and the device's time for it)
             both, single = medians(self._probe[0::2]), medians(self._probe[1::2])
-            self.overlap_prior = both[1] <= single[1]
+            self.overlap_prior = max(both) <= max(single)
             host_s, device_s = both if self.overlap_prior else single
             streams = (f"; prior {'beside the likelihood' if self.overlap_prior else 'behind the likelihood'}: "
-                       f"{1e6 * both[1]:.0f} us on two streams / {1e6 * single[1]:.0f} us on one")
+                       f"{1e6 * max(both):.0f} us on two streams / {1e6 * max(single):.0f} us on one")
         else:
             host_s, device_s = medians(self._probe)
         self._probe = []
@@ -1176,7 +1177,7 @@ class FitSession:
         else:
             # the host takes a good part of the epoch's time: capture, time AUTO_PROBE replays the same way, keep the faster
             self.use_graph = True
-            self._trial = {"by_value": device_s, "host": host_s, "events": [], "streams": streams}
+            self._trial = {"by_value": max(device_s, host_s), "host": host_s, "events": [], "streams": streams}
             self.graph_policy = (f"captured epochs (on trial: by value enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us "
                                  f"per epoch{streams})")
 
