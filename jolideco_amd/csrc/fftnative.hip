@@ -58,10 +58,8 @@ __device__ __forceinline__ void lds_wave_fence() {
 #ifndef JD_FFT_LOOP_OUTSIDE
 #define JD_FFT_LOOP_OUTSIDE 0  // 1: one butterfly loop per radix (switch outside): more registers, fewer instructions
 #endif
-#ifndef JD_FFT_POOLED_PREFETCH
-#define JD_FFT_POOLED_PREFETCH 0  // 1: the pooled middle launch of 576-thread blocks loads the next spectrum row while it transforms
-                                  // (measured, c6: 68 -> 88 us per launch -- 96 registers are not enough for it: 92 bytes of scratch)
-#endif
+// (measured and removed, round 5: a register prefetch of the pooled launch's next spectrum row while the block transforms the
+// current one -- c6: 68 -> 88 us per launch, 96 registers are not enough for it; the rows are summed before ONE transform now)
 #ifndef JD_FFT_LIN
 #define JD_FFT_LIN 0           // 1: linear padded indices where a pass allows them (jd_fftcore.h)
 #endif
@@ -608,7 +606,7 @@ __global__ __launch_bounds__((LANES * CBS > 512 ? 1024 : 512), (LANES * CBS > 51
 // -- and added to the block's own spectrum row (as a real part: + FFT(Im c_s); as an imaginary part: + i FFT(Re c_s)), so
 // that a seam block runs one transform like every other block: with two, the seam blocks set the duration of the whole
 // launch (every block of these launches is resident at once).
-template <int T>
+template <int T, bool ADD = false>  // ADD: buf += the row (a thread owns the same elements in every call: no barrier in between)
 __device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* work, int Nx, int y, int Hh, int Ny, int ra, int rb,
                                                   int tid) {
   const bool spill_up = y >= Hh - ra, spill_down = y < rb;
@@ -616,7 +614,12 @@ __device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* wor
   if (!(spill_up || spill_down)) {  // (block-uniform)
     for (int x = 2 * tid; x < Nx; x += 2 * T) {
       const float4 v = *reinterpret_cast<const float4*>(src + x);
-      buf[lp(x)] = float2{v.x, v.y}, buf[lp(x + 1)] = float2{v.z, v.w};
+      float2 o0 = float2{v.x, v.y}, o1 = float2{v.z, v.w};
+      if (ADD) {
+        const float2 p0 = buf[lp(x)], p1 = buf[lp(x + 1)];
+        o0 = float2{p0.x + o0.x, p0.y + o0.y}, o1 = float2{p1.x + o1.x, p1.y + o1.y};
+      }
+      buf[lp(x)] = o0, buf[lp(x + 1)] = o1;
     }
   } else {
     const float2* sp = work + (size_t)(spill_up ? Ny - Hh + y : Hh + y) * Nx;
@@ -630,6 +633,10 @@ __device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* wor
       } else {  // + i (C[k] + conj C[-k]) / 2 = (-(Im C[k] - Im C[-k]) / 2, (Re C[k] + Re C[-k]) / 2)
         o0 = float2{v.x - 0.5f * (c.y - m0.y), v.y + 0.5f * (c.x + m0.x)};
         o1 = float2{v.z - 0.5f * (c.w - m1.y), v.w + 0.5f * (c.z + m1.x)};
+      }
+      if (ADD) {
+        const float2 p0 = buf[lp(x)], p1 = buf[lp(x + 1)];
+        o0 = float2{p0.x + o0.x, p0.y + o0.y}, o1 = float2{p1.x + o1.x, p1.y + o1.y};
       }
       buf[lp(x)] = o0, buf[lp(x + 1)] = o1;
     }
@@ -966,19 +973,14 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
 #pragma unroll
     for (int c = 0; c < G; ++c) pu[q][c] = pd[q][c] = 0.f;
   const int Wd = a.W / U, Hdh = a.Hh / U;
-  // 576-thread blocks (two per CU): the spectrum row of flux row j + 1 is loaded into registers while the block transforms
-  // row j (a block with a single round of loads per transform leaves the memory system idle while it computes)
-  constexpr bool PREFETCH = S::T == 576 && JD_FFT_POOLED_PREFETCH;
-  float4 pre[S::PRE];
-  if constexpr (PREFETCH) load_spectrum_row_regs<S::T, S::PRE>(pre, work, Nx, U * Y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  // The sum-pool over the U flux rows of a counts row is linear and so is the row transform: the U spectrum rows are ADDED
+  // in the Fourier domain (each with its seam term) and ONE inverse transform gives the row sums -- until the middle of
+  // round 5 a block ran U inverse transforms and added their results (c6: three dependent 4608-point transforms per block,
+  // now two).  The pool over x is summed left to right from the transform's result.
+  load_spectrum_row<S::T>(bufa, work, Nx, U * Y, a.Hh, a.Ny, a.ra, a.rb, tid);
 #pragma unroll 1
-  for (int j = 0; j < U; ++j) {
-    if constexpr (PREFETCH) {
-      store_spectrum_row_regs<S::T, S::PRE>(bufa, pre, Nx, tid);
-      if (j + 1 < U) load_spectrum_row_regs<S::T, S::PRE>(pre, work, Nx, U * Y + j + 1, a.Hh, a.Ny, a.ra, a.rb, tid);
-    } else {
-      load_spectrum_row<S::T>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
-    }
+  for (int j = 1; j < U; ++j) load_spectrum_row<S::T, true>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+  {
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) {
@@ -989,7 +991,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
         const int e = lp(x + 4 * sub);
         const float2 v[4] = {r[e], r[e + 1], r[e + 2], r[e + 3]};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pu[q][(4 * sub + i) / U] += v[i].x, pd[q][(4 * sub + i) / U] += v[i].y;  // (row by row, left to right)
+        for (int i = 0; i < 4; ++i) pu[q][(4 * sub + i) / U] += v[i].x, pd[q][(4 * sub + i) / U] += v[i].y;
       }
     }
     __syncthreads();  // the result buffer is the next transform's work space
