@@ -436,7 +436,7 @@ def cpu_baseline(cfg_name, sample_edge=1024, max_steps=10, budget_s=15.0):
     }
 
 
-def warm_policy(session, cap=96):
+def warm_policy(session, cap=128):
     """Epochs until the session's "auto" policy has decided (probe epochs on two streams / one, a trial of replayed
     epochs where the host weighs in): nothing of that belongs into a timed region."""
     n = 0

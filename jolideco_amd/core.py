@@ -1129,6 +1129,7 @@ class FitSession:
 
     AUTO_PROBE = 8  # by-value epochs timed before the "auto" policy decides
     AUTO_CLEAR = 0.4  # host enqueue time / device time of an epoch below which the device bounds the fit for certain
+    AUTO_MARGIN = 0.95  # replayed epochs stay if they take at most this fraction of the by-value epochs' time
 
     def _epoch_probe(self):
         """A by-value epoch of the "auto" policy's probe phase: timed on the host and, by an event pair, on the device.
@@ -1177,12 +1178,17 @@ class FitSession:
         else:
             # the host takes a good part of the epoch's time: capture, time AUTO_PROBE replays the same way, keep the faster
             self.use_graph = True
-            self._trial = {"by_value": max(device_s, host_s), "host": host_s, "events": [], "streams": streams}
+            # (replayed, the host's share of the stream forms' cost is gone: both forms are captured and timed in turn)
+            forms = [True, False] if two_forms else [self.overlap_prior]
+            self._trial = {"by_value": max(device_s, host_s), "by_value_form": self.overlap_prior, "host": host_s, "events": [],
+                           "streams": streams, "forms": forms, "times": {}}
+            self.overlap_prior = forms[0]
             self.graph_policy = (f"captured epochs (on trial: by value enqueue {1e6 * host_s:.0f} us / device {1e6 * device_s:.0f} us "
                                  f"per epoch{streams})")
 
     def _trial_replay(self, graph):
-        """A replayed epoch of the trial: timed like the probe epochs; after AUTO_PROBE of them the faster form stays."""
+        """A replayed epoch of the trial: timed like the probe epochs; after AUTO_PROBE of them per stream form the fastest
+        of {by value, replayed on two streams, replayed on one} stays."""
         trial = self._trial
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record()
@@ -1192,16 +1198,27 @@ class FitSession:
         if len(trial["events"]) < self.AUTO_PROBE:
             return
         end.synchronize()
-        replay_s = 1e-3 * float(np.median([a.elapsed_time(b) for a, b in trial["events"][2:]]))
-        by_value_s = trial["by_value"]
+        trial["times"][self.overlap_prior] = 1e-3 * float(np.median([a.elapsed_time(b) for a, b in trial["events"][2:]]))
+        trial["events"] = []
+        remaining = [form for form in trial["forms"] if form not in trial["times"]]
+        if remaining:  # the other stream form: captured anew (after its eager epochs) and timed
+            self.overlap_prior, self._graphs, self._epochs_done = remaining[0], {}, 0
+            return
+        times, by_value_s = trial["times"], trial["by_value"]
+        best = min(times, key=times.get)
         self._trial = None
-        numbers = (f"replayed {1e6 * replay_s:.0f} us / by value {1e6 * by_value_s:.0f} us per epoch, enqueue {1e6 * trial['host']:.0f} us"
+        replays = " / ".join(f"{1e6 * t:.0f} us {'on two streams' if form else 'on one stream'}" for form, t in times.items())
+        numbers = (f"replayed {replays} / by value {1e6 * by_value_s:.0f} us per epoch, enqueue {1e6 * trial['host']:.0f} us"
                    f"{trial['streams']}")
-        if replay_s <= by_value_s:
+        # (the by-value epochs were timed first, on a device that was still settling: a replay has to win by a margin)
+        if times[best] <= self.AUTO_MARGIN * by_value_s:
             self.graph_policy = f"captured epochs (measured: {numbers})"
+            if best != self.overlap_prior:  # (the form captured last lost: capture the other one again)
+                self.overlap_prior, self._graphs, self._epochs_done = best, {}, 0
         else:
             self.use_graph = False
             self._graphs = {}
+            self.overlap_prior = trial["by_value_form"]
             self.graph_policy = f"by value (measured: {numbers})"
 
     def _epoch_by_value(self):

@@ -160,11 +160,12 @@ def test_an_option_set_between_epochs_invalidates_the_captured_epochs(monkeypatc
 
 def test_the_auto_policy_decides_after_its_probe_epochs(monkeypatch):
     """Default policy: epochs 1 .. 8 by value with the GMM prior's first phase beside the likelihood, epochs 9 .. 16 on one
-    stream, both timed: the faster stays; a fit whose host time is a good part of the device's is then captured and 8
-    replays are timed against them, the faster form stays.  Whichever way it goes the fit is the by-value fit bit for bit."""
+    stream, both timed: the faster stays; a fit whose host time is a good part of the device's is then captured in both
+    stream forms, 8 replays of each are timed, and the fastest of the three stays.  Whichever way it goes the fit is the by-value fit bit for bit."""
     from jolideco_amd import MAPDeconvolver
 
-    n_epochs = 34  # first epoch, 2 x 8 probe epochs, 3 eager planned epochs, 2 captures, 8 timed replays, 4 more
+    n_epochs = 56  # first epoch, 2 x 8 probe epochs, per stream form 3 eager planned epochs + 2 captures + 8 timed replays, 5 to
+    # capture the winner again if it was not the last one, 8 more
     monkeypatch.delenv("JOLIDECO_PRIOR_OVERLAP", raising=False)
     by_value = _fit(monkeypatch, "host", _build_joint, n_epochs, "joint")
     monkeypatch.delenv("JOLIDECO_GRAPH", raising=False)
