@@ -148,12 +148,16 @@ def c6_roofline(plan, counts_shape, n_obs, u, kernel_ms):
         return best
 
     nx, ny = fft_length(W + max((kw - 1) // 2, kw - 1 - (kw - 1) // 2)), fft_length(hh + kh - 1, False)
+    pool = u if (u > 1 and ny % u == 0 and hh % u == 0 and os.environ.get("JD_FFT_POOL_IO", "1") != "0") else 1
     img, cnt = 4.0 * H * W, 4.0 * counts_shape[0] * counts_shape[1]
     spec, kept, khat = 8.0 * hh * nx, 8.0 * (hh + kh - 1) * nx, 8.0 * nx * ny
     launches = {  # timer -> (what, algorithmic bytes per observation, launches per observation)
         "fft_r2c": ("rows: flux (shifted) + exposure in, row spectra out", 2 * img + spec, 1),
-        "cmul": ("columns: spectra + kernel spectrum in, kept rows out (forward and adjoint)", 2 * (spec + khat + kept), 2),
-        "poisson_fused": ("pooled middle: kept rows + background + counts in, row spectra of g out", kept + 2 * cnt + spec, 1),
+        # (round 5: the column passes hand the pooled launch the SUMS of U rows and take ONE row per counts row back)
+        "cmul": ("columns: spectra + kernel spectrum in, kept rows out (forward: sums of U rows out; adjoint: one row per counts row in)",
+                 2 * khat + (spec + kept) * (1 + 1 / pool), 2),
+        "poisson_fused": ("pooled middle: kept row sums + background + counts in, one row spectrum of g per counts row out",
+                          (kept + spec) / pool + 2 * cnt, 1),
         "fft_c2r": ("rows^-1 + adjoint epilogue: kept rows + exposure in, exposure x corr out", kept + 2 * img, 1),
         # (one launch over all observations: each reads its own exposure x corr image; the flux and the gradient -- read and
         # written ONCE by the launch since round 5, in registers over the datasets -- are shared: counted once per launch)

@@ -533,6 +533,11 @@ struct ColsArgs {
   int keep_lo, keep_hi;  // rows [0, keep_lo) and [keep_hi, Ny) of the result are written (the others are never read)
   const FftBatch* batch;  // device memory, nullable; n_batch > 0: block b = column group b / n of dataset d0 + b % n (spec, work, khat from the table)
   int n_batch, d0;
+  // Up-sampled likelihood steps (round 5): the only reader of the forward pass's result sum-pools U rows, and the adjoint
+  // pass's input is U copies of every row -- both linear in the column direction too.  pool_out = U > 1: the SUMS of the
+  // result's row groups [U P, U P + U) are written, to row P (groups with a kept row); pool_in = U > 1: input row r is row
+  // r / U of `spec`.  Half (1 / U) of the traffic between these launches and the pooled row launch.
+  int pool_out, pool_in;
   FftPasses f;
 };
 
@@ -577,7 +582,7 @@ __global__ __launch_bounds__((LANES * CBS > 512 ? 1024 : 512), (LANES * CBS > 51
   for (int i = tid; i < Ny * half; i += LANES * CB) {
     const int row = i / half, piece = i - row * half;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < a.Hh) v = *reinterpret_cast<const float4*>(spec_in + (size_t)row * a.Nx + x0 + 2 * piece);
+    if (row < a.Hh) v = *reinterpret_cast<const float4*>(spec_in + (size_t)(a.pool_in > 1 ? row / a.pool_in : row) * a.Nx + x0 + 2 * piece);
     float2* c0 = lds + (size_t)(2 * piece) * stride;
     c0[lp(row)] = float2{v.x, v.y};
     c0[stride + lp(row)] = float2{v.z, v.w};
@@ -589,6 +594,21 @@ __global__ __launch_bounds__((LANES * CBS > 512 ? 1024 : 512), (LANES * CBS > 51
   else column_conv_inplace<LANES>(col, Ny, a.f, a.tw, kcol, a.conj, lane);
   __syncthreads();
   // ---- store: rows [0, keep_lo) and [keep_hi, Ny), row-major pieces --------------------------------------------------
+  if (a.pool_out > 1) {  // (uniform) sums of U rows, in row order
+    const int U = a.pool_out;
+    for (int i = tid; i < (Ny / U) * half; i += LANES * CB) {
+      const int P = i / half, piece = i - P * half, row = U * P;
+      if (row >= a.keep_lo && row + U - 1 < a.keep_hi) continue;
+      const float2* c0 = lds + (size_t)(2 * piece) * stride;
+      float2 p = c0[lp(row)], q = c0[stride + lp(row)];
+      for (int j = 1; j < U; ++j) {
+        const float2 p1 = c0[lp(row + j)], q1 = c0[stride + lp(row + j)];
+        p = float2{p.x + p1.x, p.y + p1.y}, q = float2{q.x + q1.x, q.y + q1.y};
+      }
+      *reinterpret_cast<float4*>(work_out + (size_t)P * a.Nx + x0 + 2 * piece) = make_float4(p.x, p.y, q.x, q.y);
+    }
+    return;
+  }
   for (int i = tid; i < Ny * half; i += LANES * CB) {
     const int row = i / half, piece = i - row * half;
     if (row >= a.keep_lo && row < a.keep_hi) continue;
@@ -935,6 +955,7 @@ struct RowsPooledArgs {
   double* partials;           // [Hh / U]: block sums of the Poisson terms
   double* partials_b;         // nullable [Hh / U]: block sums of g * background (d loss / d log norm up to the scale)
   int H, W, Hh, Nx, Ny, ra, rb;
+  int pooled_io;              // 1: `work` holds the row-group sums (ColsArgs::pool_out) and `spec` takes ONE row per counts row
   float eps, inv_n;
   const FftBatch* batch;      // device memory, nullable; n_batch > 0: block b = counts-row pair b / n of dataset d0 + b % n
   int n_batch, d0;
@@ -977,9 +998,13 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   // in the Fourier domain (each with its seam term) and ONE inverse transform gives the row sums -- until the middle of
   // round 5 a block ran U inverse transforms and added their results (c6: three dependent 4608-point transforms per block,
   // now two).  The pool over x is summed left to right from the transform's result.
-  load_spectrum_row<S::T>(bufa, work, Nx, U * Y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  if (a.pooled_io) {  // (uniform) the column pass has summed the rows: row Y of the pooled array, its seam rows in pooled units
+    load_spectrum_row<S::T>(bufa, work, Nx, Y, a.Hh / U, a.Ny / U, (a.ra + U - 1) / U, (a.rb + U - 1) / U, tid);
+  } else {
+    load_spectrum_row<S::T>(bufa, work, Nx, U * Y, a.Hh, a.Ny, a.ra, a.rb, tid);
 #pragma unroll 1
-  for (int j = 1; j < U; ++j) load_spectrum_row<S::T, true>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+    for (int j = 1; j < U; ++j) load_spectrum_row<S::T, true>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
+  }
   {
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
@@ -1045,8 +1070,12 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   for (int x = 2 * tid; x < Nx; x += 2 * S::T) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     const float4 v = make_float4(c0.x, c0.y, c1.x, c1.y);
+    if (a.pooled_io) {
+      *reinterpret_cast<float4*>(spec + (size_t)Y * Nx + x) = v;  // (the adjoint's column pass reads it for its U rows)
+    } else {
 #pragma unroll
-    for (int j = 0; j < U; ++j) *reinterpret_cast<float4*>(spec + (size_t)(U * Y + j) * Nx + x) = v;
+      for (int j = 0; j < U; ++j) *reinterpret_cast<float4*>(spec + (size_t)(U * Y + j) * Nx + x) = v;
+    }
   }
 }
 
@@ -1167,13 +1196,14 @@ int lds_attr(const void* kernel, size_t bytes) {
 }
 
 int launch_cols(const FftNative& n, const float2* khat, int adjoint, hipStream_t stream, const FftBatch* batch = nullptr, int n_batch = 0,
-                int d0 = 0) {
+                int d0 = 0, int pool = 1) {
   const FftPasses fy = passes_of(n.Ny);
   const int ra = adjoint ? n.kh - 1 - n.oy : n.oy, rb = adjoint ? n.oy : n.kh - 1 - n.oy;
   ColsArgs a{};
   a.spec = n.spec, a.work = n.work, a.khat = khat, a.tw = n.tw_y, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.conj = adjoint ? 1 : 0;
   a.keep_lo = n.Hh + rb, a.keep_hi = n.Ny - ra, a.f = fy;
   a.batch = batch, a.n_batch = n_batch, a.d0 = d0;
+  a.pool_out = adjoint ? 1 : pool, a.pool_in = adjoint ? pool : 1;
   const size_t per_col = (size_t)lp_size(n.Ny) * sizeof(float2);
   const int lanes = column_lanes(n.Ny, fy);
   if (!lanes) return fail(JD_ERR_INVALID, "native FFT: no column kernel for length %d", n.Ny);
@@ -1341,6 +1371,15 @@ bool fftn_pooled_supported(const FftNative& n, int upsampling) {
 }
 
 namespace {
+// U where the column passes around the pooled launch exchange row-group sums / single rows with it (ColsArgs::pool_out):
+// the groups must line up in the image half, in the spill rows behind it (Hh + y) and in those in front (Ny - Hh + y)
+int pooled_column_io(const FftNative& n, int upsampling) {
+  const int U = upsampling, ra = n.oy, rb = n.kh - 1 - n.oy;
+  const bool ok = U > 1 && n.Hh % U == 0 && n.Ny % U == 0 && n.Hh / U >= (ra + U - 1) / U + (rb + U - 1) / U + 1 &&
+                  opt_value(OPT_FFT_POOL_IO, 1) != 0;  // (JD_FFT_POOL_IO=0: full rows both ways, as until the middle of round 5)
+  return ok ? U : 1;
+}
+
 int launch_rows_pooled(const FftNative& n, int upsampling, const RowsPooledArgs& a, hipStream_t stream, int blocks) {
   static void (*const kernels2[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 2, );
   static void (*const kernels3[N_ROW_SCHED])(RowsPooledArgs) = JD_ROW_KERNELS(fftn_rows_pooled_kernel, 3, );
@@ -1358,17 +1397,19 @@ int fftn_poisson_step_pooled(const FftNative& n, int upsampling, const float* fl
                              float* norm_grad_out, const float* shift_xy, float shift_scale) {
   int rc = launch_rows_fwd(n, flux, exposure, stream, shift_xy, shift_scale);
   if (rc) return rc;
-  if ((rc = launch_cols(n, khat, 0, stream))) return rc;
+  const int pool = pooled_column_io(n, upsampling);
+  if ((rc = launch_cols(n, khat, 0, stream, nullptr, 0, 0, pool))) return rc;
   {
     RowsPooledArgs a{};
     a.work = n.work, a.spec = n.spec, a.tw = n.tw_x, a.background = background, a.counts = counts, a.log_bkg_norm = log_bkg_norm;
     a.partials = partials, a.partials_b = norm_grad_out ? partials_b : nullptr;
     a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
+    a.pooled_io = pool > 1;
     a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx);
     rc = launch_rows_pooled(n, upsampling, a, stream, n.Hh / upsampling);
     if (rc) return rc;
   }
-  if ((rc = launch_cols(n, khat, 1, stream))) return rc;
+  if ((rc = launch_cols(n, khat, 1, stream, nullptr, 0, 0, pool))) return rc;
   const SepLossFold fold{partials, n.Hh / upsampling, loss_scale, loss_offset, loss_out};
   const SepLossFold fold2{partials_b, n.Hh / upsampling, norm_grad_scale, 0.0, norm_grad_out};
   return launch_rows_inv(n, target, exposure, 1, coef, accumulate, stream, &fold, norm_grad_out ? &fold2 : nullptr);
@@ -1424,16 +1465,18 @@ int fftn_poisson_step_pooled_batch(const FftNative& n, int upsampling, int nd, c
     const int d0 = sequential ? gi : 0;
     int rc = launch_rows_fwd(n, flux, nullptr, stream, nullptr, (float)upsampling, batch_dev, per_launch, d0);
     if (rc) return rc;
-    if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, per_launch, d0))) return rc;
+    const int pool = pooled_column_io(n, upsampling);
+    if ((rc = launch_cols(n, nullptr, 0, stream, batch_dev, per_launch, d0, pool))) return rc;
     {
       RowsPooledArgs a{};
       a.tw = n.tw_x, a.partials = partials, a.partials_b = partials_b;
       a.H = n.H, a.W = n.W, a.Hh = n.Hh, a.Nx = n.Nx, a.Ny = n.Ny, a.ra = n.oy, a.rb = n.kh - 1 - n.oy;
+      a.pooled_io = pool > 1;
       a.eps = eps, a.inv_n = inv_n, a.f = passes_of(n.Nx), a.batch = batch_dev, a.n_batch = per_launch, a.d0 = d0;
       rc = launch_rows_pooled(n, upsampling, a, stream, per * per_launch);
       if (rc) return rc;
     }
-    if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, per_launch, d0))) return rc;
+    if ((rc = launch_cols(n, nullptr, 1, stream, batch_dev, per_launch, d0, pool))) return rc;
     // rows^-1 + adjoint epilogue into every dataset's own image (the blocks of row pairs 0 / 1 finalise its loss / norm
     // gradient)
     {

@@ -34,6 +34,7 @@ OptionSlot g_options[OPT_COUNT] = {
     {"JD_FFT_BATCH", {INT_MIN}},  // 0: the batched joint steps of a native FFT plan run their per-dataset calls; the calibrated
                                   // one beyond 2048 flux rows: 3 per-dataset calls, 4 per-dataset FFT launches + one tail
     {"JD_FFT_TINY", {INT_MIN}},   // longest row (points) of the one-wave generic row kernels; 0: off (default 1024)
+    {"JD_FFT_POOL_IO", {INT_MIN}},  // 0: the column passes around the pooled launch of an up-sampled step move full rows
 };
 
 int parse(const char* text) {
