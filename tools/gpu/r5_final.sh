@@ -1,0 +1,5 @@
+#!/bin/bash
+O=gpurun_out/r5final; mkdir -p $O
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; echo "smoke rc=$?"
+python -m pytest tests -x -q -m gpu > $O/full.log 2>&1; echo "rc=$?" >> $O/full.log
+tail -n 4 $O/full.log
