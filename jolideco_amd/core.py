@@ -635,7 +635,10 @@ class FitSession:
         # compete for the same CUs: +6-9 % at 2048^2 x 8 and 4096^2, -10 % at 1024^2 x 4 -- profiles/r05/ab_prior_overlap.txt)
         self.overlap_mode = {"1": "on", "0": "off"}.get(os.environ.get("JOLIDECO_PRIOR_OVERLAP", ""), "auto")
         self.overlap_prior = self.overlap_mode != "off"
-        self._side_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # JOLIDECO_PRIOR_STREAM_PRIORITY (tuning): priority of the side stream (-1: its launches are dispatched first)
+        side_priority = int(os.environ.get("JOLIDECO_PRIOR_STREAM_PRIORITY", "0"))
+        self._side_stream = (torch.cuda.Stream(device=device, priority=side_priority)
+                             if torch.device(device).type == "cuda" else None)
         self.step_scalars = None
         self._graphs = {}
         self._epochs_done = 0
