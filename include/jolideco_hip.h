@@ -362,6 +362,17 @@ int jd_elementwise_prior_fwd_bwd(int kind, const float* flux, size_t n, float al
  * use_log_flux == 0: flux = theta [* mask] (the parameter is the flux itself, no positivity). */
 int jd_flux_from_theta(const float* theta, const float* mask, float* flux, size_t n, int use_log_flux, void* stream);
 
+/* Flux components that SHARE one forward operator.  NPredModels.from_dataset_numpy (models/npred.py:279-295) builds the
+ * model of every component of a dataset from the same exposure and -- unless `psf` is a dict -- the same PSF, and
+ * NPredModels.evaluate (models/npred.py:241-261) adds clip(PSF * (flux_c x exposure), 0) over the components: with a
+ * non-negative PSF, exposure and fluxes no term is ever clipped, so by linearity ONE convolution of (sum_c flux_c) x exposure
+ * gives npred, and d loss / d flux_c is the same image for every c.  The host side (jolideco_amd/loss.py) then runs the
+ * single-component launches between these two helpers:
+ *   jd_sum_images:    out[i] = ((srcs[0][i] + srcs[1][i]) + ...)    n_srcs in [1, 4], host array of device pointers
+ *   jd_copy_image_to: dsts[d][i] = src[i]                           n_dsts in [1, 4] */
+int jd_sum_images(float* out, const float* const* srcs, int n_srcs, size_t n, void* stream);
+int jd_copy_image_to(const float* src, float* const* dsts, int n_dsts, size_t n, void* stream);
+
 /* Device-resident step scalars (see jd_gmm_prior_fwd_bwd): dst[0 .. n) <- host_row[0 .. n), read by ONE small block
  * straight from PINNED host memory (hipHostMalloc'ed, e.g. a torch tensor after pin_memory(): device-accessible) -- the
  * epoch's shifts and bias terms reach the device without a copy-engine hand-over on the stream.  The caller keeps the row

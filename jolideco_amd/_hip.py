@@ -101,6 +101,8 @@ EXPORTS = {
         [c_int, c_void_p, c_size_t, c_float, c_float, c_float, c_void_p, c_float, c_void_p, c_void_p],
     ),
     "jd_flux_from_theta": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "jd_sum_images": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    "jd_copy_image_to": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
     "jd_step_scalars_fetch": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "jd_adam_step": (
         c_int,

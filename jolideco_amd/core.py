@@ -603,6 +603,11 @@ class FitSession:
             [li for _, li in self.local_idx]
         )
         self.batch_joint = self.joint and batchable
+        # every flux is exp(theta) [x a non-negative mask]: components that share one forward operator are then evaluated as
+        # ONE image, their sum (`PoissonLoss.fwd_bwd_batch`, models/npred.py:241-261)
+        self.flux_nonneg = all(
+            st.use_log_flux and (st.mask is None or bool((st.mask >= 0).all())) for st in self.states
+        )
         # calibrated / up-sampled datasets of one flux component on the native FFT path: their own batched step
         self.batch_joint_calibrated = bool(
             self.joint and not batchable and not os.environ.get("JOLIDECO_NO_BATCH") and self.n_c == 1
@@ -1064,6 +1069,7 @@ class FitSession:
                 total_loss.poisson_loss.fwd_bwd_batch(
                     [li for _, li in self.local_idx], fluxes if n_c > 1 else fluxes[0],
                     [slot(gslot) for gslot, _ in self.local_idx], grad=grads if n_c > 1 else grads[0], accumulate=False,
+                    flux_nonneg=self.flux_nonneg,
                 )
                 first = False
             elif self.batch_joint_calibrated:
@@ -1077,7 +1083,8 @@ class FitSession:
             else:
                 for gslot, li in self.local_idx:
                     self._cal_zero_grad(li)
-                    total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
+                    total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first,
+                                                    flux_nonneg=self.flux_nonneg)
                     first = False
             if first:
                 for g in grads:
@@ -1092,18 +1099,19 @@ class FitSession:
                 calls = self._prior_calls(coef, plan["shifts"][j], plan["flux_bias"][j])
                 early = self._start_priors(calls)
                 self._cal_zero_grad(li)
-                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
+                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False,
+                                                flux_nonneg=self.flux_nonneg)
                 flux_step(self._finish_priors(calls, early), plan["flux_bias"][j])
                 cal_steps(plan["cal_items"][j], plan["cal_bias"][j])
             stale = [st.flux_trace for st in states]
             if self.batch_trace:
                 total_loss.poisson_loss.fwd_bwd_batch(
                     [li for _, li in self.local_idx], stale if n_c > 1 else stale[0],
-                    [slot(gslot) for gslot, _ in self.local_idx],
+                    [slot(gslot) for gslot, _ in self.local_idx], flux_nonneg=self.flux_nonneg,
                 )
             else:
                 for gslot, li in self.local_idx:
-                    total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
+                    total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot), flux_nonneg=self.flux_nonneg)
             trace_shifts = plan["shifts"][-1]
             for ci, (st, prior) in enumerate(zip(states, priors)):
                 if getattr(prior, "value_is_zero", False):
@@ -1240,6 +1248,7 @@ class FitSession:
                 total_loss.poisson_loss.fwd_bwd_batch(
                     [li for _, li in self.local_idx], fluxes if n_c > 1 else fluxes[0],
                     [slot(gslot) for gslot, _ in self.local_idx], grad=grads if n_c > 1 else grads[0], accumulate=False,
+                    flux_nonneg=self.flux_nonneg,
                 )
                 first = False
             elif self.batch_joint_calibrated:
@@ -1253,7 +1262,8 @@ class FitSession:
             else:
                 for gslot, li in self.local_idx:
                     self._cal_zero_grad(li)
-                    total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first)
+                    total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=not first,
+                                                    flux_nonneg=self.flux_nonneg)
                     first = False
             if first:
                 for g in grads:
@@ -1319,7 +1329,8 @@ class FitSession:
                 fluxes = [st.flux_cur for st in states]
                 grads = [st.grad for st in states]
                 self._cal_zero_grad(li)
-                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False)
+                total_loss.poisson_loss.fwd_bwd(li, fluxes, slot(gslot), grads=grads, accumulate=False,
+                                                flux_nonneg=self.flux_nonneg)
                 coef = -float(cfg.beta) / total_loss.prior_weight
                 stepped = set()
                 for ci, (st, prior) in enumerate(zip(states, priors)):
@@ -1336,11 +1347,11 @@ class FitSession:
             if self.batch_trace:
                 total_loss.poisson_loss.fwd_bwd_batch(
                     [li for _, li in self.local_idx], stale if n_c > 1 else stale[0],
-                    [slot(gslot) for gslot, _ in self.local_idx],
+                    [slot(gslot) for gslot, _ in self.local_idx], flux_nonneg=self.flux_nonneg,
                 )
             else:
                 for gslot, li in self.local_idx:
-                    total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot))
+                    total_loss.poisson_loss.fwd_bwd(li, stale, slot(gslot), flux_nonneg=self.flux_nonneg)
             for ci, (st, prior) in enumerate(zip(states, priors)):
                 prior.device_fwd_bwd(st.flux_trace, slot(n_d + ci))
         if self.n_val:

@@ -3,6 +3,7 @@
 // exp/chain-rule + Adam/SGD (K6) and the element-wise priors.  All are streaming kernels:
 // one pass over each operand, 16 B per lane where the row alignment allows it, fp64 block
 // partials + a single fixed-order finalize for every scalar so results are run-to-run identical.
+#include <cstdint>
 #include <cstdlib>
 
 #include "jd_common.h"
@@ -592,6 +593,78 @@ extern "C" int jd_flux_from_theta(const float* theta, const float* mask, float* 
   flux_from_theta_kernel<<<(unsigned)blocks, BLOCK, 0, as_stream(stream)>>>(theta, mask, flux, n, use_log_flux ? 0 : 1);
   JD_LAUNCH_CHECK();
   return JD_OK;
+}
+
+// Components that share one forward operator (models/npred.py:279-295 builds every component's model of a dataset from
+// the SAME exposure and, unless `psf` is a dict, the same PSF): npred = sum_c clip(PSF * (flux_c E), 0) = PSF * ((sum_c
+// flux_c) E) wherever no term is negative, and d loss / d flux_c is ONE image for all c.  The two helpers either side of
+// the single-component launches (jolideco_amd/loss.py): the sum of the component fluxes, left to right, and the copy of
+// the gradient image into the other components' gradient images.  16-byte accesses where n and the pointers allow.
+struct ImagePtrs {
+  const float* src[4];
+  float* dst[4];
+  int n_src, n_dst;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(BLOCK) void sum_images_kernel(ImagePtrs p, size_t n) {
+  const size_t stride = (size_t)gridDim.x * BLOCK;
+  if (VEC) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += stride) {
+      float4 v = reinterpret_cast<const float4*>(p.src[0])[i];
+      for (int c = 1; c < p.n_src; ++c) {
+        const float4 w = reinterpret_cast<const float4*>(p.src[c])[i];
+        v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+      }
+      for (int d = 0; d < p.n_dst; ++d) reinterpret_cast<float4*>(p.dst[d])[i] = v;
+    }
+  } else {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+      float v = p.src[0][i];
+      for (int c = 1; c < p.n_src; ++c) v += p.src[c][i];
+      for (int d = 0; d < p.n_dst; ++d) p.dst[d][i] = v;
+    }
+  }
+}
+
+static int launch_sum_images(const ImagePtrs& p, size_t n, void* stream) {
+  bool vec = n % 4 == 0;
+  for (int c = 0; c < p.n_src; ++c) vec = vec && (reinterpret_cast<uintptr_t>(p.src[c]) & 15) == 0;
+  for (int d = 0; d < p.n_dst; ++d) vec = vec && (reinterpret_cast<uintptr_t>(p.dst[d]) & 15) == 0;
+  size_t blocks = ((vec ? n / 4 : n) + BLOCK - 1) / BLOCK;
+  if (blocks > 8192) blocks = 8192;
+  if (vec)
+    sum_images_kernel<true><<<(unsigned)blocks, BLOCK, 0, as_stream(stream)>>>(p, n);
+  else
+    sum_images_kernel<false><<<(unsigned)blocks, BLOCK, 0, as_stream(stream)>>>(p, n);
+  JD_LAUNCH_CHECK();
+  return JD_OK;
+}
+
+extern "C" int jd_sum_images(float* out, const float* const* srcs, int n_srcs, size_t n, void* stream) {
+  JD_REQUIRE(out && srcs && n > 0, "jd_sum_images: null argument or n == 0");
+  JD_REQUIRE(n_srcs >= 1 && n_srcs <= 4, "jd_sum_images: %d source images (1 to 4)", n_srcs);
+  ImagePtrs p{};
+  for (int c = 0; c < n_srcs; ++c) {
+    JD_REQUIRE(srcs[c], "jd_sum_images: source %d is null", c);
+    p.src[c] = srcs[c];
+  }
+  p.n_src = n_srcs, p.dst[0] = out, p.n_dst = 1;
+  return launch_sum_images(p, n, stream);
+}
+
+extern "C" int jd_copy_image_to(const float* src, float* const* dsts, int n_dsts, size_t n, void* stream) {
+  JD_REQUIRE(src && dsts && n > 0, "jd_copy_image_to: null argument or n == 0");
+  JD_REQUIRE(n_dsts >= 1 && n_dsts <= 4, "jd_copy_image_to: %d destination images (1 to 4)", n_dsts);
+  ImagePtrs p{};
+  p.src[0] = src, p.n_src = 1;
+  for (int d = 0; d < n_dsts; ++d) {
+    JD_REQUIRE(dsts[d] && dsts[d] != src, "jd_copy_image_to: destination %d is null or the source", d);
+    p.dst[d] = dsts[d];
+  }
+  p.n_dst = n_dsts;
+  return launch_sum_images(p, n, stream);
 }
 
 // The step scalars of an epoch from a pinned host row (device-accessible: zero-copy reads over the host link) into their

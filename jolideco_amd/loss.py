@@ -5,6 +5,8 @@ Each has the autograd-visible methods of the reference (`evaluate`, `__call__`, 
 and a fused device path (`*_fwd_bwd`) that the fit loop uses: values land in device scalars, the
 gradients are accumulated by the HIP kernels without autograd.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -74,11 +76,12 @@ class PoissonLoss:
     def __call__(self, fluxes):
         return torch.sum(self.evaluate(fluxes=fluxes))
 
-    def fwd_bwd(self, idx, fluxes, loss_out, grads=None, accumulate=False, grad_scale=1.0, npred_out=None):
+    def fwd_bwd(self, idx, fluxes, loss_out, grads=None, accumulate=False, grad_scale=1.0, npred_out=None,
+                flux_nonneg=False):
         """Fused forward model + Poisson NLL (+ gradient) of dataset ``idx``."""
         self.npred_models_all[idx].fwd_bwd(
             fluxes, self.counts_all[idx], self.stirling_all[idx], loss_out, grads=grads, accumulate=accumulate,
-            grad_scale=grad_scale, npred_out=npred_out,
+            grad_scale=grad_scale, npred_out=npred_out, flux_nonneg=flux_nonneg,
         )
 
     def batchable(self, indices):
@@ -132,12 +135,44 @@ class PoissonLoss:
             upsampling=models[0].upsampling_factor or 1, grad=grad, accumulate=accumulate, grad_scale=grad_scale,
         )
 
-    def fwd_bwd_batch(self, indices, flux, loss_outs, grad=None, accumulate=False, grad_scale=1.0):
+    def mergeable(self, indices):
+        """True if every dataset of `indices` evaluates all its flux components through ONE non-negative forward
+        operator (`NPredModels.shared_operator`): the batched step may then run on the SUM of the component fluxes.
+        JOLIDECO_MERGE_COMPONENTS=0: never (testing / A-B)."""
+        key = tuple(indices)
+        cache = self.__dict__.setdefault("_mergeable", {})
+        if key not in cache:
+            cache[key] = os.environ.get("JOLIDECO_MERGE_COMPONENTS", "1") != "0" and all(
+                getattr(self.npred_models_all[i], "shared_operator", False) for i in indices
+            )
+        return cache[key]
+
+    def fwd_bwd_batch(self, indices, flux, loss_outs, grad=None, accumulate=False, grad_scale=1.0, flux_nonneg=False):
         """Forward model + Poisson NLL (+ gradient, summed over the datasets in order) of the datasets `indices`
         in three launches (+ one adjoint launch per further component); requires `batchable(indices)`.
-        ``flux`` / ``grad``: a tensor (one component) or lists with one tensor per component, in component order."""
+        ``flux`` / ``grad``: a tensor (one component) or lists with one tensor per component, in component order.
+        ``flux_nonneg``: the caller guarantees flux >= 0 everywhere (exp(theta) [x mask]); together with
+        `mergeable(indices)` the components are then evaluated as ONE flux image, their sum: one forward model and one
+        adjoint per dataset whatever the number of components (models/npred.py:241-261: no term is clipped)."""
         per_dataset = [list(self.npred_models_all[i].values()) for i in indices]
         single = torch.is_tensor(flux)
+        if not single and len(flux) > 1 and flux_nonneg and not accumulate and self.mergeable(indices):
+            from .ops import copy_image_to, sum_images
+
+            total = self.__dict__.get("_merged_flux")
+            if total is None or total.shape != flux[0].shape or total.device != flux[0].device:
+                total = self._merged_flux = torch.empty_like(flux[0])
+            sum_images(total, list(flux))
+            per_dataset[0][0].plan.npred_poisson_batch_fwd_bwd(
+                flux=total, exposures=[models[0].exposure for models in per_dataset],
+                khats=[models[0].khat for models in per_dataset],
+                backgrounds=[self.npred_models_all[i].background for i in indices],
+                counts=[self.counts_all[i] for i in indices], stirlings=[self.stirling_all[i] for i in indices],
+                loss_outs=loss_outs, grad=None if grad is None else grad[0], accumulate=False, grad_scale=grad_scale,
+            )
+            if grad is not None:
+                copy_image_to(grad[0], list(grad[1:]))
+            return
         exposures = [[m.exposure for m in models] for models in per_dataset]
         khats = [[m.khat for m in models] for models in per_dataset]
         if single:

@@ -5,6 +5,8 @@
 `evaluate` are differentiable through the HIP convolution (`ops.ConvSameFunction`); the fit loop
 uses the fused `fwd_bwd` instead (one C-ABI call per dataset).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -377,7 +379,35 @@ class NPredModels(nn.ModuleDict):
         background = _to_device_image(dataset["background"], device)[None, None]
         if calibration is not None:
             calibration = calibration.to(device)
-        return cls(background, calibration, values)
+        models = cls(background, calibration, values)
+        models.shared_operator = cls._components_share_the_operator(psfs, values, calibration)
+        return models
+
+    # Several components, ONE operator.  The reference builds every component's model of a dataset from the same exposure
+    # and, unless `psf` is a dict by component, the same PSF (models/npred.py:279-295), and adds the clipped convolutions
+    # (models/npred.py:241-261, 194).  With a non-negative rank-1 PSF (the separable kernels then add products of
+    # non-negative numbers only), a non-negative exposure and non-negative fluxes (exp(theta)) no term is ever clipped, so
+    #   sum_c clip(PSF * (flux_c E), 0) = PSF * ((sum_c flux_c) E)      and      d loss / d flux_c = E x corr(g, PSF) for all c:
+    # ONE forward model and ONE adjoint per dataset instead of one per component (`PoissonLoss.fwd_bwd_batch`).
+    shared_operator = False
+
+    @staticmethod
+    def _components_share_the_operator(psfs, values, calibration):
+        if len(values) < 2 or calibration is not None:
+            return False
+        arrays = [np.asarray(p) for p in psfs.values()]
+        first = arrays[0]
+        if any(a.shape != first.shape or not np.array_equal(a, first) for a in arrays[1:]):
+            return False
+        if not (np.isfinite(first).all() and first.min() >= 0.0) or psf_separable_rank(first) != 1:
+            return False
+        models = [m for _, m in values]
+        if any(m.plan is not models[0].plan or m.plan.method != "separable" for m in models):
+            return False
+        if len({m.upsampling_factor or 1 for m in models}) != 1 or (models[0].upsampling_factor or 1) != 1:
+            return False
+        exposure = models[0].exposure
+        return bool(torch.isfinite(exposure).all()) and bool((exposure >= 0).all())
 
     # fused path ----------------------------------------------------------------------------
     @property
@@ -419,9 +449,28 @@ class NPredModels(nn.ModuleDict):
         )
 
     def fwd_bwd(self, fluxes, counts, stirling, loss_out, grads=None, accumulate=False, grad_scale=1.0,
-                npred_out=None):
-        """One fused C-ABI call: forward model + Poisson NLL (+ d loss / d flux_c)."""
+                npred_out=None, flux_nonneg=False):
+        """One fused C-ABI call: forward model + Poisson NLL (+ d loss / d flux_c).  ``flux_nonneg``: the caller
+        guarantees flux >= 0; components that share the operator (`shared_operator`) are then evaluated as their sum."""
         models = list(self.values())
+        if (flux_nonneg and self.shared_operator and len(models) > 1 and not accumulate and npred_out is None
+                and os.environ.get("JOLIDECO_MERGE_COMPONENTS", "1") != "0"):
+            from ..ops import copy_image_to, sum_images
+
+            fluxes = list(fluxes)
+            total = self.__dict__.get("_merged_flux")
+            if total is None or total.shape != fluxes[0].shape or total.device != fluxes[0].device:
+                total = torch.empty_like(fluxes[0])
+                object.__setattr__(self, "_merged_flux", total)
+            sum_images(total, fluxes)
+            self.plan.npred_poisson_fwd_bwd(
+                fluxes=[total], exposures=[models[0].exposure], khats=[models[0].khat], background=self.background,
+                counts=counts, stirling=stirling, loss_out=loss_out, grads=None if grads is None else [grads[0]],
+                accumulate=False, grad_scale=grad_scale, npred_out=None, upsampling=1, calibration=None,
+            )
+            if grads is not None:
+                copy_image_to(grads[0], list(grads[1:]))
+            return
         calibration = self.calibration_pointers(grads is not None)
         self.plan.npred_poisson_fwd_bwd(
             fluxes=list(fluxes), exposures=[m.exposure for m in models], khats=[m.khat for m in models],

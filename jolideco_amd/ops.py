@@ -562,6 +562,31 @@ def add_rolled_bands_step(shape, shifts, bands, chunk, y_ranges, step):
                                               stream_ptr(bands.device)))
 
 
+def sum_images(out, srcs):
+    """out <- ((srcs[0] + srcs[1]) + ...) (jd_sum_images: the summed flux of components that share one forward operator)."""
+    out = require_hip_tensor(out, "out")
+    if not 1 <= len(srcs) <= 4:
+        raise ValueError("1 to 4 source images")
+    for t in srcs:
+        require_hip_tensor(t, "source")
+        if t.numel() != out.numel() or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("sources must be contiguous float32 images of the size of `out`")
+    check(_hip.lib().jd_sum_images(ptr(out), ptr_array(list(srcs)), len(srcs), out.numel(), stream_ptr(out.device)))
+    return out
+
+
+def copy_image_to(src, dsts):
+    """dsts[d] <- src for every d (jd_copy_image_to: one gradient image for all components that share an operator)."""
+    src = require_hip_tensor(src, "src")
+    if not 1 <= len(dsts) <= 4:
+        raise ValueError("1 to 4 destination images")
+    for t in dsts:
+        require_hip_tensor(t, "destination")
+        if t.numel() != src.numel() or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("destinations must be contiguous float32 images of the size of `src`")
+    check(_hip.lib().jd_copy_image_to(ptr(src), ptr_array(list(dsts)), len(dsts), src.numel(), stream_ptr(src.device)))
+
+
 def adam_bias_terms(step, lr, beta1, beta2):
     """step_size and sqrt(bias_correction2) exactly as torch.optim.Adam computes them
     (python floats = float64), torch/optim/adam.py `_single_tensor_adam`."""
