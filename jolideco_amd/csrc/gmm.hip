@@ -444,6 +444,29 @@ __device__ __forceinline__ int bucket_chunk_size(const GmmBucketArgs& a, int c) 
   return used < full ? used : full;
 }
 
+// The keys of elements i, i + 256, ... (UN of them; i < size) of a chunk of candidate RECORDS (a.seg_cnt != nullptr) with
+// every load unconditional and the independent ones issued together: record -> (patch, bound, component), then the
+// patch's final bound.  Through bucket_key, element by element, a thread ran three dependent round trips per record
+// (patch, final bound, then -- under the test -- the component).  key = -3: no element (past the chunk's used slots).
+template <int UN>
+__device__ __forceinline__ void record_keys(const GmmBucketArgs& a, int base, int i, int size, int (&key)[UN], int (&patch)[UN]) {
+  int n[UN], kk[UN];
+  float ub[UN], lf[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) n[u] = base + (i + 256 * u < size ? i + 256 * u : i);
+#pragma unroll
+  for (int u = 0; u < UN; ++u) patch[u] = a.rec_n[n[u]], ub[u] = a.rec_ub[n[u]], kk[u] = a.argmax[n[u]];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) lf[u] = a.lfinal[patch[u]];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    bool stale = !(ub[u] >= lf[u] - a.margin);
+    if (a.dense_mark) stale = stale || a.dense_mark[patch[u]] != 0;  // (logsumexp screen only)
+    key[u] = i + 256 * u < size ? (stale ? -2 : kk[u]) : -3;
+  }
+}
+constexpr int BUCKET_UN = 2;
+
 constexpr int BUCKET_CHUNK = 1024;  // patches per chunk of the backward sort
 constexpr int BUCKET_MAX_K = 4096;  // LDS histogram capacity
 
@@ -456,6 +479,16 @@ __global__ __launch_bounds__(256) void gmm_bucket_count_kernel(GmmBucketArgs a) 
   const int n_chunks = (a.n_end - a.n_begin + a.chunk - 1) / a.chunk;
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int base = a.n_begin + c * a.chunk, size = bucket_chunk_size(a, c);
+    if (a.seg_cnt) {  // (uniform) candidate records: batched loads
+      for (int i = threadIdx.x; i < size; i += 256 * BUCKET_UN) {
+        int key[BUCKET_UN], patch[BUCKET_UN];
+        record_keys<BUCKET_UN>(a, base, i, size, key, patch);
+#pragma unroll
+        for (int u = 0; u < BUCKET_UN; ++u)
+          if (key[u] >= 0) atomicAdd(&hist[key[u]], 1);
+      }
+      continue;
+    }
     for (int i = threadIdx.x; i < size; i += 256) {
       const int k = bucket_key(a, base + i);
       if (k >= 0) atomicAdd(&hist[k], 1);
@@ -492,6 +525,57 @@ __global__ __launch_bounds__(256) void gmm_bucket_binscan_kernel(GmmBucketArgs a
     run += v;
   }
   if (threadIdx.x == 255) a.counts[k] = part[cur][255];
+}
+
+// The same scan with the thread's counts held in registers (n_blk <= 256 PER): ONE batch of unconditional loads, a wave
+// scan by cross-lane moves + the four wave totals through LDS, one batch of stores.  The loop form above runs a load and a
+// wait per count, twice (12 dependent round trips at 2040 blocks: 5 us for 1 MB).
+template <int PER>
+__global__ __launch_bounds__(256) void gmm_bucket_binscan_reg_kernel(GmmBucketArgs a, int n_blk) {
+  __shared__ int wave_total[4];
+  const int k = blockIdx.x;
+  const int per = (n_blk + 255) / 256;
+  const int b0 = threadIdx.x * per;
+  int* bin = a.blk_counts + (size_t)k * n_blk;
+  int vals[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int b = b0 + j;
+    const int v = bin[b < n_blk ? b : n_blk - 1];
+    vals[j] = (j < per && b < n_blk) ? v : 0;
+  }
+  int local = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) local += vals[j];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wave_total[wv] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wv; ++w) before += wave_total[w];
+  int run = before + incl - local;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int b = b0 + j;
+    if (j < per && b < n_blk) bin[b] = run;
+    run += vals[j];
+  }
+  if (threadIdx.x == 255) a.counts[k] = before + incl;
+}
+
+static void launch_binscan(const GmmBucketArgs& bk, int K, int n_blk, hipStream_t s) {
+  const int per = (n_blk + 255) / 256;
+  if (per <= 8)
+    gmm_bucket_binscan_reg_kernel<8><<<K, 256, 0, s>>>(bk, n_blk);
+  else if (per <= 32)
+    gmm_bucket_binscan_reg_kernel<32><<<K, 256, 0, s>>>(bk, n_blk);
+  else
+    gmm_bucket_binscan_kernel<<<K, 256, 0, s>>>(bk, n_blk);
 }
 
 // Exclusive scan of the padded bucket sizes, by EVERY block of the scatter kernel for itself (K bin totals: a few hundred
@@ -552,6 +636,20 @@ __global__ __launch_bounds__(256) void gmm_bucket_scatter_kernel(GmmBucketArgs a
   // place the elements (the order inside a bucket does not influence any result)
   for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
     const int base = a.n_begin + c * a.chunk, size = bucket_chunk_size(a, c);
+    if (a.seg_cnt && !a.ptab) {  // (uniform) candidate records of the arg-max screen: batched loads, same walk as the count kernel
+      for (int i = threadIdx.x; i < size; i += 256 * BUCKET_UN) {
+        int key[BUCKET_UN], patch[BUCKET_UN];
+        record_keys<BUCKET_UN>(a, base, i, size, key, patch);
+#pragma unroll
+        for (int u = 0; u < BUCKET_UN; ++u)
+          if (key[u] >= 0) {
+            const int pos = atomicAdd(&hist[key[u]], 1);
+            a.order[pos] = base + i + 256 * u;
+            if (a.order_n) a.order_n[pos] = patch[u];
+          }
+      }
+      continue;
+    }
     for (int i = threadIdx.x; i < size; i += 256) {
       const int n = base + i;
       const int k = bucket_key(a, n);
@@ -1745,11 +1843,32 @@ __global__ __launch_bounds__(256) void gmm_best_kernel(GmmBestArgs a) {
   const int base = a.n_begin + blockIdx.x * BEST_CHUNK;
   const bool slots = a.winner && *a.flag != a.gen;
   double local = 0.0;
+  // (the block's keys by unconditional loads, all in flight at once: under the bounds test the compiler emitted load, wait,
+  // store, wait per 256 patches -- eight dependent round trips in a launch of one block per CU)
+  unsigned long long keys[BEST_CHUNK / 256];
+#pragma unroll
+  for (int i = 0; i < BEST_CHUNK / 256; ++i) {
+    const int n = base + i * 256 + threadIdx.x;
+    keys[i] = a.best[n < a.n_end ? n : a.n_end - 1];
+  }
+  if (slots && !a.argmax_out) {  // (block-uniform) the fit's path: nothing but the winner slots to store, no loads in the loop
+#pragma unroll
+    for (int i = 0; i < BEST_CHUNK / 256; ++i) {
+      const int n = base + i * 256 + threadIdx.x;
+      if (n < a.n_end) {
+        const unsigned long long key = keys[i];
+        const bool ok = key != 0ull;
+        const float v = best_value(key);
+        a.winner[n] = ok && v > -INFINITY ? best_component(key) : -1;
+        if (ok) local += (double)v;
+      }
+    }
+  } else
 #pragma unroll
   for (int i = 0; i < BEST_CHUNK / 256; ++i) {
     const int n = base + i * 256 + threadIdx.x;
     if (n < a.n_end) {
-      const unsigned long long key = a.best[n];
+      const unsigned long long key = keys[i];
       const bool ok = key != 0ull;
       const float v = best_value(key);
       int k = ok ? best_component(key) : -1;
@@ -1995,6 +2114,7 @@ struct GmmGatherArgs {
   // g = step.grad_flux[pixel] + coef * sum (the other gradient terms, read only) and applies the update of adam_kernel to
   // the pixel -- one pass less over the gradient image and one launch less per step
   int do_step;
+  int preload;  // do_step: the step's streams are loaded before the patch rows (JD_GMM_GATHER_PRELOAD=0: behind the barrier)
   AdamArgs step;
 };
 
@@ -2085,20 +2205,54 @@ __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
     }
     return;
   }
+  // the optimizer step's own streams (gradient, parameter, flux, moments, mask of the thread's four pixels) do not depend
+  // on the patch rows: their loads are issued FIRST, so that they are in flight beside the winner -> row chain below
+  // instead of behind the block barrier (three dependent round trips per block become two)
+  const int Yt = Y0 + (tid >> 3), Xt = X0 + (tid & 7) * 4;
+  const bool pre = a.do_step && a.vec && Yt < a.y_end && Xt >= 0 && Xt + 3 < a.W;
+  const bool early = pre && a.preload;
+  float4 pre_g = make_float4(0.f, 0.f, 0.f, 0.f), pre_t = pre_g, pre_f = pre_g, pre_m = pre_g, pre_v = pre_g;
+  float4 pre_k = make_float4(1.f, 1.f, 1.f, 1.f);
+  auto load_step_streams = [&]() {
+    const AdamArgs& st = a.step;
+    const size_t idx = (size_t)wrap(Yt - a.shift_y, a.H) * a.W + wrap(Xt - a.shift_x, a.W);
+    pre_g = *reinterpret_cast<const float4*>(st.grad_flux + idx);
+    pre_t = *reinterpret_cast<const float4*>(st.theta + idx), pre_f = *reinterpret_cast<const float4*>(st.flux_in + idx);
+    if (!st.sgd) pre_m = *reinterpret_cast<const float4*>(st.m + idx), pre_v = *reinterpret_cast<const float4*>(st.v + idx);
+    if (st.mask) pre_k = *reinterpret_cast<const float4*>(st.mask + idx);
+  };
   if (touched) {
     const bool slots = a.winner && *a.flag != a.gen;
-    for (int p = tid >> 4; p < npy * npx; p += 16) {
-      const int py = py0 + p / npx, px = px0 + p % npx;
-      const float* src;
-      if (slots) {
-        const int slot = a.winner[(size_t)py * a.nPx + px];
-        src = slot >= 0 ? a.grec + (size_t)slot * D : nullptr;
-      } else {
-        src = a.gpatch + ((size_t)(py - a.row_begin) * a.nPx + px) * D;
+    // a wave's loads return in the order they were issued: FIRST the winner slots of all the thread's patches, then the
+    // step's streams, then the rows -- the wait for the slots does not wait for the streams, and the streams have landed
+    // by the time the rows have (the step's streams in front of the slots: measured slower, 56.9 against 49.9 us)
+    constexpr int PER = (GATHER_MAX_P * GATHER_MAX_PX + 15) / 16;
+    int slot_of[PER];  // slots: the winner's bucket slot (< 0: none); else the patch's row of gpatch
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int p = (tid >> 4) + 16 * j;
+      slot_of[j] = -1;
+      if (p < npy * npx) {
+        const int py = py0 + p / npx, px = px0 + p % npx;
+        slot_of[j] = slots ? a.winner[(size_t)py * a.nPx + px] : (py - a.row_begin) * a.nPx + px;
       }
-      const float4 v = src ? reinterpret_cast<const float4*>(src)[tid & 15] : make_float4(0.f, 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(&rows[p][(tid & 15) * 4]) = v;
     }
+    if (early) load_step_streams();
+    const float* base = slots ? a.grec : a.gpatch;
+    // (every load unconditional -- row 0 stands in for "no row" -- so that all of them are in flight at once: with the load
+    // under the condition the compiler emitted load, wait, LDS store per patch, six dependent round trips per thread)
+    float4 rowv[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      rowv[j] = reinterpret_cast<const float4*>(base + (size_t)(slot_of[j] >= 0 ? slot_of[j] : 0) * D)[tid & 15];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int p = (tid >> 4) + 16 * j;
+      if (p < npy * npx)
+        *reinterpret_cast<float4*>(&rows[p][(tid & 15) * 4]) = slot_of[j] >= 0 ? rowv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else if (early) {
+    load_step_streams();
   }
   __syncthreads();
   const int Y = Y0 + (tid >> 3);
@@ -2137,20 +2291,13 @@ __global__ __launch_bounds__(256) void gmm_gather_tile_kernel(GmmGatherArgs a) {
     // the un-rolled column of the group is a multiple of 4 and the group does not wrap (W % 4 == 0)
     const size_t idx = row + wrap(Xg - a.shift_x, a.W);
     if (a.do_step) {
-      const AdamArgs& st = a.step;
-      const float4 g4 = *reinterpret_cast<const float4*>(st.grad_flux + idx);
+      const AdamArgs& st = a.step;  // (`pre` holds here: the loads were issued at the top of the kernel)
+      if (!early) load_step_streams();  // (JD_GMM_GATHER_PRELOAD=0: behind the barrier, as before)
+      const float4 g4 = pre_g, t4 = pre_t, f4 = pre_f, m4 = pre_m, v4 = pre_v, k4 = pre_k;
       float g[4] = {g4.x, g4.y, g4.z, g4.w};
-      const float4 t4 = *reinterpret_cast<const float4*>(st.theta + idx), f4 = *reinterpret_cast<const float4*>(st.flux_in + idx);
-      float th[4] = {t4.x, t4.y, t4.z, t4.w}, f[4] = {f4.x, f4.y, f4.z, f4.w}, m[4] = {0.f, 0.f, 0.f, 0.f}, v[4] = {0.f, 0.f, 0.f, 0.f};
-      float mk[4] = {1.f, 1.f, 1.f, 1.f};
-      if (!st.sgd) {
-        const float4 m4 = *reinterpret_cast<const float4*>(st.m + idx), v4 = *reinterpret_cast<const float4*>(st.v + idx);
-        m[0] = m4.x, m[1] = m4.y, m[2] = m4.z, m[3] = m4.w, v[0] = v4.x, v[1] = v4.y, v[2] = v4.z, v[3] = v4.w;
-      }
-      if (st.mask) {
-        const float4 k4 = *reinterpret_cast<const float4*>(st.mask + idx);
-        mk[0] = k4.x, mk[1] = k4.y, mk[2] = k4.z, mk[3] = k4.w;
-      }
+      float th[4] = {t4.x, t4.y, t4.z, t4.w}, f[4] = {f4.x, f4.y, f4.z, f4.w};
+      float m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+      float mk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (any[i]) g[i] += a.coef * sum[i];
@@ -2756,7 +2903,8 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
 
   // chunks of the record sort: one record segment per block unless there are too many (the kernels stride then)
   unsigned chunks = (unsigned)n_seg;
-  const unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
+  unsigned max_blocks = std::max<unsigned>(2u * g->n_cu, (1u << 20) / (unsigned)g->K);
+  if (opt_value(OPT_GMM_SORT_BLOCKS, 0) > 0) max_blocks = (unsigned)opt_value(OPT_GMM_SORT_BLOCKS, 0);
   if (chunks > max_blocks) chunks = max_blocks;
   if ((rc = grow(&g->blk_counts, &g->blk_counts_cap, (size_t)chunks * g->K))) return rc;
   const bool kc_lds = g->K <= SCREEN_KC_MAX && !opt_is_set(OPT_GMM_SCREEN_NO_LDS_CONSTS);  // (testing: the global-load path)
@@ -2817,7 +2965,7 @@ static int screened_forward(jd_gmm* g, const GmmFwdArgs& a, hipStream_t s, int* 
   {
     ProfScope stage(JD_KERNEL_GMM_SORT, s);
     gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
-    gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
+    launch_binscan(bk, g->K, (int)chunks, s);
     gmm_bucket_scatter_kernel<<<chunks, 256, 3 * hist_bytes + sizeof(int), s>>>(bk);
   }
   JD_LAUNCH_CHECK();
@@ -3084,7 +3232,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     {
       ProfScope prof(JD_KERNEL_GMM_BWD, s);
       gmm_bucket_count_kernel<<<chunks, 256, hist_bytes, s>>>(bk);
-      gmm_bucket_binscan_kernel<<<g->K, 256, 0, s>>>(bk, (int)chunks);
+      launch_binscan(bk, g->K, (int)chunks, s);
       gmm_bucket_scatter_kernel<<<chunks, 256, 3 * hist_bytes + sizeof(int), s>>>(bk);
       GmmBwdArgs b{};
       b.flux = flux, b.afrag = g->afrag, b.mfrag = g->mfrag, b.gfrag = g->gfrag, b.argmax = arg, b.order = g->order;
@@ -3126,6 +3274,7 @@ static int gmm_prior_impl(jd_gmm* g, const float* flux, int H, int W, int stride
     ga.vec = W % 4 == 0 && aligned(grad_flux_accum) ? 1 : 0;
     if (step) {
       ga.do_step = 1, ga.step = *step, ga.y_begin = 0, ga.y_end = H;  // every pixel of the image takes the step
+      ga.preload = opt_value(OPT_GMM_GATHER_PRELOAD, 1) != 0;
       ga.vec = ga.vec && aligned(step->theta) && aligned(step->flux_in) && aligned(step->flux_out) && aligned(step->m) &&
                aligned(step->v) && aligned(step->mask);
     }

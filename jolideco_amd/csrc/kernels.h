@@ -74,7 +74,7 @@ enum JdOption {
   OPT_GMM_SCREEN_NP, OPT_GMM_SCREEN_NO_LDS_CONSTS, OPT_GMM_SCREEN_DEBUG, OPT_GMM_SCREEN, OPT_GMM_FUSED_BWD,
   OPT_GMM_GATHER_TILED, OPT_GMM_LSE_SCREEN, OPT_GMM_WINNER_ROWS, OPT_SEP_JOINT, OPT_SEP_JOINT_ROWS, OPT_SEP_JOINT_CHUNK,
   OPT_SEP_WALK_ADJ_ALL, OPT_SEP_WALK_COST33, OPT_SEP_WALK_ROWS33, OPT_SEP_NO_TRIM, OPT_SEP_WALK_ADJ_ROWS33,
-  OPT_SEP_WALK_ADJ33, OPT_FFT_NATIVE, OPT_DIRECT_AUTO_ALL, OPT_FFT_BATCH, OPT_FFT_TINY, OPT_FFT_POOL_IO, OPT_COUNT
+  OPT_SEP_WALK_ADJ33, OPT_FFT_NATIVE, OPT_DIRECT_AUTO_ALL, OPT_FFT_BATCH, OPT_FFT_TINY, OPT_FFT_POOL_IO, OPT_GMM_SORT_BLOCKS, OPT_GMM_GATHER_PRELOAD, OPT_COUNT
 };
 bool opt_is_set(int id);
 int opt_value(int id, int unset_value);

@@ -35,6 +35,9 @@ OptionSlot g_options[OPT_COUNT] = {
                                   // one beyond 2048 flux rows: 3 per-dataset calls, 4 per-dataset FFT launches + one tail
     {"JD_FFT_TINY", {INT_MIN}},   // longest row (points) of the one-wave generic row kernels; 0: off (default 1024)
     {"JD_FFT_POOL_IO", {INT_MIN}},  // 0: the column passes around the pooled launch of an up-sampled step move full rows
+    {"JD_GMM_SORT_BLOCKS", {INT_MIN}},  // tuning: most blocks of the record sort's count / scatter launches (default: one
+                                        // record segment per block up to max(2 CUs, 2^20 / K))
+    {"JD_GMM_GATHER_PRELOAD", {INT_MIN}},  // 0: the gather kernel loads the optimizer step's streams behind its block barrier
 };
 
 int parse(const char* text) {
