@@ -380,30 +380,25 @@ __device__ __forceinline__ void column_conv_inplace(float2* x, int N, const FftP
 // the row does not exist (the lower half of an image with an odd number of rows is one row short) -- zeros, no store.
 __device__ __forceinline__ float4 row_ld4(const float* row, int x, int W, bool ragged, bool live = true) {
   if (!live) return make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!ragged) return *reinterpret_cast<const float4*>(row + x);
-  if (x + 4 <= W) {
-    const F4U4 v = *reinterpret_cast<const F4U4*>(row + x);
-    return make_float4(v.x, v.y, v.z, v.w);
-  }
+  if (!ragged) return gld4(row + x);  // (global-memory accessors of jd_common.h: no flat loads through table pointers)
+  if (x + 4 <= W) return gld4u(row + x);
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (x < W) r.x = row[x];
-  if (x + 1 < W) r.y = row[x + 1];
-  if (x + 2 < W) r.z = row[x + 2];
+  if (x < W) r.x = gld(row + x);
+  if (x + 1 < W) r.y = gld(row + x + 1);
+  if (x + 2 < W) r.z = gld(row + x + 2);
   return r;
 }
 
 __device__ __forceinline__ void row_st4(float* row, int x, int W, bool ragged, float4 v, bool live = true) {
   if (!live) return;
   if (!ragged) {
-    *reinterpret_cast<float4*>(row + x) = v;
+    gst4(row + x, v);
   } else if (x + 4 <= W) {
-    F4U4 u;
-    u.x = v.x, u.y = v.y, u.z = v.z, u.w = v.w;
-    *reinterpret_cast<F4U4*>(row + x) = u;
+    gst4u(row + x, v);
   } else {
-    if (x < W) row[x] = v.x;
-    if (x + 1 < W) row[x + 1] = v.y;
-    if (x + 2 < W) row[x + 2] = v.z;
+    if (x < W) gst(row + x, v.x);
+    if (x + 1 < W) gst(row + x + 1, v.y);
+    if (x + 2 < W) gst(row + x + 2, v.z);
   }
 }
 
@@ -447,41 +442,45 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
     // the window leaves the image) -- the arithmetic of shift_fwd_kernel, whose launch and image this replaces
     const ShiftGeom g = shift_geom(shift_xy, a.shift_scale);
     const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
-    auto shifted_row = [&](int yrow, float (&dst)[MAXQ][4]) {
-      const int r0 = yrow + g.fy, r1 = r0 + 1;
-      const bool in_r0 = r0 >= 0 && r0 < a.H, in_r1 = r1 >= 0 && r1 < a.H;
-      const float* row0 = a.in + (size_t)(in_r0 ? r0 : 0) * a.W;
-      const float* row1 = a.in + (size_t)(in_r1 ? r1 : 0) * a.W;
+    // every source row piece by ONE unconditional 16-byte load + one float at clamped coordinates (issue_row5, jd_common.h),
+    // the pieces of a chunk -- two halves x two source rows x QB pieces, and their exposure -- in flight together, the zeros
+    // of the outside put in afterwards in registers.  (Loads under the window's bounds tests ran one after the other, each
+    // behind a full wait.)  QB = 2 pieces per chunk, 1 for the one-wave rows of small fits (four pieces per thread there).
+    constexpr int QB = (MAXQ < 2 || S::T <= 64) ? 1 : 2;
 #pragma unroll
-      for (int q = 0; q < MAXQ; ++q) {
+    for (int q0 = 0; q0 < MAXQ; q0 += QB) {
+      Raw5 raw[2][2][QB];
+      float4 su[QB], sv[QB];
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        const int q = q0 + j < MAXQ ? q0 + j : MAXQ - 1;
+        const int x = 4 * (tid + q * S::T), xs = x < a.W ? x : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r0 = y + h * a.Hh + g.fy;
+          raw[h][0][j] = issue_row5(a.in, a.H, a.W, r0, xs + g.fx);
+          raw[h][1][j] = issue_row5(a.in, a.H, a.W, r0 + 1, xs + g.fx);
+        }
+        su[j] = sv[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (scale) su[j] = row_ld4(scale + ra, xs, a.W, ragged), sv[j] = row_ld4(scale + rb, xs, a.W, ragged, lower);
+      }
+#pragma unroll
+      for (int j = 0; j < QB; ++j) {
+        const int q = q0 + j;
+        if (q >= MAXQ) continue;
         const int x = 4 * (tid + q * S::T);
-        float t0[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, t1[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (x < a.W) {
-          const int c0 = x + g.fx;
-          if (c0 >= 0 && c0 + 4 < a.W) {
-            if (in_r0) {
-              const F4U4 v = *reinterpret_cast<const F4U4*>(row0 + c0);
-              t0[0] = v.x, t0[1] = v.y, t0[2] = v.z, t0[3] = v.w, t0[4] = row0[c0 + 4];
-            }
-            if (in_r1) {
-              const F4U4 v = *reinterpret_cast<const F4U4*>(row1 + c0);
-              t1[0] = v.x, t1[1] = v.y, t1[2] = v.z, t1[3] = v.w, t1[4] = row1[c0 + 4];
-            }
-          } else {
+        const float se[2][4] = {{su[j].x, su[j].y, su[j].z, su[j].w}, {sv[j].x, sv[j].y, sv[j].z, sv[j].w}};
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-              const bool in_c = c0 + i >= 0 && c0 + i < a.W;
-              t0[i] = in_c && in_r0 ? row0[c0 + i] : 0.f;
-              t1[i] = in_c && in_r1 ? row1[c0 + i] : 0.f;
-            }
+        for (int h = 0; h < 2; ++h) {
+          const Row5 t0 = finish_row5(raw[h][0][j]), t1 = finish_row5(raw[h][1][j]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float v = x < a.W ? t0.v[i] * w00 + t0.v[i + 1] * w10 + t1.v[i] * w01 + t1.v[i + 1] * w11 : 0.f;
+            (h ? pv : pu)[q][i] = scale ? v * se[h][i] : v;  // (the product of the loop below, made here)
           }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[q][i] = t0[i] * w00 + t0[i + 1] * w10 + t1[i] * w01 + t1[i + 1] * w11;
       }
-    };
-    shifted_row(y, pu);
-    shifted_row(y + a.Hh, pv);
+    }
     if (ragged || !lower) {  // (the interpolation of neighbours inside the image gives non-zero values for pixels outside it)
 #pragma unroll
       for (int q = 0; q < MAXQ; ++q)
@@ -506,7 +505,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   for (int q = 0; q < MAXQ; ++q) {
     const int x = 4 * (tid + q * S::T);
     if (x >= Nx) continue;
-    if (scale && x < a.W) {
+    if (scale && x < a.W && !shift_xy) {  // (shifted rows: the exposure arrived with the pieces and is applied already)
       const float4 su = row_ld4(scale + ra, x, a.W, ragged), sv = row_ld4(scale + rb, x, a.W, ragged, lower);
       pu[q][0] *= su.x, pu[q][1] *= su.y, pu[q][2] *= su.z, pu[q][3] *= su.w;
       pv[q][0] *= sv.x, pv[q][1] *= sv.y, pv[q][2] *= sv.z, pv[q][3] *= sv.w;
@@ -520,7 +519,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   float2* out = spec + (size_t)y * Nx;
   for (int x = 2 * tid; x < Nx; x += 2 * S::T) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
-    *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
+    gst4(out + x, make_float4(c0.x, c0.y, c1.x, c1.y));
   }
 }
 
@@ -582,7 +581,7 @@ __global__ __launch_bounds__((LANES * CBS > 512 ? 1024 : 512), (LANES * CBS > 51
   for (int i = tid; i < Ny * half; i += LANES * CB) {
     const int row = i / half, piece = i - row * half;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < a.Hh) v = *reinterpret_cast<const float4*>(spec_in + (size_t)(a.pool_in > 1 ? row / a.pool_in : row) * a.Nx + x0 + 2 * piece);
+    if (row < a.Hh) v = gld4(spec_in + (size_t)(a.pool_in > 1 ? row / a.pool_in : row) * a.Nx + x0 + 2 * piece);
     float2* c0 = lds + (size_t)(2 * piece) * stride;
     c0[lp(row)] = float2{v.x, v.y};
     c0[stride + lp(row)] = float2{v.z, v.w};
@@ -605,7 +604,7 @@ __global__ __launch_bounds__((LANES * CBS > 512 ? 1024 : 512), (LANES * CBS > 51
         const float2 p1 = c0[lp(row + j)], q1 = c0[stride + lp(row + j)];
         p = float2{p.x + p1.x, p.y + p1.y}, q = float2{q.x + q1.x, q.y + q1.y};
       }
-      *reinterpret_cast<float4*>(work_out + (size_t)P * a.Nx + x0 + 2 * piece) = make_float4(p.x, p.y, q.x, q.y);
+      gst4(work_out + (size_t)P * a.Nx + x0 + 2 * piece, make_float4(p.x, p.y, q.x, q.y));
     }
     return;
   }
@@ -614,7 +613,7 @@ __global__ __launch_bounds__((LANES * CBS > 512 ? 1024 : 512), (LANES * CBS > 51
     if (row >= a.keep_lo && row < a.keep_hi) continue;
     const float2* c0 = lds + (size_t)(2 * piece) * stride;
     const float2 p = c0[lp(row)], q = c0[stride + lp(row)];
-    *reinterpret_cast<float4*>(work_out + (size_t)row * a.Nx + x0 + 2 * piece) = make_float4(p.x, p.y, q.x, q.y);
+    gst4(work_out + (size_t)row * a.Nx + x0 + 2 * piece, make_float4(p.x, p.y, q.x, q.y));
   }
 }
 
@@ -631,34 +630,58 @@ __device__ __forceinline__ void load_spectrum_row(float2* buf, const float2* wor
                                                   int tid) {
   const bool spill_up = y >= Hh - ra, spill_down = y < rb;
   const float2* src = work + (size_t)y * Nx;
+  // (CH pieces per thread and round: their loads are unconditional -- a piece past the row's end re-reads the round's first --
+  // and issued together, then stored to LDS.  One load, one wait, one LDS store per piece made a 4608-point row four
+  // dependent round trips per thread.)
+  constexpr int CH = T <= 64 ? 2 : 4;  // (one-wave rows of small fits: their launches live on blocks per CU, not on registers)
   if (!(spill_up || spill_down)) {  // (block-uniform)
-    for (int x = 2 * tid; x < Nx; x += 2 * T) {
-      const float4 v = *reinterpret_cast<const float4*>(src + x);
-      float2 o0 = float2{v.x, v.y}, o1 = float2{v.z, v.w};
-      if (ADD) {
-        const float2 p0 = buf[lp(x)], p1 = buf[lp(x + 1)];
-        o0 = float2{p0.x + o0.x, p0.y + o0.y}, o1 = float2{p1.x + o1.x, p1.y + o1.y};
+    for (int x0 = 2 * tid; x0 < Nx; x0 += 2 * T * CH) {
+      float4 v[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) v[j] = gld4(src + (x0 + 2 * T * j < Nx ? x0 + 2 * T * j : x0));
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int x = x0 + 2 * T * j;
+        if (x >= Nx) continue;
+        float2 o0 = float2{v[j].x, v[j].y}, o1 = float2{v[j].z, v[j].w};
+        if (ADD) {
+          const float2 p0 = buf[lp(x)], p1 = buf[lp(x + 1)];
+          o0 = float2{p0.x + o0.x, p0.y + o0.y}, o1 = float2{p1.x + o1.x, p1.y + o1.y};
+        }
+        buf[lp(x)] = o0, buf[lp(x + 1)] = o1;
       }
-      buf[lp(x)] = o0, buf[lp(x + 1)] = o1;
     }
   } else {
     const float2* sp = work + (size_t)(spill_up ? Ny - Hh + y : Hh + y) * Nx;
-    for (int x = 2 * tid; x < Nx; x += 2 * T) {
-      const float4 v = *reinterpret_cast<const float4*>(src + x), c = *reinterpret_cast<const float4*>(sp + x);
-      const float2 m0 = sp[x == 0 ? 0 : Nx - x], m1 = sp[Nx - x - 1];  // C[-x], C[-(x + 1)]
-      float2 o0, o1;
-      if (spill_up) {  // + (C[k] - conj C[-k]) / 2i = ((Im C[k] + Im C[-k]) / 2, -(Re C[k] - Re C[-k]) / 2)
-        o0 = float2{v.x + 0.5f * (c.y + m0.y), v.y - 0.5f * (c.x - m0.x)};
-        o1 = float2{v.z + 0.5f * (c.w + m1.y), v.w - 0.5f * (c.z - m1.x)};
-      } else {  // + i (C[k] + conj C[-k]) / 2 = (-(Im C[k] - Im C[-k]) / 2, (Re C[k] + Re C[-k]) / 2)
-        o0 = float2{v.x - 0.5f * (c.y - m0.y), v.y + 0.5f * (c.x + m0.x)};
-        o1 = float2{v.z - 0.5f * (c.w - m1.y), v.w + 0.5f * (c.z + m1.x)};
+    for (int x0 = 2 * tid; x0 < Nx; x0 += 2 * T * CH) {
+      float4 vv[CH], cc[CH];
+      float2 mm0[CH], mm1[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int x = x0 + 2 * T * j < Nx ? x0 + 2 * T * j : x0;
+        vv[j] = gld4(src + x), cc[j] = gld4(sp + x);
+        mm0[j] = gld2(sp + (x == 0 ? 0 : Nx - x)), mm1[j] = gld2(sp + (Nx - x - 1));  // C[-x], C[-(x + 1)]
       }
-      if (ADD) {
-        const float2 p0 = buf[lp(x)], p1 = buf[lp(x + 1)];
-        o0 = float2{p0.x + o0.x, p0.y + o0.y}, o1 = float2{p1.x + o1.x, p1.y + o1.y};
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int x = x0 + 2 * T * j;
+        if (x >= Nx) continue;
+        const float4 v = vv[j], c = cc[j];
+        const float2 m0 = mm0[j], m1 = mm1[j];
+        float2 o0, o1;
+        if (spill_up) {  // + (C[k] - conj C[-k]) / 2i = ((Im C[k] + Im C[-k]) / 2, -(Re C[k] - Re C[-k]) / 2)
+          o0 = float2{v.x + 0.5f * (c.y + m0.y), v.y - 0.5f * (c.x - m0.x)};
+          o1 = float2{v.z + 0.5f * (c.w + m1.y), v.w - 0.5f * (c.z - m1.x)};
+        } else {  // + i (C[k] + conj C[-k]) / 2 = (-(Im C[k] - Im C[-k]) / 2, (Re C[k] + Re C[-k]) / 2)
+          o0 = float2{v.x - 0.5f * (c.y - m0.y), v.y + 0.5f * (c.x + m0.x)};
+          o1 = float2{v.z - 0.5f * (c.w - m1.y), v.w + 0.5f * (c.z + m1.x)};
+        }
+        if (ADD) {
+          const float2 p0 = buf[lp(x)], p1 = buf[lp(x + 1)];
+          o0 = float2{p0.x + o0.x, p0.y + o0.y}, o1 = float2{p1.x + o1.x, p1.y + o1.y};
+        }
+        buf[lp(x)] = o0, buf[lp(x + 1)] = o1;
       }
-      buf[lp(x)] = o0, buf[lp(x + 1)] = o1;
     }
   }
   __syncthreads();
@@ -676,10 +699,10 @@ __device__ __forceinline__ void load_spectrum_row_regs(float4 (&pre)[ROW_PRE], c
   for (int i = 0; i < ROW_PRE; ++i) {
     const int x = 2 * (tid + i * T);
     if (x >= Nx) continue;
-    float4 v = *reinterpret_cast<const float4*>(src + x);
+    float4 v = gld4(src + x);
     if (spill_up || spill_down) {  // (block-uniform; see load_spectrum_row)
-      const float4 c = *reinterpret_cast<const float4*>(sp + x);
-      const float2 m0 = sp[x == 0 ? 0 : Nx - x], m1 = sp[Nx - x - 1];
+      const float4 c = gld4(sp + x);
+      const float2 m0 = gld2(sp + (x == 0 ? 0 : Nx - x)), m1 = gld2(sp + (Nx - x - 1));
       if (spill_up) {
         v = make_float4(v.x + 0.5f * (c.y + m0.y), v.y - 0.5f * (c.x - m0.x), v.z + 0.5f * (c.w + m1.y), v.w - 0.5f * (c.z - m1.x));
       } else {
@@ -740,10 +763,23 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   float2* bufa = lds;
   float2* bufb = lds + lp_size(Nx);
   constexpr int MAXQ = S::MAXQ;
-  load_spectrum_row<S::T>(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
-  const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
   const size_t o1 = (size_t)y * a.W, o2 = (size_t)(y + a.Hh) * a.W;
   const bool ragged = (a.W & 3) != 0, lower = y + a.Hh < a.H;
+  // the epilogue's exposure rows do not depend on the transform: requested FIRST, so that they arrive while the block loads
+  // its spectrum row and transforms it, not in a round trip of their own behind it
+  // (not the one-wave rows of small fits: four pieces per thread there, and their launches live on blocks per CU)
+  constexpr bool PRE = ADJ && S::T > 64;
+  float4 s1[PRE ? MAXQ : 1], s2[PRE ? MAXQ : 1];
+  if (PRE) {
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int x = 4 * (tid + q * S::T), xs = x < a.W ? x : 0;
+      s1[q] = s2[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (scale) s1[q] = row_ld4(scale + o1, xs, a.W, ragged), s2[q] = row_ld4(scale + o2, xs, a.W, ragged, lower);
+    }
+  }
+  load_spectrum_row<S::T>(bufa, work, Nx, y, a.Hh, a.Ny, a.ra, a.rb, tid);
+  const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
 #pragma unroll
   for (int q = 0; q < MAXQ; ++q) {
     const int x = 4 * (tid + q * S::T);
@@ -755,14 +791,15 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
       up.x *= a.coef, up.y *= a.coef, up.z *= a.coef, up.w *= a.coef;
       dn.x *= a.coef, dn.y *= a.coef, dn.z *= a.coef, dn.w *= a.coef;
       if (scale) {
-        const float4 s1 = row_ld4(scale + o1, x, a.W, ragged), s2 = row_ld4(scale + o2, x, a.W, ragged, lower);
-        up.x *= s1.x, up.y *= s1.y, up.z *= s1.z, up.w *= s1.w;
-        dn.x *= s2.x, dn.y *= s2.y, dn.z *= s2.z, dn.w *= s2.w;
+        const float4 e1 = PRE ? s1[PRE ? q : 0] : row_ld4(scale + o1, x, a.W, ragged);
+        const float4 e2 = PRE ? s2[PRE ? q : 0] : row_ld4(scale + o2, x, a.W, ragged, lower);
+        up.x *= e1.x, up.y *= e1.y, up.z *= e1.z, up.w *= e1.w;
+        dn.x *= e2.x, dn.y *= e2.y, dn.z *= e2.z, dn.w *= e2.w;
       }
       if (a.accumulate && !nb) {
-        const float4 g1 = row_ld4(out + o1, x, a.W, ragged), g2 = row_ld4(out + o2, x, a.W, ragged, lower);
-        up.x += g1.x, up.y += g1.y, up.z += g1.z, up.w += g1.w;
-        dn.x += g2.x, dn.y += g2.y, dn.z += g2.z, dn.w += g2.w;
+        const float4 p1 = row_ld4(out + o1, x, a.W, ragged), p2 = row_ld4(out + o2, x, a.W, ragged, lower);
+        up.x += p1.x, up.y += p1.y, up.z += p1.z, up.w += p1.w;
+        dn.x += p2.x, dn.y += p2.y, dn.z += p2.z, dn.w += p2.w;
       }
     }
     row_st4(out + o1, x, a.W, ragged, up);
@@ -941,7 +978,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
   float2* out = spec + (size_t)y * Nx;
   for (int x = 2 * tid; x < Nx; x += 2 * S::T) {
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
-    *reinterpret_cast<float4*>(out + x) = make_float4(c0.x, c0.y, c1.x, c1.y);
+    gst4(out + x, make_float4(c0.x, c0.y, c1.x, c1.y));
   }
 }
 
@@ -1005,8 +1042,23 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
 #pragma unroll 1
     for (int j = 1; j < U; ++j) load_spectrum_row<S::T, true>(bufa, work, Nx, U * Y + j, a.Hh, a.Ny, a.ra, a.rb, tid);
   }
+  // background and counts of the thread's counts pixels: unconditional global loads (clamped to the row), issued here so that
+  // they are in flight while the pooled sums are read from LDS (under the bounds tests, through the table's generic
+  // pointers, they were flat loads with a full wait each, behind the transform)
+  float bgu[MAXP][G], bgd[MAXP][G], cnu[MAXP][G], cnd[MAXP][G];
   {
     const float2* r = row_fft<1, S, R0, R1, R2, R3>(bufa, bufb, Nx, a.f, a.tw, tid);
+#pragma unroll
+    for (int q = 0; q < MAXP; ++q) {
+      const int x = PX * (tid + q * S::T);
+#pragma unroll
+      for (int c = 0; c < G; ++c) {
+        const int xc = min((x < a.W ? x : 0) / U + c, Wd - 1);
+        const size_t o1 = (size_t)Y * Wd + xc, o2 = (size_t)(Y + Hdh) * Wd + xc;
+        bgu[q][c] = gld(background + o1), bgd[q][c] = gld(background + o2);
+        cnu[q][c] = gld(counts + o1), cnd[q][c] = gld(counts + o2);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < MAXP; ++q) {
       const int x = PX * (tid + q * S::T);
@@ -1021,7 +1073,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
     }
     __syncthreads();  // the result buffer is the next transform's work space
   }
-  const float norm = log_bkg_norm ? expf(log_bkg_norm[0]) : 1.f;
+  const float norm = log_bkg_norm ? expf(gld(log_bkg_norm)) : 1.f;
   float gu[MAXP][G], gd[MAXP][G];
   double local = 0.0, local_b = 0.0;
 #pragma unroll
@@ -1033,14 +1085,13 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
 #pragma unroll
     for (int c = 0; c < G; ++c) {
       if (x / U + c >= Wd) continue;  // (the last piece of a row may hold fewer counts pixels)
-      const size_t o1 = (size_t)Y * Wd + x / U + c, o2 = (size_t)(Y + Hdh) * Wd + x / U + c;
-      const float b1 = log_bkg_norm ? background[o1] * norm : background[o1];
-      const float b2 = log_bkg_norm ? background[o2] * norm : background[o2];
+      const float b1 = log_bkg_norm ? bgu[q][c] * norm : bgu[q][c];
+      const float b2 = log_bkg_norm ? bgd[q][c] * norm : bgd[q][c];
       float term, g;
-      poisson_point(fmaxf(pu[q][c], 0.f) + b1, counts[o1], a.eps, a.inv_n, term, g);
+      poisson_point(fmaxf(pu[q][c], 0.f) + b1, cnu[q][c], a.eps, a.inv_n, term, g);
       local += (double)term, local_b += (double)(g * b1);
       gu[q][c] = pu[q][c] >= 0.f ? g : 0.f;  // clamp backward
-      poisson_point(fmaxf(pd[q][c], 0.f) + b2, counts[o2], a.eps, a.inv_n, term, g);
+      poisson_point(fmaxf(pd[q][c], 0.f) + b2, cnd[q][c], a.eps, a.inv_n, term, g);
       local += (double)term, local_b += (double)(g * b2);
       gd[q][c] = pd[q][c] >= 0.f ? g : 0.f;
     }
@@ -1071,10 +1122,10 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
     const float2 c0 = res[lp(x)], c1 = res[lp(x + 1)];
     const float4 v = make_float4(c0.x, c0.y, c1.x, c1.y);
     if (a.pooled_io) {
-      *reinterpret_cast<float4*>(spec + (size_t)Y * Nx + x) = v;  // (the adjoint's column pass reads it for its U rows)
+      gst4(spec + (size_t)Y * Nx + x, v);  // (the adjoint's column pass reads it for its U rows)
     } else {
 #pragma unroll
-      for (int j = 0; j < U; ++j) *reinterpret_cast<float4*>(spec + (size_t)(U * Y + j) * Nx + x) = v;
+      for (int j = 0; j < U; ++j) gst4(spec + (size_t)(U * Y + j) * Nx + x, v);
     }
   }
 }

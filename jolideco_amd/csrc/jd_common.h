@@ -106,6 +106,84 @@ __device__ __forceinline__ ShiftGeom shift_geom(const float* shift_xy, float sca
   return g;
 }
 
+// GLOBAL-memory accessors.  A pointer read from memory (a per-dataset pointer table) or selected between such a pointer and
+// a kernel argument is a GENERIC pointer to the compiler: every access through it becomes a flat_load / flat_store, which
+// count on vmcnt AND lgkmcnt and may return out of order with LDS traffic, so each is followed by a full
+// `s_waitcnt vmcnt(0) lgkmcnt(0)` -- the loads of a kernel that also works in LDS (every FFT kernel) run one at a time.
+// These accessors go through address space 1 explicitly (global_load / global_store, counted waits).  Neither a cast to
+// address space 1 and back nor __builtin_assume(!is_shared && !is_private) survives to the pass that would use it
+// (measured on this toolchain, tools/asm notes in DESIGN_LOG.md).  Builtin vector types: HIP's float4 / float2 structs have
+// no copy from an address-space-qualified reference.
+#define JD_AS1 __attribute__((address_space(1)))
+typedef float jd_v4f __attribute__((ext_vector_type(4)));
+typedef float jd_v2f __attribute__((ext_vector_type(2)));
+typedef jd_v4f jd_v4f_a4 __attribute__((aligned(4)));  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
+__device__ __forceinline__ float gld(const float* p) { return *(const JD_AS1 float*)p; }
+__device__ __forceinline__ void gst(float* p, float v) { *(JD_AS1 float*)p = v; }
+__device__ __forceinline__ float4 gld4(const float* p) {  // 16-byte aligned
+  const jd_v4f v = *(const JD_AS1 jd_v4f*)(const JD_AS1 float*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 gld4u(const float* p) {  // 4-byte aligned
+  const jd_v4f v = *(const JD_AS1 jd_v4f_a4*)(const JD_AS1 float*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 gld4(const float2* p) {  // two complex numbers, 16-byte aligned
+  const jd_v4f v = *(const JD_AS1 jd_v4f*)(const JD_AS1 float2*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 gld2(const float2* p) {
+  const jd_v2f v = *(const JD_AS1 jd_v2f*)(const JD_AS1 float2*)p;
+  return float2{v.x, v.y};
+}
+__device__ __forceinline__ void gst4(float* p, float4 v) { *(JD_AS1 jd_v4f*)(JD_AS1 float*)p = jd_v4f{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void gst4u(float* p, float4 v) { *(JD_AS1 jd_v4f_a4*)(JD_AS1 float*)p = jd_v4f{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void gst4(float2* p, float4 v) { *(JD_AS1 jd_v4f*)(JD_AS1 float2*)p = jd_v4f{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void gst2(float2* p, float2 v) { *(JD_AS1 jd_v2f*)(JD_AS1 float2*)p = jd_v2f{v.x, v.y}; }
+
+// The same five pixels in two steps: `issue_row5` is ONE unconditional 16-byte load + one float at clamped coordinates
+// (global address space), `finish_row5` puts the zeros of the outside in -- register moves only.  With load_row5's three
+// exits the compiler gave every row's vector load a full `s_waitcnt vmcnt(0)` (the border exit's scalar loads write the
+// same registers) and took the pointers of the batch table for generic ones (flat loads): the 14 row loads of a dataset,
+// meant to be in flight together, ran as 14 dependent round trips.  Needs W >= 5.
+struct Raw5 {
+  float q[5];
+  int delta;  // wanted first column minus loaded first column
+  bool yin;   // the row exists
+};
+
+__device__ __forceinline__ Raw5 issue_row5(const float* img, int H, int W, int y, int x) {
+  Raw5 r;
+  const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 5);
+  r.yin = y == yc, r.delta = x - xc;
+  const float* row = img + ((size_t)yc * W + xc);
+  const float4 q = gld4u(row);
+  r.q[0] = q.x, r.q[1] = q.y, r.q[2] = q.z, r.q[3] = q.w, r.q[4] = gld(row + 4);
+  return r;
+}
+
+struct Row5 {
+  float v[5];
+};
+
+__device__ __forceinline__ Row5 finish_row5(const Raw5& r) {
+  Row5 o;
+  if (r.delta == 0) {  // (all but the threads at the left and right image border)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) o.v[i] = r.yin ? r.q[i] : 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int j = i + r.delta;  // column x + i is element j of the loaded five, or outside the image
+      float v = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 5; ++jj) v = j == jj ? r.q[jj] : v;
+      o.v[i] = r.yin ? v : 0.f;
+    }
+  }
+  return o;
+}
+
 struct __attribute__((packed, aligned(4))) F4U4 {  // 16 bytes at a 4-byte aligned address: one global_load_dwordx4
   float x, y, z, w;
 };

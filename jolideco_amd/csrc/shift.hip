@@ -137,26 +137,7 @@ __global__ __launch_bounds__(256) void shift_bwd_batch_kernel(const float* __res
 // operation rounded on its own) is that of the scalar kernels above: the same v, bit for bit; the shift-gradient partial
 // sums are per block and dataset (wave sums by xor-butterfly, waves in index order: `block_sum`'s order), so their
 // grouping -- not their terms -- follows the tiling below.
-struct Row5 {
-  float v[5];
-};
-
-__device__ __forceinline__ Row5 load_row5(const float* img, int H, int W, int y, int x) {  // img[y][x .. x + 4], zero outside
-  Row5 r;
-#pragma unroll
-  for (int i = 0; i < 5; ++i) r.v[i] = 0.f;
-  if (y < 0 || y >= H) return r;
-  const float* row = img + (size_t)y * W;
-  if (x >= 0 && x + 4 < W) {
-    const F4U4 q = *reinterpret_cast<const F4U4*>(row + x);
-    r.v[0] = q.x, r.v[1] = q.y, r.v[2] = q.z, r.v[3] = q.w, r.v[4] = row[x + 4];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-      if (x + i >= 0 && x + i < W) r.v[i] = row[x + i];
-  }
-  return r;
-}
+// (`issue_row5` / `finish_row5`: the same five pixels by unconditional loads, jd_common.h)
 
 // Tiling of an H x W image: a block's 256 threads are `segs` row segments of `tpr` threads (a power of two <= 256: narrow
 // images put several row segments into a block instead of idle threads), a thread owns R rows: the block covers
@@ -227,14 +208,21 @@ __global__ __launch_bounds__(256) void shift_bwd4_kernel(ShiftBwdArgs a) {
           // gs rows y - fy - 1 (prev) and y - fy (cur) at columns x - fx - 1 ..; flux rows y + fy (north), y + fy + 1 (south)
           Row5 gr[R + 1], fl[R + 1];
           float4 go[R];
+          {
+            Raw5 gr_raw[R + 1], fl_raw[R + 1];
 #pragma unroll
-          for (int k = 0; k <= R; ++k) {
-            gr[k] = load_row5(gs, H, W, y0 + k - g.fy - 1, x - g.fx - 1);
-            fl[k] = load_row5(a.in, H, W, y0 + k + g.fy, x + g.fx);
+            for (int k = 0; k <= R; ++k) {
+              gr_raw[k] = issue_row5(gs, H, W, y0 + k - g.fy - 1, x - g.fx - 1);
+              fl_raw[k] = issue_row5(a.in, H, W, y0 + k + g.fy, x + g.fx);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {  // (unconditional too: the last existing row stands in for one below the image)
+              const float4 q = gld4(gs + ((size_t)min(y0 + k, H - 1) * W + x));
+              go[k] = y0 + k < H ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k <= R; ++k) gr[k] = finish_row5(gr_raw[k]), fl[k] = finish_row5(fl_raw[k]);
           }
-#pragma unroll
-          for (int k = 0; k < R; ++k)
-            go[k] = y0 + k < H ? *reinterpret_cast<const float4*>(gs + (size_t)(y0 + k) * W + x) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int k = 0; k < R; ++k) {
             const float gov[4] = {go[k].x, go[k].y, go[k].z, go[k].w};
@@ -300,7 +288,7 @@ static int launch_shift_bwd4(const ShiftBwdArgs& base, int* n_blocks, hipStream_
 }
 
 static bool shift_vec_ok(const void* a, const void* b, const void* c, int W) {
-  return W % 4 == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+  return W % 4 == 0 && W >= 8 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
 }
 
 int launch_shift_bwd_batch(const float* in, const FftBatch* batch, int n_datasets, float* grad_in, int accumulate, int H, int W,
