@@ -285,7 +285,13 @@ __device__ __forceinline__ void column_mid_inplace(float2* x_, int N, const floa
     if (b < nb) {
       cf kh[R];
 #pragma unroll
-      for (int t = 0; t < R; ++t) kh[t] = kcol[b + t * nb];
+      for (int t = 0; t < R; ++t) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (address space 1: the table's pointer is generic; cf is a builtin vector on the device only)
+        kh[t] = *((const JD_AS1 cf*)kcol + (b + t * nb));
+#else
+        kh[t] = kcol[b + t * nb];
+#endif
+      }
       {
         cf w[R];
         w[1] = tw[b];  // k = b, nb / p = 1
@@ -578,13 +584,29 @@ __global__ __launch_bounds__((LANES * CBS > 512 ? 1024 : 512), (LANES * CBS > 51
   float2* col = lds + (size_t)wc * stride;
   // ---- load: row-major pieces of CB columns, two columns (16 bytes) per thread ---------------------------------------
   const int half = CB / 2;  // float4 pieces per row
-  for (int i = tid; i < Ny * half; i += LANES * CB) {
-    const int row = i / half, piece = i - row * half;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < a.Hh) v = gld4(spec_in + (size_t)(a.pool_in > 1 ? row / a.pool_in : row) * a.Nx + x0 + 2 * piece);
-    float2* c0 = lds + (size_t)(2 * piece) * stride;
-    c0[lp(row)] = float2{v.x, v.y};
-    c0[stride + lp(row)] = float2{v.z, v.w};
+  // (CHL pieces per thread and round, loaded unconditionally and issued together, then stored to LDS: with the load under the row test the
+  // compiler emitted load, full wait, LDS store per piece -- nine dependent round trips per thread for a 2304-point column)
+  constexpr int CHL = 5;
+  const int total = Ny * half, step = LANES * CB;
+  for (int i0 = tid; i0 < total; i0 += CHL * step) {
+    float4 v[CHL];
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) {
+      // (a piece past the end or in the zero padding below row Hh re-reads the thread's first piece: an L1 hit, no traffic)
+      const int i = i0 + j * step < a.Hh * half ? i0 + j * step : i0;
+      const int row = i / half, piece = i - row * half, rc = row < a.Hh ? row : a.Hh - 1;
+      v[j] = gld4(spec_in + (size_t)(a.pool_in > 1 ? rc / a.pool_in : rc) * a.Nx + x0 + 2 * piece);
+    }
+#pragma unroll
+    for (int j = 0; j < CHL; ++j) {
+      const int i = i0 + j * step;
+      if (i >= total) continue;
+      const int row = i / half, piece = i - row * half;
+      const float4 w = row < a.Hh ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float2* c0 = lds + (size_t)(2 * piece) * stride;
+      c0[lp(row)] = float2{w.x, w.y};
+      c0[stride + lp(row)] = float2{w.z, w.w};
+    }
   }
   __syncthreads();
   // ---- per column: FFT, product with the kernel spectrum, inverse FFT ------------------------------------------------

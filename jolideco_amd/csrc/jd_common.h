@@ -136,6 +136,8 @@ __device__ __forceinline__ float2 gld2(const float2* p) {
   const jd_v2f v = *(const JD_AS1 jd_v2f*)(const JD_AS1 float2*)p;
   return float2{v.x, v.y};
 }
+__device__ __forceinline__ jd_v2f gld2(const float* p) { return *(const JD_AS1 jd_v2f*)(const JD_AS1 float*)p; }  // 8-byte aligned
+__device__ __forceinline__ void gst2(float* p, jd_v2f v) { *(JD_AS1 jd_v2f*)(JD_AS1 float*)p = v; }
 __device__ __forceinline__ void gst4(float* p, float4 v) { *(JD_AS1 jd_v4f*)(JD_AS1 float*)p = jd_v4f{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void gst4u(float* p, float4 v) { *(JD_AS1 jd_v4f_a4*)(JD_AS1 float*)p = jd_v4f{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void gst4(float2* p, float4 v) { *(JD_AS1 jd_v4f*)(JD_AS1 float2*)p = jd_v4f{v.x, v.y, v.z, v.w}; }
