@@ -446,7 +446,7 @@ __global__ __launch_bounds__((RowSched<R0, R1, R2, R3>::T), (RowSched<R0, R1, R2
     // the bilinearly shifted rows of both halves, straight from global memory: per piece the five source columns of the two
     // source rows (one 16-byte load at a 4-byte aligned address + one float each; element-wise with bounds checks where
     // the window leaves the image) -- the arithmetic of shift_fwd_kernel, whose launch and image this replaces
-    const ShiftGeom g = shift_geom(shift_xy, a.shift_scale);
+    const ShiftGeom g = shift_geom_of(cld(shift_xy), cld(shift_xy + 1), a.shift_scale);
     const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
     // every source row piece by ONE unconditional 16-byte load + one float at clamped coordinates (issue_row5, jd_common.h),
     // the pieces of a chunk -- two halves x two source rows x QB pieces, and their exposure -- in flight together, the zeros

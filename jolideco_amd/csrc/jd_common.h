@@ -96,6 +96,21 @@ struct ShiftGeom {
   float wy0, wy1, wx0, wx1;  // weights of rows fy, fy + 1 / columns fx, fx + 1
 };
 
+__device__ __forceinline__ ShiftGeom shift_geom_of(float shift_x, float shift_y, float scale) {
+  const float sx = scale * shift_x, sy = scale * shift_y;
+  const float flx = floorf(sx), fly = floorf(sy);
+  ShiftGeom g;
+  g.fx = (int)flx, g.fy = (int)fly;
+  g.wx1 = sx - flx, g.wx0 = 1.f - g.wx1;
+  g.wy1 = sy - fly, g.wy0 = 1.f - g.wy1;
+  return g;
+}
+
+// A uniform read-only value through the CONSTANT address space: a scalar load (s_load, SGPR result, lgkmcnt) instead of a
+// flat vector load with a full wait.  For values no launch of the library writes while it reads them (the calibration
+// parameters: the optimizer step that changes them is a launch of its own).
+__device__ __forceinline__ float cld(const float* p) { return *(const __attribute__((address_space(4))) float*)p; }
+
 __device__ __forceinline__ ShiftGeom shift_geom(const float* shift_xy, float scale) {
   const float sx = scale * shift_xy[0], sy = scale * shift_xy[1];
   const float flx = floorf(sx), fly = floorf(sy);

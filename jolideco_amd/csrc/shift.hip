@@ -195,15 +195,24 @@ __global__ __launch_bounds__(256) void shift_bwd4_kernel(ShiftBwdArgs a) {
   }
   for (int d0 = 0; d0 < a.n_datasets; d0 += SHIFT_CHUNK) {
     const int dn = min(SHIFT_CHUNK, a.n_datasets - d0);
+    // the shift of dataset d + 1 is requested (two scalar loads: pointer, then value) while dataset d is processed: read at
+    // the top of its own iteration it was a flat load with a full wait in front of the iteration's 24 row loads
+    const float* next_xy = a.batch ? a.batch->shift_xy[d0] : a.shift0;
+    float next_sx = next_xy ? cld(next_xy) : 0.f, next_sy = next_xy ? cld(next_xy + 1) : 0.f;
     for (int dd = 0; dd < dn; ++dd) {
       const int d = d0 + dd;
       const float* gs = a.batch ? a.batch->gshift[d] : a.gs0;
-      const float* shift_xy = a.batch ? a.batch->shift_xy[d] : a.shift0;
+      const float* shift_xy = next_xy;
+      const float shift_x = next_sx, shift_y = next_sy;
+      if (dd + 1 < dn) {
+        next_xy = a.batch ? a.batch->shift_xy[d + 1] : a.shift0;
+        next_sx = next_xy ? cld(next_xy) : 0.f, next_sy = next_xy ? cld(next_xy + 1) : 0.f;
+      }
       const bool add = a.accumulate || d > 0;
       if (shift_xy) {  // (uniform)
         double dsx = 0.0, dsy = 0.0;
         if (live) {
-          const ShiftGeom g = shift_geom(shift_xy, a.scale);
+          const ShiftGeom g = shift_geom_of(shift_x, shift_y, a.scale);
           const float w00 = g.wx0 * g.wy0, w10 = g.wx1 * g.wy0, w01 = g.wx0 * g.wy1, w11 = g.wx1 * g.wy1;
           // gs rows y - fy - 1 (prev) and y - fy (cur) at columns x - fx - 1 ..; flux rows y + fy (north), y + fy + 1 (south)
           Row5 gr[R + 1], fl[R + 1];
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(256) void shift_bwd4_kernel(ShiftBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < R; ++k) {
           if (y0 + k >= H) continue;
-          const float4 q = *reinterpret_cast<const float4*>(gs + (size_t)(y0 + k) * W + x);
+          const float4 q = gld4(gs + (size_t)(y0 + k) * W + x);
           const float qv[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {

@@ -79,7 +79,7 @@ def main():
     text = f"""## r05 (round 5)
 
 Kernel statistics, PMC traffic and SQ counters: `tools/profile_round.sh r05` in one `gpurun` call (by-value epochs on one
-stream under the tracer: a kernel's own duration).  Bench lines, rank-share tables and the small fits: `tools/gpu/r5_g20.sh`
+stream under the tracer: a kernel's own duration).  Bench lines and kernel statistics: `tools/gpu/r5_final2.sh` (third session: `tools/gpu/r5_profile_lite.sh`); rank-share tables, small fits, SQ counters, RCCL probe: `tools/gpu/r5_g20.sh` (second session; those kernels are unchanged)
 on the last build of the round (board clock {round(b3['clock_mhz'])} MHz by `jd_clock_probe`).  This section is generated from the
 files by `tools/profiles_readme_r05.py`.
 
@@ -99,7 +99,7 @@ files by `tools/profiles_readme_r05.py`.
 | `r05/sq_counters.txt` | SQ counters of the c3 step, per launch |
 | `r05/rccl_probe.json` | `tools/rccl_probe.py`: a one-rank RCCL group running the calls of a sharded step: host time of the three `torch.distributed` calls, on-stream floor of the two collectives |
 | `r05/conv_method_crossover.txt` | MFMA Toeplitz against native FFT convolution by PSF size (the rule of the method "auto") |
-| `r05/ab_*.txt` | A/B runs of the round: `ab_fft1_*` (packed complex arithmetic, 576-thread rows, linear LDS indices), `ab_fft3_*` / `ab_fft4_*` (batching, columns per block, pooled prefetch), `ab_c6_transposed_shift_rows_outside.txt`, `ab_prior_overlap.txt` (the prior's first phase beside the likelihood), `ab_c3_tile_heights_with_overlap.txt` |
+| `r05/ab_*.txt` | A/B runs of the round: `ab_fft1_*` (packed complex arithmetic, 576-thread rows, linear LDS indices), `ab_fft3_*` / `ab_fft4_*` (batching, columns per block, pooled prefetch), `ab_c6_transposed_shift_rows_outside.txt`, `ab_prior_overlap.txt` (the prior's first phase beside the likelihood), `ab_c3_tile_heights_with_overlap.txt`; third session: `ab_prior_schedule.txt` (side-stream priority, the likelihood fenced behind the screen launch), `ab_shared_operator.txt` (flux components on one PSF evaluated as their sum), `ab_gmm_backend_loads.txt` and `ab_fft_global_loads.txt` (batched loads, global-memory accessors) |
 
 c3, per kernel (`r05/c3_n1_kernel_stats.csv`, AverageNs; algorithmic bytes / flop of DESIGN.md section 3):
 
@@ -115,7 +115,7 @@ c3, per kernel (`r05/c3_n1_kernel_stats.csv`, AverageNs; algorithmic bytes / flo
 
 The step is {1e3 * b3['ms_per_step']:.0f} us against {fw + ad17 + ad33 + sc + ex + ga + stg + sca + cnt + bs + best + dn:.0f} us of kernels: the prior's first phase (stage .. arg-max, {sc + ex + stg + sca + cnt + bs + best + dn:.0f} us) runs on
 a second stream beside the likelihood's three launches ({fw + ad17 + ad33:.0f} us) -- `ab_prior_overlap.txt`.  These kernels are the round-4
-kernels (the walk kernels and the GMM back end were not changed this round).
+kernels; the third session of round 5 batched the loads of the GMM back end (record sort, arg-max pass, gather: `ab_gmm_backend_loads.txt`).
 c4 (`r05/c4_n1_kernel_stats.csv`): forward + Poisson {f4:.1f} us (335 MB -> {335 / f4:.2f} TB/s = {335 / f4 / 8 * 100:.1f} %; PMC {sum(pmc('c4', 'walk_kernel<17, 4, 2, true')):.0f} MB).
 c3 through the native FFT convolution (`r05/c3fft_n1_kernel_stats.csv`, per observation): rows {rows:.1f} us, columns {cols:.1f} us, rows^-1 + Poisson + rows
 of g {mid:.1f} us, rows^-1 + adjoint epilogue {inv:.1f} us; {rows + 2 * cols + mid + inv:.0f} us per observation (round 4: 76).
