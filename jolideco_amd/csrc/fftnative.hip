@@ -1199,6 +1199,7 @@ bool fftn_supported(int H, int W, int kh, int kw) {
   // multiple of 4 is read and written at 4-byte alignment (row_ld4 / row_st4)
   const int Hh = (H + 1) / 2;
   if (H < 2 || Hh < kh || kh < 1 || kw < 1) return false;
+  if (W < 8) return false;  // (the five-pixel windows of a calibrated row load, issue_row5, need W >= 5; narrower images: rocFFT)
   if (W > 4 * ROW_THREADS * 5) return false;
   const int ox = (kw - 1) / 2;
   const int nx = next_length(W + std::max(ox, kw - 1 - ox)), ny = next_length(Hh + kh - 1, false);

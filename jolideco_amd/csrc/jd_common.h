@@ -171,7 +171,7 @@ struct Raw5 {
 
 __device__ __forceinline__ Raw5 issue_row5(const float* img, int H, int W, int y, int x) {
   Raw5 r;
-  const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 5);
+  const int yc = min(max(y, 0), H - 1), xc = max(min(x, W - 5), 0);  // (W >= 5: the callers' launch conditions ask for W >= 8)
   r.yin = y == yc, r.delta = x - xc;
   const float* row = img + ((size_t)yc * W + xc);
   const float4 q = gld4u(row);
