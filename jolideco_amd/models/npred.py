@@ -168,7 +168,7 @@ def estimate_dataset_cost(dataset, components, calibrated=False):
     convolution method "auto" would choose, from the PSF shapes and their separable ranks."""
     method = default_conv_method()
     counts_shape = np.shape(dataset["counts"])
-    total = 0.0
+    total, units = 0.0, []
     for name, psf in dataset_psfs(dataset, components).items():
         edge = max(psf.shape[-2:])
         up = components[name].upsampling_factor or 1
@@ -186,6 +186,17 @@ def estimate_dataset_cost(dataset, components, calibrated=False):
             else:
                 unit = COST_FFT
         total += unit * up * up  # (the flux grid has up^2 pixels per counts pixel)
+        units.append(unit * up * up)
+    # components that share the operator are evaluated as their sum: ONE forward model and ONE adjoint per dataset
+    # (`NPredModels.shared_operator`; the host-side conditions here: one non-negative rank-1 PSF for all components, no
+    # calibration, no up-sampling, the separable path)
+    psfs = list(dataset_psfs(dataset, components).values())
+    if (len(psfs) > 1 and not calibrated and method == "auto" and os.environ.get("JOLIDECO_MERGE_COMPONENTS", "1") != "0"
+            and all((c.upsampling_factor or 1) == 1 and bool(getattr(c, "use_log_flux", True)) for c in components.values())
+            and all(p.shape == psfs[0].shape and np.array_equal(p, psfs[0]) for p in psfs[1:])
+            and psfs[0].ndim == 2 and float(np.min(psfs[0])) >= 0.0 and max(psfs[0].shape) <= WALK_MAX_EDGE
+            and psf_separable_rank(psfs[0]) == 1):
+        return max(units)
     return total
 
 

@@ -254,6 +254,14 @@ def test_dataset_cost_estimate_follows_the_psf():
     assert estimate_dataset_cost(data(gaussian_kernel(3.2, (33, 33))), comps) == COST_WALK33
     assert estimate_dataset_cost(data(instrument_like_psf(0, (65, 65))), comps) == COST_FFT
     assert estimate_dataset_cost(data(gaussian_kernel(2.0, (17, 17))), comps, calibrated=True) > COST_WALK17
+    # two components: on ONE PSF they are evaluated as their sum (one unit); with a PSF each, one unit per component
+    comps["points"] = SpatialFluxComponent.from_numpy(flux=np.ones((64, 64)))
+    shared = gaussian_kernel(2.0, (17, 17))
+    assert estimate_dataset_cost(data(shared), comps) == COST_WALK17
+    own = {"flux": shared, "points": gaussian_kernel(1.2, (17, 17))}
+    assert estimate_dataset_cost(data(own), comps) == 2 * COST_WALK17
+    comps["points"] = SpatialFluxComponent.from_numpy(flux=np.ones((64, 64)), use_log_flux=False)  # may turn negative: no sum
+    assert estimate_dataset_cost(data(shared), comps) == 2 * COST_WALK17
 
 
 def _helpers_worker(rank, world_size, port):
