@@ -54,6 +54,8 @@ def main():
     b1, b2, b3, b3d, b4, b5, b6, be = (line(n) for n in ("c1_n1_bench", "c2_n1_bench", "c3_n1_bench", "c3_n1_bench_driver_flags", "c4_n1_bench",
                                                          "c5_n1_bench", "c6_n1_bench", "e0102_bench"))
     br = line("c3_rank2_of_8_bench")
+    shared = (f"; side run `shared_psf` (one PSF per dataset for both components: evaluated as their sum) {b5['shared_psf']['value']:.0f} it/s"
+              if "shared_psf" in b5 else "")
     fw = find(c3, "walk_mixed_kernel")
     ad17, ad33 = find(c3, "walk_kernel<17, 4, 3, false, false, 6"), find(c3, "walk_kernel<33, 2, 2, false, false, 2")
     sc, ex, ga, stg = find(c3, "gmm_screen_kernel<2, false, true, false, false>"), find(c3, "gmm_exact_kernel"), find(c3, "gmm_gather_tile"), find(c3, "gmm_stage")
@@ -88,7 +90,7 @@ files by `tools/profiles_readme_r05.py`.
 | `r05/c3_n1_bench.json` | `python bench.py`: **{b3['value']:.0f} it/s, {b3['ms_per_step']:.4f} ms/step** (regions {b3['ms_per_step_min']:.4f}-{b3['ms_per_step_max']:.4f}); policy: {b3['graph_policy']}; host enqueue {b3['host_enqueue_ms_per_step']:.3f} ms/step; `graph_replay` (every epoch replayed) {b3['graph_replay']['value']:.0f} it/s at {b3['graph_replay']['host_enqueue_ms_per_step']:.3f} ms of host time per step; `fft_psf` {b3.get('fft_psf', {}).get('value', float('nan')):.0f} it/s; `odd_size_fft` (2047 x 2050 image through the FFT path) native {b3['odd_size_fft']['native']['value']:.0f} against rocFFT {b3['odd_size_fft']['rocfft']['value']:.0f} it/s; `dense_fp32_gmm` {b3['dense_fp32_gmm']['value']:.0f} it/s; CPU oracle {b3['cpu_baseline']['value']:.2f} it/s on {b3['cpu_baseline']['cores']} cores |
 | `r05/c3_n1_bench_driver_flags.json` | the same box, `--steps 20 --warmup 5` (the driver's flags): {b3d['value']:.0f} it/s, {b3d['ms_per_step']:.4f} ms/step |
 | `r05/c1_n1_bench.json` | `--config c1` (BASELINE configs[0]: 128^2, one observation, uniform prior, the reference's sequential loop): **{b1['value']:.0f} epochs/s** ({1e3 * b1['ms_per_step']:.1f} us per epoch; {b1['graph_policy']}); CPU oracle, the full workload: {b1['cpu_baseline']['value']:.0f} epochs/s |
-| `r05/c2_n1_bench.json`, `c4_n1_bench.json`, `c5_n1_bench.json` | c2 {b2['value']:.0f} it/s ({b2['ms_per_step']:.3f} ms; {b2['graph_policy'].split(';')[-1].strip(' )')}), c4 {b4['value']:.0f} it/s ({b4['ms_per_step']:.3f} ms), c5 {b5['value']:.0f} it/s ({b5['ms_per_step']:.3f} ms; {b5['graph_policy'].split(';')[-1].strip(' )')}) |
+| `r05/c2_n1_bench.json`, `c4_n1_bench.json`, `c5_n1_bench.json` | c2 {b2['value']:.0f} it/s ({b2['ms_per_step']:.3f} ms; {b2['graph_policy'].split(';')[-1].strip(' )')}), c4 {b4['value']:.0f} it/s ({b4['ms_per_step']:.3f} ms), c5 {b5['value']:.0f} it/s ({b5['ms_per_step']:.3f} ms; {b5['graph_policy'].split(';')[-1].strip(' )')}){shared} |
 | `r05/c6_n1_bench.json` | `--config c6` (2048^2 counts grid, up-sampling x2, 8 calibrated observations, general 65x65 PSFs, K = 128): **{b6['value']:.0f} it/s, {b6['ms_per_step']:.2f} ms/step** (round 4: 187); `roofline_c6`: {r6['frac']:.2f} of 8 TB/s over the six launches of an observation (table below) |
 | `r05/e0102_bench.json` | `--config e0102`: the reference's only published runtime ("about 30 min on an M1 cpu"), 24 observations, 128x128 PSFs, x2 up-sampling, calibrations, 250 sequential epochs on an ASSUMED 256^2 counts grid, through `MAPDeconvolver.run()`: **{be['value']:.2f} s** ({be['ms_per_step']:.3f} ms per optimizer step; {be['graph_policy'].split(';')[0]}) |
 | `r05/c3_rank2_of_8_bench.json` | `bench.py --shard-of 8 --rank 2`: the share of rank 2 of an 8-rank job, no transport: {1e3 * br['ms_per_step']:.0f} us per step |
